@@ -1,0 +1,519 @@
+"""Semantic problem model for one Solve() call, and its KSP1 text serialisation.
+
+This is the *input closure* of the reference hot path -- everything
+`provisioning.(*Provisioner).NewScheduler` (reference
+pkg/controllers/provisioning/provisioner.go:237-296), `scheduling.NewTopology`
+(pkg/controllers/provisioning/scheduling/topology.go:56-80) and
+`(*Scheduler).Solve` (scheduler.go:96-133) read: pending pods, daemonset pods,
+provisioners (-> MachineTemplates), the instance-type catalogue, the state nodes
+and the cluster pods/nodes that `countDomains` (topology.go:231-276) would list
+through the API server.
+
+Names follow the Kubernetes / karpenter domain (pods, provisioners, instance
+types, offerings, taints, tolerations, topology spread constraints); nothing
+here is ML vocabulary.  The objects are plain dataclasses; `Problem.to_ksp()`
+writes the line-oriented KSP1 format that both the C++ host library
+(karpenter_core_amd/host/ksp.hpp) and the CPU oracle (oracle/) parse.
+
+KSP1 grammar (tokens separated by whitespace; `~` is the empty string; every
+list is `<count> item*`):
+
+  quantity : Kubernetes resource.Quantity text ("100m", "1.8G", "10Mi", "4")
+  expr     : key op nvals val*        op in In NotIn Exists DoesNotExist Gt Lt
+  selector : NIL | SEL nlabels {k v}* nexprs expr*
+  term     : topologyKey nns ns* selector          (namespaces pre-resolved by the host,
+                                                    topology.go:324-347 needs the API server)
+  podspec  : uid namespace creationTs
+             L nlabels {k v}*  NS n {k v}*  RA nterms {nexpr expr*}*
+             PA nterms {weight nexpr expr*}*  TOL n {key op value effect}*
+             C ncont {nreq {res qty}* nlim {res qty}* nports {ip port proto}*}*
+             I ninit {nreq {res qty}* nlim {res qty}*}*
+             TS n {maxSkew key whenUnsatisfiable selector}*
+             AFR n term*  AFP n {weight term}*  ANR n term*  ANP n {weight term}*
+"""
+from __future__ import annotations
+
+import dataclasses
+import io
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+# ---- label / taint constants (reference pkg/apis/v1alpha5/labels.go:26-110, k8s.io/api core/v1) ----
+LABEL_ZONE = "topology.kubernetes.io/zone"
+LABEL_REGION = "topology.kubernetes.io/region"
+LABEL_HOSTNAME = "kubernetes.io/hostname"
+LABEL_INSTANCE_TYPE = "node.kubernetes.io/instance-type"
+LABEL_ARCH = "kubernetes.io/arch"
+LABEL_OS = "kubernetes.io/os"
+LABEL_CAPACITY_TYPE = "karpenter.sh/capacity-type"
+LABEL_PROVISIONER = "karpenter.sh/provisioner-name"
+LABEL_INITIALIZED = "karpenter.sh/initialized"
+
+DO_NOT_SCHEDULE = "DoNotSchedule"
+SCHEDULE_ANYWAY = "ScheduleAnyway"
+
+NO_SCHEDULE = "NoSchedule"
+PREFER_NO_SCHEDULE = "PreferNoSchedule"
+NO_EXECUTE = "NoExecute"
+
+RES_CPU = "cpu"
+RES_MEMORY = "memory"
+RES_PODS = "pods"
+RES_EPHEMERAL = "ephemeral-storage"
+
+
+def _tok(s: str) -> str:
+    s = str(s)
+    if s == "":
+        return "~"
+    if any(c.isspace() for c in s) or s == "~":
+        raise ValueError(f"KSP1 tokens may not contain whitespace or be '~': {s!r}")
+    return s
+
+
+@dataclass
+class Expr:
+    """v1.NodeSelectorRequirement / metav1.LabelSelectorRequirement."""
+    key: str
+    op: str                      # In NotIn Exists DoesNotExist Gt Lt
+    values: List[str] = field(default_factory=list)
+
+    def ksp(self, w):
+        w.write(f" {_tok(self.key)} {self.op} {len(self.values)}")
+        for v in self.values:
+            w.write(" " + _tok(v))
+
+
+@dataclass
+class LabelSelector:
+    """metav1.LabelSelector; `None` (nil) selects nothing, empty selects everything
+    (reference topologygroup.go:246-252 via metav1.LabelSelectorAsSelector)."""
+    match_labels: Dict[str, str] = field(default_factory=dict)
+    match_expressions: List[Expr] = field(default_factory=list)
+
+
+def _ksp_selector(sel: Optional[LabelSelector], w):
+    if sel is None:
+        w.write(" NIL")
+        return
+    w.write(f" SEL {len(sel.match_labels)}")
+    for k in sorted(sel.match_labels):
+        w.write(f" {_tok(k)} {_tok(sel.match_labels[k])}")
+    w.write(f" {len(sel.match_expressions)}")
+    for e in sel.match_expressions:
+        e.ksp(w)
+
+
+@dataclass
+class PodAffinityTerm:
+    topology_key: str
+    label_selector: Optional[LabelSelector] = None
+    namespaces: List[str] = field(default_factory=list)   # empty -> the pod's own namespace
+
+    def ksp(self, w):
+        w.write(f" {_tok(self.topology_key)} {len(self.namespaces)}")
+        for n in self.namespaces:
+            w.write(" " + _tok(n))
+        _ksp_selector(self.label_selector, w)
+
+
+@dataclass
+class WeightedPodAffinityTerm:
+    weight: int
+    term: PodAffinityTerm
+
+
+@dataclass
+class TopologySpreadConstraint:
+    max_skew: int
+    topology_key: str
+    when_unsatisfiable: str = DO_NOT_SCHEDULE
+    label_selector: Optional[LabelSelector] = None
+
+
+@dataclass
+class Toleration:
+    key: str = ""
+    operator: str = ""          # "", Equal, Exists
+    value: str = ""
+    effect: str = ""
+
+
+@dataclass
+class Taint:
+    key: str
+    value: str = ""
+    effect: str = NO_SCHEDULE
+
+
+@dataclass
+class HostPort:
+    port: int
+    protocol: str = "TCP"
+    host_ip: str = ""           # "" -> 0.0.0.0 (reference hostportusage.go:133-136)
+
+
+@dataclass
+class Container:
+    requests: Dict[str, str] = field(default_factory=dict)
+    limits: Dict[str, str] = field(default_factory=dict)
+    ports: List[HostPort] = field(default_factory=list)
+
+
+@dataclass
+class PreferredTerm:
+    weight: int
+    exprs: List[Expr]
+
+
+@dataclass
+class Pod:
+    """The v1.Pod fields the path reads (requirements.go:61-78, resources.go:25-119,
+    taints.go:28, hostportusage.go:122-144, topology.go:278-322, preferences.go:36-145)."""
+    uid: str
+    namespace: str = "default"
+    creation_ts: int = 0
+    labels: Dict[str, str] = field(default_factory=dict)
+    node_selector: Dict[str, str] = field(default_factory=dict)
+    required_affinity: List[List[Expr]] = field(default_factory=list)      # NodeSelectorTerms (OR)
+    preferred_affinity: List[PreferredTerm] = field(default_factory=list)
+    tolerations: List[Toleration] = field(default_factory=list)
+    containers: List[Container] = field(default_factory=list)
+    init_containers: List[Container] = field(default_factory=list)
+    spread: List[TopologySpreadConstraint] = field(default_factory=list)
+    affinity_required: List[PodAffinityTerm] = field(default_factory=list)
+    affinity_preferred: List[WeightedPodAffinityTerm] = field(default_factory=list)
+    anti_required: List[PodAffinityTerm] = field(default_factory=list)
+    anti_preferred: List[WeightedPodAffinityTerm] = field(default_factory=list)
+
+    def ksp(self, w):
+        w.write(f"{_tok(self.uid)} {_tok(self.namespace)} {int(self.creation_ts)}")
+        w.write(f" L {len(self.labels)}")
+        for k in sorted(self.labels):
+            w.write(f" {_tok(k)} {_tok(self.labels[k])}")
+        w.write(f" NS {len(self.node_selector)}")
+        for k in sorted(self.node_selector):
+            w.write(f" {_tok(k)} {_tok(self.node_selector[k])}")
+        w.write(f" RA {len(self.required_affinity)}")
+        for term in self.required_affinity:
+            w.write(f" {len(term)}")
+            for e in term:
+                e.ksp(w)
+        w.write(f" PA {len(self.preferred_affinity)}")
+        for pt in self.preferred_affinity:
+            w.write(f" {int(pt.weight)} {len(pt.exprs)}")
+            for e in pt.exprs:
+                e.ksp(w)
+        w.write(f" TOL {len(self.tolerations)}")
+        for t in self.tolerations:
+            w.write(f" {_tok(t.key)} {_tok(t.operator)} {_tok(t.value)} {_tok(t.effect)}")
+        w.write(f" C {len(self.containers)}")
+        for c in self.containers:
+            _ksp_reslist(c.requests, w)
+            _ksp_reslist(c.limits, w)
+            w.write(f" {len(c.ports)}")
+            for hp in c.ports:
+                w.write(f" {_tok(hp.host_ip)} {int(hp.port)} {_tok(hp.protocol)}")
+        w.write(f" I {len(self.init_containers)}")
+        for c in self.init_containers:
+            _ksp_reslist(c.requests, w)
+            _ksp_reslist(c.limits, w)
+        w.write(f" TS {len(self.spread)}")
+        for s in self.spread:
+            w.write(f" {int(s.max_skew)} {_tok(s.topology_key)} {s.when_unsatisfiable}")
+            _ksp_selector(s.label_selector, w)
+        w.write(f" AFR {len(self.affinity_required)}")
+        for t in self.affinity_required:
+            t.ksp(w)
+        w.write(f" AFP {len(self.affinity_preferred)}")
+        for wt in self.affinity_preferred:
+            w.write(f" {int(wt.weight)}")
+            wt.term.ksp(w)
+        w.write(f" ANR {len(self.anti_required)}")
+        for t in self.anti_required:
+            t.ksp(w)
+        w.write(f" ANP {len(self.anti_preferred)}")
+        for wt in self.anti_preferred:
+            w.write(f" {int(wt.weight)}")
+            wt.term.ksp(w)
+
+
+def _ksp_reslist(rl: Dict[str, str], w):
+    w.write(f" {len(rl)}")
+    for k in sorted(rl):
+        w.write(f" {_tok(k)} {_tok(rl[k])}")
+
+
+@dataclass
+class Offering:
+    """cloudprovider.Offering (reference pkg/cloudprovider/types.go:106-114)."""
+    capacity_type: str
+    zone: str
+    price: float
+    available: bool = True
+
+
+@dataclass
+class InstanceType:
+    """cloudprovider.InstanceType (types.go:72-89); `overhead` is Overhead.Total() (types.go:100-102)."""
+    name: str
+    requirements: List[Expr]
+    offerings: List[Offering]
+    capacity: Dict[str, str]
+    overhead: Dict[str, str] = field(default_factory=dict)
+
+
+@dataclass
+class Provisioner:
+    """v1alpha5.Provisioner fields read by NewMachineTemplate (machinetemplate.go:46-62),
+    OrderByWeight (apis/v1alpha5/provisioner.go:132-136) and NewScheduler (scheduler.go:46-75)."""
+    name: str
+    weight: int = 0
+    labels: Dict[str, str] = field(default_factory=dict)
+    requirements: List[Expr] = field(default_factory=list)
+    taints: List[Taint] = field(default_factory=list)
+    limits: Optional[Dict[str, str]] = None     # None == Spec.Limits nil
+    instance_types: List[int] = field(default_factory=list)   # indices into Problem.instance_types
+
+
+@dataclass
+class StateNode:
+    """state.Node as the scheduler sees it (state/node.go:61-159): only the *derived* values are
+    carried -- Taints() (ephemeral/startup taints already removed), Available(), Capacity(),
+    DaemonSetRequests(), HostPortUsage()."""
+    name: str
+    labels: Dict[str, str] = field(default_factory=dict)
+    taints: List[Taint] = field(default_factory=list)
+    available: Dict[str, str] = field(default_factory=dict)
+    capacity: Dict[str, str] = field(default_factory=dict)
+    daemonset_requests: Dict[str, str] = field(default_factory=dict)
+    host_ports: List[HostPort] = field(default_factory=list)
+    in_state: bool = True       # passed to NewScheduler as a stateNode (helpers.go:48-61 drops candidates)
+
+    @property
+    def owned(self) -> bool:    # state/node.go Owned(): provisioner-name label non-empty
+        return self.labels.get(LABEL_PROVISIONER, "") != ""
+
+
+@dataclass
+class ClusterPod:
+    """A pod already bound in the cluster, as seen by countDomains (topology.go:231-276) and
+    updateInverseAffinities (topology.go:181-199).  Only countable pods are listed (scheduled,
+    not terminal, not terminating -- topology.go:404-406)."""
+    uid: str
+    namespace: str
+    node_name: str
+    labels: Dict[str, str] = field(default_factory=dict)
+    anti_required: List[PodAffinityTerm] = field(default_factory=list)
+
+
+@dataclass
+class Problem:
+    instance_types: List[InstanceType]
+    provisioners: List[Provisioner]
+    pods: List[Pod]
+    daemonset_pods: List[Pod] = field(default_factory=list)
+    nodes: List[StateNode] = field(default_factory=list)
+    cluster_pods: List[ClusterPod] = field(default_factory=list)
+    extra_well_known: List[str] = field(default_factory=list)   # fake provider adds size/special/integer
+    simulation_mode: bool = False
+
+    def to_ksp(self) -> str:
+        w = io.StringIO()
+        w.write("KSP1\n")
+        w.write(f"WELLKNOWN {len(self.extra_well_known)}")
+        for k in self.extra_well_known:
+            w.write(" " + _tok(k))
+        w.write("\n")
+        w.write(f"ITS {len(self.instance_types)}\n")
+        for it in self.instance_types:
+            w.write(f"IT {_tok(it.name)} {len(it.requirements)}")
+            for e in it.requirements:
+                e.ksp(w)
+            w.write(f" {len(it.offerings)}")
+            for o in it.offerings:
+                w.write(f" {_tok(o.capacity_type)} {_tok(o.zone)} {float(o.price)!r} {1 if o.available else 0}")
+            _ksp_reslist(it.capacity, w)
+            _ksp_reslist(it.overhead, w)
+            w.write("\n")
+        w.write(f"PROVS {len(self.provisioners)}\n")
+        for p in self.provisioners:
+            w.write(f"PROV {_tok(p.name)} {int(p.weight)} {len(p.labels)}")
+            for k in sorted(p.labels):
+                w.write(f" {_tok(k)} {_tok(p.labels[k])}")
+            w.write(f" {len(p.requirements)}")
+            for e in p.requirements:
+                e.ksp(w)
+            w.write(f" {len(p.taints)}")
+            for t in p.taints:
+                w.write(f" {_tok(t.key)} {_tok(t.value)} {_tok(t.effect)}")
+            if p.limits is None:
+                w.write(" -1")
+            else:
+                _ksp_reslist(p.limits, w)
+            w.write(f" {len(p.instance_types)}")
+            for i in p.instance_types:
+                w.write(f" {int(i)}")
+            w.write("\n")
+        w.write(f"NODES {len(self.nodes)}\n")
+        for n in self.nodes:
+            w.write(f"NODE {_tok(n.name)} {1 if n.in_state else 0} {len(n.labels)}")
+            for k in sorted(n.labels):
+                w.write(f" {_tok(k)} {_tok(n.labels[k])}")
+            w.write(f" {len(n.taints)}")
+            for t in n.taints:
+                w.write(f" {_tok(t.key)} {_tok(t.value)} {_tok(t.effect)}")
+            _ksp_reslist(n.available, w)
+            _ksp_reslist(n.capacity, w)
+            _ksp_reslist(n.daemonset_requests, w)
+            w.write(f" {len(n.host_ports)}")
+            for hp in n.host_ports:
+                w.write(f" {_tok(hp.host_ip)} {int(hp.port)} {_tok(hp.protocol)}")
+            w.write("\n")
+        w.write(f"CPODS {len(self.cluster_pods)}\n")
+        for cp in self.cluster_pods:
+            w.write(f"CPOD {_tok(cp.uid)} {_tok(cp.namespace)} {_tok(cp.node_name)} {len(cp.labels)}")
+            for k in sorted(cp.labels):
+                w.write(f" {_tok(k)} {_tok(cp.labels[k])}")
+            w.write(f" {len(cp.anti_required)}")
+            for t in cp.anti_required:
+                t.ksp(w)
+            w.write("\n")
+        w.write(f"DAEMONS {len(self.daemonset_pods)}\n")
+        for p in self.daemonset_pods:
+            w.write("POD ")
+            p.ksp(w)
+            w.write("\n")
+        w.write(f"SIM {1 if self.simulation_mode else 0}\n")
+        w.write(f"PODS {len(self.pods)}\n")
+        for p in self.pods:
+            w.write("POD ")
+            p.ksp(w)
+            w.write("\n")
+        w.write("END\n")
+        return w.getvalue()
+
+
+# ---------------------------------------------------------------------------------------------
+# Result side: what callers read from Solve()'s return values: Node.Pods,
+# Node.InstanceTypeOptions, Node.Requirements, Node.Requests, ExistingNode.Pods.
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class RequirementOut:
+    key: str
+    complement: bool
+    values: Tuple[str, ...]
+    greater_than: Optional[int]
+    less_than: Optional[int]
+
+    def operator(self) -> str:   # reference requirement.go:186-197
+        if self.complement:
+            return "NotIn" if self.values else "Exists"
+        return "In" if self.values else "DoesNotExist"
+
+
+@dataclass
+class NewNodeOut:
+    provisioner: str
+    pods: List[int]                       # pod indices (into Problem.pods), commit order
+    instance_types: List[str]             # order-preserving filter of the provisioner's list
+    requests: Dict[str, int]              # milli-units, only keys present in the Go ResourceList
+    requirements: Dict[str, RequirementOut]
+
+
+@dataclass
+class SolveResult:
+    new_nodes: List[NewNodeOut]
+    existing: Dict[str, List[int]]        # state-node name -> pod indices, commit order
+    unscheduled: List[int]                # q.List() at exit (queue order)
+    final_stage: List[int]                # relaxation stage each pod ended at
+    stats: Dict[str, int] = field(default_factory=dict)
+
+    def canonical(self) -> dict:
+        """Comparable structure (bit-identical parity means these compare equal)."""
+        return {
+            "new_nodes": [
+                {
+                    "provisioner": n.provisioner,
+                    "pods": list(n.pods),
+                    "instance_types": list(n.instance_types),
+                    "requests": dict(sorted(n.requests.items())),
+                    "requirements": {
+                        k: (r.complement, tuple(sorted(r.values)), r.greater_than, r.less_than)
+                        for k, r in sorted(n.requirements.items())
+                    },
+                }
+                for n in self.new_nodes
+            ],
+            "existing": {k: list(v) for k, v in sorted(self.existing.items()) if v},
+            "unscheduled": list(self.unscheduled),
+            "final_stage": list(self.final_stage),
+        }
+
+
+def parse_result(text: str) -> SolveResult:
+    """Parse the KSR1 result text emitted by both the oracle and the host library.
+
+      KSR1
+      NEWNODES n
+      NODE provisioner npods idx* ntypes name* nreq {res milli}* nrequirements {key c nvals val* gt lt}*
+      EXISTING n
+      ENODE name npods idx*
+      UNSCHEDULED n idx*
+      STAGES n stage*
+      STATS n {name value}*
+      END
+    """
+    toks = text.split()
+    pos = 0
+
+    def nxt():
+        nonlocal pos
+        t = toks[pos]
+        pos += 1
+        return "" if t == "~" else t
+
+    def expect(s):
+        t = nxt()
+        if t != s:
+            raise ValueError(f"KSR1: expected {s!r} got {t!r} at token {pos}")
+
+    expect("KSR1")
+    expect("NEWNODES")
+    nn = int(nxt())
+    new_nodes = []
+    for _ in range(nn):
+        expect("NODE")
+        prov = nxt()
+        pods = [int(nxt()) for _ in range(int(nxt()))]
+        its = [nxt() for _ in range(int(nxt()))]
+        requests = {}
+        for _ in range(int(nxt())):
+            k = nxt()
+            requests[k] = int(nxt())
+        reqs = {}
+        for _ in range(int(nxt())):
+            key = nxt()
+            c = nxt() == "1"
+            vals = tuple(nxt() for _ in range(int(nxt())))
+            gt = nxt()
+            lt = nxt()
+            reqs[key] = RequirementOut(key, c, vals, None if gt == "-" else int(gt), None if lt == "-" else int(lt))
+        new_nodes.append(NewNodeOut(prov, pods, its, requests, reqs))
+    expect("EXISTING")
+    existing = {}
+    for _ in range(int(nxt())):
+        expect("ENODE")
+        name = nxt()
+        existing[name] = [int(nxt()) for _ in range(int(nxt()))]
+    expect("UNSCHEDULED")
+    unscheduled = [int(nxt()) for _ in range(int(nxt()))]
+    expect("STAGES")
+    stages = [int(nxt()) for _ in range(int(nxt()))]
+    expect("STATS")
+    stats = {}
+    for _ in range(int(nxt())):
+        k = nxt()
+        stats[k] = int(nxt())
+    expect("END")
+    return SolveResult(new_nodes, existing, unscheduled, stages, stats)

@@ -1,0 +1,87 @@
+"""ctypes binding of oracle/liboracle.so (TEST INFRASTRUCTURE ONLY -- never imported by the product)."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "oracle.cpp")
+    hdr = os.path.join(_HERE, "..", "karpenter_core_amd", "host", "ksp.hpp")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        l = ctypes.CDLL(build())
+        l.ko_solve.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        l.ko_solve.restype = ctypes.c_int
+        l.ko_free.argtypes = [ctypes.c_void_p]
+        l.ko_req_intersection.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+        l.ko_req_has.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        l.ko_req_operator.argtypes = [ctypes.c_char_p]
+        l.ko_req_len.argtypes = [ctypes.c_char_p]
+        l.ko_req_len.restype = ctypes.c_longlong
+        l.ko_reqs_compatible.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
+        l.ko_parse_quantity_milli.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+        l.ko_parse_quantity_milli.restype = ctypes.c_longlong
+        _LIB = l
+    return _LIB
+
+
+def solve_text(ksp_text: str, inert_topology: bool = False) -> str:
+    data = ksp_text.encode()
+    out = ctypes.c_void_p()
+    rc = lib().ko_solve(data, len(data), 1 if inert_topology else 0, ctypes.byref(out))
+    text = ctypes.string_at(out).decode()
+    lib().ko_free(out)
+    if rc != 0:
+        raise RuntimeError("oracle: " + text)
+    return text
+
+
+def solve(problem, inert_topology: bool = False):
+    from karpenter_core_amd.model import parse_result
+    return parse_result(solve_text(problem.to_ksp(), inert_topology))
+
+
+def _spec(op, values):
+    return (op + " " + str(len(values)) + "".join(" " + v for v in values)).encode()
+
+
+def req_intersection(a, b):
+    buf = ctypes.create_string_buffer(4096)
+    lib().ko_req_intersection(_spec(*a), _spec(*b), buf, 4096)
+    return buf.value.decode()
+
+
+def req_has(a, value):
+    return bool(lib().ko_req_has(_spec(*a), value.encode()))
+
+
+def req_operator(a):
+    return ["In", "NotIn", "Exists", "DoesNotExist", "Gt", "Lt"][lib().ko_req_operator(_spec(*a))]
+
+
+def req_len(a):
+    return int(lib().ko_req_len(_spec(*a)))
+
+
+def reqs_compatible(key, well_known, a, b):
+    sa = b"-" if a is None else _spec(*a)
+    sb = b"-" if b is None else _spec(*b)
+    return bool(lib().ko_reqs_compatible(key.encode(), 1 if well_known else 0, sa, sb))
+
+
+def parse_quantity_milli(s):
+    err = ctypes.c_int()
+    v = lib().ko_parse_quantity_milli(s.encode(), ctypes.byref(err))
+    if err.value:
+        raise ValueError(s)
+    return int(v)
