@@ -517,3 +517,54 @@ def parse_result(text: str) -> SolveResult:
         stats[k] = int(nxt())
     expect("END")
     return SolveResult(new_nodes, existing, unscheduled, stages, stats)
+
+
+# ---------------------------------------------------------------------------------------------
+# resource.Quantity text -> exact int64 milli-units (mirrors ksp::parse_quantity_milli)
+# ---------------------------------------------------------------------------------------------
+_SUFFIX = {"": 1000, "m": 1, "k": 10**6, "M": 10**9, "G": 10**12, "T": 10**15, "P": 10**18, "E": 10**21,
+           "Ki": 1000 << 10, "Mi": 1000 << 20, "Gi": 1000 << 30, "Ti": 1000 << 40, "Pi": 1000 << 50, "Ei": 1000 << 60}
+
+
+def parse_quantity_milli(s: str) -> int:
+    import re
+    from fractions import Fraction
+    m = re.fullmatch(r"([+-]?)(\d*)(?:\.(\d*))?((?:[eE][+-]?\d+)|[A-Za-z]*)", s)
+    if not m or (m.group(2) == "" and not m.group(3)):
+        raise ValueError(f"bad quantity {s!r}")
+    sign, ip, fp, suf = m.group(1), m.group(2) or "0", m.group(3) or "", m.group(4)
+    mant = Fraction(int(ip + fp), 10 ** len(fp))
+    if suf[:1] in ("e", "E") and len(suf) > 1 and suf[1:].lstrip("+-").isdigit():
+        mult = Fraction(1000) * Fraction(10) ** int(suf[1:])
+    elif suf in _SUFFIX:
+        mult = Fraction(_SUFFIX[suf])
+    else:
+        raise ValueError(f"bad quantity suffix {s!r}")
+    v = mant * mult
+    if v.denominator != 1:
+        raise ValueError(f"quantity finer than 1 milli-unit: {s!r}")
+    return -int(v) if sign == "-" else int(v)
+
+
+def format_milli(v: int) -> str:
+    """Exact text form of a milli-unit value."""
+    return str(v // 1000) if v % 1000 == 0 else f"{v}m"
+
+
+def pod_requests_milli(pod: "Pod") -> Dict[str, int]:
+    """resources.RequestsForPods(pod) (reference utils/resources/resources.go:25-33,78-119) in milli-units."""
+    def merged(c):
+        r = {k: parse_quantity_milli(v) for k, v in c.requests.items()}
+        for k, v in c.limits.items():
+            r.setdefault(k, parse_quantity_milli(v))
+        return r
+    total: Dict[str, int] = {}
+    for c in pod.containers:
+        for k, v in merged(c).items():
+            total[k] = total.get(k, 0) + v
+    for c in pod.init_containers:
+        for k, v in merged(c).items():
+            if k not in total or v > total[k]:
+                total[k] = v
+    total["pods"] = 1000
+    return total

@@ -1,0 +1,260 @@
+"""Seeded synthetic Solve() problems: the five BASELINE.json configs and the
+reference benchmark's pod mix (scheduling_benchmark_test.go:185-288), restated.
+
+Every generator returns a `model.Problem`; all randomness comes from numpy's legacy RandomState so a
+seed pins the problem bit-for-bit on both the build container and the GPU box.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+
+from . import fake
+from .model import (ClusterPod, Container, Expr, HostPort, LabelSelector, Pod, PodAffinityTerm, Problem, StateNode,
+                    Taint, Toleration, TopologySpreadConstraint, DO_NOT_SCHEDULE, LABEL_ARCH, LABEL_CAPACITY_TYPE,
+                    LABEL_HOSTNAME, LABEL_INSTANCE_TYPE, LABEL_OS, LABEL_PROVISIONER, LABEL_ZONE, NO_SCHEDULE)
+
+CPU_CHOICES = [100, 250, 500, 1000, 1500]                 # scheduling_benchmark_test.go:285
+MEM_CHOICES = [100, 256, 512, 1024, 2048, 4096]           # :280
+LABEL_VALUES = ["a", "b", "c", "d", "e", "f", "g"]        # :275
+ZONES = ["test-zone-1", "test-zone-2", "test-zone-3"]
+
+
+def _container(rs) -> Container:
+    return Container(requests={"cpu": f"{CPU_CHOICES[rs.randint(len(CPU_CHOICES))]}m",
+                               "memory": f"{MEM_CHOICES[rs.randint(len(MEM_CHOICES))]}Mi"})
+
+
+def _lab(rs) -> str:
+    return LABEL_VALUES[rs.randint(len(LABEL_VALUES))]
+
+
+def generic_pod(rs, uid) -> Pod:                           # makeGenericPods :235-250
+    return Pod(uid=uid, labels={"my-label": _lab(rs)}, containers=[_container(rs)])
+
+
+def spread_pod(rs, uid, key) -> Pod:                       # makeTopologySpreadPods :210-233
+    return Pod(uid=uid, labels={"my-label": _lab(rs)}, containers=[_container(rs)],
+               spread=[TopologySpreadConstraint(1, key, DO_NOT_SCHEDULE, LabelSelector({"my-label": _lab(rs)}))])
+
+
+def affinity_pod(rs, uid, key) -> Pod:                     # makePodAffinityPods :199-208
+    return Pod(uid=uid, labels={"my-affininity": _lab(rs)}, containers=[_container(rs)],
+               affinity_required=[PodAffinityTerm(key, LabelSelector({"my-affininity": _lab(rs)}))])
+
+
+def anti_affinity_pod(rs, uid, key, self_selecting=True) -> Pod:
+    v = _lab(rs)
+    sel = v if self_selecting else _lab(rs)
+    return Pod(uid=uid, labels={"my-affininity": v}, containers=[_container(rs)],
+               anti_required=[PodAffinityTerm(key, LabelSelector({"my-affininity": sel}))])
+
+
+def diverse_pods(rs, count: int, uid_prefix="pod") -> List[Pod]:
+    """makeDiversePods (:185-197): 1/7 generic, 1/7 zonal spread, 1/7 hostname spread, 1/7 hostname
+    affinity, 1/7 zonal affinity, remainder generic.  UIDs are unique (the reference leaves them
+    empty, which makes its queue order sort-implementation dependent -- SURVEY App. C.2)."""
+    pods: List[Pod] = []
+    n = count // 7
+    k = [0]
+
+    def uid():
+        k[0] += 1
+        return f"{uid_prefix}-{k[0]:07d}"
+    pods += [generic_pod(rs, uid()) for _ in range(n)]
+    pods += [spread_pod(rs, uid(), LABEL_ZONE) for _ in range(n)]
+    pods += [spread_pod(rs, uid(), LABEL_HOSTNAME) for _ in range(n)]
+    pods += [affinity_pod(rs, uid(), LABEL_HOSTNAME) for _ in range(n)]
+    pods += [affinity_pod(rs, uid(), LABEL_ZONE) for _ in range(n)]
+    pods += [generic_pod(rs, uid()) for _ in range(count - len(pods))]
+    return pods
+
+
+def reference_benchmark(pod_count: int, instance_count: int = 400, seed: int = 42) -> Problem:
+    """benchmarkScheduler (:113-133): 1 provisioner, fake.InstanceTypes(n), makeDiversePods; run the
+    oracle with inert_topology=True to mirror the reference's `&scheduling.Topology{}` (:123)."""
+    rs = np.random.RandomState(seed)
+    its = fake.instance_types(instance_count)
+    return Problem(instance_types=its, provisioners=[fake.provisioner("default", len(its), limits={}, discovery_label=True)],
+                   pods=diverse_pods(rs, pod_count), extra_well_known=fake.EXTRA_WELL_KNOWN)
+
+
+# ---- config #1: 1k pods, 50 instance types, no affinity/topology ----
+def config1(pods: int = 1000, types: int = 50, seed: int = 42) -> Problem:
+    rs = np.random.RandomState(seed)
+    its = fake.instance_types(types)
+    ps = [Pod(uid=f"pod-{i:07d}", containers=[_container(rs)]) for i in range(pods)]
+    return Problem(instance_types=its, provisioners=[fake.provisioner("default", len(its))], pods=ps,
+                   extra_well_known=fake.EXTRA_WELL_KNOWN)
+
+
+TAINT_KEYS = [f"taint-{i}" for i in range(8)]
+
+
+def _taint_catalogue(sizes, zone_sets, ct_sets):
+    return fake.assorted_ladder(sizes, ["amd64", "arm64"], ["linux", "windows"], zone_sets, ct_sets)
+
+
+# ---- config #2: 10k pods, 500 instance types, taints + nodeSelector ----
+def config2(pods: int = 10_000, sizes: int = 25, seed: int = 43) -> Problem:
+    rs = np.random.RandomState(seed)
+    zone_sets = [[ZONES[0]], [ZONES[1]], [ZONES[2]], ZONES[:2], ZONES]
+    its = _taint_catalogue(sizes, zone_sets, [["spot", "on-demand"]])        # sizes*2*2*5 types (500 at 25)
+    n = len(its)
+    # four tainted provisioners (weights 40..10) and one untainted catch-all; 4 of the 8 taint keys are used
+    used = [int(x) for x in rs.choice(8, size=4, replace=False)]
+    provs = []
+    for i, tk in enumerate(used):
+        taints = [Taint(TAINT_KEYS[tk], "true", NO_SCHEDULE)]
+        if i == 0:
+            taints.append(Taint(TAINT_KEYS[used[1]], "true", NO_SCHEDULE))
+        provs.append(fake.provisioner(f"tainted-{i}", n, weight=40 - 10 * i, taints=taints))
+    provs.append(fake.provisioner("default", n, weight=0))
+    ps = []
+    for i in range(pods):
+        tol = [Toleration(key=TAINT_KEYS[k], operator="Exists", effect=NO_SCHEDULE) for k in range(8) if rs.rand() < 0.5]
+        sel = {}
+        if rs.rand() < 0.5:
+            sel[LABEL_ARCH] = ["amd64", "arm64"][rs.randint(2)]
+        if rs.rand() < 0.3:
+            sel[LABEL_ZONE] = ZONES[rs.randint(3)]
+        if rs.rand() < 0.2:
+            sel[LABEL_CAPACITY_TYPE] = ["spot", "on-demand"][rs.randint(2)]
+        ps.append(Pod(uid=f"pod-{i:07d}", labels={"my-label": _lab(rs)}, node_selector=sel, tolerations=tol,
+                      containers=[_container(rs)]))
+    return Problem(instance_types=its, provisioners=provs, pods=ps, extra_well_known=fake.EXTRA_WELL_KNOWN)
+
+
+# ---- config #3: 100k pods, 2k instance types, topology spread + pod anti-affinity ----
+def config3(pods: int = 100_000, sizes: int = 50, seed: int = 44) -> Problem:
+    rs = np.random.RandomState(seed)
+    zone_sets = [[ZONES[0]], [ZONES[1]], [ZONES[2]], ZONES[:2], ZONES]
+    its = _taint_catalogue(sizes, zone_sets, [["spot", "on-demand"], ["on-demand"]])   # sizes*2*2*5*2 (2000 at 50)
+    n = pods // 7
+    ps: List[Pod] = []
+    k = [0]
+
+    def uid():
+        k[0] += 1
+        return f"pod-{k[0]:07d}"
+    ps += [generic_pod(rs, uid()) for _ in range(n)]
+    ps += [spread_pod(rs, uid(), LABEL_ZONE) for _ in range(n)]
+    ps += [spread_pod(rs, uid(), LABEL_HOSTNAME) for _ in range(n)]
+    ps += [anti_affinity_pod(rs, uid(), LABEL_HOSTNAME, True) for _ in range(n)]
+    ps += [generic_pod(rs, uid()) for _ in range(pods - len(ps))]
+    return Problem(instance_types=its, provisioners=[fake.provisioner("default", len(its))], pods=ps,
+                   extra_well_known=fake.EXTRA_WELL_KNOWN)
+
+
+# ---- config #5: 1M pods, 5k instance types, full constraint set ----
+def config5(pods: int = 1_000_000, sizes: int = 50, seed: int = 46) -> Problem:
+    rs = np.random.RandomState(seed)
+    zone_sets = [[ZONES[0]], [ZONES[1]], [ZONES[2]], ZONES[:2], ZONES]
+    its = fake.assorted_ladder(sizes, ["amd64", "arm64"], ["linux", "windows"], zone_sets,
+                               [["spot", "on-demand"], ["on-demand"], ["spot"], ["on-demand", "spot"], ["on-demand"]][: max(1, 5000 // (sizes * 20))])
+    n = len(its)
+    provs = [fake.provisioner("high", n, weight=10, limits={"cpu": str(max(1000, pods // 8))},
+                              taints=[Taint(TAINT_KEYS[0], "true", NO_SCHEDULE)]),
+             fake.provisioner("default", n, weight=0)]
+    ps: List[Pod] = []
+    for i in range(pods):
+        kind = i % 10
+        uid = f"pod-{i:07d}"
+        tol = [Toleration(key=TAINT_KEYS[0], operator="Exists")] if rs.rand() < 0.3 else []
+        c = _container(rs)
+        if kind == 0:
+            p = spread_pod(rs, uid, LABEL_ZONE)
+        elif kind == 1:
+            p = spread_pod(rs, uid, LABEL_HOSTNAME)
+        elif kind == 2:
+            p = spread_pod(rs, uid, LABEL_CAPACITY_TYPE)
+        elif kind == 3:
+            p = anti_affinity_pod(rs, uid, LABEL_HOSTNAME, True)
+        elif kind == 4:
+            p = affinity_pod(rs, uid, LABEL_ZONE)
+        elif kind == 5:
+            p = Pod(uid=uid, labels={"my-label": _lab(rs)}, containers=[c],
+                    required_affinity=[[Expr(fake.LABEL_INTEGER, "Gt", [str(2 * (1 + rs.randint(8)))])]])
+        else:
+            p = generic_pod(rs, uid)
+        p.tolerations = tol
+        if rs.rand() < 0.01:
+            p.containers[0].ports = [HostPort(port=8000 + int(rs.randint(4)))]
+        if kind >= 6 and rs.rand() < 0.3:
+            p.node_selector = {LABEL_ARCH: ["amd64", "arm64"][rs.randint(2)]}
+        ps.append(p)
+    return Problem(instance_types=its, provisioners=provs, pods=ps, extra_well_known=fake.EXTRA_WELL_KNOWN)
+
+
+# ---- config #4: consolidation what-ifs over one cluster snapshot ----
+def cluster_snapshot(existing: int = 2048, sizes: int = 50, seed: int = 45):
+    """E existing (owned, initialised) nodes running 8-40 pods each at 30-70 % utilisation; returns
+    (instance_types, provisioner, nodes, per-node bound pods as `Pod` objects)."""
+    rs = np.random.RandomState(seed)
+    zone_sets = [[ZONES[0]], [ZONES[1]], [ZONES[2]], ZONES[:2], ZONES]
+    its = _taint_catalogue(sizes, zone_sets, [["spot", "on-demand"], ["on-demand"]])
+    prov = fake.provisioner("default", len(its))
+    nodes, bound = [], []
+    uid = 0
+    for e in range(existing):
+        ti = int(rs.randint(len(its)))
+        it = its[ti]
+        cpu_m = int(it.capacity["cpu"]) * 1000 - 100
+        mem_mi = int(it.capacity["memory"][:-2]) * 1024 - 10
+        zone = it.offerings[rs.randint(len(it.offerings))]
+        arch = [r for r in it.requirements if r.key == LABEL_ARCH][0].values[0]
+        os_ = [r for r in it.requirements if r.key == LABEL_OS][0].values[0]
+        target = rs.uniform(0.3, 0.7)
+        npods = int(rs.randint(8, 41))
+        pods_here, used_cpu, used_mem = [], 0, 0
+        for _ in range(npods):
+            p = generic_pod(rs, f"bound-{uid:07d}")
+            uid += 1
+            c = int(p.containers[0].requests["cpu"][:-1])
+            m = int(p.containers[0].requests["memory"][:-2])
+            if used_cpu + c > target * cpu_m or used_mem + m > target * mem_mi:
+                break
+            used_cpu += c
+            used_mem += m
+            pods_here.append(p)
+        name = f"node-{e:05d}"
+        labels = {LABEL_PROVISIONER: "default", LABEL_INSTANCE_TYPE: it.name, LABEL_ZONE: zone.zone,
+                  LABEL_CAPACITY_TYPE: zone.capacity_type, LABEL_ARCH: arch, LABEL_OS: os_, LABEL_HOSTNAME: name,
+                  "karpenter.sh/initialized": "true"}
+        alloc_pods = int(it.capacity["pods"])
+        nodes.append(StateNode(name=name, labels=labels,
+                               available={"cpu": f"{cpu_m - used_cpu}m", "memory": f"{mem_mi - used_mem}Mi",
+                                          "pods": str(alloc_pods - len(pods_here))},
+                               capacity=dict(it.capacity)))
+        bound.append(pods_here)
+    return its, prov, nodes, bound
+
+
+def whatif(its, prov, nodes, bound, candidates: List[int]) -> Problem:
+    """simulateScheduling (deprovisioning/helpers.go:42-115): candidate nodes leave the state-node list,
+    their pods become the pending batch; the cluster still holds the bound pods (excluded by UID,
+    topology.go:66-70,249)."""
+    cand = set(candidates)
+    ns = [StateNode(name=n.name, labels=n.labels, taints=n.taints, available=n.available, capacity=n.capacity,
+                    daemonset_requests=n.daemonset_requests, host_ports=n.host_ports, in_state=(i not in cand))
+          for i, n in enumerate(nodes)]
+    pods = [p for i in candidates for p in bound[i]]
+    cps = [ClusterPod(uid=p.uid, namespace=p.namespace, node_name=nodes[i].name, labels=p.labels)
+           for i in range(len(nodes)) for p in bound[i]]
+    return Problem(instance_types=its, provisioners=[prov], pods=pods, nodes=ns, cluster_pods=cps,
+                   extra_well_known=fake.EXTRA_WELL_KNOWN, simulation_mode=True)
+
+
+def config4(whatifs: int = 512, existing: int = 2048, sizes: int = 50, seed: int = 45) -> List[Problem]:
+    """512 what-ifs: half are multi-node prefixes (multinodeconsolidation.go:86-90), half singletons
+    (singlenodeconsolidation.go:54)."""
+    its, prov, nodes, bound = cluster_snapshot(existing, sizes, seed)
+    out = []
+    half = whatifs // 2
+    for i in range(half):
+        out.append(whatif(its, prov, nodes, bound, list(range(0, i + 1))))          # prefix [0..i]
+    rs = np.random.RandomState(seed + 1)
+    for _ in range(whatifs - half):
+        out.append(whatif(its, prov, nodes, bound, [int(rs.randint(existing))]))      # singleton
+    return out
