@@ -1,0 +1,233 @@
+/* ksolve.h -- C ABI of libksolve.so: the MI355X (gfx950) drop-in for karpenter-core's provisioning
+ * scheduler hot path.
+ *
+ * What it replaces (reference paths relative to aws/karpenter-core):
+ *   ks_solve / ks_solve_dev      <->  (*Scheduler).Solve       pkg/controllers/provisioning/scheduling/scheduler.go:96-133
+ *                                     called from provisioner.go:307 and deprovisioning/helpers.go:93
+ *   ks_solve_batch               <->  N independent simulateScheduling what-ifs, deprovisioning/helpers.go:42-115
+ *                                     (multinodeconsolidation.go:74-114, singlenodeconsolidation.go:43-78)
+ *   ks_feasibility_grid          <->  filterInstanceTypesByRequirements for a fresh node, node.go:137-159
+ *                                     (compatible && fits && hasOffering over every instance type)
+ *   ks_probe_*                   <->  Requirement.Intersection/Has/Operator, Requirements.Compatible
+ *                                     pkg/scheduling/requirement.go:117-204, requirements.go:123-206
+ *
+ * The reference has no FFI for this path (pure Go); a Go shim would flatten
+ * []*v1.Pod / []*cloudprovider.InstanceType / []*state.Node into `ks_problem` (INTEGRATION.md shows
+ * the cgo stub).  Everything crossing the boundary is plain pointers + sizes: no torch types, no C++
+ * types, no callbacks.  Buffers are owned by the caller and only read during the call (cgo pointer
+ * rules); results are written into caller-allocated arrays.
+ *
+ * Encoding (DESIGN.md "Data layout"):
+ *   keys      K <= 32 "narrow" label keys, each with a universe of <= 64 values interned in ascending
+ *             byte-wise string order (bit i of a mask == value i).  A requirement on key k is
+ *             {present, complement, mask, gt, lt} == reference Requirement{complement, values,
+ *             greaterThan, lessThan} (requirement.go:36-42).
+ *   instance-type key  handled through a finite intersection-closed set of "it-states" (tables
+ *             its_inter / its_fail / its_types) because its universe is the whole catalogue.
+ *   hostname key       implicit: new node n owns a placeholder hostname no pod can name (node.go:46);
+ *             existing node e owns hostname e.  Pod classes carry {mode, list of existing-node ids}.
+ *   resources R <= 8 int64 milli-units; index 0 = cpu, 1 = memory, 2 = pods.
+ *   taints    <= 64 distinct (key,value,effect) triples -> u64 masks; tolerations pre-evaluated.
+ *   offerings zone x capacity-type pairs (<= 64) -> u64 per instance type.
+ *   pods      deduplicated into classes (one per distinct pod spec x relaxation stage); a pod is a
+ *             chain of class ids, one per Preferences.Relax stage (preferences.go:36-56).
+ *   topology  groups (spread / affinity / anti-affinity, inverse anti-affinity) with pre-counted
+ *             domains (topology.go:231-276 needs the API server and therefore stays host-side).
+ */
+#ifndef KSOLVE_H
+#define KSOLVE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KS_MAX_KEYS 32
+#define KS_MAX_RES 8
+#define KS_MAX_VALUES 64
+#define KS_MAX_ITSTATES 256
+#define KS_NO_BOUND_GT INT32_MIN /* "no greaterThan" */
+#define KS_NO_BOUND_LT INT32_MAX /* "no lessThan"   */
+#define KS_KEY_HOSTNAME (-2)
+#define KS_KEY_NONE (-1)
+
+/* error codes (Solve itself never fails: scheduler.go:132 always returns a nil error) */
+#define KS_OK 0
+#define KS_ERR_INVALID (-1)     /* malformed ks_problem */
+#define KS_ERR_UNSUPPORTED (-2) /* feature outside the supported encoding */
+#define KS_ERR_DEVICE (-3)      /* HIP failure / no gfx950 device: the library never falls back to a CPU path */
+#define KS_ERR_CAPACITY (-4)    /* more new nodes than max_new_nodes */
+
+/* A family of requirement sets (reference scheduling.Requirements), n sets x K keys, SoA. */
+typedef struct ks_reqsets {
+  uint32_t n;
+  const uint32_t* present;    /* [n]   bit k: key k has a requirement                         */
+  const uint32_t* complement; /* [n]   bit k: requirement.go:38 `complement`                  */
+  const uint64_t* mask;       /* [n*K] value set over the key's universe                      */
+  const int32_t* gt;          /* [n*K] greaterThan or KS_NO_BOUND_GT                          */
+  const int32_t* lt;          /* [n*K] lessThan    or KS_NO_BOUND_LT                          */
+  const int32_t* it_state;    /* [n]   state of the instance-type key (0 == key absent)       */
+} ks_reqsets;
+
+typedef struct ks_problem {
+  /* ---- dimensions ---- */
+  uint32_t P;  /* pods in the batch                                   */
+  uint32_t C;  /* pod classes                                         */
+  uint32_t T;  /* instance types (TW = ceil(T/64) mask words)         */
+  uint32_t M;  /* machine templates == provisioners, weight order     */
+  uint32_t E;  /* existing (owned, in-state) nodes, caller's order    */
+  uint32_t K;  /* narrow keys                                         */
+  uint32_t R;  /* resources                                           */
+  uint32_t G;  /* topology groups (topologies first, then inverse)    */
+  uint32_t GH; /* groups whose key is the hostname                    */
+  uint32_t S;  /* instance-type-key states                            */
+  uint32_t max_new_nodes; /* capacity for scheduling.Node records (<= P is always enough) */
+  uint32_t flags;         /* KS_FLAG_* */
+
+  /* ---- keys ---- */
+  uint32_t wellknown_mask;     /* bit k: key k in v1alpha5.WellKnownLabels (labels.go:84-92 + provider additions) */
+  const uint32_t* key_nvalues; /* [K] */
+  const int32_t* value_int;    /* [K*64] strconv.Atoi of the value or INT32_MIN when not an integer (requirement.go:232) */
+  int32_t key_zone, key_ct;    /* narrow-key index of topology.kubernetes.io/zone, karpenter.sh/capacity-type, or -1 */
+  uint32_t n_ct;               /* offering pair index = zone_value * n_ct + ct_value */
+
+  /* ---- instance types (cloudprovider.InstanceType, types.go:72-89), SoA over T ---- */
+  const uint32_t* it_present;    /* [T] */
+  const uint32_t* it_complement; /* [T] */
+  const uint64_t* it_mask;       /* [K*T]  it_mask[k*T+t] */
+  const int64_t* it_alloc;       /* [R*T]  Allocatable() = Capacity - Overhead.Total(), types.go:87-102 */
+  const int64_t* it_cap;         /* [R*T]  Capacity (provisioner limits, scheduler.go:273-309) */
+  const uint64_t* it_offer;      /* [T]    available (zone,capacity-type) pairs, types.go:106-128 */
+  /* instance-type key lattice */
+  const uint8_t* its_inter;  /* [S*S] state of a∩b                                                    */
+  const uint8_t* its_fail;   /* [S*S] Requirements.Intersects error for existing=a, incoming=b         */
+  const uint8_t* its_nidne;  /* [S]   operator in {NotIn, DoesNotExist}                                */
+  const uint64_t* its_types; /* [S*TW] types whose own `instance-type In [name]` passes against state s */
+
+  /* ---- machine templates (machinetemplate.go:46-62), order = OrderByWeight (provisioner.go:132-136) ---- */
+  ks_reqsets tmpl;               /* n = M */
+  const uint64_t* tmpl_taints;   /* [M] */
+  const int64_t* tmpl_daemon;    /* [M*R] getDaemonOverhead, scheduler.go:250-267 */
+  const uint32_t* tmpl_daemon_present; /* [M] resource presence bits of that ResourceList */
+  const uint64_t* tmpl_types;    /* [M*TW] the provisioner's instance types */
+  const uint32_t* tmpl_limit_present;  /* [M] bit r: resource r is limited; 0xFFFFFFFF == Spec.Limits nil (scheduler.go:71-75) */
+  const int64_t* tmpl_remaining; /* [M*R] remainingResources after existing nodes (scheduler.go:244-246) */
+
+  /* ---- existing nodes (existingnode.go:41-75) ---- */
+  ks_reqsets en;               /* n = E : NewLabelRequirements(node.Labels) (hostname implicit) */
+  const uint64_t* en_taints;   /* [E] */
+  const int64_t* en_avail;     /* [E*R] state.Node.Available() */
+  const int64_t* en_requests;  /* [E*R] remaining daemon requests, clamped at 0 (existingnode.go:44-53) */
+  const uint32_t* en_requests_present; /* [E] */
+  const uint32_t* en_port_off; /* [E+1] into ports[] */
+
+  /* ---- pod classes ---- */
+  ks_reqsets cls;                 /* n = C : NewPodRequirements, requirements.go:61-78 */
+  const uint8_t* cls_hn_mode;     /* [C] hostname requirement: 0 none, 1 In list, 2 NotIn list (Exists = 2 + empty) */
+  const uint32_t* cls_hn_off;     /* [C+1] into hn_list[] (existing-node indices) */
+  const uint32_t* hn_list;
+  const int64_t* cls_requests;    /* [C*R] resources.RequestsForPods(pod), resources.go:25-33 */
+  const uint32_t* cls_requests_present; /* [C] */
+  const uint64_t* cls_tolerated;  /* [C] bit i: some toleration ToleratesTaint(taint i) (taints.go:28-40) */
+  const uint32_t* cls_port_off;   /* [C+1] into ports[] */
+  const uint64_t* ports;          /* proto<<56 | port<<32 | ip_id (ip_id 0 == unspecified 0.0.0.0/::), hostportusage.go:39-57 */
+  /* topology membership of a class (CSR lists of group ids) */
+  const uint32_t* cls_own_off;  /* [C+1] groups in Topology.topologies owned by the pod; entry = g | selfSelecting<<31 */
+  const uint32_t* own_list;
+  const uint32_t* cls_sel_off;  /* [C+1] non-inverse groups whose selector selects the pod (Record, topology.go:120-133) */
+  const uint32_t* sel_list;
+  const uint32_t* cls_isel_off; /* [C+1] inverse groups selecting the pod (getMatchingTopologies, topology.go:358-362) */
+  const uint32_t* isel_list;
+  const uint32_t* cls_iown_off; /* [C+1] inverse groups owned by the pod (Record, topology.go:136-141) */
+  const uint32_t* iown_list;
+
+  /* ---- pods ---- */
+  const uint32_t* pod_stage_off; /* [P+1] into stage_cls[]: one class per relaxation stage */
+  const uint32_t* stage_cls;
+  const uint32_t* queue;         /* [P] initial queue order: byCPUAndMemoryDescending, queue.go:74-110 */
+
+  /* ---- topology groups (topologygroup.go:53-86) ---- */
+  const uint8_t* grp_type;      /* [G] 0 spread, 1 pod affinity, 2 pod anti-affinity */
+  const int32_t* grp_key;       /* [G] narrow key index or KS_KEY_HOSTNAME */
+  const int32_t* grp_max_skew;  /* [G] */
+  const uint8_t* grp_active;    /* [G] 1: exists after NewTopology; 0: created by a later Topology.Update (topology.go:86-117) */
+  const uint32_t* grp_filter_off; /* [G+1] TopologyNodeFilter terms (topologynodefilter.go:28-70) into `flt`; empty == always */
+  ks_reqsets flt;
+  const int32_t* grp_count;     /* [G*64] initial domain counts (countDomains, topology.go:231-276); -1 == not a registered domain */
+  const int32_t* grp_hslot;     /* [G] row in the hostname tables or -1 */
+  const int32_t* grph_count;    /* [GH*E] initial counts on the existing nodes' hostnames; -1 unregistered */
+  const int32_t* grph_extra_pos;/* [GH] hostnames outside the state nodes with count > 0 (pod affinity options) */
+  uint32_t n_topologies;        /* groups [0, n_topologies) are Topology.topologies, the rest inverseTopologies */
+} ks_problem;
+
+#define KS_FLAG_SIMULATION 1u /* SchedulerOptions.SimulationMode (scheduler.go:37-40); informational */
+#define KS_FLAG_STATS 2u      /* also count the reference algorithm's attempts / scanned types (DESIGN.md roofline) */
+
+/* Result of one Solve: caller allocates the arrays (sizes below), the library fills them. */
+typedef struct ks_result {
+  /* per pod */
+  int32_t* pod_node;   /* [P] -1 unscheduled, [0,E) existing node, E+j new node j */
+  int32_t* pod_stage;  /* [P] relaxation stage the pod ended at */
+  int32_t* pod_seq;    /* [P] commit sequence number (orders Node.Pods), -1 if unscheduled */
+  /* unscheduled pods in final queue order (q.List(), queue.go:70-72) */
+  uint32_t n_unscheduled;
+  int32_t* unscheduled; /* [P] */
+  /* per new node (creation order) -- what callers read from scheduling.Node */
+  uint32_t n_new;
+  int32_t* node_tmpl;      /* [max_new_nodes] */
+  uint64_t* node_types;    /* [max_new_nodes*TW] InstanceTypeOptions as a bitmask */
+  int64_t* node_requests;  /* [max_new_nodes*R] */
+  uint32_t* node_requests_present; /* [max_new_nodes] */
+  uint32_t* node_present;  /* [max_new_nodes] Requirements after FinalizeScheduling (node.go:111-115) */
+  uint32_t* node_complement;
+  uint64_t* node_mask;     /* [max_new_nodes*K] */
+  int32_t* node_gt;        /* [max_new_nodes*K] */
+  int32_t* node_lt;        /* [max_new_nodes*K] */
+  int32_t* node_it_state;  /* [max_new_nodes] */
+  /* counters */
+  uint64_t stats[16];      /* KS_STAT_* */
+} ks_result;
+
+enum {
+  KS_STAT_POPS = 0,        /* queue pops                                             */
+  KS_STAT_RELAX = 1,       /* relaxations                                            */
+  KS_STAT_FULLCHECKS = 2,  /* candidate nodes that reached the instance-type filter  */
+  KS_STAT_FULLFAILS = 3,   /* ... and failed it                                      */
+  KS_STAT_REF_ATTEMPTS = 4,/* Node.Add/ExistingNode.Add calls the reference would make (KS_FLAG_STATS) */
+  KS_STAT_REF_TYPES = 5,   /* instance types the reference would scan (KS_FLAG_STATS)  */
+  KS_STAT_CYCLES = 6,      /* s_memtime ticks spent in the pack kernel (block 0)       */
+  KS_STAT_ERR = 7          /* device-side error code (0 ok)                            */
+};
+
+/* ---- device-resident problem: upload once, solve many times (inputs resident in HBM) ---- */
+typedef struct ks_dev_problem ks_dev_problem;
+
+int ks_device_count(void);                                     /* number of gfx950 devices visible, 0 if none */
+int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem** out);
+void ks_problem_free(ks_dev_problem* d);
+/* Solve on the uploaded problem; kernel time (ms, HIP events on the solve stream) is returned in *kernel_ms if non-NULL. */
+int ks_solve_dev(ks_dev_problem* d, ks_result* out, float* kernel_ms);
+/* Convenience: upload + solve + free. */
+int ks_solve(const ks_problem* p, ks_result* out);
+/* N independent problems (consolidation what-ifs): one workgroup each, one launch. */
+int ks_solve_batch_dev(ks_dev_problem* const* d, uint32_t n, ks_result* const* out, float* kernel_ms);
+int ks_solve_batch(const ks_problem* const* p, uint32_t n, ks_result* const* out);
+
+/* The static pod-class x instance-type feasibility grid for fresh nodes of every template:
+ * out_grid[(m*C + c)*TW + w].  Exposed for parity tests and roofline measurement. */
+int ks_feasibility_grid(ks_dev_problem* d, uint64_t* out_grid, float* kernel_ms);
+
+/* ---- requirement-algebra probes (one key); the same device functions the kernels use ---- */
+typedef struct ks_req1 { uint64_t mask; int32_t gt, lt; uint8_t present, complement; } ks_req1;
+/* value_int: [64] integer value of each universe entry or INT32_MIN.  on_device != 0 runs a 1-thread kernel. */
+int ks_probe_intersection(const ks_req1* a, const ks_req1* b, const int32_t* value_int, uint32_t nvalues, int on_device, ks_req1* out);
+int ks_probe_compatible(const ks_req1* a, const ks_req1* b, int well_known, const int32_t* value_int, uint32_t nvalues, int on_device, int* ok);
+
+const char* ks_last_error(void); /* thread-local message of the last non-OK return */
+const char* ks_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KSOLVE_H */

@@ -1,0 +1,676 @@
+// encode.cpp -- see encode.hpp.  Reference citations are relative to aws/karpenter-core pkg/.
+#include "encode.hpp"
+
+#include <cstring>
+#include <sstream>
+#include <unordered_map>
+
+namespace ksh {
+
+namespace {
+
+using ksp::Expr; using ksp::Pod; using ksp::StrMap;
+
+const char* kBuiltinWellKnown[] = {ksp::kProvisionerName, ksp::kZone, ksp::kRegion, ksp::kInstanceType, ksp::kArch, ksp::kOS, ksp::kCapacityType};
+
+struct TermRef { int type; std::string key; std::set<std::string> namespaces; ksp::Selector selector; int32_t max_skew; };   // one topology constraint of a pod spec
+
+std::string selector_identity(const ksp::Selector& s) {
+  if (s.nil) return "nil";
+  std::string r = "sel{";
+  for (auto& kv : s.match_labels) r += kv.first + "=" + kv.second + ",";
+  std::vector<std::string> es;
+  for (auto& e : s.match_exprs) { std::vector<std::string> vs = e.values; std::sort(vs.begin(), vs.end()); std::string x = e.key + ":" + std::to_string((int)e.op) + "["; for (auto& v : vs) x += v + ","; es.push_back(x + "]"); }
+  std::sort(es.begin(), es.end()); for (auto& e : es) r += e + ";";
+  return r + "}";
+}
+
+struct Filter { bool always = true; std::vector<Requirements> terms; };   // TopologyNodeFilter, topologynodefilter.go:28
+Filter MakeTopologyNodeFilter(const Pod& p) {                             // :30-50
+  Filter f; f.always = false;
+  Requirements sel = Requirements::FromLabels(p.node_selector);
+  if (p.required_affinity.empty()) { f.terms.push_back(sel); return f; }
+  for (auto& term : p.required_affinity) { Requirements r; r.Add(sel); r.Add(Requirements::FromExprs(term)); f.terms.push_back(r); }
+  return f;
+}
+bool FilterMatches(const Filter& f, const Requirements& reqs, const std::set<std::string>& wk) {   // MatchesRequirements :57-70
+  if (f.always || f.terms.empty()) return true;
+  for (auto& t : f.terms) if (reqs.Compatible(t, wk)) return true;
+  return false;
+}
+// hashstructure v2.0.2 hashes exported fields only: of a filter term (map[string]*Requirement) only the keys.
+std::string filter_identity(const Filter& f) {
+  if (f.always) return "nofilter";
+  std::vector<std::string> terms;
+  for (auto& t : f.terms) { std::string x = "("; for (auto& kv : t.m) x += kv.first + ","; terms.push_back(x + ")"); }
+  std::sort(terms.begin(), terms.end()); std::string r; for (auto& x : terms) r += x; return r;
+}
+std::string filter_content(const Filter& f) {
+  if (f.always) return "nofilter";
+  std::string r;
+  for (auto& t : f.terms) { r += "("; for (auto& kv : t.m) r += kv.first + ":" + kv.second.identity() + ";"; r += ")"; }
+  return r;
+}
+
+struct Group {
+  int type; std::string key; std::set<std::string> namespaces; ksp::Selector selector; int32_t max_skew; Filter filter; bool inverse; bool active;
+  std::string filter_sig;
+  std::map<std::string, int32_t> counts;   // domain -> count (registered domains only)
+};
+
+// Preferences.Relax (preferences.go:36-145) applied to a spec copy; returns false when nothing is left to relax.
+bool Relax(Pod& pod, bool toleratePreferNoSchedule) {
+  if (pod.required_affinity.size() > 1) { pod.required_affinity.erase(pod.required_affinity.begin()); return true; }
+  auto byw = [](const ksp::WeightedTerm& a, const ksp::WeightedTerm& b) { return a.weight > b.weight; };
+  if (!pod.affinity_preferred.empty()) { std::stable_sort(pod.affinity_preferred.begin(), pod.affinity_preferred.end(), byw); pod.affinity_preferred.erase(pod.affinity_preferred.begin()); return true; }
+  if (!pod.anti_preferred.empty()) { std::stable_sort(pod.anti_preferred.begin(), pod.anti_preferred.end(), byw); pod.anti_preferred.erase(pod.anti_preferred.begin()); return true; }
+  if (!pod.preferred_affinity.empty()) {
+    std::stable_sort(pod.preferred_affinity.begin(), pod.preferred_affinity.end(), [](const ksp::PreferredTerm& a, const ksp::PreferredTerm& b) { return a.weight > b.weight; });
+    pod.preferred_affinity.erase(pod.preferred_affinity.begin()); return true;
+  }
+  for (size_t i = 0; i < pod.spread.size(); ++i) if (pod.spread[i].schedule_anyway) { pod.spread[i] = pod.spread.back(); pod.spread.pop_back(); return true; }
+  if (toleratePreferNoSchedule) {
+    for (auto& t : pod.tolerations) if (t.key.empty() && t.effect == "PreferNoSchedule" && t.op == "Exists" && t.value.empty()) return false;
+    pod.tolerations.push_back({"", "Exists", "", "PreferNoSchedule"}); return true;
+  }
+  return false;
+}
+
+std::string canon_ip(const std::string& s) {
+  int a, b, c, d; char tail;
+  if (sscanf(s.c_str(), "%d.%d.%d.%d%c", &a, &b, &c, &d, &tail) == 4 && a >= 0 && a < 256 && b >= 0 && b < 256 && c >= 0 && c < 256 && d >= 0 && d < 256) { char buf[32]; snprintf(buf, sizeof buf, "%d.%d.%d.%d", a, b, c, d); return buf; }
+  std::string r = s; for (auto& ch : r) ch = (char)tolower(ch);
+  if (r == "0:0:0:0:0:0:0:0") r = "::";
+  return r;
+}
+
+void sig_map(std::string& s, const StrMap& m) { for (auto& kv : m) { s += kv.first; s += '\1'; s += kv.second; s += '\2'; } s += '\3'; }
+void sig_exprs(std::string& s, const std::vector<Expr>& es) { for (auto& e : es) { s += e.key; s += '\1'; s += (char)('0' + (int)e.op); for (auto& v : e.values) { s += v; s += '\1'; } s += '\2'; } s += '\3'; }
+void sig_res(std::string& s, const ksp::ResList& r) { for (auto& kv : r) { s += kv.first; s += '\1'; s += std::to_string(kv.second); s += '\2'; } s += '\3'; }
+void sig_selector(std::string& s, const ksp::Selector& sel) { s += selector_identity(sel); s += '\3'; }
+void sig_term(std::string& s, const ksp::AffinityTerm& t) { s += t.topology_key; s += '\1'; for (auto& n : t.namespaces) { s += n; s += '\1'; } sig_selector(s, t.selector); }
+std::string spec_signature(const Pod& p) {
+  std::string s; s.reserve(256);
+  s += p.ns; s += '\3'; sig_map(s, p.labels); sig_map(s, p.node_selector);
+  for (auto& t : p.required_affinity) sig_exprs(s, t); s += '\4';
+  for (auto& t : p.preferred_affinity) { s += std::to_string(t.weight); sig_exprs(s, t.exprs); } s += '\4';
+  for (auto& t : p.tolerations) { s += t.key; s += '\1'; s += t.op; s += '\1'; s += t.value; s += '\1'; s += t.effect; s += '\2'; } s += '\4';
+  for (auto& c : p.containers) { sig_res(s, c.requests); sig_res(s, c.limits); for (auto& hp : c.ports) { s += hp.ip; s += '\1'; s += std::to_string(hp.port); s += hp.proto; s += '\2'; } s += '\3'; } s += '\4';
+  for (auto& c : p.init_containers) { sig_res(s, c.requests); sig_res(s, c.limits); } s += '\4';
+  for (auto& t : p.spread) { s += std::to_string(t.max_skew); s += t.key; s += t.schedule_anyway ? 'A' : 'D'; sig_selector(s, t.selector); } s += '\4';
+  for (auto& t : p.affinity_required) sig_term(s, t); s += '\4';
+  for (auto& t : p.affinity_preferred) { s += std::to_string(t.weight); sig_term(s, t.term); } s += '\4';
+  for (auto& t : p.anti_required) sig_term(s, t); s += '\4';
+  for (auto& t : p.anti_preferred) { s += std::to_string(t.weight); sig_term(s, t.term); } s += '\4';
+  return s;
+}
+
+struct Builder {
+  Encoded& E; const ksp::Problem& pr; uint32_t flags;
+  std::set<std::string> wellKnown;
+  std::map<std::string, int> key_id; std::vector<std::set<std::string>> key_vals;   // pre-pass universes
+  std::map<std::string, int> res_id;
+  std::map<std::string, int> taint_id;
+  std::map<std::string, uint32_t> ip_id, proto_id;
+  std::map<std::string, std::set<std::string>> domains;   // topology domain universe, provisioner.go:267-276
+  std::map<std::string, int> hostname_to_existing;
+  std::vector<std::unique_ptr<Group>> groups; std::map<std::string, int> topo_by_id, inverse_by_id;   // creation order; inverse flagged
+  std::vector<Requirement> it_reqs; std::map<std::string, int> it_state_id;   // instance-type states (index 0 = absent)
+  std::set<std::string> batch_uids;
+  std::map<std::string, const ksp::StateNode*> node_by_name;
+  bool toleratePreferNoSchedule = false;
+  uint32_t K = 0, R = 0, T = 0, TW = 0;
+
+  Builder(Encoded& e, uint32_t f) : E(e), pr(e.src), flags(f) {}
+
+  // ---------- universes ----------
+  int key_of(const std::string& k, bool create) {
+    auto it = key_id.find(k); if (it != key_id.end()) return it->second;
+    if (!create) return -1;
+    int id = (int)key_vals.size(); key_id[k] = id; key_vals.emplace_back(); return id;
+  }
+  static bool special_key(const std::string& k) { return k == ksp::kHostname || k == ksp::kInstanceType; }
+  void note_expr(const Expr& e) {
+    std::string k = ksp::normalize_key(e.key); if (special_key(k)) return;
+    int id = key_of(k, true);
+    if (e.op == Op::In || e.op == Op::NotIn) for (auto& v : e.values) key_vals[id].insert(v);
+  }
+  void note_label(const std::string& key, const std::string& v) { std::string k = ksp::normalize_key(key); if (special_key(k)) return; key_vals[key_of(k, true)].insert(v); }
+  int res_of(const std::string& r) { auto it = res_id.find(r); if (it != res_id.end()) return it->second; int id = (int)res_id.size(); res_id[r] = id; return id; }
+  void note_res(const ksp::ResList& l) { for (auto& kv : l) res_of(kv.first); }
+  void note_pod(const Pod& p) {
+    for (auto& kv : p.node_selector) note_label(kv.first, kv.second);
+    for (auto& t : p.required_affinity) for (auto& e : t) note_expr(e);
+    for (auto& t : p.preferred_affinity) for (auto& e : t.exprs) note_expr(e);
+    for (auto& c : p.containers) { note_res(c.requests); note_res(c.limits); }
+    for (auto& c : p.init_containers) { note_res(c.requests); note_res(c.limits); }
+    auto topo_key = [&](const std::string& k) { if (k == ksp::kInstanceType) throw Unsupported("topology key node.kubernetes.io/instance-type"); if (k != ksp::kHostname) key_of(k, true); };
+    for (auto& s : p.spread) topo_key(s.key);
+    for (auto& t : p.affinity_required) topo_key(t.topology_key);
+    for (auto& t : p.affinity_preferred) topo_key(t.term.topology_key);
+    for (auto& t : p.anti_required) topo_key(t.topology_key);
+    for (auto& t : p.anti_preferred) topo_key(t.term.topology_key);
+  }
+
+  void collect_universes() {
+    for (auto k : kBuiltinWellKnown) wellKnown.insert(k);
+    for (auto& k : pr.extra_well_known) wellKnown.insert(k);
+    res_of("cpu"); res_of("memory"); res_of("pods");
+    key_of(ksp::kZone, true); key_of(ksp::kCapacityType, true);
+    for (auto& it : pr.instance_types) {
+      for (auto& e : it.requirements) { if (e.op == Op::Gt || e.op == Op::Lt) throw Unsupported("instance type requirement with Gt/Lt bounds"); note_expr(e); }
+      for (auto& o : it.offerings) { key_vals[key_of(ksp::kZone, true)].insert(o.zone); key_vals[key_of(ksp::kCapacityType, true)].insert(o.capacity_type); }
+      note_res(it.capacity); note_res(it.overhead);
+    }
+    for (auto& p : pr.provisioners) {
+      for (auto& e : p.requirements) { if (ksp::normalize_key(e.key) == ksp::kHostname) throw Unsupported("provisioner requirement on kubernetes.io/hostname"); note_expr(e); }
+      for (auto& kv : p.labels) { if (ksp::normalize_key(kv.first) == ksp::kHostname) throw Unsupported("provisioner label kubernetes.io/hostname"); note_label(kv.first, kv.second); }
+      note_label(ksp::kProvisionerName, p.name);
+      if (p.has_limits) note_res(p.limits);
+      for (auto& t : p.taints) if (t.effect == "PreferNoSchedule") toleratePreferNoSchedule = true;
+    }
+    for (auto& p : pr.pods) note_pod(p);
+    for (auto& p : pr.daemons) note_pod(p);
+    for (auto& cp : pr.cluster_pods) for (auto& t : cp.anti_required) { if (t.topology_key != ksp::kHostname) key_of(t.topology_key, true); }
+    // node labels: only keys something else references matter (existing-node requirements are never
+    // returned); values of referenced keys join the universe (they become topology domains / In sets)
+    for (auto& n : pr.nodes) {
+      for (auto& kv : n.labels) { std::string k = ksp::normalize_key(kv.first); auto it = key_id.find(k); if (it != key_id.end()) key_vals[it->second].insert(kv.second);
+        auto raw = key_id.find(kv.first); if (raw != key_id.end() && raw->first != k) key_vals[raw->second].insert(kv.second); }
+      note_res(n.available); note_res(n.capacity); note_res(n.daemonset_requests);
+    }
+    K = (uint32_t)key_vals.size(); R = (uint32_t)res_id.size(); T = (uint32_t)pr.instance_types.size(); TW = (T + 63) / 64;
+    if (K > KS_MAX_KEYS) throw Unsupported("more than 32 distinct label keys on the path");
+    if (R > KS_MAX_RES) throw Unsupported("more than 8 distinct resource names");
+    E.key_names.assign(K, ""); for (auto& kv : key_id) E.key_names[kv.second] = kv.first;
+    E.key_values.resize(K); E.key_nvalues.assign(K, 0); E.value_int.assign((size_t)K * 64, INT32_MIN);
+    for (uint32_t k = 0; k < K; ++k) {
+      if (key_vals[k].size() > 64) throw Unsupported("label key " + E.key_names[k] + " has more than 64 distinct values");
+      E.key_values[k].assign(key_vals[k].begin(), key_vals[k].end()); E.key_nvalues[k] = (uint32_t)E.key_values[k].size();
+      for (size_t v = 0; v < E.key_values[k].size(); ++v) { long long x; if (Atoi(E.key_values[k][v], &x)) { if (x <= INT32_MIN + 1 || x >= INT32_MAX - 1) throw Unsupported("integer label value outside int32"); E.value_int[k * 64 + v] = (int32_t)x; } }
+    }
+    E.res_names.assign(R, ""); for (auto& kv : res_id) E.res_names[kv.second] = kv.first;
+  }
+
+  int value_id(int k, const std::string& v) const {
+    auto& vs = E.key_values[k]; auto it = std::lower_bound(vs.begin(), vs.end(), v);
+    if (it == vs.end() || *it != v) return -1; return (int)(it - vs.begin());
+  }
+
+  // ---------- requirement encoding ----------
+  int it_state_of(const Requirement& r) {
+    std::string id = r.identity(); auto it = it_state_id.find(id); if (it != it_state_id.end()) return it->second;
+    if (it_reqs.size() >= KS_MAX_ITSTATES) throw Unsupported("more than 255 distinct instance-type requirements (closure)");
+    int s = (int)it_reqs.size(); it_reqs.push_back(r); it_state_id[id] = s; return s;
+  }
+  // Appends one requirement set; returns its index.  `hn` receives the hostname requirement if any.
+  uint32_t push_reqs(ReqSetsStore& st, const Requirements& rs, const Requirement** hn, bool allow_hostname) {
+    uint32_t idx = st.n++; st.present.push_back(0); st.complement.push_back(0); st.it_state.push_back(0);
+    st.mask.resize((size_t)st.n * K, 0); st.gt.resize((size_t)st.n * K, KS_NO_BOUND_GT); st.lt.resize((size_t)st.n * K, KS_NO_BOUND_LT);
+    if (hn) *hn = nullptr;
+    for (auto& kv : rs.m) {
+      const Requirement& r = kv.second;
+      if (kv.first == ksp::kHostname) { if (!allow_hostname) throw Unsupported("hostname requirement outside a pod spec"); if (hn) *hn = &kv.second; continue; }
+      if (kv.first == ksp::kInstanceType) { st.it_state[idx] = it_state_of(r); continue; }
+      int k = key_of(kv.first, false); if (k < 0) throw std::logic_error("key missing from universe: " + kv.first);
+      st.present[idx] |= 1u << k; if (r.complement) st.complement[idx] |= 1u << k;
+      uint64_t m = 0; for (auto& v : r.values) { int vid = value_id(k, v); if (vid < 0) throw std::logic_error("value missing from universe: " + v); m |= 1ull << vid; }
+      st.mask[(size_t)idx * K + k] = m;
+      if (r.greaterThan) { if (*r.greaterThan <= INT32_MIN + 1 || *r.greaterThan >= INT32_MAX - 1) throw Unsupported("Gt bound outside int32"); st.gt[(size_t)idx * K + k] = (int32_t)*r.greaterThan; }
+      if (r.lessThan) { if (*r.lessThan <= INT32_MIN + 1 || *r.lessThan >= INT32_MAX - 1) throw Unsupported("Lt bound outside int32"); st.lt[(size_t)idx * K + k] = (int32_t)*r.lessThan; }
+    }
+    return idx;
+  }
+  Requirements restrict_to_known_keys(const Requirements& rs) const {   // drop keys nothing references (existing-node labels)
+    Requirements out; for (auto& kv : rs.m) if (kv.first == ksp::kInstanceType || key_id.count(kv.first)) out.m.emplace(kv.first, kv.second); return out;
+  }
+  void res_vec(const ksp::ResList& l, std::vector<int64_t>& out, uint32_t* present) {
+    size_t base = out.size(); out.resize(base + R, 0); uint32_t p = 0;
+    for (auto& kv : l) { int r = res_id.at(kv.first); out[base + r] = kv.second; p |= 1u << r; }
+    if (present) *present = p;
+  }
+  uint64_t taint_mask(const std::vector<ksp::Taint>& ts) {
+    uint64_t m = 0;
+    for (auto& t : ts) { std::string id = t.key + "\1" + t.value + "\1" + t.effect; auto it = taint_id.find(id); int i;
+      if (it == taint_id.end()) { if (taint_id.size() >= 64) throw Unsupported("more than 64 distinct taints"); i = (int)taint_id.size(); taint_id[id] = i; taints.push_back(t); } else i = it->second;
+      m |= 1ull << i; }
+    return m;
+  }
+  std::vector<ksp::Taint> taints;
+  uint64_t port_entry(const std::string& ip_in, int32_t port, const std::string& proto) {
+    std::string ip = canon_ip(ip_in.empty() ? "0.0.0.0" : ip_in);
+    uint32_t iid = 0; if (!(ip == "0.0.0.0" || ip == "::")) { auto it = ip_id.find(ip); if (it == ip_id.end()) { iid = (uint32_t)ip_id.size() + 1; ip_id[ip] = iid; } else iid = it->second; }
+    uint32_t pid; auto pt = proto_id.find(proto); if (pt == proto_id.end()) { pid = (uint32_t)proto_id.size() + 1; if (pid > 255) throw Unsupported("too many protocols"); proto_id[proto] = pid; } else pid = pt->second;
+    return ((uint64_t)pid << 56) | ((uint64_t)(uint32_t)port << 32) | iid;
+  }
+
+  // ---------- instance types ----------
+  std::vector<Requirements> it_requirements;
+  void encode_instance_types() {
+    E.it_present.assign(T, 0); E.it_complement.assign(T, 0); E.it_mask.assign((size_t)K * T, 0); E.it_offer.assign(T, 0);
+    E.it_alloc.assign((size_t)R * T, 0); E.it_cap.assign((size_t)R * T, 0);
+    const int kz = key_id.at(ksp::kZone), kc = key_id.at(ksp::kCapacityType);
+    const uint32_t nct = E.key_nvalues[kc];
+    if ((uint64_t)E.key_nvalues[kz] * nct > 64 || nct > 32) throw Unsupported("more than 64 zone x capacity-type pairs");
+    it_requirements.resize(T);
+    for (uint32_t t = 0; t < T; ++t) {
+      const auto& it = pr.instance_types[t];
+      Requirements rs = Requirements::FromExprs(it.requirements); it_requirements[t] = rs;
+      for (auto& kv : rs.m) {
+        if (kv.first == ksp::kInstanceType) continue;
+        if (kv.first == ksp::kHostname) throw Unsupported("instance type requirement on hostname");
+        int k = key_id.at(kv.first);
+        E.it_present[t] |= 1u << k; if (kv.second.complement) E.it_complement[t] |= 1u << k;
+        uint64_t m = 0; for (auto& v : kv.second.values) m |= 1ull << value_id(k, v);
+        E.it_mask[(size_t)k * T + t] = m;
+      }
+      for (auto& o : it.offerings) if (o.available) E.it_offer[t] |= 1ull << (value_id(kz, o.zone) * nct + value_id(kc, o.capacity_type));
+      ksp::ResList alloc = Subtract(it.capacity, it.overhead);   // Allocatable(), types.go:87-89
+      for (auto& kv : alloc) E.it_alloc[(size_t)res_id.at(kv.first) * T + t] = kv.second;
+      for (auto& kv : it.capacity) E.it_cap[(size_t)res_id.at(kv.first) * T + t] = kv.second;
+    }
+  }
+
+  // ---------- templates ----------
+  std::vector<Requirements> tmpl_reqs;
+  void encode_templates() {
+    for (auto& p : pr.provisioners) E.templates.push_back(&p);
+    std::stable_sort(E.templates.begin(), E.templates.end(), [](const ksp::Provisioner* a, const ksp::Provisioner* b) { return a->weight > b->weight; });   // OrderByWeight
+    if (E.templates.empty()) throw ksp::Error("no provisioners found");
+    const uint32_t M = (uint32_t)E.templates.size();
+    E.tmpl_types.assign((size_t)M * TW, 0);
+    for (uint32_t m = 0; m < M; ++m) {
+      const auto& p = *E.templates[m];
+      Requirements rs; rs.Add(Requirements::FromExprs(p.requirements));   // NewMachineTemplate, machinetemplate.go:46-62
+      StrMap labels = p.labels; labels[ksp::kProvisionerName] = p.name; rs.Add(Requirements::FromLabels(labels));
+      tmpl_reqs.push_back(rs);
+      push_reqs(E.tmpl, rs, nullptr, false);
+      E.tmpl_taints.push_back(taint_mask(p.taints));
+      for (int idx : p.instance_types) { if (idx < 0 || (uint32_t)idx >= T) throw ksp::Error("instance type index out of range"); E.tmpl_types[(size_t)m * TW + idx / 64] |= 1ull << (idx % 64); }
+      // topology domain universe, provisioner.go:267-276
+      for (int idx : p.instance_types) for (auto& kv : it_requirements[idx].m) for (auto& v : kv.second.values) domains[kv.first].insert(v);
+      Requirements preq = Requirements::FromExprs(p.requirements);
+      for (auto& kv : preq.m) if (kv.second.Operator() == Op::In) for (auto& v : kv.second.values) domains[kv.first].insert(v);
+    }
+  }
+
+  // ---------- existing nodes ----------
+  void encode_existing() {
+    for (size_t i = 0; i < pr.nodes.size(); ++i) { node_by_name[pr.nodes[i].name] = &pr.nodes[i]; if (pr.nodes[i].in_state && pr.nodes[i].owned()) E.existing.push_back((int)i); }
+    const uint32_t NE = (uint32_t)E.existing.size();
+    E.en_port_off.assign(1, 0);
+    for (uint32_t e = 0; e < NE; ++e) {
+      const auto& n = pr.nodes[E.existing[e]];
+      auto hl = n.labels.find(ksp::kHostname); std::string hostname = (hl == n.labels.end() || hl->second.empty()) ? n.name : hl->second;
+      hostname_to_existing[hostname] = (int)e;
+      // existing host-port reservations come first in ports[] (the kernel seeds its pool from them)
+      for (auto& hp : n.host_ports) E.ports.push_back(port_entry(hp.ip, hp.port, hp.proto));
+      E.en_port_off.push_back((uint32_t)E.ports.size());
+    }
+  }
+  void encode_existing_rest() {
+    const uint32_t NE = (uint32_t)E.existing.size();
+    const uint32_t M = (uint32_t)E.templates.size();
+    // remainingResources, scheduler.go:71-75,244-246
+    std::vector<ksp::ResList> remaining(M);
+    for (uint32_t m = 0; m < M; ++m) if (E.templates[m]->has_limits) remaining[m] = E.templates[m]->limits;
+    for (uint32_t e = 0; e < NE; ++e) {
+      const auto& n = pr.nodes[E.existing[e]];
+      Requirements full = Requirements::FromLabels(n.labels);
+      Requirements hostless; for (auto& kv : full.m) if (kv.first != ksp::kHostname) hostless.m.emplace(kv.first, kv.second);
+      push_reqs(E.en, restrict_to_known_keys(hostless), nullptr, false);
+      E.en_taints.push_back(taint_mask(n.taints));
+      res_vec(n.available, E.en_avail, nullptr);
+      // daemons that should still land on this node, scheduler.go:229-240 + existingnode.go:41-53
+      ksp::ResList dr; int count = 0;
+      for (auto& d : pr.daemons) { Pod dp = d; if (!Tolerates(n.taints, dp)) continue; if (!full.Compatible(NewPodRequirements(dp), wellKnown)) continue; dr = Merge(dr, RequestsForPod(d)); ++count; }
+      dr["pods"] = (int64_t)count * 1000;
+      ksp::ResList rem = Subtract(dr, n.daemonset_requests); for (auto& kv : rem) if (kv.second < 0) kv.second = 0;
+      uint32_t pm; res_vec(rem, E.en_requests, &pm); E.en_requests_present.push_back(pm);
+      auto pl = n.labels.find(ksp::kProvisionerName);
+      for (uint32_t m = 0; m < M; ++m) if (E.templates[m]->has_limits && E.templates[m]->name == pl->second) remaining[m] = Subtract(remaining[m], n.capacity);
+    }
+    for (uint32_t m = 0; m < M; ++m) {
+      const auto& p = *E.templates[m];
+      // getDaemonOverhead, scheduler.go:250-267
+      ksp::ResList dr; int count = 0;
+      for (auto& d : pr.daemons) { Pod dp = d; if (!Tolerates(p.taints, dp)) continue; if (!tmpl_reqs[m].Compatible(NewPodRequirements(dp), wellKnown)) continue; dr = Merge(dr, RequestsForPod(d)); ++count; }
+      dr["pods"] = (int64_t)count * 1000;
+      uint32_t pm; res_vec(dr, E.tmpl_daemon, &pm); E.tmpl_daemon_present.push_back(pm);
+      uint32_t lm = 0xFFFFFFFFu; if (p.has_limits) { lm = 0; for (auto& kv : p.limits) lm |= 1u << res_id.at(kv.first); }
+      E.tmpl_limit_present.push_back(lm);
+      res_vec(remaining[m], E.tmpl_remaining, nullptr);
+    }
+  }
+
+  // ---------- topology groups ----------
+  // countDomains, topology.go:231-276 (the API-server lookups are answered from the cluster snapshot)
+  void count_domains(Group& g) {
+    for (auto& cp : pr.cluster_pods) {
+      if (!g.namespaces.count(cp.ns)) continue;
+      if (!(g.selector.nil || SelectorMatches(g.selector, cp.labels))) continue;   // TopologyListOptions: nil selector lists everything
+      if (batch_uids.count(cp.uid)) continue;
+      auto nit = node_by_name.find(cp.node_name); if (nit == node_by_name.end()) continue;
+      const auto& node = *nit->second;
+      auto lt = node.labels.find(g.key); bool ok = lt != node.labels.end(); std::string domain = ok ? lt->second : "";
+      if (!ok && g.key == ksp::kHostname) { domain = node.name; ok = true; }
+      if (!ok) continue;
+      if (!FilterMatches(g.filter, Requirements::FromLabels(node.labels), wellKnown)) continue;
+      g.counts[domain]++;
+    }
+  }
+  int get_group(bool inverse, int type, const std::string& key, const std::set<std::string>& nss, const ksp::Selector& sel, int32_t max_skew, const Pod& owner, bool active_now) {
+    Filter f; if (type == 0) f = MakeTopologyNodeFilter(owner);
+    std::string id = key + "|" + std::to_string(type) + "|"; for (auto& n : nss) id += n + ","; id += "|" + selector_identity(sel) + "|" + std::to_string(max_skew) + "|" + filter_identity(f);
+    auto& index = inverse ? inverse_by_id : topo_by_id;
+    auto it = index.find(id);
+    if (it != index.end()) {
+      Group& g = *groups[it->second];
+      if (!g.active && !active_now && g.filter_sig != filter_content(f)) throw Unsupported("late-created topology group whose node filter depends on which pod relaxes first");
+      return it->second;
+    }
+    auto g = std::make_unique<Group>(); g->type = type; g->key = key; g->namespaces = nss; g->selector = sel; g->max_skew = max_skew; g->filter = f; g->inverse = inverse; g->active = active_now;
+    g->filter_sig = filter_content(f);
+    auto d = domains.find(key); if (d != domains.end()) for (auto& v : d->second) g->counts[v] = 0;   // NewTopologyGroup, topologygroup.go:64-68
+    if (!inverse) count_domains(*g);
+    int idx = (int)groups.size(); groups.push_back(std::move(g)); index[id] = idx; return idx;
+  }
+  static std::set<std::string> ns_list(const std::string& ns, const std::vector<std::string>& l) { if (l.empty()) return {ns}; return std::set<std::string>(l.begin(), l.end()); }
+
+  struct SpecGroups { std::vector<int> own, iown; };
+  // Topology.Update for one spec (topology.go:86-117); active_now == called from NewTopology
+  SpecGroups groups_of(const Pod& p, bool active_now) {
+    SpecGroups sg;
+    if (!p.anti_required.empty() || !p.anti_preferred.empty())
+      for (auto& t : p.anti_required) { int g = get_group(true, 2, t.topology_key, ns_list(p.ns, t.namespaces), t.selector, INT32_MAX, p, true); if (std::find(sg.iown.begin(), sg.iown.end(), g) == sg.iown.end()) sg.iown.push_back(g); }
+    auto add = [&](int g) { if (std::find(sg.own.begin(), sg.own.end(), g) == sg.own.end()) sg.own.push_back(g); };
+    for (auto& cs : p.spread) add(get_group(false, 0, cs.key, {p.ns}, cs.selector, cs.max_skew, p, active_now));
+    for (auto& t : p.affinity_required) add(get_group(false, 1, t.topology_key, ns_list(p.ns, t.namespaces), t.selector, INT32_MAX, p, active_now));
+    for (auto& w : p.affinity_preferred) add(get_group(false, 1, w.term.topology_key, ns_list(p.ns, w.term.namespaces), w.term.selector, INT32_MAX, p, active_now));
+    for (auto& t : p.anti_required) add(get_group(false, 2, t.topology_key, ns_list(p.ns, t.namespaces), t.selector, INT32_MAX, p, active_now));
+    for (auto& w : p.anti_preferred) add(get_group(false, 2, w.term.topology_key, ns_list(p.ns, w.term.namespaces), w.term.selector, INT32_MAX, p, active_now));
+    return sg;
+  }
+
+  // ---------- pods / classes ----------
+  struct StageInfo { Pod spec; Requirements reqs; SpecGroups sg; };
+  struct SpecInfo { std::vector<StageInfo> stages; std::vector<uint32_t> cls; };
+  std::vector<SpecInfo> specs; std::unordered_map<std::string, int> spec_by_sig; std::vector<int> pod_spec;
+  struct ClassRec { std::string sig; };
+  std::unordered_map<std::string, uint32_t> class_by_sig;
+  std::vector<std::pair<std::string, StrMap>> labelsets; std::map<std::string, int> labelset_id;   // (ns, labels)
+  std::vector<int> cls_labelset; std::vector<SpecGroups> cls_groups;
+
+  void encode_pods() {
+    const uint32_t P = (uint32_t)pr.pods.size();
+    for (auto& p : pr.pods) batch_uids.insert(p.uid);
+    if (batch_uids.size() != P) throw ksp::Error("pod UIDs must be unique (queue.go:102-108 needs a total order)");
+    // updateInverseAffinities, topology.go:181-199 (cluster pods with required anti-affinity, not in the batch)
+    for (auto& cp : pr.cluster_pods) {
+      if (cp.anti_required.empty() || batch_uids.count(cp.uid)) continue;
+      auto nit = node_by_name.find(cp.node_name); if (nit == node_by_name.end()) continue;
+      Pod dummy; dummy.ns = cp.ns;
+      for (auto& t : cp.anti_required) {
+        int gi = get_group(true, 2, t.topology_key, ns_list(cp.ns, t.namespaces), t.selector, INT32_MAX, dummy, true);
+        auto lt = nit->second->labels.find(groups[gi]->key); if (lt != nit->second->labels.end()) groups[gi]->counts[lt->second]++;
+      }
+    }
+    // pass A: NewTopology's Update(pod) over stage-0 specs in input order; distinct specs only
+    pod_spec.resize(P);
+    for (uint32_t i = 0; i < P; ++i) {
+      std::string sig = spec_signature(pr.pods[i]);
+      auto it = spec_by_sig.find(sig);
+      if (it == spec_by_sig.end()) {
+        SpecInfo si; StageInfo st; st.spec = pr.pods[i]; st.spec.uid.clear(); st.reqs = NewPodRequirements(st.spec); st.sg = groups_of(st.spec, true);
+        si.stages.push_back(std::move(st));
+        int id = (int)specs.size(); specs.push_back(std::move(si)); spec_by_sig.emplace(std::move(sig), id); pod_spec[i] = id;
+      } else pod_spec[i] = it->second;
+    }
+    // pass B: relaxation chains (Preferences.Relax + Topology.Update after each relaxation)
+    for (auto& si : specs) {
+      for (;;) {
+        Pod next = si.stages.back().spec;
+        if (!Relax(next, toleratePreferNoSchedule)) break;
+        StageInfo st; st.spec = std::move(next); st.reqs = NewPodRequirements(st.spec); st.sg = groups_of(st.spec, false);
+        si.stages.push_back(std::move(st));
+        if (si.stages.size() > 64) throw Unsupported("more than 64 relaxation stages");
+      }
+    }
+    // classes
+    E.cls_hn_off.assign(1, 0); E.cls_port_off.assign(1, (uint32_t)E.ports.size());
+    for (auto& si : specs) for (auto& st : si.stages) si.cls.push_back(class_of(st));
+    // pods -> stage chains, queue order
+    E.pod_stage_off.assign(1, 0);
+    for (uint32_t i = 0; i < P; ++i) { for (uint32_t c : specs[pod_spec[i]].cls) E.stage_cls.push_back(c); E.pod_stage_off.push_back((uint32_t)E.stage_cls.size()); }
+    // NewQueue: byCPUAndMemoryDescending, queue.go:74-110
+    const int rc = res_id.at("cpu"), rm = res_id.at("memory");
+    E.queue.resize(P); for (uint32_t i = 0; i < P; ++i) E.queue[i] = i;
+    std::sort(E.queue.begin(), E.queue.end(), [&](uint32_t a, uint32_t b) {
+      const uint32_t ca = E.stage_cls[E.pod_stage_off[a]], cb = E.stage_cls[E.pod_stage_off[b]];
+      const int64_t cpua = E.cls_requests[(size_t)ca * R + rc], cpub = E.cls_requests[(size_t)cb * R + rc]; if (cpua != cpub) return cpua > cpub;
+      const int64_t mema = E.cls_requests[(size_t)ca * R + rm], memb = E.cls_requests[(size_t)cb * R + rm]; if (mema != memb) return mema > memb;
+      if (pr.pods[a].creation_ts != pr.pods[b].creation_ts) return pr.pods[a].creation_ts < pr.pods[b].creation_ts;
+      return pr.pods[a].uid < pr.pods[b].uid;
+    });
+  }
+
+  uint32_t class_of(const StageInfo& st) {
+    const Pod& p = st.spec;
+    // label set (namespace + labels decide which selectors select the pod)
+    std::string ls = p.ns; ls += '\3'; sig_map(ls, p.labels);
+    int lsid; auto li = labelset_id.find(ls); if (li == labelset_id.end()) { lsid = (int)labelsets.size(); labelsets.emplace_back(p.ns, p.labels); labelset_id[ls] = lsid; } else lsid = li->second;
+    // signature of everything Node.Add reads
+    std::string sig; sig.reserve(256);
+    for (auto& kv : st.reqs.m) { sig += kv.first; sig += '\1'; sig += kv.second.identity(); sig += '\2'; } sig += '\4';
+    ksp::ResList req = RequestsForPod(p); sig_res(sig, req);
+    uint64_t tol = 0; for (size_t i = 0; i < taints.size(); ++i) { bool ok = false; for (auto& t : p.tolerations) ok = ok || ToleratesTaint(t, taints[i]); if (ok) tol |= 1ull << i; }
+    sig += std::to_string(tol); sig += '\4';
+    std::vector<uint64_t> pe; for (auto& c : p.containers) for (auto& hp : c.ports) if (hp.port != 0) pe.push_back(port_entry(hp.ip, hp.port, hp.proto));
+    for (auto e : pe) { sig += std::to_string(e); sig += ','; } sig += '\4';
+    sig += std::to_string(lsid); sig += '\4';
+    for (int g : st.sg.own) { sig += std::to_string(g); sig += ','; } sig += '\4';
+    for (int g : st.sg.iown) { sig += std::to_string(g); sig += ','; } sig += '\4';
+    auto it = class_by_sig.find(sig); if (it != class_by_sig.end()) return it->second;
+    const Requirement* hn = nullptr;
+    uint32_t c = push_reqs(E.cls, st.reqs, &hn, true);
+    uint8_t mode = 0;
+    if (hn) {
+      if (hn->greaterThan || hn->lessThan) throw Unsupported("Gt/Lt on kubernetes.io/hostname");
+      mode = hn->complement ? 2 : 1;
+      for (auto& v : hn->values) { auto e = hostname_to_existing.find(v); if (e != hostname_to_existing.end()) E.hn_list.push_back((uint32_t)e->second); }
+    }
+    E.cls_hn_mode.push_back(mode); E.cls_hn_off.push_back((uint32_t)E.hn_list.size());
+    uint32_t pm; res_vec(req, E.cls_requests, &pm); E.cls_requests_present.push_back(pm);
+    E.cls_tolerated.push_back(tol);
+    for (auto e : pe) E.ports.push_back(e); E.cls_port_off.push_back((uint32_t)E.ports.size());
+    cls_labelset.push_back(lsid); cls_groups.push_back(st.sg);
+    if (mode != 0) for (int g : st.sg.own) if (groups[g]->key == ksp::kHostname && groups[g]->type == 1) throw Unsupported("hostname pod-affinity combined with a hostname node selector");
+    class_by_sig.emplace(std::move(sig), c);
+    return c;
+  }
+
+  // the taint universe must be complete before classes compute `tolerated`
+  void collect_taints() { for (auto& p : pr.provisioners) taint_mask(p.taints); for (auto& n : pr.nodes) if (n.in_state && n.owned()) taint_mask(n.taints); }
+
+  // ---------- group tables + per-class membership lists ----------
+  void encode_groups() {
+    // order: topologies first, then inverse (ks_problem.n_topologies)
+    std::vector<int> order, remap(groups.size(), -1);
+    for (size_t g = 0; g < groups.size(); ++g) if (!groups[g]->inverse) order.push_back((int)g);
+    const uint32_t ntopo = (uint32_t)order.size();
+    for (size_t g = 0; g < groups.size(); ++g) if (groups[g]->inverse) order.push_back((int)g);
+    for (size_t i = 0; i < order.size(); ++i) remap[order[i]] = (int)i;
+    const uint32_t G = (uint32_t)order.size(); const uint32_t NE = (uint32_t)E.existing.size();
+    E.grp_count.assign((size_t)G * 64, -1); E.grp_filter_off.assign(1, 0);
+    uint32_t GH = 0;
+    for (uint32_t gi = 0; gi < G; ++gi) {
+      Group& g = *groups[order[gi]];
+      E.grp_type.push_back((uint8_t)g.type); E.grp_max_skew.push_back(g.max_skew); E.grp_active.push_back(g.active ? 1 : 0);
+      if (!g.filter.always) for (auto& t : g.filter.terms) {
+        for (auto& kv : t.m) if (kv.first == ksp::kHostname) throw Unsupported("topology node filter on hostname");
+        push_reqs(E.flt, t, nullptr, false);
+      }
+      E.grp_filter_off.push_back(E.flt.n);
+      if (g.key == ksp::kHostname) {
+        E.grp_key.push_back(KS_KEY_HOSTNAME); E.grp_hslot.push_back((int32_t)GH); ++GH;
+        int32_t extra = 0; std::vector<int32_t> row(NE, g.active ? 0 : -1);   // NewExistingNode registers its hostname in every group that exists (existingnode.go:73)
+        for (auto& kv : g.counts) { auto e = hostname_to_existing.find(kv.first); if (e != hostname_to_existing.end()) row[e->second] = kv.second; else if (kv.second > 0) ++extra; }
+        E.grph_count.insert(E.grph_count.end(), row.begin(), row.end()); E.grph_extra_pos.push_back(extra);
+      } else {
+        int k = key_id.at(g.key); E.grp_key.push_back(k); E.grp_hslot.push_back(-1);
+        for (auto& kv : g.counts) { int v = value_id(k, kv.first); if (v < 0) { key_missing(g.key, kv.first); } E.grp_count[(size_t)gi * 64 + v] = kv.second; }
+      }
+    }
+    E.prob.G = G; E.prob.GH = GH; E.prob.n_topologies = ntopo;
+    // which groups select each label set (TopologyGroup.selects, topologygroup.go:246-252)
+    std::vector<std::vector<uint32_t>> sel(labelsets.size()), isel(labelsets.size());
+    for (size_t l = 0; l < labelsets.size(); ++l) for (uint32_t gi = 0; gi < G; ++gi) {
+      const Group& g = *groups[order[gi]];
+      if (g.namespaces.count(labelsets[l].first) && SelectorMatches(g.selector, labelsets[l].second)) (g.inverse ? isel[l] : sel[l]).push_back(gi);
+    }
+    const uint32_t C = E.cls.n;
+    E.cls_own_off.assign(1, 0); E.cls_sel_off.assign(1, 0); E.cls_isel_off.assign(1, 0); E.cls_iown_off.assign(1, 0);
+    for (uint32_t c = 0; c < C; ++c) {
+      const int l = cls_labelset[c];
+      for (int g : cls_groups[c].own) { uint32_t gi = (uint32_t)remap[g]; bool self = std::find(sel[l].begin(), sel[l].end(), gi) != sel[l].end(); E.own_list.push_back(gi | (self ? 0x80000000u : 0)); }
+      if (cls_groups[c].own.size() + isel[l].size() > 24) throw Unsupported("a pod is constrained by more than 24 topology groups");
+      E.cls_own_off.push_back((uint32_t)E.own_list.size());
+      for (uint32_t gi : sel[l]) E.sel_list.push_back(gi); E.cls_sel_off.push_back((uint32_t)E.sel_list.size());
+      for (uint32_t gi : isel[l]) E.isel_list.push_back(gi); E.cls_isel_off.push_back((uint32_t)E.isel_list.size());
+      for (int g : cls_groups[c].iown) E.iown_list.push_back((uint32_t)remap[g]); E.cls_iown_off.push_back((uint32_t)E.iown_list.size());
+      // touched-key budget of the kernel (KS_MAX_TOUCH = 12)
+      std::set<int> touched; for (uint32_t k = 0; k < K; ++k) if ((E.cls.present[c] >> k) & 1u) touched.insert((int)k);
+      for (int g : cls_groups[c].own) if (groups[g]->key != ksp::kHostname) touched.insert(key_id.at(groups[g]->key));
+      for (uint32_t gi : isel[l]) if (E.grp_key[gi] >= 0) touched.insert(E.grp_key[gi]);
+      if (touched.size() > 12) throw Unsupported("a pod touches more than 12 label keys");
+    }
+  }
+  [[noreturn]] void key_missing(const std::string& k, const std::string& v) { throw std::logic_error("topology domain " + v + " of key " + k + " missing from the universe"); }
+
+  // ---------- instance-type-key lattice ----------
+  void encode_it_states() {
+    // closure under intersection
+    if (it_reqs.empty()) it_reqs.push_back(Requirement());   // state 0 placeholder ("absent")
+    for (size_t a = 1; a < it_reqs.size(); ++a) for (size_t b = 1; b < it_reqs.size(); ++b) it_state_of(it_reqs[a].Intersection(it_reqs[b]));
+    // (it_state_of appends; the loops above run until no new state appears because size() grows)
+    const uint32_t S = (uint32_t)it_reqs.size();
+    E.its_inter.assign((size_t)S * S, 0); E.its_fail.assign((size_t)S * S, 0); E.its_nidne.assign(S, 0); E.its_types.assign((size_t)S * TW, 0);
+    for (uint32_t a = 0; a < S; ++a) for (uint32_t b = 0; b < S; ++b) {
+      uint32_t r; bool fail = false;
+      if (a == 0) r = b; else if (b == 0) r = a;
+      else { Requirement x = it_reqs[b].Intersection(it_reqs[a]); r = (uint32_t)it_state_id.at(x.identity()); fail = x.Len() == 0 && !(it_reqs[b].IsNotInOrDoesNotExist() && it_reqs[a].IsNotInOrDoesNotExist()); }
+      E.its_inter[(size_t)a * S + b] = (uint8_t)r; E.its_fail[(size_t)a * S + b] = fail ? 1 : 0;
+    }
+    for (uint32_t s = 1; s < S; ++s) E.its_nidne[s] = it_reqs[s].IsNotInOrDoesNotExist() ? 1 : 0;
+    for (uint32_t s = 0; s < S; ++s) for (uint32_t t = 0; t < T; ++t) {
+      bool pass = true;
+      if (s != 0) { auto it = it_requirements[t].m.find(ksp::kInstanceType);
+        if (it != it_requirements[t].m.end()) { const Requirement& a = it->second; Requirement x = a.Intersection(it_reqs[s]); if (x.Len() == 0 && !(it_reqs[s].IsNotInOrDoesNotExist() && a.IsNotInOrDoesNotExist())) pass = false; } }
+      if (pass) E.its_types[(size_t)s * TW + t / 64] |= 1ull << (t % 64);
+    }
+    E.it_states = it_reqs; E.prob.S = S;
+  }
+
+  void finish() {
+    ks_problem& p = E.prob;
+    p.P = (uint32_t)pr.pods.size(); p.C = E.cls.n; p.T = T; p.M = (uint32_t)E.templates.size(); p.E = (uint32_t)E.existing.size(); p.K = K; p.R = R;
+    p.max_new_nodes = p.P ? p.P : 1; p.flags = flags | (pr.simulation_mode ? KS_FLAG_SIMULATION : 0);
+    p.wellknown_mask = 0; for (uint32_t k = 0; k < K; ++k) if (wellKnown.count(E.key_names[k])) p.wellknown_mask |= 1u << k;
+    p.key_nvalues = E.key_nvalues.data(); p.value_int = E.value_int.data(); p.key_zone = key_id.at(ksp::kZone); p.key_ct = key_id.at(ksp::kCapacityType); p.n_ct = E.key_nvalues[p.key_ct];
+    p.it_present = E.it_present.data(); p.it_complement = E.it_complement.data(); p.it_mask = E.it_mask.data(); p.it_alloc = E.it_alloc.data(); p.it_cap = E.it_cap.data(); p.it_offer = E.it_offer.data();
+    p.its_inter = E.its_inter.data(); p.its_fail = E.its_fail.data(); p.its_nidne = E.its_nidne.data(); p.its_types = E.its_types.data();
+    p.tmpl = E.tmpl.view(); p.tmpl_taints = E.tmpl_taints.data(); p.tmpl_daemon = E.tmpl_daemon.data(); p.tmpl_daemon_present = E.tmpl_daemon_present.data(); p.tmpl_types = E.tmpl_types.data();
+    p.tmpl_limit_present = E.tmpl_limit_present.data(); p.tmpl_remaining = E.tmpl_remaining.data();
+    p.en = E.en.view(); p.en_taints = E.en_taints.data(); p.en_avail = E.en_avail.data(); p.en_requests = E.en_requests.data(); p.en_requests_present = E.en_requests_present.data(); p.en_port_off = E.en_port_off.data();
+    p.cls = E.cls.view(); p.cls_hn_mode = E.cls_hn_mode.data(); p.cls_hn_off = E.cls_hn_off.data(); p.hn_list = E.hn_list.data(); p.cls_requests = E.cls_requests.data(); p.cls_requests_present = E.cls_requests_present.data();
+    p.cls_tolerated = E.cls_tolerated.data(); p.cls_port_off = E.cls_port_off.data(); p.ports = E.ports.data();
+    p.cls_own_off = E.cls_own_off.data(); p.own_list = E.own_list.data(); p.cls_sel_off = E.cls_sel_off.data(); p.sel_list = E.sel_list.data();
+    p.cls_isel_off = E.cls_isel_off.data(); p.isel_list = E.isel_list.data(); p.cls_iown_off = E.cls_iown_off.data(); p.iown_list = E.iown_list.data();
+    p.pod_stage_off = E.pod_stage_off.data(); p.stage_cls = E.stage_cls.data(); p.queue = E.queue.data();
+    p.grp_type = E.grp_type.data(); p.grp_key = E.grp_key.data(); p.grp_max_skew = E.grp_max_skew.data(); p.grp_active = E.grp_active.data(); p.grp_filter_off = E.grp_filter_off.data(); p.flt = E.flt.view();
+    p.grp_count = E.grp_count.data(); p.grp_hslot = E.grp_hslot.data(); p.grph_count = E.grph_count.data(); p.grph_extra_pos = E.grph_extra_pos.data();
+  }
+
+  void run() {
+    collect_universes();
+    encode_instance_types();
+    it_reqs.push_back(Requirement());            // it-state 0 == key absent
+    encode_templates();
+    encode_existing();
+    collect_taints();
+    encode_pods();
+    encode_existing_rest();
+    encode_groups();
+    encode_it_states();
+    // C == 0 corner: CSR arrays still need their terminating offset
+    finish();
+  }
+};
+
+}  // namespace
+
+std::unique_ptr<Encoded> encode(ksp::Problem&& pr, uint32_t flags) {
+  auto e = std::make_unique<Encoded>(); e->src = std::move(pr);
+  Builder b(*e, flags); b.run();
+  return e;
+}
+
+std::unique_ptr<Encoded::ResultBuf> Encoded::make_result() const {
+  auto rb = std::make_unique<ResultBuf>(); const ks_problem& p = prob; const size_t N = p.max_new_nodes, TW = (p.T + 63) / 64;
+  rb->pod_node.resize(p.P + 1); rb->pod_stage.resize(p.P + 1); rb->pod_seq.resize(p.P + 1); rb->unscheduled.resize(p.P + 1);
+  rb->node_tmpl.resize(N); rb->node_types.resize(N * TW); rb->node_requests.resize(N * p.R); rb->node_requests_present.resize(N);
+  rb->node_present.resize(N); rb->node_complement.resize(N); rb->node_mask.resize(N * p.K + 1); rb->node_gt.resize(N * p.K + 1); rb->node_lt.resize(N * p.K + 1); rb->node_it_state.resize(N);
+  ks_result& r = rb->r;
+  r.pod_node = rb->pod_node.data(); r.pod_stage = rb->pod_stage.data(); r.pod_seq = rb->pod_seq.data(); r.unscheduled = rb->unscheduled.data();
+  r.node_tmpl = rb->node_tmpl.data(); r.node_types = rb->node_types.data(); r.node_requests = rb->node_requests.data(); r.node_requests_present = rb->node_requests_present.data();
+  r.node_present = rb->node_present.data(); r.node_complement = rb->node_complement.data(); r.node_mask = rb->node_mask.data(); r.node_gt = rb->node_gt.data(); r.node_lt = rb->node_lt.data(); r.node_it_state = rb->node_it_state.data();
+  return rb;
+}
+
+static std::string tokq(const std::string& s) { return s.empty() ? "~" : s; }
+
+std::string Encoded::decode(const ks_result& r, double solve_seconds) const {
+  const ks_problem& p = prob; const uint32_t TW = (p.T + 63) / 64, NE = p.E;
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> pods_of(NE + r.n_new);   // (seq, pod)
+  for (uint32_t i = 0; i < p.P; ++i) if (r.pod_node[i] >= 0) pods_of[r.pod_node[i]].push_back({r.pod_seq[i], (int32_t)i});
+  for (auto& v : pods_of) std::sort(v.begin(), v.end());
+  std::ostringstream o;
+  o << "KSR1\nNEWNODES " << r.n_new << "\n";
+  for (uint32_t j = 0; j < r.n_new; ++j) {
+    const auto& prov = *templates[r.node_tmpl[j]];
+    o << "NODE " << tokq(prov.name) << " " << pods_of[NE + j].size(); for (auto& sp : pods_of[NE + j]) o << " " << sp.second;
+    std::vector<const std::string*> names;
+    for (int idx : prov.instance_types) if ((r.node_types[(size_t)j * TW + idx / 64] >> (idx % 64)) & 1ull) names.push_back(&src.instance_types[idx].name);   // order-preserving filter (lo.Filter, node.go:138)
+    o << " " << names.size(); for (auto* n : names) o << " " << tokq(*n);
+    const uint32_t pm = r.node_requests_present[j]; std::map<std::string, int64_t> req;
+    for (uint32_t rr = 0; rr < p.R; ++rr) if ((pm >> rr) & 1u) req[res_names[rr]] = r.node_requests[(size_t)j * p.R + rr];
+    o << " " << req.size(); for (auto& kv : req) o << " " << kv.first << " " << kv.second;
+    struct Out { bool c; std::vector<std::string> vals; std::string gt, lt; };
+    std::map<std::string, Out> reqs;
+    for (uint32_t k = 0; k < p.K; ++k) if ((r.node_present[j] >> k) & 1u) {
+      Out x; x.c = (r.node_complement[j] >> k) & 1u; const uint64_t m = r.node_mask[(size_t)j * p.K + k];
+      for (size_t v = 0; v < key_values[k].size(); ++v) if ((m >> v) & 1ull) x.vals.push_back(key_values[k][v]);
+      const int32_t gt = r.node_gt[(size_t)j * p.K + k], lt = r.node_lt[(size_t)j * p.K + k];
+      x.gt = gt == KS_NO_BOUND_GT ? "-" : std::to_string(gt); x.lt = lt == KS_NO_BOUND_LT ? "-" : std::to_string(lt);
+      reqs[key_names[k]] = std::move(x);
+    }
+    if (r.node_it_state[j] > 0) {
+      const Requirement& q = it_states[r.node_it_state[j]]; Out x; x.c = q.complement; x.vals.assign(q.values.begin(), q.values.end());
+      x.gt = q.greaterThan ? std::to_string(*q.greaterThan) : "-"; x.lt = q.lessThan ? std::to_string(*q.lessThan) : "-"; reqs[ksp::kInstanceType] = std::move(x);
+    }
+    o << " " << reqs.size();
+    for (auto& kv : reqs) { o << " " << kv.first << " " << (kv.second.c ? 1 : 0) << " " << kv.second.vals.size(); for (auto& v : kv.second.vals) o << " " << tokq(v); o << " " << kv.second.gt << " " << kv.second.lt; }
+    o << "\n";
+  }
+  o << "EXISTING " << NE << "\n";
+  for (uint32_t e = 0; e < NE; ++e) { o << "ENODE " << tokq(src.nodes[existing[e]].name) << " " << pods_of[e].size(); for (auto& sp : pods_of[e]) o << " " << sp.second; o << "\n"; }
+  o << "UNSCHEDULED " << r.n_unscheduled; for (uint32_t i = 0; i < r.n_unscheduled; ++i) o << " " << r.unscheduled[i]; o << "\n";
+  o << "STAGES " << p.P; for (uint32_t i = 0; i < p.P; ++i) o << " " << r.pod_stage[i]; o << "\n";
+  o << "STATS 9 queue_pops " << r.stats[KS_STAT_POPS] << " relaxations " << r.stats[KS_STAT_RELAX] << " full_checks " << r.stats[KS_STAT_FULLCHECKS] << " full_fails " << r.stats[KS_STAT_FULLFAILS]
+    << " attempts " << r.stats[KS_STAT_REF_ATTEMPTS] << " types_scanned " << r.stats[KS_STAT_REF_TYPES] << " kernel_cycles " << r.stats[KS_STAT_CYCLES]
+    << " classes " << p.C << " solve_ns " << (int64_t)(solve_seconds * 1e9) << "\n";
+  o << "END\n";
+  return o.str();
+}
+
+}  // namespace ksh

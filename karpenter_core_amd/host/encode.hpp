@@ -1,0 +1,62 @@
+// encode.hpp -- flattening of a semantic Solve() problem (ksp::Problem) into the C-ABI `ks_problem`
+// (include/ksolve.h) and decoding of `ks_result` back into the reference's result shape.
+//
+// This is the host half of the boundary: what a Go shim would do inside
+// provisioning.(*Provisioner).NewScheduler (provisioner.go:237-296), scheduling.NewTopology
+// (topology.go:56-80, countDomains :231-276), scheduling.NewScheduler (scheduler.go:42-94) and
+// NewQueue (queue.go:35-41) before handing the flat structure-of-arrays problem to the GPU.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ksolve.h"
+#include "hreq.hpp"
+#include "ksp.hpp"
+
+namespace ksh {
+
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
+
+struct ReqSetsStore {
+  std::vector<uint32_t> present, complement; std::vector<uint64_t> mask; std::vector<int32_t> gt, lt, it_state;
+  uint32_t n = 0;
+  ks_reqsets view() const { ks_reqsets v; v.n = n; v.present = present.data(); v.complement = complement.data(); v.mask = mask.data(); v.gt = gt.data(); v.lt = lt.data(); v.it_state = it_state.data(); return v; }
+};
+
+struct Encoded {
+  ksp::Problem src;
+  // ---- naming tables for decode ----
+  std::vector<std::string> key_names;                      // narrow keys
+  std::vector<std::vector<std::string>> key_values;        // universe per key (ascending)
+  std::vector<std::string> res_names;
+  std::vector<const ksp::Provisioner*> templates;          // weight order
+  std::vector<int> existing;                                // indices into src.nodes
+  std::vector<Requirement> it_states;                      // instance-type-key requirement per state (index 0 unused)
+  // ---- flat storage behind ks_problem ----
+  std::vector<uint32_t> key_nvalues; std::vector<int32_t> value_int;
+  std::vector<uint32_t> it_present, it_complement; std::vector<uint64_t> it_mask, it_offer; std::vector<int64_t> it_alloc, it_cap;
+  std::vector<uint8_t> its_inter, its_fail, its_nidne; std::vector<uint64_t> its_types;
+  ReqSetsStore tmpl, en, cls, flt;
+  std::vector<uint64_t> tmpl_taints, tmpl_types; std::vector<int64_t> tmpl_daemon, tmpl_remaining; std::vector<uint32_t> tmpl_daemon_present, tmpl_limit_present;
+  std::vector<uint64_t> en_taints; std::vector<int64_t> en_avail, en_requests; std::vector<uint32_t> en_requests_present, en_port_off;
+  std::vector<uint8_t> cls_hn_mode; std::vector<uint32_t> cls_hn_off, hn_list; std::vector<int64_t> cls_requests; std::vector<uint32_t> cls_requests_present;
+  std::vector<uint64_t> cls_tolerated; std::vector<uint32_t> cls_port_off; std::vector<uint64_t> ports;
+  std::vector<uint32_t> cls_own_off, own_list, cls_sel_off, sel_list, cls_isel_off, isel_list, cls_iown_off, iown_list;
+  std::vector<uint32_t> pod_stage_off, stage_cls, queue;
+  std::vector<uint8_t> grp_type, grp_active; std::vector<int32_t> grp_key, grp_max_skew, grp_count, grp_hslot, grph_count, grph_extra_pos; std::vector<uint32_t> grp_filter_off;
+  ks_problem prob{};
+
+  // ---- result buffers ----
+  struct ResultBuf {
+    std::vector<int32_t> pod_node, pod_stage, pod_seq, unscheduled, node_tmpl, node_gt, node_lt, node_it_state;
+    std::vector<uint64_t> node_types, node_mask; std::vector<int64_t> node_requests; std::vector<uint32_t> node_requests_present, node_present, node_complement;
+    ks_result r{};
+  };
+  std::unique_ptr<ResultBuf> make_result() const;
+  std::string decode(const ks_result& r, double solve_seconds) const;   // KSR1 text (see model.py parse_result)
+};
+
+std::unique_ptr<Encoded> encode(ksp::Problem&& pr, uint32_t flags);
+
+}  // namespace ksh

@@ -1,0 +1,213 @@
+"""Host-side mirror of the reference scheduler interface for the hot path, over the C ABI.
+
+Reference call sites this stands in for (paths relative to aws/karpenter-core pkg/):
+
+    scheduler, err := p.NewScheduler(ctx, pods, stateNodes, opts)     controllers/provisioning/provisioner.go:301
+    nodes, existing, err := scheduler.Solve(ctx, pods)                 provisioner.go:307, deprovisioning/helpers.go:93
+
+`NewScheduler(...)` assembles the semantic problem (provisioners -> machine templates, instance types,
+state nodes, cluster pods for topology counting, daemonset pods) and hands it to libkshost.so, which
+runs the host half (NewTopology / flattening, host/encode.cpp) and calls libksolve.so's HIP kernels
+through the C ABI (include/ksolve.h).  `Scheduler.Solve(pods)` returns `(new_nodes, existing_nodes,
+None)` -- the error is always None, exactly like scheduler.go:132.
+
+There is NO CPU scheduling path: if the HIP library is missing, or no gfx950 device is visible, every
+call raises.  (The CPU oracle lives in oracle/ and is test infrastructure only.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+from .model import (ClusterPod, InstanceType, NewNodeOut, Pod, Problem, Provisioner, SolveResult, StateNode,
+                    parse_result)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = None
+
+KS_OK, KS_ERR_INVALID, KS_ERR_UNSUPPORTED, KS_ERR_DEVICE, KS_ERR_CAPACITY = 0, -1, -2, -3, -4
+KS_FLAG_SIMULATION, KS_FLAG_STATS = 1, 2
+
+
+class KSolveError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ksolve error {code}: {msg}")
+        self.code = code
+
+
+def libs():
+    """Load libksolve.so (HIP kernels + C ABI) and libkshost.so (host side).  Fails loudly."""
+    global _LIBS
+    if _LIBS is None:
+        ks_path = os.path.join(_HERE, "libksolve.so")
+        kh_path = os.path.join(_HERE, "libkshost.so")
+        for p in (ks_path, kh_path):
+            if not os.path.exists(p):
+                raise KSolveError(KS_ERR_DEVICE, f"{p} is missing -- build it with __graft_entry__.build(); "
+                                                 "there is no Python/CPU fallback for the scheduling path")
+        ks = ctypes.CDLL(ks_path, mode=ctypes.RTLD_GLOBAL)
+        kh = ctypes.CDLL(kh_path)
+        ks.ks_device_count.restype = ctypes.c_int
+        ks.ks_last_error.restype = ctypes.c_char_p
+        ks.ks_version.restype = ctypes.c_char_p
+        kh.ksh_last_error.restype = ctypes.c_char_p
+        kh.ksh_open.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+        kh.ksh_close.argtypes = [ctypes.c_void_p]
+        kh.ksh_upload.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        kh.ksh_solve.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
+        kh.ksh_solve_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
+        kh.ksh_grid.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        kh.ksh_dims.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        kh.ksh_free.argtypes = [ctypes.c_void_p]
+        _LIBS = (ks, kh)
+    return _LIBS
+
+
+def device_count() -> int:
+    return int(libs()[0].ks_device_count())
+
+
+class FlatProblem:
+    """A Solve() problem flattened to the C-ABI `ks_problem` (host side only until `upload`)."""
+
+    def __init__(self, problem: Problem, stats: bool = False):
+        ks, kh = libs()
+        text = problem.to_ksp().encode()
+        self._h = ctypes.c_void_p()
+        flags = KS_FLAG_STATS if stats else 0
+        rc = kh.ksh_open(text, len(text), flags, ctypes.byref(self._h))
+        if rc != KS_OK:
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+        d = (ctypes.c_uint32 * 10)()
+        kh.ksh_dims(self._h, d)
+        self.dims = dict(zip(["P", "C", "T", "M", "E", "K", "R", "G", "GH", "S"], [int(x) for x in d]))
+        self.kernel_ms = None
+        self.wall_ms = None
+
+    def close(self):
+        if self._h:
+            libs()[1].ksh_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, device: int = 0):
+        rc = libs()[1].ksh_upload(self._h, device)
+        if rc != KS_OK:
+            raise KSolveError(rc, libs()[1].ksh_last_error().decode())
+
+    def solve(self, decode: bool = True) -> Optional[SolveResult]:
+        ks, kh = libs()
+        out = ctypes.c_void_p()
+        kms, wms = ctypes.c_float(), ctypes.c_double()
+        rc = kh.ksh_solve(self._h, ctypes.byref(out) if decode else None, ctypes.byref(kms), ctypes.byref(wms))
+        if rc != KS_OK:
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+        self.kernel_ms, self.wall_ms = float(kms.value), float(wms.value)
+        if not decode:
+            return None
+        text = ctypes.string_at(out).decode()
+        kh.ksh_free(out)
+        return parse_result(text)
+
+    def grid(self, want_bits: bool = True):
+        """ks_feasibility_grid: returns (numpy uint64 [M, C, TW] or None, kernel milliseconds)."""
+        import numpy as np
+        kh = libs()[1]
+        tw = (self.dims["T"] + 63) // 64
+        arr = np.zeros((self.dims["M"], self.dims["C"], tw), dtype=np.uint64) if want_bits else None
+        ms = ctypes.c_float()
+        rc = kh.ksh_grid(self._h, arr.ctypes.data if arr is not None else None, ctypes.byref(ms))
+        if rc != KS_OK:
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+        return arr, float(ms.value)
+
+
+def solve_batch(flats: Sequence[FlatProblem], decode: bool = True):
+    """N independent Solve() calls in one launch (consolidation what-ifs)."""
+    kh = libs()[1]
+    n = len(flats)
+    hs = (ctypes.c_void_p * n)(*[f._h for f in flats])
+    outs = (ctypes.c_void_p * n)()
+    kms, wms = ctypes.c_float(), ctypes.c_double()
+    rc = kh.ksh_solve_batch(hs, n, outs if decode else None, ctypes.byref(kms), ctypes.byref(wms))
+    if rc != KS_OK:
+        raise KSolveError(rc, kh.ksh_last_error().decode())
+    res = None
+    if decode:
+        res = []
+        for i in range(n):
+            res.append(parse_result(ctypes.string_at(outs[i]).decode()))
+            kh.ksh_free(outs[i])
+    return res, float(kms.value), float(wms.value)
+
+
+def solve_problem(problem: Problem, stats: bool = False) -> SolveResult:
+    fp = FlatProblem(problem, stats=stats)
+    try:
+        return fp.solve()
+    finally:
+        fp.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# Reference-shaped interface
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class SchedulerOptions:
+    """scheduling.SchedulerOptions, scheduler.go:36-40."""
+    SimulationMode: bool = False
+
+
+@dataclass
+class Node:
+    """scheduling.Node as its callers read it: embedded MachineTemplate fields + Pods."""
+    ProvisionerName: str
+    Pods: List[Pod]
+    InstanceTypeOptions: List[InstanceType]
+    Requirements: Dict[str, object]
+    Requests: Dict[str, int]
+
+
+@dataclass
+class ExistingNode:
+    """scheduling.ExistingNode: the state node plus the pods Solve placed on it."""
+    Node: StateNode
+    Pods: List[Pod]
+
+
+class Scheduler:
+    """scheduling.Scheduler (scheduler.go:81-94)."""
+
+    def __init__(self, provisioners, instance_types, state_nodes, daemonset_pods, cluster_pods, extra_well_known, opts):
+        self.provisioners, self.instance_types, self.state_nodes = provisioners, instance_types, state_nodes
+        self.daemonset_pods, self.cluster_pods, self.extra_well_known, self.opts = daemonset_pods, cluster_pods, extra_well_known, opts
+
+    def Solve(self, pods: Sequence[Pod]) -> Tuple[List[Node], List[ExistingNode], None]:
+        problem = Problem(instance_types=self.instance_types, provisioners=self.provisioners, pods=list(pods),
+                          daemonset_pods=self.daemonset_pods, nodes=self.state_nodes, cluster_pods=self.cluster_pods,
+                          extra_well_known=self.extra_well_known, simulation_mode=self.opts.SimulationMode)
+        res = solve_problem(problem)
+        self.last_result = res
+        by_name = {it.name: it for it in self.instance_types}
+        nodes = [Node(n.provisioner, [pods[i] for i in n.pods], [by_name[x] for x in n.instance_types], n.requirements, n.requests)
+                 for n in res.new_nodes]
+        state = {n.name: n for n in self.state_nodes}
+        existing = [ExistingNode(state[name], [pods[i] for i in idxs]) for name, idxs in res.existing.items()]
+        return nodes, existing, None
+
+
+def NewScheduler(provisioners: Sequence[Provisioner], instance_types: Sequence[InstanceType],
+                 state_nodes: Sequence[StateNode] = (), daemonset_pods: Sequence[Pod] = (),
+                 cluster_pods: Sequence[ClusterPod] = (), extra_well_known: Sequence[str] = (),
+                 opts: Optional[SchedulerOptions] = None) -> Scheduler:
+    """provisioning.(*Provisioner).NewScheduler (provisioner.go:237-296): every provisioner offers the
+    instance types listed in `Provisioner.instance_types` (indices into `instance_types`)."""
+    return Scheduler(list(provisioners), list(instance_types), list(state_nodes), list(daemonset_pods), list(cluster_pods),
+                     list(extra_well_known), opts or SchedulerOptions())

@@ -1,0 +1,76 @@
+"""CPU-side checks of the boundary: the library builds, loads, exports every symbol include/ksolve.h
+declares, the host flattening runs on every config shape, and -- because there is no GPU here -- the
+compute entry points refuse loudly instead of falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as ge
+from karpenter_core_amd import scheduler as S, workloads as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    ge.build()
+
+
+def test_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ksolve.h")).read()
+    names = set(re.findall(r"\b(ks_[a-z_0-9]+)\s*\(", hdr))
+    assert {"ks_solve", "ks_solve_dev", "ks_solve_batch", "ks_solve_batch_dev", "ks_problem_upload", "ks_problem_free",
+            "ks_feasibility_grid", "ks_probe_intersection", "ks_probe_compatible", "ks_device_count", "ks_last_error",
+            "ks_version"} <= names
+    ks, _ = S.libs()
+    for n in names:
+        assert hasattr(ks, n), f"libksolve.so does not export {n}"
+
+
+def test_no_cpu_fallback_without_gpu():
+    if S.device_count() > 0:
+        pytest.skip("GPU present")
+    fp = S.FlatProblem(W.config1(pods=20, types=5))
+    with pytest.raises(S.KSolveError) as ei:
+        fp.solve()
+    assert ei.value.code == S.KS_ERR_DEVICE
+
+
+def test_product_does_not_reference_oracle():
+    pkg = os.path.join(ROOT, "karpenter_core_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                src = open(os.path.join(dp, f), errors="ignore").read()
+                assert "liboracle" not in src and "oracle_py" not in src and "ko_solve" not in src, f
+
+
+@pytest.mark.parametrize("name,problem,dims", [
+    ("config1", lambda: W.config1(), dict(P=1000, T=50, M=1, E=0, G=0)),
+    ("config2-small", lambda: W.config2(pods=1500), dict(P=1500, T=500, M=5)),
+    ("config3-small", lambda: W.config3(pods=3500), dict(P=3500, T=2000, M=1)),
+    ("config5-small", lambda: W.config5(pods=3000, sizes=10), dict(P=3000, M=2)),
+])
+def test_flattening_shapes(name, problem, dims):
+    fp = S.FlatProblem(problem())
+    for k, v in dims.items():
+        assert fp.dims[k] == v, (name, fp.dims)
+    assert fp.dims["K"] <= 32 and fp.dims["R"] <= 8 and fp.dims["C"] <= fp.dims["P"] * 3
+    fp.close()
+
+
+def test_whatif_flattening():
+    its, prov, nodes, bound = W.cluster_snapshot(existing=64, sizes=5, seed=3)
+    pr = W.whatif(its, prov, nodes, bound, [0, 1, 2])
+    fp = S.FlatProblem(pr)
+    assert fp.dims["E"] == 61 and fp.dims["P"] == sum(len(b) for b in bound[:3])
+    fp.close()
+
+
+def test_unsupported_is_loud():
+    pr = W.reference_benchmark(50, instance_count=100)   # `integer` label with 100 distinct values
+    with pytest.raises(S.KSolveError) as ei:
+        S.FlatProblem(pr)
+    assert ei.value.code == S.KS_ERR_UNSUPPORTED

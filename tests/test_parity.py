@@ -1,0 +1,119 @@
+"""Parity proper: the HIP path (through the C ABI) against the CPU oracle, bit-identical on the canonical
+result (new nodes in creation order with pod lists in commit order, instance-type option lists, request
+vectors, requirement sets; existing-node pod lists; unscheduled queue; relaxation stages)."""
+import numpy as np
+import pytest
+
+from helpers import solve
+from karpenter_core_amd import fake, scheduler as S, workloads as W
+from karpenter_core_amd.model import Problem
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same(problem, **kw):
+    got = S.solve_problem(problem).canonical()
+    want = O.solve(problem).canonical()
+    if got != want:
+        for k in want:
+            if got[k] != want[k]:
+                if k == "new_nodes":
+                    assert len(got[k]) == len(want[k]), f"new node count {len(got[k])} != {len(want[k])}"
+                    for i, (a, b) in enumerate(zip(got[k], want[k])):
+                        assert a == b, f"new node {i} differs:\n gpu   {a}\n oracle {b}"
+                assert got[k] == want[k], k
+    return want
+
+
+@pytest.mark.parametrize("pods,types,seed", [(1, 5, 1), (50, 5, 2), (1000, 50, 42), (3000, 64, 5)])
+def test_config1_resources_only(pods, types, seed):
+    assert_same(W.config1(pods=pods, types=types, seed=seed))
+
+
+@pytest.mark.parametrize("pods,sizes,seed", [(300, 5, 1), (2000, 10, 43), (4000, 25, 44)])
+def test_config2_taints_and_selectors(pods, sizes, seed):
+    assert_same(W.config2(pods=pods, sizes=sizes, seed=seed))
+
+
+@pytest.mark.parametrize("pods,sizes,seed", [(140, 3, 1), (700, 10, 7), (3500, 20, 44)])
+def test_config3_topology(pods, sizes, seed):
+    assert_same(W.config3(pods=pods, sizes=sizes, seed=seed))
+
+
+@pytest.mark.parametrize("pods,seed", [(700, 1), (2100, 2)])
+def test_reference_benchmark_mix(pods, seed):
+    # makeDiversePods incl. pod-affinity pods, with topology live (64-size ladder keeps `integer` <= 64 values)
+    rs = np.random.RandomState(seed)
+    its = fake.instance_types(64)
+    pr = Problem(instance_types=its, provisioners=[fake.provisioner("default", len(its), limits={}, discovery_label=True)],
+                 pods=W.diverse_pods(rs, pods), extra_well_known=fake.EXTRA_WELL_KNOWN)
+    assert_same(pr)
+
+
+@pytest.mark.parametrize("pods,seed", [(1000, 3), (4000, 46)])
+def test_config5_full_constraint_set(pods, seed):
+    assert_same(W.config5(pods=pods, sizes=10, seed=seed))
+
+
+def test_whatifs_single_and_batched():
+    its, prov, nodes, bound = W.cluster_snapshot(existing=96, sizes=8, seed=45)
+    probs = [W.whatif(its, prov, nodes, bound, list(range(0, i + 1))) for i in range(6)] + \
+            [W.whatif(its, prov, nodes, bound, [i]) for i in (7, 20, 33)]
+    wants = [O.solve(p).canonical() for p in probs]
+    flats = [S.FlatProblem(p) for p in probs]
+    res, kms, _ = S.solve_batch(flats)
+    for r, w in zip(res, wants):
+        assert r.canonical() == w
+    for p, w in zip(probs[:3], wants[:3]):
+        assert S.solve_problem(p).canonical() == w
+
+
+def test_feasibility_grid_matches_first_pod_option_lists():
+    # grid[m][c] must equal the InstanceTypeOptions of a fresh node that receives one pod of class c
+    pr = W.config2(pods=120, sizes=6, seed=9)
+    fp = S.FlatProblem(pr)
+    grid, ms = fp.grid()
+    assert grid.shape[0] == 5
+    its = pr.instance_types
+    seen = 0
+    for i, pod in enumerate(pr.pods[:40]):
+        single = Problem(instance_types=its, provisioners=pr.provisioners, pods=[pod], extra_well_known=pr.extra_well_known)
+        want = O.solve(single)
+        f1 = S.FlatProblem(single)
+        g1, _ = f1.grid()
+        # templates are in weight order; the oracle opens the first template that works
+        if not want.new_nodes:
+            assert not g1.any()
+            continue
+        names = want.new_nodes[0].instance_types
+        m = [p.name for p in sorted(pr.provisioners, key=lambda p: -p.weight)].index(want.new_nodes[0].provisioner)
+        bits = [its[t].name for t in range(len(its)) if (int(g1[m, 0, t // 64]) >> (t % 64)) & 1]
+        assert bits == names
+        for mm in range(m):
+            assert not g1[mm, 0].any()
+        seen += 1
+    assert seen > 10
+
+
+def test_properties_at_scale_config3():
+    """Size-independent properties at a size the oracle is too slow for."""
+    pr = W.config3(pods=20000, sizes=50, seed=44)
+    res = S.solve_problem(pr)
+    placed = [i for n in res.new_nodes for i in n.pods]
+    assert len(placed) == len(set(placed))
+    assert sorted(placed + res.unscheduled) == list(range(len(pr.pods)))
+    from karpenter_core_amd.model import pod_requests_milli, parse_quantity_milli
+    alloc = {it.name: {k: parse_quantity_milli(v) - parse_quantity_milli(it.overhead.get(k, "0")) for k, v in it.capacity.items()} for it in pr.instance_types}
+    for n in res.new_nodes:
+        tot = {}
+        for i in n.pods:
+            for k, v in pod_requests_milli(pr.pods[i]).items():
+                tot[k] = tot.get(k, 0) + v
+        assert tot == n.requests
+        assert n.instance_types, "a node with no instance type option"
+        for name in n.instance_types:                      # every surviving option fits the packed requests
+            assert all(v <= alloc[name].get(k, 0) for k, v in tot.items())
+        # hostname anti-affinity: at most one pod per my-affininity value on a node
+        vals = [pr.pods[i].labels.get("my-affininity") for i in n.pods if pr.pods[i].anti_required]
+        assert len(vals) == len(set(vals))
