@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- pod-placement decisions/sec through Solve() on MI355X (BASELINE.json metric).
+
+A "step" is one full Solve() of the workload with the flattened problem already resident in HBM
+(ksh_upload before the timed region): queue pop -> ... -> last commit, result read-back included.
+decisions = len(pods) per Solve -- the reference's own definition (scheduling_benchmark_test.go:170).
+
+N=1 workload: BASELINE configs[2] -- 100k pending pods, 2k instance types, topology spread + hostname
+pod anti-affinity (the configuration the metric "@100k pods" is quoted on; it fits one GPU).
+N>1: a single Solve() is a serial dependency chain and does not shard ("replicas only"); what
+shards is the consolidation what-if fan-out, so every rank runs its own independent what-if Solve() of the
+same shape (different seed) and ONE RCCL all-gather of fixed-size result records closes the step
+(weak scaling; value = total decisions of all ranks / max-over-ranks time).
+
+Extra objects on the JSON line:
+  roofline     dominant kernel ks_pack: algorithmic bytes of the REFERENCE algorithm for this workload
+               (SURVEY 8d formula; attempts / scanned-type counts come from an untimed KS_FLAG_STATS launch)
+               divided by the mean launch duration measured with HIP events on the solve stream.
+  grid         the feasibility-grid kernels' own HBM roofline numbers.
+  cpu_baseline the CPU oracle (a restatement of the Go path; the Go toolchain is absent) timed on 1 host
+               core on a bounded sample: the same generator at 10k pods.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def algorithmic_bytes(dims, stats, n_new):
+    """bytes(p) = B_pod + sum_attempted(B_node + |alive| B_it) + B_node(write-back)."""
+    R, K, TW = dims["R"], dims["K"], (dims["T"] + 63) // 64
+    b_pod = 8 * R + 16 * K + 16
+    b_it = 8 * R + 16 * K + 8
+    b_node = 8 * R + 16 * K + 8 + 8 * TW
+    placed = dims["P"]
+    return stats["queue_pops"] * b_pod + stats["attempts"] * b_node + stats["types_scanned"] * b_it + placed * b_node
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pods", type=int, default=100_000)
+    ap.add_argument("--sizes", type=int, default=50, help="ladder sizes; instance types = sizes*40")
+    ap.add_argument("--cpu-sample-pods", type=int, default=10_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")       # RCCL on ROCm
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from karpenter_core_amd import scheduler as S, workloads as W
+
+    # ---- problem (untimed): generate, flatten, upload ----
+    t0 = time.time()
+    problem = W.config3(pods=args.pods, sizes=args.sizes, seed=44 + rank)
+    fp = S.FlatProblem(problem)
+    fp.upload(local_rank)
+    _, grid_ms = fp.grid(want_bits=False)               # static tables + feasibility grid (built once per problem)
+    prep_s = time.time() - t0
+    dims = fp.dims
+    TW = (dims["T"] + 63) // 64
+
+    def step():
+        fp.solve(decode=False)
+        if world > 1:
+            rec = torch.tensor([rank, dims["P"]], device="cuda", dtype=torch.int64)
+            out = [torch.empty_like(rec) for _ in range(world)]
+            dist.all_gather(out, rec)                   # the one exchange step: chosen-machine records over xGMI
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms, lat_ms = [], []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        step()
+        lat_ms.append((time.perf_counter() - t1) * 1e3)
+        kernel_ms.append(fp.kernel_ms)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank != 0:
+        return
+    decisions = dims["P"] * args.steps * world
+    value = decisions / elapsed
+
+    # ---- roofline of the dominant kernel (untimed stats launch gives the reference algorithm's work) ----
+    fps = S.FlatProblem(problem, stats=True)
+    fps.upload(local_rank)
+    res = fps.solve()
+    st = res.stats
+    abytes = algorithmic_bytes(dims, st, len(res.new_nodes))
+    mean_kernel_s = statistics.mean(kernel_ms) / 1e3
+    achieved = abytes / mean_kernel_s / 1e9
+    grid_bytes = dims["C"] * (8 * dims["R"] + 16 * dims["K"] + 16) + dims["T"] * (8 * dims["R"] + 16 * dims["K"] + 8) + dims["M"] * dims["C"] * TW * 8
+    out = {
+        "metric": "pod-placement decisions/sec (Solve())", "value": value, "unit": "decisions/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[2]: {dims['P']} pods, {dims['T']} instance types, zonal+hostname topology spread and "
+                               f"hostname pod anti-affinity (workloads.config3 seed 44)", "pods": dims["P"], "instance_types": dims["T"],
+                   "pod_classes": dims["C"], "topology_groups": dims["G"], "new_nodes": len(res.new_nodes),
+                   "unschedulable": len(res.unscheduled),
+                   "parallelism": "1 Solve per GPU" + (f", {world} independent what-if Solves + 1 RCCL all-gather" if world > 1 else "")},
+        "p50_solve_latency_ms": statistics.median(lat_ms),
+        "kernel_ms_mean": statistics.mean(kernel_ms), "prep_seconds_untimed": prep_s,
+        "roofline": {"kernel": "ks_pack", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": abytes,
+                     "ref_attempts": st["attempts"], "ref_types_scanned": st["types_scanned"],
+                     "note": "one Solve() is a serial dependency chain executed by ONE workgroup (1 of 256 CUs); it is latency-bound, "
+                             "the HBM fraction is reported for completeness (see DESIGN.md)"},
+        "grid": {"kernel": "ks_grid_mc+ks_grid_types", "ms": grid_ms, "algorithmic_bytes": grid_bytes,
+                 "achieved_GBs": grid_bytes / (grid_ms / 1e3) / 1e9 if grid_ms else None},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import oracle_py
+        sample = W.config3(pods=args.cpu_sample_pods, sizes=args.sizes, seed=44)
+        text = sample.to_ksp()
+        from karpenter_core_amd.model import parse_result
+        r = parse_result(oracle_py.solve_text(text))
+        secs = r.stats["solve_ns"] / 1e9
+        out["cpu_baseline"] = {"value": args.cpu_sample_pods / secs, "unit": "decisions/s", "cores": 1, "kind": "port",
+                               "host_cores": os.cpu_count(), "seconds": secs,
+                               "sample": f"same generator at {args.cpu_sample_pods} pods / {dims['T']} instance types (Solve() only, "
+                                         "single thread like the Go path); the oracle's cost grows super-linearly with pods, so "
+                                         "this over-states the CPU rate at 100k pods"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

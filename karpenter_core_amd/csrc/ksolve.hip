@@ -10,12 +10,12 @@
 //                         instance type (its requirement masks / allocatable vector live in registers,
 //                         loaded once, coalesced SoA), streams over (template,class) records that are
 //                         wave-uniform, and emits one 64-bit word per __ballot.  HBM-bound.
-//   ks_pack               one persistent workgroup per Solve(): the first-fit-decreasing loop of
-//                         scheduler.go:96-219.  Per pod: all open nodes are screened in parallel (one
-//                         lane per node: taints, host ports, requirement intersection, topology domain
-//                         choice, resource screen), a wave-shuffle + LDS arg-min picks the first feasible
-//                         node in the reference's visiting order, the instance-type filter runs
-//                         word-parallel on T-bit masks, and one lane commits.
+//   ks_pack               one persistent single-wavefront workgroup per Solve(): the first-fit-decreasing
+//                         loop of scheduler.go:96-219 with no barriers.  Per pod the next 64 open nodes in
+//                         the reference's visiting order are screened one-per-lane (taints, host ports,
+//                         requirement intersection, topology domain choice, resource screen), __ballot +
+//                         count-trailing-zeros is the first-fit pick, the instance-type filter runs on
+//                         T-bit masks (word per lane, then type per lane), lane-parallel stores commit.
 //
 // The reference functions each device function restates are cited inline (paths relative to
 // aws/karpenter-core pkg/).  There is deliberately NO CPU fallback in this library: if no gfx950
@@ -31,7 +31,6 @@
 #include "../../include/ksolve.h"
 #include "ks_algebra.h"
 
-#define KS_NT 1024           // threads per pack workgroup (16 waves on one CU)
 #define KS_MAX_TOPO 24       // topology groups evaluated per pod class
 #define KS_MAX_TOUCH 12      // distinct narrow keys a class may touch (own requirements + topology keys)
 
@@ -71,16 +70,17 @@ struct DevProb {
   u64* grid;         // [M*C*TW]
 };
 
-// Mutable state of one Solve (device memory, one allocation).
+// Mutable state of one Solve (device memory).
 struct DevState {
   // queue (queue.go:29-72)
   u32* q; u32* lastlen; u32* lastgen; i32* pod_stage; i32* pod_node; i32* pod_seq;
-  // slots: [0,E) existing nodes, [E,E+NMAX) new nodes
-  u32* s_present; u32* s_complement; u64* s_mask; i32* s_gt; i32* s_lt; i32* s_it;
-  i64* s_req; u32* s_reqmask; i64* s_cap; u64* s_taints; i32* s_porthead;
-  i32* n_tmpl; u32* n_count; u64* n_key; u64* n_alive;   // new nodes only, indexed by j = slot-E
+  // node records (AoS, see Rec): slots [0,E) existing nodes, [E,E+NMAX) new nodes
+  u8* rec; u32 rec_stride;
+  i32* n_tmpl; u64* n_alive;          // new nodes only, indexed by j = slot-E; n_alive has one spare row
+  u32* bstart;                        // [P+3] count-bucket boundaries of the visiting-order array
+  u32* order_g;                       // [NMAX] global-memory home of the visiting order once it outgrows LDS
   // topology
-  i32* gcnt; u64* g_reg; u64* g_pos; u8* g_active; i32* hcnt; i32* g_hpos;
+  i32* gcnt; u64* g_reg; u64* g_pos; u8* g_active; i32* hcnt /* [slot][GH] */; i32* g_hpos;
   // provisioner limits
   i64* remaining;
   // host-port pool
@@ -88,6 +88,7 @@ struct DevState {
   // outputs
   u64* stats; u32* out_counts;   // out_counts: [0]=n_new [1]=n_unscheduled
   i32* unscheduled;
+  u32* o_present; u32* o_complement; u64* o_mask; i32* o_gt; i32* o_lt; i32* o_it; i64* o_req; u32* o_reqmask;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -226,7 +227,22 @@ __global__ __launch_bounds__(256) void ks_grid_types(DevProb P, u32 chunks) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// pack kernel
+// pack kernel: ONE wavefront per Solve(), no barriers.
+//
+// The Solve() loop is a serial dependency chain (pod k sees the state pods 0..k-1 left behind), so
+// the only parallelism inside one pod step is across candidate nodes and across instance types.  One
+// 64-lane wave owns the whole Solve:
+//   * open nodes are kept in an array sorted in the reference's visiting order -- the stable
+//     `sort.Slice(newNodes, len(Pods))` of scheduler.go:183 -- which is maintained incrementally (a node
+//     whose pod count grows moves to the FRONT of the next count bucket; a new node is appended to the
+//     BACK of the count-1 bucket);
+//   * per step the wave takes the next 64 nodes in that order, one lane per node, evaluates
+//     Node.Add up to the instance-type filter in registers, and __ballot + count-trailing-zeros IS the
+//     first-fit pick (the reference's "first node whose Add succeeds");
+//   * the instance-type filter runs on T-bit masks (one 64-bit word per lane, then one type per lane
+//     for resources.Fits), and the commit is a handful of lane-parallel stores.
+// Node state is an array of fixed-stride records (AoS: a lane touches one or two cache lines per
+// candidate); instance-type allocatable vectors and the visiting order live in LDS.
 // ------------------------------------------------------------------------------------------------
 struct TopoItem {
   i32 g; i32 key; i32 hslot; i32 maxskew; i32 minc; u8 type; u8 self; u8 inverse; u8 pod_has; u64 PD; u64 reg; u64 pos;
@@ -237,19 +253,40 @@ struct ClsL {      // the popped pod's class, staged in LDS once per pod
   i64 req[KS_MAX_RES]; u32 reqmask; u64 tol; u32 port_off, port_cnt;
   int ntopo; TopoItem topo[KS_MAX_TOPO];
 };
-struct ReqOut {    // requirement set of the winning node after the pod is added (written by lane 0)
+struct ReqOut {    // requirement set of the winning node after the pod is added (written by the winning lane)
   u32 present, complement; i32 it_state; u64 mask[KS_MAX_KEYS]; i32 gt[KS_MAX_KEYS]; i32 lt[KS_MAX_KEYS]; u32 changed; u32 topo_narrowed;
 };
+
+// ---- slot record (AoS).  Offsets in bytes; stride = ks_rec_stride(R,K) ----
+//   0 u64 taints | 8 u32 present | 12 u32 complement | 16 i32 it_state | 20 u32 reqmask | 24 i32 porthead | 28 u32 count
+//   32 i64 req[R] | 32+8R i64 cap[R] | 32+16R u64 mask[K] | +8K i32 gt[K] | +4K i32 lt[K]
+__host__ __device__ inline u32 ks_rec_stride(u32 R, u32 K) { return (32 + 16 * R + 16 * K + 15) & ~15u; }
+struct Rec {
+  u8* p; u32 R, K;
+  __device__ __forceinline__ u64& taints() const { return *(u64*)p; }
+  __device__ __forceinline__ u32& present() const { return *(u32*)(p + 8); }
+  __device__ __forceinline__ u32& complement() const { return *(u32*)(p + 12); }
+  __device__ __forceinline__ i32& it_state() const { return *(i32*)(p + 16); }
+  __device__ __forceinline__ u32& reqmask() const { return *(u32*)(p + 20); }
+  __device__ __forceinline__ i32& porthead() const { return *(i32*)(p + 24); }
+  __device__ __forceinline__ u32& count() const { return *(u32*)(p + 28); }
+  __device__ __forceinline__ i64* req() const { return (i64*)(p + 32); }
+  __device__ __forceinline__ i64* cap() const { return (i64*)(p + 32 + 8 * R); }
+  __device__ __forceinline__ u64* mask() const { return (u64*)(p + 32 + 16 * R); }
+  __device__ __forceinline__ i32* gt() const { return (i32*)(p + 32 + 16 * R + 8 * K); }
+  __device__ __forceinline__ i32* lt() const { return (i32*)(p + 32 + 16 * R + 12 * K); }
+};
+__device__ __forceinline__ Rec slot_rec(const DevProb& P, const DevState& S, u32 s) { Rec r; r.p = S.rec + (size_t)s * S.rec_stride; r.R = P.R; r.K = P.K; return r; }
+
 struct NodeView {  // where a candidate node's state lives (an open slot, or a template∩class record for a fresh node)
   u32 present, complement; i32 it_state; const u64* mask; const i32* gt; const i32* lt;
   u64 taints; i32 porthead; const i64* req; u32 reqmask; const i64* cap; i32 slot; bool existing; bool fresh;
 };
-
 __device__ __forceinline__ NodeView slot_view(const DevProb& P, const DevState& S, u32 s) {
-  NodeView v; v.present = S.s_present[s]; v.complement = S.s_complement[s]; v.it_state = S.s_it[s];
-  v.mask = S.s_mask + (size_t)s * P.K; v.gt = S.s_gt + (size_t)s * P.K; v.lt = S.s_lt + (size_t)s * P.K;
-  v.taints = S.s_taints[s]; v.porthead = S.s_porthead[s]; v.req = S.s_req + (size_t)s * P.R; v.reqmask = S.s_reqmask[s];
-  v.cap = S.s_cap + (size_t)s * P.R; v.slot = (i32)s; v.existing = s < P.E; v.fresh = false; return v;
+  const Rec r = slot_rec(P, S, s);
+  NodeView v; v.present = r.present(); v.complement = r.complement(); v.it_state = r.it_state();
+  v.mask = r.mask(); v.gt = r.gt(); v.lt = r.lt(); v.taints = r.taints(); v.porthead = r.porthead(); v.req = r.req(); v.reqmask = r.reqmask();
+  v.cap = r.cap(); v.slot = (i32)s; v.existing = s < P.E; v.fresh = false; return v;
 }
 
 __device__ __forceinline__ bool cls_allows_hostname(const DevProb& P, const ClsL& c, const NodeView& v) {
@@ -277,6 +314,8 @@ __device__ __forceinline__ bool ports_conflict(const DevProb& P, const DevState&
 // Returns 0: fails before the filter; 1: reaches the filter but fails the resource screen;
 // 2: passes everything evaluated here.  With `out` != nullptr also writes the node's requirement set
 // after Add (nodeRequirements after :80 and :90 of node.go / :105 and :115 of existingnode.go).
+// `merged`: the pod's own requirements are already folded into the view (fresh node built from the
+// template∩class record), only topology is evaluated on top.
 __device__ int eval_node(const DevProb& P, const DevState& S, const ClsL& c, const NodeView& v, ReqOut* out, bool merged = false) {
   // Taints.Tolerates, taints.go:28-40
   if (v.taints & ~c.tol) return 0;
@@ -301,7 +340,6 @@ __device__ int eval_node(const DevProb& P, const DevState& S, const ClsL& c, con
   }
   i32 it_state = v.it_state;
   if (c.it_state && !merged) { if (P.its_fail[v.it_state * P.S + c.it_state]) return 0; it_state = P.its_inter[v.it_state * P.S + c.it_state]; }
-  const int n_own = nt;   // entries [0,n_own) come from the pod's own requirements
 
   // Topology.AddRequirements, topology.go:149-167, then Compatible + Add of the result (node.go:83-90)
   u32 topo_keys = 0; bool host_ok = true;
@@ -309,13 +347,12 @@ __device__ int eval_node(const DevProb& P, const DevState& S, const ClsL& c, con
   for (int i = 0; i < c.ntopo; ++i) {
     const TopoItem& t = c.topo[i];
     if (t.key == KS_KEY_HOSTNAME) {
-      const bool allowed = true;   // cls_allows_hostname already held above
       i32 cnt;
       if (v.fresh) cnt = S.g_active[t.g] ? 0 : -1;           // NewNode registers the placeholder first (node.go:47)
-      else cnt = S.hcnt[(size_t)t.hslot * (P.E + P.NMAX) + v.slot];
+      else cnt = S.hcnt[(size_t)v.slot * P.GH + t.hslot];
       bool ok;
       if (t.type == 0) ok = cnt >= 0 && (i64)cnt + t.self <= (i64)t.maxskew;                         // nextDomainTopologySpread, min==0 for hostname (topologygroup.go:184-188)
-      else if (t.type == 2) ok = allowed && cnt == 0;                                                 // nextDomainAntiAffinity :235-243
+      else if (t.type == 2) ok = cnt == 0;                                                            // nextDomainAntiAffinity :235-243
       else { const bool anypos = S.g_hpos[t.hslot] > 0; ok = anypos ? (cnt > 0) : (t.self && cnt >= 0); }   // nextDomainAffinity :202-233
       if (!ok) host_ok = false;
       continue;
@@ -340,7 +377,7 @@ __device__ int eval_node(const DevProb& P, const DevState& S, const ClsL& c, con
     } else if (t.type == 1) {                                 // affinity
       options = t.reg & t.PD & t.pos;
       if (!options && t.self) {
-        KReq pd; pd.present = true; pd.complement = true; pd.mask = 0; pd.gt = KS_NOGT; pd.lt = KS_NOLT;
+        KReq pd = kreq_exists();
         if (t.pod_has) pd = load_req(c.present, c.complement, c.mask, c.gt, c.lt, k);
         const u64 I = kreq_has_mask(kreq_intersect(pd, nd, vi, nv), vi, nv);
         const u64 a = t.reg & I, b = t.reg & t.PD;
@@ -366,9 +403,9 @@ __device__ int eval_node(const DevProb& P, const DevState& S, const ClsL& c, con
       if (!((P.wellknown_mask >> k) & 1u)) return 0;          // custom key the node does not define
       treq[e] = in;
     } else {
-      KReq merged = kreq_intersect(in, before, vi, nv);
-      if (kreq_len0(merged) && !kreq_nidne(before)) return 0;
-      treq[e] = merged;
+      KReq merged_req = kreq_intersect(in, before, vi, nv);
+      if (kreq_len0(merged_req) && !kreq_nidne(before)) return 0;
+      treq[e] = merged_req;
     }
     if (treq[e].mask != before.mask || treq[e].complement != before.complement || treq[e].present != before.present) narrowed |= 1u << k;
   }
@@ -383,7 +420,6 @@ __device__ int eval_node(const DevProb& P, const DevState& S, const ClsL& c, con
       out->present |= 1u << k; out->complement = r.complement ? (out->complement | (1u << k)) : (out->complement & ~(1u << k));
       out->mask[k] = r.mask; out->gt[k] = r.gt; out->lt[k] = r.lt;
     }
-    (void)n_own;
   }
   // new nodes: necessary resource screen against the per-resource maximum over the surviving types
   if (!v.existing && !v.fresh) {
@@ -439,11 +475,11 @@ __device__ __forceinline__ void grp_record(const DevProb& P, const DevState& S, 
   i32& c = S.gcnt[(size_t)g * 64 + d]; c = c < 0 ? 1 : c + 1; S.g_reg[g] |= 1ull << d; S.g_pos[g] |= 1ull << d;
 }
 __device__ __forceinline__ void grp_record_host(const DevProb& P, const DevState& S, int g, u32 slot) {
-  const i32 h = P.grp_hslot[g]; i32& c = S.hcnt[(size_t)h * (P.E + P.NMAX) + slot];
+  const i32 h = P.grp_hslot[g]; i32& c = S.hcnt[(size_t)slot * P.GH + h];
   if (c <= 0) S.g_hpos[h]++;
   c = c < 0 ? 1 : c + 1;
 }
-// Topology.Record, topology.go:120-143 (lane 0)
+// Topology.Record, topology.go:120-143 (one lane)
 __device__ void topology_record(const DevProb& P, const DevState& S, const ClsL& c, const ReqOut& rq, u32 slot) {
   for (u32 i = P.cls_sel_off[c.c]; i < P.cls_sel_off[c.c + 1]; ++i) {
     const int g = P.sel_list[i];
@@ -464,50 +500,31 @@ __device__ void topology_record(const DevProb& P, const DevState& S, const ClsL&
   }
 }
 
-struct PackShared {
+struct WaveShared {
   ClsL cls; ReqOut rq;
-  u64 red_key[KS_NT / 64]; u32 red_slot[KS_NT / 64];
-  i64 red_i64[KS_NT / 64][KS_MAX_RES];
-  u32 any_flag; u32 pod; i32 bcast_i; u64 bcast_key; u32 bcast_slot; u32 limit_any;
-  u64 floor_key;
+  i64 req_new[KS_MAX_RES]; i64 cap_new[KS_MAX_RES];
 };
 
-// block-wide arg-min of (key, slot); every thread gets the result
-__device__ __forceinline__ void block_argmin(PackShared& sh, u64& key, u32& slot) {
-  for (int off = 32; off > 0; off >>= 1) {
-    const u64 ok = __shfl_xor(key, off); const u32 os = __shfl_xor(slot, off);
-    if (ok < key) { key = ok; slot = os; }
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) { sh.red_key[wave] = key; sh.red_slot[wave] = slot; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    u64 bk = sh.red_key[0]; u32 bs = sh.red_slot[0];
-    for (int i = 1; i < KS_NT / 64; ++i) if (sh.red_key[i] < bk) { bk = sh.red_key[i]; bs = sh.red_slot[i]; }
-    sh.bcast_key = bk; sh.bcast_slot = bs;
-  }
-  __syncthreads();
-  key = sh.bcast_key; slot = sh.bcast_slot;
-  __syncthreads();
-}
+#define WSYNC() __syncthreads()     /* single-wave workgroup: an LDS/global ordering point, not a real barrier */
+
+__device__ __forceinline__ i64 wave_max_i64(i64 v) { for (int off = 32; off > 0; off >>= 1) { const i64 o = __shfl_xor(v, off); if (o > v) v = o; } return v; }
 
 // Load the pod's class into LDS and pre-evaluate the per-pod part of every matching topology group
 // (getMatchingTopologies, topology.go:351-364; domainMinCount, topologygroup.go:184-200).
-__device__ void stage_class(const DevProb& P, const DevState& S, PackShared& sh, u32 c) {
+__device__ void stage_class(const DevProb& P, const DevState& S, WaveShared& sh, u32 c, int lane) {
   ClsL& L = sh.cls;
-  if (threadIdx.x < P.K) { const u32 k = threadIdx.x; L.mask[k] = P.cls.mask[(size_t)c * P.K + k]; L.gt[k] = P.cls.gt[(size_t)c * P.K + k]; L.lt[k] = P.cls.lt[(size_t)c * P.K + k]; }
-  if (threadIdx.x >= 64 && threadIdx.x < 64 + P.R) { const u32 r = threadIdx.x - 64; L.req[r] = P.cls_requests[(size_t)c * P.R + r]; }
-  if (threadIdx.x == 128) {
+  if ((u32)lane < P.K) { const u32 k = lane; L.mask[k] = P.cls.mask[(size_t)c * P.K + k]; L.gt[k] = P.cls.gt[(size_t)c * P.K + k]; L.lt[k] = P.cls.lt[(size_t)c * P.K + k]; }
+  if (lane >= 32 && (u32)lane < 32 + P.R) { const u32 r = lane - 32; L.req[r] = P.cls_requests[(size_t)c * P.R + r]; }
+  if (lane == 63) {
     L.c = c; L.present = P.cls.present[c]; L.complement = P.cls.complement[c]; L.it_state = P.cls.it_state[c];
     L.hn_mode = P.cls_hn_mode[c]; L.hn_off = P.cls_hn_off[c]; L.hn_cnt = P.cls_hn_off[c + 1] - P.cls_hn_off[c];
     L.reqmask = P.cls_requests_present[c]; L.tol = P.cls_tolerated[c]; L.port_off = P.cls_port_off[c]; L.port_cnt = P.cls_port_off[c + 1] - P.cls_port_off[c];
   }
-  __syncthreads();
-  // topology items: owned groups first, then inverse groups selecting the pod
+  WSYNC();
   const u32 ob = P.cls_own_off[c], oe = P.cls_own_off[c + 1], ib = P.cls_isel_off[c], ie = P.cls_isel_off[c + 1];
   const u32 n = (oe - ob) + (ie - ib);
-  if (threadIdx.x < n && threadIdx.x < KS_MAX_TOPO) {
-    const u32 i = threadIdx.x; TopoItem t;
+  if ((u32)lane < n && lane < KS_MAX_TOPO) {
+    const u32 i = lane; TopoItem t;
     u32 ent; if (i < oe - ob) { ent = P.own_list[ob + i]; t.inverse = 0; } else { ent = P.isel_list[ib + (i - (oe - ob))]; t.inverse = 1; }
     t.g = ent & 0x7FFFFFFFu; t.self = ent >> 31; t.type = P.grp_type[t.g]; t.key = P.grp_key[t.g]; t.hslot = P.grp_hslot[t.g]; t.maxskew = P.grp_max_skew[t.g];
     t.minc = 0; t.PD = ~0ull; t.pod_has = 0; t.reg = 0; t.pos = 0;
@@ -522,302 +539,317 @@ __device__ void stage_class(const DevProb& P, const DevState& S, PackShared& sh,
     }
     L.topo[i] = t;
   }
-  if (threadIdx.x == 0) L.ntopo = n < KS_MAX_TOPO ? (int)n : KS_MAX_TOPO;
-  __syncthreads();
+  if (lane == 0) L.ntopo = n < KS_MAX_TOPO ? (int)n : KS_MAX_TOPO;
+  WSYNC();
 }
 
-// Instance-type filter for the node described by (alive words, requests) after adding the pod:
-// alive' = alive & passTypes(changed keys) & offerings & fits.  Block-wide; returns any(alive').
-// `alive_out` (global, TW words) receives alive'.  Also reduces the new per-resource maxima of
-// Allocatable over alive' into sh.red_i64 (used as the resource screen of later pods).
-__device__ bool filter_types(const DevProb& P, PackShared& sh, const u64* alive_in, u64* alive_out, const i64* req_new, u32 reqmask_new,
-                             u32 changed_keys, bool check_offer, bool check_it, i64* cap_out) {
+// Instance-type filter (filterInstanceTypesByRequirements, node.go:137-141) on T-bit masks, one wave:
+//   alive' = alive & passTypes(changed keys) & its_types(state) & offerings & fits(requests)
+// Lane w owns word w of the mask; for every non-empty word all 64 lanes then test one type each against
+// the request vector (resources.Fits) and __ballot rebuilds the word.  Also returns, per resource, the
+// maximum Allocatable over alive' (the resource screen of later pods) in sh.cap_new.
+__device__ bool filter_types(const DevProb& P, WaveShared& sh, const i64* alloc, const u64* alive_in, u64* alive_out, u32 reqmask_new,
+                             u32 changed_keys, bool check_offer, bool check_it, int lane) {
   const ReqOut& rq = sh.rq;
-  __shared__ u64 words[KS_NT];      // up to 1024 words == 65536 types per pass
-  const u32 tid = threadIdx.x;
-  if (tid == 0) sh.any_flag = 0;
-  __syncthreads();
   i64 mx[KS_MAX_RES];
-  for (u32 r = 0; r < P.R; ++r) mx[r] = INT64_MIN;
+#pragma unroll
+  for (int r = 0; r < KS_MAX_RES; ++r) mx[r] = INT64_MIN;
   bool any = false;
-  for (u32 wbase = 0; wbase < P.TW; wbase += KS_NT) {
-    // step 1: requirement / offering masks, one word per thread
-    const u32 w = wbase + tid; u64 a = 0;
+  for (u32 wbase = 0; wbase < P.TW; wbase += 64) {
+    const u32 w = wbase + lane; u64 a = 0;
     if (w < P.TW) {
       a = alive_in[w];
       for (u32 bits = changed_keys; bits && a; bits &= bits - 1) { const int k = __builtin_ctz(bits); a &= pass_types_word(P, k, load_req(rq.present, rq.complement, rq.mask, rq.gt, rq.lt, k), w); }
       if (check_it && a) a &= P.its_types[(size_t)rq.it_state * P.TW + w];
       if (check_offer && a) a &= offer_types_word(P, rq, w);
     }
-    words[tid] = a;
-    __syncthreads();
-    // step 2: fits, one type per lane
-    const u32 nwords = min((u32)KS_NT, P.TW - wbase);
-    for (u32 tl = tid; tl < nwords * 64; tl += KS_NT) {
-      const u32 wl = tl >> 6; const u64 aw = words[wl]; bool ok = (aw >> (tl & 63)) & 1ull;
-      const u32 t = (wbase + wl) * 64 + (tl & 63);
-      if (ok) { for (u32 bits = reqmask_new; bits; bits &= bits - 1) { const int r = __builtin_ctz(bits); if (req_new[r] > P.it_alloc[(size_t)r * P.T + t]) { ok = false; break; } } }
-      if (ok) for (u32 r = 0; r < P.R; ++r) { const i64 al = P.it_alloc[(size_t)r * P.T + t]; if (al > mx[r]) mx[r] = al; }
+    for (u64 nz = ballot64(a != 0); nz; nz &= nz - 1) {
+      const int b = __builtin_ctzll(nz);
+      const u64 aw = __shfl(a, b);
+      const u32 t = (wbase + b) * 64 + lane;
+      bool ok = (aw >> lane) & 1ull;
+      if (ok) for (u32 bits = reqmask_new; bits; bits &= bits - 1) { const int r = __builtin_ctz(bits); if (sh.req_new[r] > alloc[(size_t)r * P.T + t]) { ok = false; break; } }
+      if (ok) for (u32 r = 0; r < P.R; ++r) { const i64 al = alloc[(size_t)r * P.T + t]; if (al > mx[r]) mx[r] = al; }
       const u64 bw = ballot64(ok);
-      if ((tl & 63) == 0) { alive_out[wbase + wl] = bw; if (bw) any = true; }
+      if (lane == b) a = bw;
     }
-    __syncthreads();
+    if (w < P.TW) alive_out[w] = a;
+    if (ballot64(a != 0)) any = true;
   }
-  if (any) sh.any_flag = 1;
-  // reduce maxima
-  for (u32 r = 0; r < P.R; ++r) { i64 v = mx[r]; for (int off = 32; off > 0; off >>= 1) { const i64 o = __shfl_xor(v, off); if (o > v) v = o; } if ((tid & 63) == 0) sh.red_i64[tid >> 6][r] = v; }
-  __syncthreads();
-  if (tid < P.R) { i64 v = sh.red_i64[0][tid]; for (int i = 1; i < KS_NT / 64; ++i) if (sh.red_i64[i][tid] > v) v = sh.red_i64[i][tid]; cap_out[tid] = v; }
-  __syncthreads();
-  return sh.any_flag != 0;
+  for (u32 r = 0; r < P.R; ++r) { const i64 v = wave_max_i64(mx[r]); if (lane == 0) sh.cap_new[r] = v; }
+  WSYNC();
+  return any;
 }
 
-__global__ __launch_bounds__(KS_NT) void ks_pack(const DevProb* probs, const DevState* states) {
+// Write the winning node's record after Add (lane-parallel stores).
+__device__ __forceinline__ void write_record(const DevProb& P, const Rec& r, const WaveShared& sh, u32 reqmask_new, bool write_cap, int lane) {
+  if ((u32)lane < P.K) { r.mask()[lane] = sh.rq.mask[lane]; r.gt()[lane] = sh.rq.gt[lane]; r.lt()[lane] = sh.rq.lt[lane]; }
+  if (lane >= 32 && (u32)lane < 32 + P.R) { const int rr = lane - 32; r.req()[rr] = sh.req_new[rr]; if (write_cap) r.cap()[rr] = sh.cap_new[rr]; }
+  if (lane == 63) { r.present() = sh.rq.present; r.complement() = sh.rq.complement; r.it_state() = sh.rq.it_state; r.reqmask() = reqmask_new; }
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char ks_dyn_lds[];
+
+__global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevState* states, u32 lds_bytes) {
   const DevProb& P = probs[blockIdx.x];
   const DevState& S = states[blockIdx.x];
-  __shared__ PackShared sh;
-  __shared__ i64 req_new[KS_MAX_RES];
-  __shared__ i64 cap_new[KS_MAX_RES];
-  __shared__ u32 s_head, s_len, s_gen, s_nnew, s_seq, s_stop, s_err, s_reqmask_new;
-  const u32 tid = threadIdx.x;
+  __shared__ WaveShared sh;
+  const int lane = threadIdx.x;
   const u32 NS = P.E + P.NMAX;
   const u64 t_start = __builtin_readcyclecounter();
 
-  // ---------------- initialise state ----------------
-  for (u32 i = tid; i < P.P; i += KS_NT) { S.q[i] = P.queue[i]; S.lastgen[i] = 0xFFFFFFFFu; S.lastlen[i] = 0; S.pod_stage[i] = 0; S.pod_node[i] = -1; S.pod_seq[i] = -1; }
-  for (u32 e = tid; e < P.E; e += KS_NT) {
-    S.s_present[e] = P.en.present[e]; S.s_complement[e] = P.en.complement[e]; S.s_it[e] = P.en.it_state[e];
-    for (u32 k = 0; k < P.K; ++k) { S.s_mask[(size_t)e * P.K + k] = P.en.mask[(size_t)e * P.K + k]; S.s_gt[(size_t)e * P.K + k] = P.en.gt[(size_t)e * P.K + k]; S.s_lt[(size_t)e * P.K + k] = P.en.lt[(size_t)e * P.K + k]; }
-    for (u32 r = 0; r < P.R; ++r) { S.s_req[(size_t)e * P.R + r] = P.en_requests[(size_t)e * P.R + r]; S.s_cap[(size_t)e * P.R + r] = P.en_avail[(size_t)e * P.R + r]; }
-    S.s_reqmask[e] = P.en_requests_present[e]; S.s_taints[e] = P.en_taints[e];
-    // existing host ports: chain the node's initial entries
-    i32 head = -1; for (u32 i = P.en_port_off[e]; i < P.en_port_off[e + 1]; ++i) { S.pp_entry[i] = P.ports[i]; S.pp_next[i] = head; head = (i32)i; }
-    S.s_porthead[e] = head;
+  // ---- dynamic LDS: instance-type Allocatable table (if it fits in half), then the visiting-order array ----
+  const size_t alloc_bytes = (size_t)P.R * P.T * sizeof(i64);
+  const i64* alloc = P.it_alloc; u32 lds_used = 0;
+  if (alloc_bytes <= lds_bytes / 2) {
+    i64* a = (i64*)ks_dyn_lds;
+    for (u32 i = lane; i < P.R * P.T; i += 64) a[i] = P.it_alloc[i];
+    alloc = a; lds_used = (u32)((alloc_bytes + 15) & ~(size_t)15);
   }
-  for (u32 i = tid; i < P.G * 64; i += KS_NT) S.gcnt[i] = P.grp_count[i];
-  for (u32 g = tid; g < P.G; g += KS_NT) {
+  u32* ord = (u32*)(ks_dyn_lds + lds_used);            // ord[pos] = new-node index j, sorted in visiting order
+  const u32 ord_cap = (lds_bytes - lds_used) / 4;
+  bool ord_in_lds = true;
+
+  // ---------------- initialise state ----------------
+  for (u32 i = lane; i < P.P; i += 64) { S.q[i] = P.queue[i]; S.lastgen[i] = 0xFFFFFFFFu; S.lastlen[i] = 0; S.pod_stage[i] = 0; S.pod_node[i] = -1; S.pod_seq[i] = -1; }
+  for (u32 e = lane; e < P.E; e += 64) {
+    const Rec r = slot_rec(P, S, e);
+    r.taints() = P.en_taints[e]; r.present() = P.en.present[e]; r.complement() = P.en.complement[e]; r.it_state() = P.en.it_state[e];
+    r.reqmask() = P.en_requests_present[e]; r.count() = 0;
+    for (u32 k = 0; k < P.K; ++k) { r.mask()[k] = P.en.mask[(size_t)e * P.K + k]; r.gt()[k] = P.en.gt[(size_t)e * P.K + k]; r.lt()[k] = P.en.lt[(size_t)e * P.K + k]; }
+    for (u32 rr = 0; rr < P.R; ++rr) { r.req()[rr] = P.en_requests[(size_t)e * P.R + rr]; r.cap()[rr] = P.en_avail[(size_t)e * P.R + rr]; }
+    i32 head = -1; for (u32 i = P.en_port_off[e]; i < P.en_port_off[e + 1]; ++i) { S.pp_entry[i] = P.ports[i]; S.pp_next[i] = head; head = (i32)i; }
+    r.porthead() = head;
+    for (u32 h = 0; h < P.GH; ++h) S.hcnt[(size_t)e * P.GH + h] = P.grph_count[(size_t)h * P.E + e];
+  }
+  for (u32 i = lane; i < P.G * 64; i += 64) S.gcnt[i] = P.grp_count[i];
+  for (u32 g = lane; g < P.G; g += 64) {
     u64 reg = 0, pos = 0; for (int d = 0; d < 64; ++d) { const i32 c = P.grp_count[(size_t)g * 64 + d]; if (c >= 0) reg |= 1ull << d; if (c > 0) pos |= 1ull << d; }
     S.g_reg[g] = reg; S.g_pos[g] = pos; S.g_active[g] = P.grp_active[g];
   }
-  for (u32 h = tid; h < P.GH; h += KS_NT) {
-    i32 np = P.grph_extra_pos[h];
-    for (u32 e = 0; e < P.E; ++e) { const i32 c = P.grph_count[(size_t)h * P.E + e]; S.hcnt[(size_t)h * NS + e] = c; if (c > 0) ++np; }
-    S.g_hpos[h] = np;
-  }
-  for (u32 i = tid; i < P.M * P.R; i += KS_NT) S.remaining[i] = P.tmpl_remaining[i];
-  if (tid == 0) { s_head = 0; s_len = P.P; s_gen = 0; s_nnew = 0; s_seq = 0; s_stop = 0; s_err = 0; for (int i = 0; i < 16; ++i) S.stats[i] = 0; }
-  __syncthreads();
-  u32 pp_used = P.E ? P.en_port_off[P.E] : 0;     // uniform across threads
-  u64 st_pops = 0, st_relax = 0, st_full = 0, st_fullfail = 0, st_ref_attempts = 0, st_ref_types = 0;   // lane-0 counters
+  for (u32 h = lane; h < P.GH; h += 64) { i32 np = P.grph_extra_pos[h]; for (u32 e = 0; e < P.E; ++e) if (P.grph_count[(size_t)h * P.E + e] > 0) ++np; S.g_hpos[h] = np; }
+  for (u32 i = lane; i < P.M * P.R; i += 64) S.remaining[i] = P.tmpl_remaining[i];
+  WSYNC();
+
+  // wave-uniform loop state lives in registers (SGPRs)
+  u32 q_head = 0, q_len = P.P, q_gen = 0, nnew = 0, seq = 0, err = 0, maxc = 0;
+  u32 pp_used = P.E ? P.en_port_off[P.E] : 0;
+  u64 st_pops = 0, st_relax = 0, st_full = 0, st_fullfail = 0, st_ref_attempts = 0, st_ref_types = 0;
   const bool want_stats = (P.flags & KS_FLAG_STATS) != 0;
+  // S.bstart[c] (1 <= c <= maxc+1): first position in `ord` whose node has >= c pods; bstart[maxc+1] == nnew
 
   // ---------------- Solve loop, scheduler.go:104-124 ----------------
   for (;;) {
     // Queue.Pop, queue.go:44-58
-    if (tid == 0) {
-      if (s_len == 0) s_stop = 1;
-      else {
-        const u32 p = S.q[s_head];
-        if (S.lastgen[p] == s_gen && S.lastlen[p] == s_len) s_stop = 1;
-        else { sh.pod = p; s_head = (s_head + 1 == P.P) ? 0 : s_head + 1; s_len--; ++st_pops; }
-      }
-    }
-    __syncthreads();
-    if (s_stop || s_err) break;
-    const u32 pod = sh.pod;
+    if (q_len == 0) break;
+    const u32 pod = S.q[q_head];
+    if (S.lastgen[pod] == q_gen && S.lastlen[pod] == q_len) break;
+    q_head = (q_head + 1 == P.P) ? 0 : q_head + 1; q_len--; ++st_pops;
     const u32 cidx = P.stage_cls[P.pod_stage_off[pod] + S.pod_stage[pod]];
-    stage_class(P, S, sh, cidx);
+    stage_class(P, S, sh, cidx, lane);
     const ClsL& c = sh.cls;
     bool placed = false;
 
     // ---- 1. existing nodes in the caller's order: first success wins (scheduler.go:176-180) ----
-    if (P.E) {
-      u64 key = ~0ull; u32 slot = 0xFFFFFFFFu;
-      for (u32 e = tid; e < P.E; e += KS_NT) {
-        NodeView v = slot_view(P, S, e);
-        if (eval_node(P, S, c, v, nullptr) == 2) { if ((u64)e < key) { key = e; slot = e; } }
+    for (u32 base = 0; base < P.E && !placed; base += 64) {
+      const u32 e = base + lane; int rc = 0;
+      if (e < P.E) { NodeView v = slot_view(P, S, e); rc = eval_node(P, S, c, v, nullptr); }
+      const u64 m = ballot64(rc == 2);
+      if (!m) { if (want_stats) st_ref_attempts += min(64u, P.E - base); continue; }
+      const int win = __builtin_ctzll(m); const u32 slot = base + win;
+      if (want_stats) st_ref_attempts += win + 1;
+      if (lane == win) { NodeView v = slot_view(P, S, slot); eval_node(P, S, c, v, &sh.rq); }
+      WSYNC();
+      const Rec r = slot_rec(P, S, slot);
+      if ((u32)lane < P.R) sh.req_new[lane] = r.req()[lane] + c.req[lane];
+      const u32 rm = r.reqmask() | c.reqmask;
+      WSYNC();
+      write_record(P, r, sh, rm, false, lane);                       // commit, existingnode.go:122-129
+      if (lane == 0) {
+        topology_record(P, S, c, sh.rq, slot);
+        for (u32 i = 0; i < c.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
+        S.pod_node[pod] = (i32)slot; S.pod_seq[pod] = (i32)seq;
       }
-      block_argmin(sh, key, slot);
-      if (want_stats && tid == 0) st_ref_attempts += (slot == 0xFFFFFFFFu) ? P.E : slot + 1;
-      if (slot != 0xFFFFFFFFu) {
-        if (tid == 0) {
-          NodeView v = slot_view(P, S, slot);
-          eval_node(P, S, c, v, &sh.rq);
-          // commit, existingnode.go:122-129
-          S.s_present[slot] = sh.rq.present; S.s_complement[slot] = sh.rq.complement; S.s_it[slot] = sh.rq.it_state;
-          for (u32 k = 0; k < P.K; ++k) { S.s_mask[(size_t)slot * P.K + k] = sh.rq.mask[k]; S.s_gt[(size_t)slot * P.K + k] = sh.rq.gt[k]; S.s_lt[(size_t)slot * P.K + k] = sh.rq.lt[k]; }
-          for (u32 r = 0; r < P.R; ++r) S.s_req[(size_t)slot * P.R + r] += c.req[r];
-          S.s_reqmask[slot] |= c.reqmask;
-          topology_record(P, S, c, sh.rq, slot);
-          for (u32 i = 0; i < c.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = S.s_porthead[slot]; S.s_porthead[slot] = (i32)(pp_used + i); }
-          S.pod_node[pod] = (i32)slot; S.pod_seq[pod] = (i32)s_seq++;
-        }
-        pp_used += c.port_cnt;
-        placed = true;
-        __threadfence_block();
-        __syncthreads();
-      }
+      pp_used += c.port_cnt; ++seq; placed = true;
+      WSYNC();
     }
 
     // ---- 2. open new nodes in `sort.Slice(newNodes, len(Pods))` order (scheduler.go:183-190) ----
-    if (!placed && s_nnew) {
-      u64 floor = 0;   // candidates must have key > floor (keys are unique); 0 is below every key
-      for (;;) {
-        u64 key = ~0ull; u32 slot = 0xFFFFFFFFu; u64 my_types = 0; u32 my_attempts = 0;
-        const u32 nn = s_nnew;
-        for (u32 j = tid; j < nn; j += KS_NT) {
-          const u64 kk = S.n_key[j];
-          if (kk <= floor && floor) continue;
-          NodeView v = slot_view(P, S, P.E + j);
-          const int rc = eval_node(P, S, c, v, nullptr);
-          if (rc == 2 && kk < key) { key = kk; slot = P.E + j; }
-        }
-        block_argmin(sh, key, slot);
-        if (slot == 0xFFFFFFFFu) break;
-        // full check of the candidate: instance-type filter
-        const u32 j = slot - P.E;
-        if (tid == 0) {
-          NodeView v = slot_view(P, S, slot);
-          eval_node(P, S, c, v, &sh.rq);
-          u32 rm = v.reqmask | c.reqmask; s_reqmask_new = rm;
-          for (u32 r = 0; r < P.R; ++r) req_new[r] = v.req[r] + c.req[r];
-          ++st_full;
-        }
-        __syncthreads();
+    for (u32 base = 0; base < nnew && !placed; base += 64) {
+      const u32 pos = base + lane; u32 j = 0xFFFFFFFFu; int rc = 0;
+      if (pos < nnew) { j = ord[pos]; NodeView v = slot_view(P, S, P.E + j); rc = eval_node(P, S, c, v, nullptr); }
+      u64 m = ballot64(rc == 2);
+      const u64 reach = ballot64(rc >= 1);
+      u32 my_alive = 0;
+      if (want_stats) { if (rc >= 1) for (u32 w = 0; w < P.TW; ++w) my_alive += __builtin_popcountll(S.n_alive[(size_t)j * P.TW + w]); }
+      u32 last_lane = min(64u, nnew - base);     // lanes the reference would have visited in this chunk (all, unless one succeeds)
+      while (m) {
+        const int win = __builtin_ctzll(m);
+        const u32 jw = __shfl(j, win); const u32 slot = P.E + jw;
+        if (lane == win) { NodeView v = slot_view(P, S, slot); eval_node(P, S, c, v, &sh.rq); }
+        const Rec r = slot_rec(P, S, slot);
+        if ((u32)lane < P.R) sh.req_new[lane] = r.req()[lane] + c.req[lane];
+        const u32 rm = r.reqmask() | c.reqmask;
+        WSYNC();
+        ++st_full;
         const bool zc = (P.key_zone >= 0 && ((sh.rq.changed >> P.key_zone) & 1u)) || (P.key_ct >= 0 && ((sh.rq.changed >> P.key_ct) & 1u));
-        const bool itc = sh.rq.it_state != S.s_it[slot];
-        u64* alive = S.n_alive + (size_t)j * P.TW;
+        const bool itc = sh.rq.it_state != r.it_state();
+        u64* alive = S.n_alive + (size_t)jw * P.TW;
         u64* scratch = S.n_alive + (size_t)P.NMAX * P.TW;     // one spare row
-        const bool ok = filter_types(P, sh, alive, scratch, req_new, s_reqmask_new, sh.rq.changed, zc, itc, cap_new);
-        if (ok) {
-          // commit, node.go:100-105
-          for (u32 w = tid; w < P.TW; w += KS_NT) alive[w] = scratch[w];
-          if (tid == 0) {
-            S.s_present[slot] = sh.rq.present; S.s_complement[slot] = sh.rq.complement; S.s_it[slot] = sh.rq.it_state;
-            for (u32 k = 0; k < P.K; ++k) { S.s_mask[(size_t)slot * P.K + k] = sh.rq.mask[k]; S.s_gt[(size_t)slot * P.K + k] = sh.rq.gt[k]; S.s_lt[(size_t)slot * P.K + k] = sh.rq.lt[k]; }
-            for (u32 r = 0; r < P.R; ++r) { S.s_req[(size_t)slot * P.R + r] = req_new[r]; S.s_cap[(size_t)slot * P.R + r] = cap_new[r]; }
-            S.s_reqmask[slot] = s_reqmask_new;
-            const u32 cnt = ++S.n_count[j];
-            const u32 seq = s_seq++;
-            S.n_key[j] = ((u64)cnt << 32) | (u64)(0xFFFFFFFFu - seq);     // moved to the FRONT of the next count bucket (stable sort)
-            topology_record(P, S, c, sh.rq, slot);
-            for (u32 i = 0; i < c.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = S.s_porthead[slot]; S.s_porthead[slot] = (i32)(pp_used + i); }
-            S.pod_node[pod] = (i32)slot; S.pod_seq[pod] = (i32)seq;
-          }
-          pp_used += c.port_cnt;
-          placed = true;
-          __threadfence_block();
-          __syncthreads();
-          break;
+        const bool ok = filter_types(P, sh, alloc, alive, scratch, rm, sh.rq.changed, zc, itc, lane);
+        if (!ok) { ++st_fullfail; m &= m - 1; continue; }
+        // commit, node.go:100-105
+        last_lane = win + 1;
+        for (u32 w = lane; w < P.TW; w += 64) alive[w] = scratch[w];
+        write_record(P, r, sh, rm, true, lane);
+        const u32 cnt = r.count();                                   // pods on the node before this one
+        if (lane == 0) {
+          r.count() = cnt + 1;
+          topology_record(P, S, c, sh.rq, slot);
+          for (u32 i = 0; i < c.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
+          S.pod_node[pod] = (i32)slot; S.pod_seq[pod] = (i32)seq;
         }
-        if (tid == 0) ++st_fullfail;
-        floor = key;       // next candidate strictly after this one in visiting order
-        __syncthreads();
-        (void)my_types; (void)my_attempts;
+        // visiting order: the node leaves position p of bucket `cnt` for the FRONT of bucket cnt+1
+        {
+          const u32 p = base + win;
+          const u32 endc = S.bstart[cnt + 1];                        // one past the last node with `cnt` pods
+          for (u32 i = p + 1; i < endc; i += 64) { const u32 ii = i + lane; u32 v = 0; if (ii < endc) v = ord[ii]; WSYNC(); if (ii < endc) ord[ii - 1] = v; }
+          WSYNC();
+          if (lane == 0) { ord[endc - 1] = jw; S.bstart[cnt + 1] = endc - 1; if (cnt + 1 > maxc) S.bstart[cnt + 2] = nnew; }
+          if (cnt + 1 > maxc) maxc = cnt + 1;
+        }
+        pp_used += c.port_cnt; ++seq; placed = true;
+        WSYNC();
+        break;
+      }
+      if (want_stats) {
+        st_ref_attempts += last_lane;
+        u32 ty = ((u32)lane < last_lane && ((reach >> lane) & 1ull)) ? my_alive : 0;
+        for (int off = 32; off > 0; off >>= 1) ty += __shfl_xor(ty, off);
+        st_ref_types += ty;
       }
     }
 
     // ---- 3. a new node from the first template that works (scheduler.go:193-217) ----
-    if (!placed) {
-      for (u32 m = 0; m < P.M && !placed; ++m) {
-        const size_t mc = (size_t)m * P.C + cidx;
-        if (!P.mc_ok[mc]) continue;
-        if (s_nnew >= P.NMAX) { if (tid == 0) s_err = (u32)(-KS_ERR_CAPACITY); __syncthreads(); break; }
-        const u32 j = s_nnew; const u32 slot = P.E + j;
-        u64* alive = S.n_alive + (size_t)j * P.TW;
-        u64* scratch = S.n_alive + (size_t)P.NMAX * P.TW;
-        const u32 lim = P.tmpl_limit_present[m];
-        // filterByRemainingResources, scheduler.go:293-309 (only when the provisioner has limits)
-        if (tid == 0) sh.limit_any = 0;
-        __syncthreads();
-        bool lany = false;
-        for (u32 tl = tid; tl < P.TW * 64; tl += KS_NT) {
-          const u32 t = tl; bool ok = t < P.T && ((P.tmpl_types[(size_t)m * P.TW + (t >> 6)] >> (t & 63)) & 1ull);
-          if (ok && lim != 0xFFFFFFFFu) for (u32 bits = lim; bits; bits &= bits - 1) { const int r = __builtin_ctz(bits); if (P.it_cap[(size_t)r * P.T + t] > S.remaining[(size_t)m * P.R + r]) { ok = false; break; } }
-          const u64 bw = ballot64(ok);
-          if ((tl & 63) == 0) { scratch[tl >> 6] = bw & P.grid[mc * P.TW + (tl >> 6)]; if (bw) lany = true; }
-        }
-        if (lany) sh.limit_any = 1;
-        __syncthreads();
-        if (!sh.limit_any) continue;            // "all available instance types exceed provisioner limits"
-        // NewNode + Node.Add on the fresh node
-        if (tid == 0) {
-          NodeView v; v.present = P.mc_present[mc]; v.complement = P.mc_complement[mc]; v.it_state = P.mc_it[mc];
-          v.mask = P.mc_mask + mc * P.K; v.gt = P.mc_gt + mc * P.K; v.lt = P.mc_lt + mc * P.K;
-          v.taints = 0; v.porthead = -1; v.req = P.tmpl_daemon + (size_t)m * P.R; v.reqmask = P.tmpl_daemon_present[m]; v.cap = nullptr; v.slot = (i32)slot; v.existing = false; v.fresh = true;
-          // the class's own requirements are already merged into mc_*: evaluate topology on top of them
-          const int rc = eval_node(P, S, c, v, &sh.rq, true);
-          sh.bcast_i = rc;
-          s_reqmask_new = P.tmpl_daemon_present[m] | c.reqmask;
-          for (u32 r = 0; r < P.R; ++r) req_new[r] = P.tmpl_daemon[(size_t)m * P.R + r] + c.req[r];
-          ++st_full;
-          if (want_stats) { st_ref_attempts += 1; }
-        }
-        __syncthreads();
-        if (sh.bcast_i != 2) continue;
-        // topology may have narrowed keys beyond template∩class: re-filter those keys (+ offerings)
-        const u32 nk = sh.rq.topo_narrowed;
-        const bool zc = (P.key_zone >= 0 && ((nk >> P.key_zone) & 1u)) || (P.key_ct >= 0 && ((nk >> P.key_ct) & 1u));
-        const bool ok = filter_types(P, sh, scratch, alive, req_new, s_reqmask_new, nk, zc, false, cap_new);
-        if (!ok) { if (tid == 0) ++st_fullfail; continue; }
-        // commit the new node (scheduler.go:214-216)
-        for (u32 h = tid; h < P.G; h += KS_NT) if (P.grp_hslot[h] >= 0) S.hcnt[(size_t)P.grp_hslot[h] * NS + slot] = S.g_active[h] ? 0 : -1;   // Topology.Register(hostname), node.go:47
-        __syncthreads();
-        // subtractMax, scheduler.go:273-290
+    for (u32 m = 0; m < P.M && !placed && !err; ++m) {
+      const size_t mc = (size_t)m * P.C + cidx;
+      const u32 lim = P.tmpl_limit_present[m];
+      const u32 j = nnew; const u32 slot = P.E + j;
+      if (nnew >= P.NMAX) { err = (u32)(-KS_ERR_CAPACITY); break; }
+      u64* alive = S.n_alive + (size_t)j * P.TW;
+      u64* scratch = S.n_alive + (size_t)P.NMAX * P.TW;
+      // filterByRemainingResources, scheduler.go:293-309 (only when the provisioner has limits)
+      bool lany = false; u32 ltypes = 0;
+      for (u32 wbase = 0; wbase < P.TW; wbase += 64) {
+        const u32 w = wbase + lane; u64 a = 0;
+        if (w < P.TW) a = P.tmpl_types[(size_t)m * P.TW + w];
         if (lim != 0xFFFFFFFFu) {
-          i64 mx[KS_MAX_RES]; for (u32 r = 0; r < P.R; ++r) mx[r] = INT64_MIN;
-          for (u32 t = tid; t < P.T; t += KS_NT) if ((alive[t >> 6] >> (t & 63)) & 1ull) for (u32 r = 0; r < P.R; ++r) { const i64 cp = P.it_cap[(size_t)r * P.T + t]; if (cp > mx[r]) mx[r] = cp; }
-          for (u32 r = 0; r < P.R; ++r) { i64 v = mx[r]; for (int off = 32; off > 0; off >>= 1) { const i64 o = __shfl_xor(v, off); if (o > v) v = o; } if ((tid & 63) == 0) sh.red_i64[tid >> 6][r] = v; }
-          __syncthreads();
-          if (tid < P.R && ((lim >> tid) & 1u)) { i64 v = sh.red_i64[0][tid]; for (int i = 1; i < KS_NT / 64; ++i) if (sh.red_i64[i][tid] > v) v = sh.red_i64[i][tid]; S.remaining[(size_t)m * P.R + tid] -= v; }
-          __syncthreads();
+          for (u64 nz = ballot64(a != 0); nz; nz &= nz - 1) {
+            const int b = __builtin_ctzll(nz); const u64 aw = __shfl(a, b); const u32 t = (wbase + b) * 64 + lane;
+            bool ok = (aw >> lane) & 1ull;
+            if (ok) for (u32 bits = lim; bits; bits &= bits - 1) { const int r = __builtin_ctz(bits); if (P.it_cap[(size_t)r * P.T + t] > S.remaining[(size_t)m * P.R + r]) { ok = false; break; } }
+            const u64 bw = ballot64(ok); if (lane == b) a = bw;
+          }
         }
-        if (tid == 0) {
-          S.s_present[slot] = sh.rq.present; S.s_complement[slot] = sh.rq.complement; S.s_it[slot] = sh.rq.it_state;
-          for (u32 k = 0; k < P.K; ++k) { S.s_mask[(size_t)slot * P.K + k] = sh.rq.mask[k]; S.s_gt[(size_t)slot * P.K + k] = sh.rq.gt[k]; S.s_lt[(size_t)slot * P.K + k] = sh.rq.lt[k]; }
-          for (u32 r = 0; r < P.R; ++r) { S.s_req[(size_t)slot * P.R + r] = req_new[r]; S.s_cap[(size_t)slot * P.R + r] = cap_new[r]; }
-          S.s_reqmask[slot] = s_reqmask_new; S.s_taints[slot] = P.tmpl_taints[m]; S.s_porthead[slot] = -1;
-          S.n_tmpl[j] = (i32)m; S.n_count[j] = 1;
-          const u32 seq = s_seq++;
-          S.n_key[j] = (1ull << 32) | (u64)seq;                         // appended: BACK of the count-1 bucket
-          topology_record(P, S, c, sh.rq, slot);
-          for (u32 i = 0; i < c.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = S.s_porthead[slot]; S.s_porthead[slot] = (i32)(pp_used + i); }
-          S.pod_node[pod] = (i32)slot; S.pod_seq[pod] = (i32)seq;
-          s_nnew = j + 1;
-        }
-        pp_used += c.port_cnt;
-        placed = true;
-        __threadfence_block();
-        __syncthreads();
+        if (ballot64(a != 0)) lany = true;
+        if (want_stats) { u32 pc = __builtin_popcountll(a); for (int off = 32; off > 0; off >>= 1) pc += __shfl_xor(pc, off); ltypes += pc; }
+        if (w < P.TW) scratch[w] = a & P.grid[mc * P.TW + w];
       }
+      if (!lany) continue;                      // "all available instance types exceed provisioner limits" (before NewNode)
+      WSYNC();
+      if (want_stats) ++st_ref_attempts;        // NewNode + node.Add is attempted for this template
+      if (!P.mc_ok[mc]) continue;               // taints / Compatible fail inside Add
+      // NewNode + Node.Add on the fresh node (its own requirements are already merged in mc_*)
+      int rc = 0;
+      if (lane == 0) {
+        NodeView v; v.present = P.mc_present[mc]; v.complement = P.mc_complement[mc]; v.it_state = P.mc_it[mc];
+        v.mask = P.mc_mask + mc * P.K; v.gt = P.mc_gt + mc * P.K; v.lt = P.mc_lt + mc * P.K;
+        v.taints = 0; v.porthead = -1; v.req = P.tmpl_daemon + (size_t)m * P.R; v.reqmask = P.tmpl_daemon_present[m]; v.cap = nullptr; v.slot = (i32)slot; v.existing = false; v.fresh = true;
+        rc = eval_node(P, S, c, v, &sh.rq, true);
+      }
+      rc = __shfl(rc, 0);
+      if ((u32)lane < P.R) sh.req_new[lane] = P.tmpl_daemon[(size_t)m * P.R + lane] + c.req[lane];
+      const u32 rm = P.tmpl_daemon_present[m] | c.reqmask;
+      WSYNC();
+      if (rc != 2) continue;
+      ++st_full; if (want_stats) st_ref_types += ltypes;
+      // topology may have narrowed keys beyond template∩class: re-filter those keys (+ offerings); fits again for the maxima
+      const u32 nk = sh.rq.topo_narrowed;
+      const bool zc = (P.key_zone >= 0 && ((nk >> P.key_zone) & 1u)) || (P.key_ct >= 0 && ((nk >> P.key_ct) & 1u));
+      const bool ok = filter_types(P, sh, alloc, scratch, alive, rm, nk, zc, false, lane);
+      if (!ok) { ++st_fullfail; continue; }
+      // commit the new node (scheduler.go:214-216); Topology.Register(hostname), node.go:47
+      for (u32 g = lane; g < P.G; g += 64) if (P.grp_hslot[g] >= 0) S.hcnt[(size_t)slot * P.GH + P.grp_hslot[g]] = S.g_active[g] ? 0 : -1;
+      // subtractMax, scheduler.go:273-290
+      if (lim != 0xFFFFFFFFu) {
+        i64 mx[KS_MAX_RES];
+#pragma unroll
+        for (int r = 0; r < KS_MAX_RES; ++r) mx[r] = INT64_MIN;
+        for (u32 t = lane; t < P.T; t += 64) if ((alive[t >> 6] >> (t & 63)) & 1ull) for (u32 r = 0; r < P.R; ++r) { const i64 cp = P.it_cap[(size_t)r * P.T + t]; if (cp > mx[r]) mx[r] = cp; }
+        for (u32 r = 0; r < P.R; ++r) { const i64 v = wave_max_i64(mx[r]); if (lane == 0 && ((lim >> r) & 1u)) S.remaining[(size_t)m * P.R + r] -= v; }
+      }
+      const Rec r = slot_rec(P, S, slot);
+      write_record(P, r, sh, rm, true, lane);
+      WSYNC();
+      if (lane == 0) {
+        r.taints() = P.tmpl_taints[m]; r.porthead() = -1; r.count() = 1; S.n_tmpl[j] = (i32)m;
+        topology_record(P, S, c, sh.rq, slot);
+        for (u32 i = 0; i < c.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
+        S.pod_node[pod] = (i32)slot; S.pod_seq[pod] = (i32)seq;
+      }
+      // visiting order: appended -> BACK of the count-1 bucket, i.e. position bstart[2]; everything after shifts right
+      {
+        if (ord_in_lds && nnew + 1 > ord_cap) {                       // spill the order array to global memory
+          for (u32 i = lane; i < nnew; i += 64) S.order_g[i] = ord[i];
+          WSYNC(); ord = S.order_g; ord_in_lds = false;
+        }
+        if (maxc == 0) { if (lane == 0) { S.bstart[1] = 0; S.bstart[2] = 1; ord[0] = j; } maxc = 1; }
+        else {
+          const u32 ins = S.bstart[2];
+          for (u32 hi = nnew; hi > ins; ) { const u32 lo = hi > ins + 64 ? hi - 64 : ins; const u32 ii = lo + lane; u32 v = 0; if (ii < hi) v = ord[ii]; WSYNC(); if (ii < hi) ord[ii + 1] = v; WSYNC(); hi = lo; }
+          if (lane == 0) ord[ins] = j;
+          for (u32 cc = 2 + lane; cc <= maxc + 1; cc += 64) S.bstart[cc] += 1;
+        }
+      }
+      nnew = j + 1; pp_used += c.port_cnt; ++seq; placed = true;
+      WSYNC();
     }
+    if (err) break;
 
     // ---- 4. failure: Preferences.Relax + Queue.Push + Topology.Update (scheduler.go:116-123) ----
-    if (!placed && !s_err) {
-      if (tid == 0) {
-        const u32 nst = P.pod_stage_off[pod + 1] - P.pod_stage_off[pod];
-        const bool relaxed = (u32)S.pod_stage[pod] + 1 < nst;
-        u32 tail = s_head + s_len; if (tail >= P.P) tail -= P.P;
-        S.q[tail] = pod; s_len++;
+    if (!placed) {
+      const u32 nst = P.pod_stage_off[pod + 1] - P.pod_stage_off[pod];
+      const i32 stg = S.pod_stage[pod];
+      const bool relaxed = (u32)stg + 1 < nst;
+      u32 tail = q_head + q_len; if (tail >= P.P) tail -= P.P;
+      q_len++;
+      if (lane == 0) {
+        S.q[tail] = pod;
         if (relaxed) {
-          S.pod_stage[pod]++; s_gen++; ++st_relax;
-          const u32 nc = P.stage_cls[P.pod_stage_off[pod] + S.pod_stage[pod]];
+          S.pod_stage[pod] = stg + 1;
+          const u32 nc = P.stage_cls[P.pod_stage_off[pod] + stg + 1];
           for (u32 i = P.cls_own_off[nc]; i < P.cls_own_off[nc + 1]; ++i) S.g_active[P.own_list[i] & 0x7FFFFFFFu] = 1;   // Topology.Update creates the group
-        } else { S.lastlen[pod] = s_len; S.lastgen[pod] = s_gen; }
+        } else { S.lastlen[pod] = q_len; S.lastgen[pod] = q_gen; }
       }
-      __threadfence_block();
-      __syncthreads();
+      if (relaxed) { q_gen++; ++st_relax; }
+      WSYNC();
     }
   }
 
   // ---------------- results ----------------
-  __syncthreads();
-  for (u32 i = tid; i < s_len; i += KS_NT) { u32 idx = s_head + i; if (idx >= P.P) idx -= P.P; S.unscheduled[i] = (i32)S.q[idx]; }
-  if (tid == 0) {
-    S.out_counts[0] = s_nnew; S.out_counts[1] = s_len;
+  WSYNC();
+  for (u32 i = lane; i < q_len; i += 64) { u32 idx = q_head + i; if (idx >= P.P) idx -= P.P; S.unscheduled[i] = (i32)S.q[idx]; }
+  for (u32 j = lane; j < nnew; j += 64) {        // de-interleave the new nodes' records into the SoA result arrays
+    const Rec r = slot_rec(P, S, P.E + j);
+    S.o_present[j] = r.present(); S.o_complement[j] = r.complement(); S.o_it[j] = r.it_state(); S.o_reqmask[j] = r.reqmask();
+    for (u32 k = 0; k < P.K; ++k) { S.o_mask[(size_t)j * P.K + k] = r.mask()[k]; S.o_gt[(size_t)j * P.K + k] = r.gt()[k]; S.o_lt[(size_t)j * P.K + k] = r.lt()[k]; }
+    for (u32 rr = 0; rr < P.R; ++rr) S.o_req[(size_t)j * P.R + rr] = r.req()[rr];
+  }
+  if (lane == 0) {
+    S.out_counts[0] = nnew; S.out_counts[1] = q_len;
     S.stats[KS_STAT_POPS] = st_pops; S.stats[KS_STAT_RELAX] = st_relax; S.stats[KS_STAT_FULLCHECKS] = st_full; S.stats[KS_STAT_FULLFAILS] = st_fullfail;
     S.stats[KS_STAT_REF_ATTEMPTS] = st_ref_attempts; S.stats[KS_STAT_REF_TYPES] = st_ref_types;
-    S.stats[KS_STAT_CYCLES] = __builtin_readcyclecounter() - t_start; S.stats[KS_STAT_ERR] = s_err;
+    S.stats[KS_STAT_CYCLES] = __builtin_readcyclecounter() - t_start; S.stats[KS_STAT_ERR] = err;
   }
 }
 
@@ -950,11 +982,15 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   // state
   DevState& s = d->hs; const size_t NS = (size_t)E + h.NMAX;
   TRY(dev_alloc(d, P, &s.q)); TRY(dev_alloc(d, P, &s.lastlen)); TRY(dev_alloc(d, P, &s.lastgen)); TRY(dev_alloc(d, P, &s.pod_stage)); TRY(dev_alloc(d, P, &s.pod_node)); TRY(dev_alloc(d, P, &s.pod_seq));
-  TRY(dev_alloc(d, NS, &s.s_present)); TRY(dev_alloc(d, NS, &s.s_complement)); TRY(dev_alloc(d, NS * K, &s.s_mask)); TRY(dev_alloc(d, NS * K, &s.s_gt)); TRY(dev_alloc(d, NS * K, &s.s_lt)); TRY(dev_alloc(d, NS, &s.s_it));
-  TRY(dev_alloc(d, NS * R, &s.s_req)); TRY(dev_alloc(d, NS, &s.s_reqmask)); TRY(dev_alloc(d, NS * R, &s.s_cap)); TRY(dev_alloc(d, NS, &s.s_taints)); TRY(dev_alloc(d, NS, &s.s_porthead));
-  TRY(dev_alloc(d, (size_t)h.NMAX, &s.n_tmpl)); TRY(dev_alloc(d, (size_t)h.NMAX, &s.n_count)); TRY(dev_alloc(d, (size_t)h.NMAX, &s.n_key)); TRY(dev_alloc(d, ((size_t)h.NMAX + 1) * TW, &s.n_alive));
+  s.rec_stride = ks_rec_stride(R, K);
+  TRY(dev_alloc(d, NS * s.rec_stride, &s.rec, 0));
+  TRY(dev_alloc(d, (size_t)h.NMAX, &s.n_tmpl)); TRY(dev_alloc(d, ((size_t)h.NMAX + 1) * TW, &s.n_alive));
+  TRY(dev_alloc(d, (size_t)P + 4, &s.bstart, 0)); TRY(dev_alloc(d, (size_t)h.NMAX, &s.order_g));
   TRY(dev_alloc(d, (size_t)G * 64, &s.gcnt)); TRY(dev_alloc(d, G, &s.g_reg)); TRY(dev_alloc(d, G, &s.g_pos)); TRY(dev_alloc(d, G, &s.g_active));
   TRY(dev_alloc(d, (size_t)p->GH * NS, &s.hcnt, 0xFF)); TRY(dev_alloc(d, p->GH, &s.g_hpos)); TRY(dev_alloc(d, (size_t)M * R, &s.remaining));
+  const size_t NM = h.NMAX;
+  TRY(dev_alloc(d, NM, &s.o_present)); TRY(dev_alloc(d, NM, &s.o_complement)); TRY(dev_alloc(d, NM * K, &s.o_mask)); TRY(dev_alloc(d, NM * K, &s.o_gt)); TRY(dev_alloc(d, NM * K, &s.o_lt));
+  TRY(dev_alloc(d, NM, &s.o_it)); TRY(dev_alloc(d, NM * R, &s.o_req)); TRY(dev_alloc(d, NM, &s.o_reqmask));
   // host-port pool: existing entries + one batch-worth of pod ports (max over stages)
   size_t pool = E ? p->en_port_off[E] : 0;
   for (u32 i = 0; i < P; ++i) { u32 mx = 0; for (u32 st = p->pod_stage_off[i]; st < p->pod_stage_off[i + 1]; ++st) { const u32 c = p->stage_cls[st]; const u32 n = p->cls_port_off[c + 1] - p->cls_port_off[c]; if (n > mx) mx = n; } pool += mx; }
@@ -1003,7 +1039,7 @@ static int download(ks_dev_problem* d, ks_result* out) {
   HIPCHK(hipMemcpy(out->stats, s.stats, 16 * sizeof(u64), hipMemcpyDeviceToHost));
   out->n_new = counts[0]; out->n_unscheduled = counts[1];
   if (out->stats[KS_STAT_ERR]) return fail(-(int)out->stats[KS_STAT_ERR], "device-side error (more new nodes than max_new_nodes?)");
-  const u32 P = h.P, K = h.K, R = h.R, TW = h.TW, E = h.E, N = out->n_new;
+  const u32 P = h.P, K = h.K, R = h.R, TW = h.TW, N = out->n_new;
   if (P) {
     HIPCHK(hipMemcpy(out->pod_node, s.pod_node, P * sizeof(i32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out->pod_stage, s.pod_stage, P * sizeof(i32), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out->pod_seq, s.pod_seq, P * sizeof(i32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out->unscheduled, s.unscheduled, P * sizeof(i32), hipMemcpyDeviceToHost));
@@ -1011,12 +1047,12 @@ static int download(ks_dev_problem* d, ks_result* out) {
   if (N) {
     HIPCHK(hipMemcpy(out->node_tmpl, s.n_tmpl, N * sizeof(i32), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out->node_types, s.n_alive, (size_t)N * TW * sizeof(u64), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out->node_requests, s.s_req + (size_t)E * R, (size_t)N * R * sizeof(i64), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out->node_requests_present, s.s_reqmask + E, N * sizeof(u32), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out->node_present, s.s_present + E, N * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out->node_complement, s.s_complement + E, N * sizeof(u32), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out->node_mask, s.s_mask + (size_t)E * K, (size_t)N * K * sizeof(u64), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out->node_gt, s.s_gt + (size_t)E * K, (size_t)N * K * sizeof(i32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out->node_lt, s.s_lt + (size_t)E * K, (size_t)N * K * sizeof(i32), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(out->node_it_state, s.s_it + E, N * sizeof(i32), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out->node_requests, s.o_req, (size_t)N * R * sizeof(i64), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out->node_requests_present, s.o_reqmask, N * sizeof(u32), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out->node_present, s.o_present, N * sizeof(u32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out->node_complement, s.o_complement, N * sizeof(u32), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out->node_mask, s.o_mask, (size_t)N * K * sizeof(u64), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out->node_gt, s.o_gt, (size_t)N * K * sizeof(i32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out->node_lt, s.o_lt, (size_t)N * K * sizeof(i32), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out->node_it_state, s.o_it, N * sizeof(i32), hipMemcpyDeviceToHost));
   }
   return KS_OK;
 }
@@ -1038,7 +1074,12 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   hipStream_t st = ds[0]->stream;
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, st));
-  hipLaunchKernelGGL(ks_pack, dim3(n), dim3(KS_NT), 0, st, dp, dsv);
+  // dynamic LDS: Allocatable table + visiting-order array.  One Solve gets most of the CU's 160 KiB;
+  // batched what-ifs take 64 KiB each so two workgroups share a CU.
+  const u32 lds_bytes = n == 1 ? 144u * 1024u : 64u * 1024u;
+  static bool attr_set = false;
+  if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)ks_pack, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+  hipLaunchKernelGGL(ks_pack, dim3(n), dim3(64), lds_bytes, st, dp, dsv, lds_bytes);
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());

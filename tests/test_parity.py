@@ -117,3 +117,31 @@ def test_properties_at_scale_config3():
         # hostname anti-affinity: at most one pod per my-affininity value on a node
         vals = [pr.pods[i].labels.get("my-affininity") for i in n.pods if pr.pods[i].anti_required]
         assert len(vals) == len(set(vals))
+
+
+@pytest.mark.parametrize("maker", [lambda: W.config1(pods=500, types=20, seed=3), lambda: W.config2(pods=800, sizes=6, seed=4),
+                                    lambda: W.config3(pods=1400, sizes=8, seed=5)])
+def test_reference_work_counters_match_oracle(maker):
+    """KS_FLAG_STATS: the kernel's count of Node.Add calls / instance types the REFERENCE algorithm would
+    scan (the roofline's algorithmic-bytes basis) equals the oracle's own counters."""
+    pr = maker()
+    want = O.solve(pr)
+    got = S.solve_problem(pr, stats=True)
+    assert got.canonical() == want.canonical()
+    assert got.stats["queue_pops"] == want.stats["queue_pops"]
+    assert got.stats["attempts"] == want.stats["attempts"]
+    assert got.stats["types_scanned"] == want.stats["types_scanned"]
+
+
+@pytest.mark.parametrize("case", ["config1_1k_50", "config2_10k_500", "config3_100k_2k"])
+def test_full_size_configs_match_oracle_fingerprint(case):
+    """BASELINE.json's full sizes: the sha256 of the canonical result equals the fingerprint the CPU oracle
+    produced offline (tests/golden/make_config_hashes.py; ~2 minutes of oracle time for the 100k case)."""
+    import hashlib
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config_hashes.json")))[case]
+    pr = {"config1_1k_50": W.config1, "config2_10k_500": W.config2, "config3_100k_2k": W.config3}[case]()
+    res = S.solve_problem(pr)
+    assert len(res.new_nodes) == gold["new_nodes"] and len(res.unscheduled) == gold["unscheduled"]
+    assert hashlib.sha256(json.dumps(res.canonical(), sort_keys=True).encode()).hexdigest() == gold["sha256"]
