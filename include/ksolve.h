@@ -186,7 +186,7 @@ typedef struct ks_result {
   int32_t* node_lt;        /* [max_new_nodes*K] */
   int32_t* node_it_state;  /* [max_new_nodes] */
   /* counters */
-  uint64_t stats[16];      /* KS_STAT_* */
+  uint64_t stats[32];      /* KS_STAT_*; [8..31] are per-phase cycle counters of the pack kernel (tools/phase_profile.py) */
 } ks_result;
 
 enum {

@@ -24,6 +24,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -32,9 +33,11 @@
 #include "ks_algebra.h"
 
 #define KS_MAX_TOPO 24       // topology groups evaluated per pod class
-#define KS_MAX_TOUCH 12      // distinct narrow keys a class may touch (own requirements + topology keys)
+#define KS_MAX_TOUCH 12      // distinct narrow keys a class may touch (own requirements + topology + recorded keys)
 
-typedef uint64_t u64; typedef uint32_t u32; typedef int64_t i64; typedef int32_t i32; typedef uint8_t u8;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define GA __attribute__((address_space(1)))   /* global address space: loads become global_load, not flat_load */
+typedef uint64_t u64; typedef uint32_t u32; typedef uint16_t u16; typedef int64_t i64; typedef int32_t i32; typedef uint8_t u8;
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -65,6 +68,10 @@ struct DevProb {
   u64* cmplx_types;  // [K*TW]    types lacking key k or with a complement requirement on k
   u64* nidnex_types; // [K*TW]    types lacking key k or with operator in {NotIn, DoesNotExist} on k
   u64* pair_types;   // [64*TW]   types with an available offering for (zone,capacity-type) pair
+  i64* ge_vals;      // [R*T]     ascending distinct Allocatable values of resource r (ge_cnt[r] of them)
+  u32* ge_cnt;       // [R]
+  u64* ge_rows;      // [(r*T+i)*TW] types whose Allocatable[r] >= ge_vals[r*T+i]   (resources.Fits as a mask)
+  void* plans;       // [C] ClsPlan: per-class plan records (ks_build_plans)
   u8* mc_ok;         // [M*C]
   u32* mc_present; u32* mc_complement; u64* mc_mask; i32* mc_gt; i32* mc_lt; i32* mc_it;   // template ∩ class
   u64* grid;         // [M*C*TW]
@@ -133,6 +140,25 @@ __global__ __launch_bounds__(256) void ks_build_type_tables(DevProb P) {
       if (valid) bit = (P.it_offer[t] >> pair) & 1ull;
       u64 m = ballot64(bit); if (lane == 0) P.pair_types[(size_t)pair * P.TW + w] = m;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ks_build_ge_rows: one wave per (resource r, distinct value i): the T-bit mask of instance types whose
+// Allocatable()[r] >= value.  resources.Fits(requests, allocatable) (resources.go:138-145) for a whole
+// catalogue then is the AND of one row per requested resource.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ks_build_ge_rows(DevProb P) {
+  const int lane = threadIdx.x & 63;
+  const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wave >= P.R * P.T) return;
+  const u32 r = wave / P.T, i = wave % P.T;
+  if (i >= P.ge_cnt[r]) return;
+  const i64 v = P.ge_vals[(size_t)r * P.T + i];
+  for (u32 w = 0; w < P.TW; ++w) {
+    const u32 t = w * 64 + lane;
+    const bool bit = t < P.T && P.it_alloc[(size_t)r * P.T + t] >= v;
+    const u64 m = ballot64(bit); if (lane == 0) P.ge_rows[(size_t)wave * P.TW + w] = m;
   }
 }
 
@@ -239,22 +265,128 @@ __global__ __launch_bounds__(256) void ks_grid_types(DevProb P, u32 chunks) {
 //   * per step the wave takes the next 64 nodes in that order, one lane per node, evaluates
 //     Node.Add up to the instance-type filter in registers, and __ballot + count-trailing-zeros IS the
 //     first-fit pick (the reference's "first node whose Add succeeds");
-//   * the instance-type filter runs on T-bit masks (one 64-bit word per lane, then one type per lane
-//     for resources.Fits), and the commit is a handful of lane-parallel stores.
-// Node state is an array of fixed-stride records (AoS: a lane touches one or two cache lines per
-// candidate); instance-type allocatable vectors and the visiting order live in LDS.
+//   * the instance-type filter runs on T-bit masks (one 64-bit word per lane; resources.Fits is one
+//     precomputed row per requested resource), and the commit is a handful of lane-parallel stores.
+// Latency, not bandwidth, bounds this kernel, so the data layout is built to make every per-pod load
+// independent: the pod's class is ONE pre-built plan record (a single coalesced load), a node is one
+// fixed-stride record (a lane touches one or two cache lines per candidate), and everything small and
+// hot (topology counters, key tables, sorted Allocatable values, the visiting order) lives in LDS.
 // ------------------------------------------------------------------------------------------------
-struct TopoItem {
-  i32 g; i32 key; i32 hslot; i32 maxskew; i32 minc; u8 type; u8 self; u8 inverse; u8 pod_has; u64 PD; u64 reg; u64 pos;
+#define KS_MAX_HOST 3
+#define KS_MAX_REC 24
+#define KS_BST_LDS 1024
+#define KS_FAST_G 64        // FAST variant: topology groups (and hostname groups) whose counters live in LDS
+#define KS_FAST_S 16        // FAST variant: instance-type-key states
+#define KS_FAST_RT 6144     // FAST variant: R*T sorted Allocatable values in LDS (48 KiB)
+
+struct PlanTouch {   // one narrow key the class touches: its own requirement (if any) and the topology items on that key
+  u64 mask; i32 gt, lt; i32 key; u8 own; u8 complement; u8 topo_begin, topo_end;
 };
-struct ClsL {      // the popped pod's class, staged in LDS once per pod
-  u32 c; u32 present, complement; i32 it_state; u32 hn_mode, hn_off, hn_cnt;
+struct PlanTopo {    // static part of one matching topology group (getMatchingTopologies, topology.go:351-364)
+  u64 PD;            // podDomains.Has(value) over the key's universe
+  i32 g; i32 maxskew; u8 type; u8 self; u8 pod_has; u8 hslot; u32 pad;
+};
+struct PlanRec { i32 g; i32 key; u8 type; u8 owned_inverse; u16 hslot; };   // one group Topology.Record must visit
+struct alignas(16) ClsPlan {
+  u32 c, present, complement; i32 it_state;
+  u32 hn_mode, hn_off, hn_cnt, reqmask;
+  u64 tol; u32 port_off, port_cnt;
+  u32 ntouch, ntopo, nhost, nrec;
+  i64 req[KS_MAX_RES];
+  PlanTouch touch[KS_MAX_TOUCH];
+  PlanTopo topo[KS_MAX_TOPO];        // narrow-key items, grouped by touch entry
+  PlanTopo host[KS_MAX_HOST];        // hostname-key items
+  PlanRec rec[KS_MAX_REC];
+  u32 overflow; u32 pad[3];
+};
+static_assert(sizeof(ClsPlan) % 16 == 0, "plan records are copied with 16-byte loads");
+
+// ------------------------------------------------------------------------------------------------
+// ks_build_plans: one thread per pod class; everything about a class that does not depend on the
+// Solve state is resolved here once (host/encode.cpp produced the CSR lists).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ks_build_plans(DevProb P, ClsPlan* plans) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= P.C) return;
+  ClsPlan pl; memset(&pl, 0, sizeof pl);
+  pl.c = c; pl.present = P.cls.present[c]; pl.complement = P.cls.complement[c]; pl.it_state = P.cls.it_state[c];
+  pl.hn_mode = P.cls_hn_mode[c]; pl.hn_off = P.cls_hn_off[c]; pl.hn_cnt = P.cls_hn_off[c + 1] - P.cls_hn_off[c];
+  pl.reqmask = P.cls_requests_present[c]; pl.tol = P.cls_tolerated[c]; pl.port_off = P.cls_port_off[c]; pl.port_cnt = P.cls_port_off[c + 1] - P.cls_port_off[c];
+  for (u32 r = 0; r < P.R; ++r) pl.req[r] = P.cls_requests[(size_t)c * P.R + r];
+  // own requirement keys, ascending
+  for (u32 k = 0; k < P.K; ++k) if ((pl.present >> k) & 1u) {
+    if (pl.ntouch >= KS_MAX_TOUCH) { pl.overflow = 1; break; }
+    PlanTouch& t = pl.touch[pl.ntouch++]; t.key = (i32)k; t.own = 1; t.complement = (pl.complement >> k) & 1u;
+    t.mask = P.cls.mask[(size_t)c * P.K + k]; t.gt = P.cls.gt[(size_t)c * P.K + k]; t.lt = P.cls.lt[(size_t)c * P.K + k];
+  }
+  // matching topology groups: owned first, then inverse groups selecting the pod
+  struct Tmp { PlanTopo it; int tidx; } tmp[KS_MAX_TOPO]; int ntmp = 0;
+  const u32 ob = P.cls_own_off[c], oe = P.cls_own_off[c + 1], ib = P.cls_isel_off[c], ie = P.cls_isel_off[c + 1];
+  for (u32 i = 0; i < (oe - ob) + (ie - ib); ++i) {
+    const u32 ent = i < oe - ob ? P.own_list[ob + i] : P.isel_list[ib + (i - (oe - ob))];
+    PlanTopo it; it.g = (i32)(ent & 0x7FFFFFFFu); it.self = ent >> 31; it.type = P.grp_type[it.g]; it.maxskew = P.grp_max_skew[it.g]; it.pod_has = 0; it.PD = ~0ull; it.hslot = 0; it.pad = 0;
+    const i32 k = P.grp_key[it.g];
+    if (k == KS_KEY_HOSTNAME) {
+      if (pl.nhost >= KS_MAX_HOST) { pl.overflow = 1; continue; }
+      it.hslot = (u8)P.grp_hslot[it.g]; pl.host[pl.nhost++] = it; continue;
+    }
+    KReq pd = kreq_exists();
+    if ((pl.present >> k) & 1u) { pd = load_req(pl.present, pl.complement, P.cls.mask + (size_t)c * P.K, P.cls.gt + (size_t)c * P.K, P.cls.lt + (size_t)c * P.K, k); it.pod_has = 1; }
+    it.PD = kreq_has_mask(pd, P.value_int + k * 64, P.key_nvalues[k]);
+    int ti = -1; for (u32 j = 0; j < pl.ntouch; ++j) if (pl.touch[j].key == k) { ti = (int)j; break; }
+    if (ti < 0) { if (pl.ntouch >= KS_MAX_TOUCH) { pl.overflow = 1; continue; } ti = (int)pl.ntouch; PlanTouch& t = pl.touch[pl.ntouch++]; t.key = k; t.own = 0; t.complement = 0; t.mask = 0; t.gt = KS_NOGT; t.lt = KS_NOLT; }
+    if (ntmp >= KS_MAX_TOPO) { pl.overflow = 1; continue; }
+    tmp[ntmp].it = it; tmp[ntmp].tidx = ti; ++ntmp;
+  }
+  for (u32 j = 0; j < pl.ntouch; ++j) {   // group the narrow items by touch entry (order inside an entry is irrelevant: the In-sets intersect)
+    pl.touch[j].topo_begin = (u8)pl.ntopo;
+    for (int i = 0; i < ntmp; ++i) if (tmp[i].tidx == (int)j) pl.topo[pl.ntopo++] = tmp[i].it;
+    pl.touch[j].topo_end = (u8)pl.ntopo;
+  }
+  // groups Topology.Record visits: non-inverse groups selecting the pod, then inverse groups it owns
+  const u32 sb = P.cls_sel_off[c], se = P.cls_sel_off[c + 1], wb = P.cls_iown_off[c], we = P.cls_iown_off[c + 1];
+  for (u32 i = 0; i < (se - sb) + (we - wb); ++i) {
+    if (pl.nrec >= KS_MAX_REC) { pl.overflow = 1; break; }
+    PlanRec& r = pl.rec[pl.nrec++];
+    const bool inv = i >= se - sb;
+    r.g = (i32)(inv ? P.iown_list[wb + (i - (se - sb))] : P.sel_list[sb + i]);
+    r.key = P.grp_key[r.g]; r.type = P.grp_type[r.g]; r.owned_inverse = inv ? 1 : 0; r.hslot = (u16)(P.grp_hslot[r.g] >= 0 ? P.grp_hslot[r.g] : 0);
+    if (r.key >= 0 && pl.ntouch < KS_MAX_TOUCH) {   // gather the recorded key with the rest so Topology.Record needs no extra loads
+      bool seen = false; for (u32 j = 0; j < pl.ntouch; ++j) if (pl.touch[j].key == r.key) seen = true;
+      if (!seen) { PlanTouch& t = pl.touch[pl.ntouch]; t.key = r.key; t.own = 0; t.complement = 0; t.mask = 0; t.gt = KS_NOGT; t.lt = KS_NOLT; t.topo_begin = t.topo_end = (u8)pl.ntopo; ++pl.ntouch; }
+    }
+  }
+  plans[c] = pl;
+}
+
+// Hot, small tables and scalars of one Solve, held in registers.  In the FAST kernel variant every
+// pointer below derives directly from a __shared__ array, so the compiler emits ds_read/ds_write for
+// them (a generic pointer loaded from memory would become a FLAT access, and every FLAT access waits on
+// vmcnt(0) AND lgkmcnt(0), serialising all outstanding global loads).
+struct Tabs {
+  const u32* key_nvalues; const i32* value_int; const u8* its_fail; const u8* its_inter;
+  i32* gcnt; u64* g_reg; u64* g_pos; u8* g_active; i32* g_hpos;
+  const i64* ge_vals; const u32* ge_cnt;
+  u32 K, R, T, TW, GH, E, S, n_ct, wellknown; i32 key_zone, key_ct;
+  // hot global arrays, typed with the global address space (pointers loaded from a descriptor in memory
+  // would otherwise be generic and every access a FLAT instruction)
+  GA u32* q; GA u32* lastgen; GA u32* lastlen; GA i32* pod_stage; GA i32* pod_node; GA i32* pod_seq;
+  const GA u32* stage_cls; const GA u32* pod_stage_off; const GA u32* grp_filter_off;
+  GA u8* rec; u32 rec_stride; GA i32* hcnt; GA u64* n_alive;
+  const GA u64* ge_rows; const GA u64* kv_types; const GA u64* cmplx_types; const GA u64* nidnex_types; const GA u64* pair_types; const GA u64* its_types; const GA u64* grid;
+};
+
+struct ReqOut {    // requirement set of the winning node after the pod is added (entries in `valid` only)
+  u32 present, complement; i32 it_state; u32 changed; u32 topo_narrowed; u32 valid; u32 rm; u32 count; i32 it_before; u32 pad[3];
   u64 mask[KS_MAX_KEYS]; i32 gt[KS_MAX_KEYS]; i32 lt[KS_MAX_KEYS];
-  i64 req[KS_MAX_RES]; u32 reqmask; u64 tol; u32 port_off, port_cnt;
-  int ntopo; TopoItem topo[KS_MAX_TOPO];
 };
-struct ReqOut {    // requirement set of the winning node after the pod is added (written by the winning lane)
-  u32 present, complement; i32 it_state; u64 mask[KS_MAX_KEYS]; i32 gt[KS_MAX_KEYS]; i32 lt[KS_MAX_KEYS]; u32 changed; u32 topo_narrowed;
+struct TopoDyn { u64 reg, pos; i32 minc; i32 pad; };
+struct alignas(16) WaveShared {
+  ClsPlan cls; ReqOut rq;
+  TopoDyn dyn[KS_MAX_TOPO]; i32 host_anypos[KS_MAX_HOST];
+  i64 req_new[KS_MAX_RES];
+  u32 bstart[KS_BST_LDS];
+  u64 la_mask[KS_MAX_TOUCH][64]; i32 la_gt[KS_MAX_TOUCH][64]; i32 la_lt[KS_MAX_TOUCH][64];   // per-lane requirement slots of eval_node
 };
 
 // ---- slot record (AoS).  Offsets in bytes; stride = ks_rec_stride(R,K) ----
@@ -262,42 +394,27 @@ struct ReqOut {    // requirement set of the winning node after the pod is added
 //   32 i64 req[R] | 32+8R i64 cap[R] | 32+16R u64 mask[K] | +8K i32 gt[K] | +4K i32 lt[K]
 __host__ __device__ inline u32 ks_rec_stride(u32 R, u32 K) { return (32 + 16 * R + 16 * K + 15) & ~15u; }
 struct Rec {
-  u8* p; u32 R, K;
-  __device__ __forceinline__ u64& taints() const { return *(u64*)p; }
-  __device__ __forceinline__ u32& present() const { return *(u32*)(p + 8); }
-  __device__ __forceinline__ u32& complement() const { return *(u32*)(p + 12); }
-  __device__ __forceinline__ i32& it_state() const { return *(i32*)(p + 16); }
-  __device__ __forceinline__ u32& reqmask() const { return *(u32*)(p + 20); }
-  __device__ __forceinline__ i32& porthead() const { return *(i32*)(p + 24); }
-  __device__ __forceinline__ u32& count() const { return *(u32*)(p + 28); }
-  __device__ __forceinline__ i64* req() const { return (i64*)(p + 32); }
-  __device__ __forceinline__ i64* cap() const { return (i64*)(p + 32 + 8 * R); }
-  __device__ __forceinline__ u64* mask() const { return (u64*)(p + 32 + 16 * R); }
-  __device__ __forceinline__ i32* gt() const { return (i32*)(p + 32 + 16 * R + 8 * K); }
-  __device__ __forceinline__ i32* lt() const { return (i32*)(p + 32 + 16 * R + 12 * K); }
+  GA u8* p; u32 R, K;
+  __device__ __forceinline__ GA u64& taints() const { return *(GA u64*)p; }
+  __device__ __forceinline__ GA u32& present() const { return *(GA u32*)(p + 8); }
+  __device__ __forceinline__ GA u32& complement() const { return *(GA u32*)(p + 12); }
+  __device__ __forceinline__ GA i32& it_state() const { return *(GA i32*)(p + 16); }
+  __device__ __forceinline__ GA u32& reqmask() const { return *(GA u32*)(p + 20); }
+  __device__ __forceinline__ GA i32& porthead() const { return *(GA i32*)(p + 24); }
+  __device__ __forceinline__ GA u32& count() const { return *(GA u32*)(p + 28); }
+  __device__ __forceinline__ GA i64* req() const { return (GA i64*)(p + 32); }
+  __device__ __forceinline__ GA i64* cap() const { return (GA i64*)(p + 32 + 8 * R); }
+  __device__ __forceinline__ GA u64* mask() const { return (GA u64*)(p + 32 + 16 * R); }
+  __device__ __forceinline__ GA i32* gt() const { return (GA i32*)(p + 32 + 16 * R + 8 * K); }
+  __device__ __forceinline__ GA i32* lt() const { return (GA i32*)(p + 32 + 16 * R + 12 * K); }
 };
-__device__ __forceinline__ Rec slot_rec(const DevProb& P, const DevState& S, u32 s) { Rec r; r.p = S.rec + (size_t)s * S.rec_stride; r.R = P.R; r.K = P.K; return r; }
-
-struct NodeView {  // where a candidate node's state lives (an open slot, or a template∩class record for a fresh node)
-  u32 present, complement; i32 it_state; const u64* mask; const i32* gt; const i32* lt;
-  u64 taints; i32 porthead; const i64* req; u32 reqmask; const i64* cap; i32 slot; bool existing; bool fresh;
-};
-__device__ __forceinline__ NodeView slot_view(const DevProb& P, const DevState& S, u32 s) {
-  const Rec r = slot_rec(P, S, s);
-  NodeView v; v.present = r.present(); v.complement = r.complement(); v.it_state = r.it_state();
-  v.mask = r.mask(); v.gt = r.gt(); v.lt = r.lt(); v.taints = r.taints(); v.porthead = r.porthead(); v.req = r.req(); v.reqmask = r.reqmask();
-  v.cap = r.cap(); v.slot = (i32)s; v.existing = s < P.E; v.fresh = false; return v;
-}
-
-__device__ __forceinline__ bool cls_allows_hostname(const DevProb& P, const ClsL& c, const NodeView& v) {
-  if (c.hn_mode == 0) return true;
-  bool inlist = false;
-  if (v.existing) for (u32 i = 0; i < c.hn_cnt; ++i) if (P.hn_list[c.hn_off + i] == (u32)v.slot) { inlist = true; break; }
-  return c.hn_mode == 1 ? inlist : !inlist;
+__device__ __forceinline__ Rec slot_rec(const DevState& S, const Tabs& tb, u32 s) { Rec r; r.p = tb.rec + (size_t)s * tb.rec_stride; r.R = tb.R; r.K = tb.K; return r; }
+__device__ __forceinline__ KReq rec_req(const Rec& r, u32 present, u32 complement, int k) {
+  KReq q; q.present = (present >> k) & 1u; q.complement = (complement >> k) & 1u; q.mask = r.mask()[k]; q.gt = r.gt()[k]; q.lt = r.lt()[k]; return q;
 }
 
 // HostPortUsage.validate, hostportusage.go:81-93 / entry.matches :45-57
-__device__ __forceinline__ bool ports_conflict(const DevProb& P, const DevState& S, const ClsL& c, i32 head) {
+__device__ __forceinline__ bool ports_conflict(const DevProb& P, const DevState& S, const ClsPlan& c, i32 head) {
   for (u32 i = 0; i < c.port_cnt; ++i) {
     const u64 a = P.ports[c.port_off + i];
     for (i32 e = head; e >= 0; e = S.pp_next[e]) {
@@ -310,546 +427,609 @@ __device__ __forceinline__ bool ports_conflict(const DevProb& P, const DevState&
   return false;
 }
 
-// One attempt of Node.Add / ExistingNode.Add up to (not including) the instance-type filter.
-// Returns 0: fails before the filter; 1: reaches the filter but fails the resource screen;
-// 2: passes everything evaluated here.  With `out` != nullptr also writes the node's requirement set
-// after Add (nodeRequirements after :80 and :90 of node.go / :105 and :115 of existingnode.go).
-// `merged`: the pod's own requirements are already folded into the view (fresh node built from the
-// template∩class record), only topology is evaluated on top.
-__device__ int eval_node(const DevProb& P, const DevState& S, const ClsL& c, const NodeView& v, ReqOut* out, bool merged = false) {
-  // Taints.Tolerates, taints.go:28-40
-  if (v.taints & ~c.tol) return 0;
-  // hostname requirement of the pod against the node's `hostname In [own]`
-  if (!merged && !cls_allows_hostname(P, c, v)) return 0;
-  // HostPortUsage.Validate
-  if (c.port_cnt && v.porthead >= 0 && ports_conflict(P, S, c, v.porthead)) return 0;
-  // ExistingNode: resources.Fits(requests, available), existingnode.go:99-103 (exact, final)
-  if (v.existing) {
-    const u32 rp = v.reqmask | c.reqmask;
-    for (u32 r = 0; r < P.R; ++r) if ((rp >> r) & 1u) { if (v.req[r] + c.req[r] > v.cap[r]) return 0; }
-  }
-  // Compatible + Add on the pod's keys
-  int nt = 0; i32 tkey[KS_MAX_TOUCH]; KReq treq[KS_MAX_TOUCH];
-  for (u32 bits = merged ? 0u : c.present; bits; bits &= bits - 1) {
-    const int k = __builtin_ctz(bits);
-    KReq a = load_req(v.present, v.complement, v.mask, v.gt, v.lt, k);
-    KReq b = load_req(c.present, c.complement, c.mask, c.gt, c.lt, k);
-    const i32* vi = P.value_int + k * 64; const u32 nv = P.key_nvalues[k];
-    if (kreq_compatible_fail(a, b, (P.wellknown_mask >> k) & 1u, vi, nv)) return 0;
-    tkey[nt] = k; treq[nt] = kreq_add(a, b, vi, nv); ++nt;
-  }
-  i32 it_state = v.it_state;
-  if (c.it_state && !merged) { if (P.its_fail[v.it_state * P.S + c.it_state]) return 0; it_state = P.its_inter[v.it_state * P.S + c.it_state]; }
+__device__ __forceinline__ bool kreq_differs(const KReq& x, const KReq& y) { return x.present != y.present || x.mask != y.mask || x.complement != y.complement || x.gt != y.gt || x.lt != y.lt; }
 
-  // Topology.AddRequirements, topology.go:149-167, then Compatible + Add of the result (node.go:83-90)
-  u32 topo_keys = 0; bool host_ok = true;
-  u64 dom[KS_MAX_TOUCH]; u32 domset = 0;   // accumulated In-sets per touched entry
-  for (int i = 0; i < c.ntopo; ++i) {
-    const TopoItem& t = c.topo[i];
-    if (t.key == KS_KEY_HOSTNAME) {
-      i32 cnt;
-      if (v.fresh) cnt = S.g_active[t.g] ? 0 : -1;           // NewNode registers the placeholder first (node.go:47)
-      else cnt = S.hcnt[(size_t)v.slot * P.GH + t.hslot];
-      bool ok;
-      if (t.type == 0) ok = cnt >= 0 && (i64)cnt + t.self <= (i64)t.maxskew;                         // nextDomainTopologySpread, min==0 for hostname (topologygroup.go:184-188)
-      else if (t.type == 2) ok = cnt == 0;                                                            // nextDomainAntiAffinity :235-243
-      else { const bool anypos = S.g_hpos[t.hslot] > 0; ok = anypos ? (cnt > 0) : (t.self && cnt >= 0); }   // nextDomainAffinity :202-233
-      if (!ok) host_ok = false;
-      continue;
-    }
-    const int k = t.key; const i32* vi = P.value_int + k * 64; const u32 nv = P.key_nvalues[k];
-    // nodeDomains = nodeRequirements[key] (after adding the pod) or Exists
-    int e = -1; for (int j = 0; j < nt; ++j) if (tkey[j] == k) { e = j; break; }
-    KReq nodeD;
-    if (e >= 0) nodeD = treq[e];
-    else { nodeD = load_req(v.present, v.complement, v.mask, v.gt, v.lt, k); if (nt >= KS_MAX_TOUCH) return 0; e = nt; tkey[nt] = k; treq[nt] = nodeD; ++nt; }
-    KReq nd = nodeD.present ? nodeD : kreq_exists();
-    const u64 ND = kreq_has_mask(nd, vi, nv);
-    u64 options = 0;
-    if (t.type == 0) {                                        // spread
-      i32 best = INT32_MAX; int bestv = -1;
-      for (u64 bits = t.reg & ND; bits; bits &= bits - 1) {
-        const int d = __builtin_ctzll(bits);
-        i32 cnt = S.gcnt[(size_t)t.g * 64 + d] + t.self;
-        if ((i64)cnt - (i64)t.minc <= (i64)t.maxskew && cnt < best) { best = cnt; bestv = d; }
+// Result of evaluating one node for the current pod: scalars in registers, the per-key requirements in
+// per-lane LDS slots (sh.la_*[touch index][lane]) so the algebra below is ONE dynamic loop body instead
+// of an unrolled copy per key, and so every lane can read the winner's slots directly.
+struct Ev {
+  int rc;                       // 0: fails before the instance-type filter; 1: reaches it but fails the resource screen; 2: passes
+  u32 present, complement, count, reqmask; i32 it_state, it0;
+  u32 tpres, tcomp, tchg, tnar; // per touch index: requirement present / complement after Add; changed; narrowed by topology
+  i64 req[KS_MAX_RES];          // the node's current requests
+};
+
+// One attempt of Node.Add / ExistingNode.Add up to (not including) the instance-type filter
+// (node.go:62-90 / existingnode.go:77-115).  Every lane evaluates its own node.
+// `merged`: the pod's own requirements are already folded into the record (a fresh node materialised
+// from the template∩class record), only topology is evaluated on top.
+__device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, const Tabs& tb, WaveShared& sh, u32 slot, bool existing, bool merged, Ev& ev, int lane) {
+  const ClsPlan& c = sh.cls;
+  const Rec r = slot_rec(S, tb, slot);
+  ev.rc = 0; ev.tpres = 0; ev.tcomp = 0; ev.tchg = 0; ev.tnar = 0;
+  // ---- gather: header, requests/capacity, first touched key, hostname counters (independent loads) ----
+  const u32x4 h0 = *(const GA u32x4*)r.p, h1 = *(const GA u32x4*)(r.p + 16);
+  const u64 taints = (u64)h0.x | ((u64)h0.y << 32); const u32 present = h0.z, complement = h0.w;
+  const i32 it0 = (i32)h1.x; const u32 reqmask = h1.y; const i32 porthead = (i32)h1.z;
+  ev.present = present; ev.complement = complement; ev.it_state = it0; ev.it0 = it0; ev.reqmask = reqmask; ev.count = h1.w;
+  i64 cap[KS_MAX_RES];
+#pragma unroll
+  for (int i = 0; i < KS_MAX_RES; ++i) { ev.req[i] = 0; cap[i] = 0; if ((u32)i < tb.R) { ev.req[i] = r.req()[i]; cap[i] = r.cap()[i]; } }
+  const u32 ntouch = c.ntouch;
+  KReq nxt = kreq_absent();
+  if (ntouch) nxt = rec_req(r, present, complement, c.touch[0].key);
+  i32 hc0 = -1, hc1 = -1, hc2 = -1;
+  if (c.nhost > 0) hc0 = tb.hcnt[(size_t)slot * tb.GH + c.host[0].hslot];
+  if (c.nhost > 1) hc1 = tb.hcnt[(size_t)slot * tb.GH + c.host[1].hslot];
+  if (c.nhost > 2) hc2 = tb.hcnt[(size_t)slot * tb.GH + c.host[2].hslot];
+
+  // ---- Taints.Tolerates, taints.go:28-40 ----
+  if (taints & ~c.tol) return;
+  // ---- the pod's hostname requirement against the node's `hostname In [own]` ----
+  if (!merged && c.hn_mode != 0) {
+    bool inlist = false;
+    if (existing) for (u32 i = 0; i < c.hn_cnt; ++i) if (P.hn_list[c.hn_off + i] == slot) { inlist = true; break; }
+    if (c.hn_mode == 1 ? !inlist : inlist) return;
+  }
+  // ---- HostPortUsage.Validate ----
+  if (c.port_cnt && porthead >= 0 && ports_conflict(P, S, c, porthead)) return;
+  // ---- resources: exact for existing nodes (existingnode.go:99-103), a necessary screen for new ones ----
+  bool fit = true;
+#pragma unroll
+  for (int i = 0; i < KS_MAX_RES; ++i) if (((reqmask | c.reqmask) >> i) & 1u) { if (ev.req[i] + c.req[i] > cap[i]) fit = false; }
+  if (existing && !fit) return;
+  if (!merged && c.it_state) { if (tb.its_fail[it0 * tb.S + c.it_state]) return; ev.it_state = tb.its_inter[it0 * tb.S + c.it_state]; }
+  // ---- Topology.AddRequirements on hostname-keyed groups: the node's only hostname domain is its own ----
+  for (u32 i = 0; i < c.nhost; ++i) {
+    const PlanTopo& t = c.host[i]; const i32 cnt = i == 0 ? hc0 : (i == 1 ? hc1 : hc2); bool ok;
+    if (t.type == 0) ok = cnt >= 0 && (i64)cnt + t.self <= (i64)t.maxskew;                        // nextDomainTopologySpread, min==0 for hostname (topologygroup.go:184-188)
+    else if (t.type == 2) ok = cnt == 0;                                                           // nextDomainAntiAffinity :235-243
+    else ok = sh.host_anypos[i] ? (cnt > 0) : (t.self && cnt >= 0);                                // nextDomainAffinity :202-233
+    if (!ok) return;
+  }
+  // ---- per touched key: Compatible + Add of the pod's own requirement (requirements.go:123-133, :87-94; one
+  //      Intersection serves both), then Topology.AddRequirements (topology.go:149-167) and the Compatible + Add
+  //      of its result (node.go:83-90).  The next key's node requirement is loaded while this one is processed. ----
+  for (u32 i = 0; i < ntouch; ++i) {
+    const PlanTouch& t = c.touch[i]; const int k = t.key;
+    KReq a = nxt;
+    if (i + 1 < ntouch) nxt = rec_req(r, present, complement, c.touch[i + 1].key);
+    const KReq orig = a;
+    const i32* vi = tb.value_int + k * 64; const u32 nv = tb.key_nvalues[k];
+    if (t.own && !merged) {
+      KReq b; b.present = true; b.complement = t.complement; b.mask = t.mask; b.gt = t.gt; b.lt = t.lt;
+      if (!a.present) { if (!((tb.wellknown >> k) & 1u) && !kreq_nidne(b)) return; a = b; }     // "label does not have known values"
+      else {
+        const KReq mg = kreq_intersect(b, a, vi, nv);
+        if (kreq_len0(mg) && !(kreq_nidne(b) && kreq_nidne(a))) return;
+        a = mg;
       }
-      if (bestv >= 0) options = 1ull << bestv;
-    } else if (t.type == 1) {                                 // affinity
-      options = t.reg & t.PD & t.pos;
-      if (!options && t.self) {
-        KReq pd = kreq_exists();
-        if (t.pod_has) pd = load_req(c.present, c.complement, c.mask, c.gt, c.lt, k);
-        const u64 I = kreq_has_mask(kreq_intersect(pd, nd, vi, nv), vi, nv);
-        const u64 a = t.reg & I, b = t.reg & t.PD;
-        if (a) options |= a & (~a + 1);
-        if (b) options |= b & (~b + 1);
+    }
+    if (t.topo_end > t.topo_begin) {
+      const KReq before = a;
+      const KReq nd = before.present ? before : kreq_exists();
+      const u64 ND = kreq_has_mask(nd, vi, nv);
+      u64 dom = ~0ull;
+      for (int j = t.topo_begin; j < t.topo_end; ++j) {
+        const PlanTopo& tt = c.topo[j]; const TopoDyn& d = sh.dyn[j]; u64 options = 0;
+        if (tt.type == 0) {                                       // spread: nextDomainTopologySpread :155-182
+          i32 best = INT32_MAX; int bestv = -1;
+          for (u64 bits = d.reg & ND; bits; bits &= bits - 1) {
+            const int dd = __builtin_ctzll(bits);
+            const i32 cnt = tb.gcnt[(size_t)tt.g * 64 + dd] + tt.self;
+            if ((i64)cnt - (i64)d.minc <= (i64)tt.maxskew && cnt < best) { best = cnt; bestv = dd; }
+          }
+          if (bestv >= 0) options = 1ull << bestv;
+        } else if (tt.type == 1) {                                // affinity: nextDomainAffinity :202-233
+          options = d.reg & tt.PD & d.pos;
+          if (!options && tt.self) {
+            KReq pd = kreq_exists();
+            if (tt.pod_has) { pd.present = true; pd.complement = t.complement; pd.mask = t.mask; pd.gt = t.gt; pd.lt = t.lt; }
+            const u64 I = kreq_has_mask(kreq_intersect(pd, nd, vi, nv), vi, nv);
+            const u64 x = d.reg & I, y = d.reg & tt.PD;
+            if (x) options |= x & (~x + 1);
+            if (y) options |= y & (~y + 1);
+          }
+        } else options = d.reg & tt.PD & ~d.pos;                  // anti-affinity :235-243
+        if (!options) return;                                     // "unsatisfiable topology constraint"
+        dom &= options;
       }
-    } else {                                                  // anti-affinity
-      options = t.reg & t.PD & ~t.pos;
+      // nodeRequirements.Compatible(topologyRequirements) on this key: the topology requirement is
+      // node ∩ In[dom]; see DESIGN.md "topology compatibility" for the reduction used here.
+      const KReq in = kreq_in(dom);
+      if (!before.present) { if (!((tb.wellknown >> k) & 1u)) return; a = in; }
+      else { const KReq mg = kreq_intersect(in, before, vi, nv); if (kreq_len0(mg) && !kreq_nidne(before)) return; a = mg; }
+      if (kreq_differs(a, before)) ev.tnar |= 1u << i;
     }
-    if (!options) return 0;                                   // "unsatisfiable topology constraint"
-    if ((domset >> e) & 1u) dom[e] &= options; else { dom[e] = options; domset |= 1u << e; }
-    topo_keys |= 1u << e;
+    if (a.present) ev.tpres |= 1u << i;
+    if (a.complement) ev.tcomp |= 1u << i;
+    if (kreq_differs(a, orig)) ev.tchg |= 1u << i;
+    sh.la_mask[i][lane] = a.mask; sh.la_gt[i][lane] = a.gt; sh.la_lt[i][lane] = a.lt;
   }
-  if (!host_ok) return 0;
-  u32 narrowed = 0;
-  for (int e = 0; e < nt; ++e) if ((topo_keys >> e) & 1u) {
-    const int k = tkey[e]; const i32* vi = P.value_int + k * 64; const u32 nv = P.key_nvalues[k];
-    const KReq before = treq[e];
-    KReq in = kreq_in(dom[e]);
-    // nodeRequirements.Compatible(topologyRequirements) on this key: the topology requirement is
-    // node ∩ In[options]; see DESIGN.md "topology compatibility" for the reduction used here.
-    if (!before.present) {
-      if (!((P.wellknown_mask >> k) & 1u)) return 0;          // custom key the node does not define
-      treq[e] = in;
-    } else {
-      KReq merged_req = kreq_intersect(in, before, vi, nv);
-      if (kreq_len0(merged_req) && !kreq_nidne(before)) return 0;
-      treq[e] = merged_req;
-    }
-    if (treq[e].mask != before.mask || treq[e].complement != before.complement || treq[e].present != before.present) narrowed |= 1u << k;
+  ev.rc = fit ? 2 : 1;
+}
+
+// Publish the winning lane's evaluation (wave-uniform after the shuffles): the node's requirement set after
+// Add (sh.rq), the new request vector and the header values the commit needs.  All lanes call this.
+__device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, const Ev& ev, int win, int lane) {
+  const ClsPlan& c = sh.cls; ReqOut& o = sh.rq;
+  const u32 tpres = __shfl(ev.tpres, win), tcomp = __shfl(ev.tcomp, win), tchg = __shfl(ev.tchg, win), tnar = __shfl(ev.tnar, win);
+  u32 np = __shfl(ev.present, win), nc = __shfl(ev.complement, win), changed = 0, narrowed = 0, valid = 0;
+  for (u32 i = 0; i < c.ntouch; ++i) {
+    const int k = c.touch[i].key;
+    if ((tpres >> i) & 1u) { np |= 1u << k; nc = ((tcomp >> i) & 1u) ? (nc | (1u << k)) : (nc & ~(1u << k)); }
+    if ((tchg >> i) & 1u) changed |= 1u << k;
+    if ((tnar >> i) & 1u) narrowed |= 1u << k;
+    valid |= 1u << k;
+    if (lane == 0) { o.mask[k] = sh.la_mask[i][win]; o.gt[k] = sh.la_gt[i][win]; o.lt[k] = sh.la_lt[i][win]; }
   }
-  if (out) {
-    out->present = v.present; out->complement = v.complement; out->it_state = it_state; out->changed = 0; out->topo_narrowed = narrowed;
-    for (u32 k = 0; k < P.K; ++k) { out->mask[k] = v.mask[k]; out->gt[k] = v.gt[k]; out->lt[k] = v.lt[k]; }
-    for (int e = 0; e < nt; ++e) {
-      const int k = tkey[e]; const KReq& r = treq[e];
-      if (!r.present) continue;
-      const bool was = (v.present >> k) & 1u;
-      if (!was || r.mask != v.mask[k] || r.complement != (bool)((v.complement >> k) & 1u) || r.gt != v.gt[k] || r.lt != v.lt[k]) out->changed |= 1u << k;
-      out->present |= 1u << k; out->complement = r.complement ? (out->complement | (1u << k)) : (out->complement & ~(1u << k));
-      out->mask[k] = r.mask; out->gt[k] = r.gt; out->lt[k] = r.lt;
-    }
-  }
-  // new nodes: necessary resource screen against the per-resource maximum over the surviving types
-  if (!v.existing && !v.fresh) {
-    for (u32 bits = c.reqmask; bits; bits &= bits - 1) { const int r = __builtin_ctz(bits); if (v.req[r] + c.req[r] > v.cap[r]) return 1; }
-  }
-  return 2;
+  const u32 rm = __shfl(ev.reqmask, win) | c.reqmask; const u32 cnt = __shfl(ev.count, win);
+  const i32 its = __shfl(ev.it_state, win), it0 = __shfl(ev.it0, win);
+  if (lane == 0) { o.present = np; o.complement = nc; o.it_state = its; o.changed = changed; o.topo_narrowed = narrowed; o.valid = valid; o.rm = rm; o.count = cnt; o.it_before = it0; }
+#pragma unroll
+  for (int i = 0; i < KS_MAX_RES; ++i) if ((u32)i < tb.R) { const i64 v = __shfl(ev.req[i], win); if (lane == 0) sh.req_new[i] = v + c.req[i]; }
+}
+
+// The node's requirement on key k after the Add that is being committed (published entries, else the record).
+__device__ __forceinline__ KReq new_req(const WaveShared& sh, const Rec& r, int k) {
+  const ReqOut& o = sh.rq; KReq q; q.present = (o.present >> k) & 1u; q.complement = (o.complement >> k) & 1u;
+  if ((o.valid >> k) & 1u) { q.mask = o.mask[k]; q.gt = o.gt[k]; q.lt = o.lt[k]; } else { q.mask = r.mask()[k]; q.gt = r.gt()[k]; q.lt = r.lt()[k]; }
+  return q;
 }
 
 // T-bit mask word of the types that pass `instanceType.Requirements.Intersects` on key k against node
 // requirement B (derivation in DESIGN.md): types lacking the key always pass.
-__device__ __forceinline__ u64 pass_types_word(const DevProb& P, int k, const KReq& B, u32 w) {
-  const i32* vi = P.value_int + k * 64; const u32 nv = P.key_nvalues[k];
+__device__ __forceinline__ u64 pass_types_word(const DevProb& P, const Tabs& tb, int k, const KReq& B, u32 w) {
+  const i32* vi = tb.value_int + k * 64; const u32 nv = tb.key_nvalues[k];
   u64 acc = 0;
-  for (u64 bits = kreq_has_mask(B, vi, nv); bits; bits &= bits - 1) acc |= P.kv_types[((size_t)k * 64 + __builtin_ctzll(bits)) * P.TW + w];
-  if (B.complement) acc |= P.cmplx_types[(size_t)k * P.TW + w];
-  if (kreq_nidne(B)) acc |= P.nidnex_types[(size_t)k * P.TW + w];
+  for (u64 bits = kreq_has_mask(B, vi, nv); bits; bits &= bits - 1) acc |= tb.kv_types[((size_t)k * 64 + __builtin_ctzll(bits)) * tb.TW + w];
+  if (B.complement) acc |= tb.cmplx_types[(size_t)k * tb.TW + w];
+  if (kreq_nidne(B)) acc |= tb.nidnex_types[(size_t)k * tb.TW + w];
   return acc;
 }
 // hasOffering (node.go:151-159) as a T-bit mask word
-__device__ __forceinline__ u64 offer_types_word(const DevProb& P, const ReqOut& rq, u32 w) {
+__device__ __forceinline__ u64 offer_types_word(const DevProb& P, const Tabs& tb, const WaveShared& sh, const Rec& r, u32 w) {
   u64 allowZ = ~0ull, allowC = ~0ull;
-  if (P.key_zone >= 0 && ((rq.present >> P.key_zone) & 1u)) { KReq z = load_req(rq.present, rq.complement, rq.mask, rq.gt, rq.lt, P.key_zone); allowZ = kreq_has_mask(z, P.value_int + P.key_zone * 64, P.key_nvalues[P.key_zone]); }
-  if (P.key_ct >= 0 && ((rq.present >> P.key_ct) & 1u)) { KReq z = load_req(rq.present, rq.complement, rq.mask, rq.gt, rq.lt, P.key_ct); allowC = kreq_has_mask(z, P.value_int + P.key_ct * 64, P.key_nvalues[P.key_ct]); }
-  if (P.n_ct == 0) return ~0ull;
-  u64 acc = 0; const u64 cm = allowC & ((1ull << P.n_ct) - 1);
+  if (tb.key_zone >= 0 && ((sh.rq.present >> tb.key_zone) & 1u)) allowZ = kreq_has_mask(new_req(sh, r, tb.key_zone), tb.value_int + tb.key_zone * 64, tb.key_nvalues[tb.key_zone]);
+  if (tb.key_ct >= 0 && ((sh.rq.present >> tb.key_ct) & 1u)) allowC = kreq_has_mask(new_req(sh, r, tb.key_ct), tb.value_int + tb.key_ct * 64, tb.key_nvalues[tb.key_ct]);
+  if (tb.n_ct == 0) return ~0ull;
+  u64 acc = 0; const u64 cm = allowC & ((1ull << tb.n_ct) - 1);
   for (u64 zz = allowZ; zz; zz &= zz - 1) {
-    const int z = __builtin_ctzll(zz); if ((u32)z * P.n_ct >= 64) break;
-    for (u64 cb = cm; cb; cb &= cb - 1) acc |= P.pair_types[((size_t)z * P.n_ct + __builtin_ctzll(cb)) * P.TW + w];
+    const int z = __builtin_ctzll(zz); if ((u32)z * tb.n_ct >= 64) break;
+    for (u64 cb = cm; cb; cb &= cb - 1) acc |= tb.pair_types[((size_t)z * tb.n_ct + __builtin_ctzll(cb)) * tb.TW + w];
   }
   return acc;
 }
 
 // TopologyNodeFilter.MatchesRequirements, topologynodefilter.go:57-70
-__device__ bool filter_matches(const DevProb& P, int g, const ReqOut& rq) {
-  const u32 b = P.grp_filter_off[g], e = P.grp_filter_off[g + 1];
+__device__ __forceinline__ bool filter_matches(const DevProb& P, const Tabs& tb, int g, const WaveShared& sh, const Rec& r) {
+  const u32 b = tb.grp_filter_off[g], e = tb.grp_filter_off[g + 1];
   if (b == e) return true;
   for (u32 f = b; f < e; ++f) {
     bool ok = true;
     const u32 fp = P.flt.present[f], fc = P.flt.complement[f];
     for (u32 bits = fp; bits && ok; bits &= bits - 1) {
       const int k = __builtin_ctz(bits);
-      KReq a = load_req(rq.present, rq.complement, rq.mask, rq.gt, rq.lt, k);
-      KReq in = load_req(fp, fc, P.flt.mask + (size_t)f * P.K, P.flt.gt + (size_t)f * P.K, P.flt.lt + (size_t)f * P.K, k);
-      if (kreq_compatible_fail(a, in, (P.wellknown_mask >> k) & 1u, P.value_int + k * 64, P.key_nvalues[k])) ok = false;
+      const KReq a = new_req(sh, r, k);
+      const KReq in = load_req(fp, fc, P.flt.mask + (size_t)f * tb.K, P.flt.gt + (size_t)f * tb.K, P.flt.lt + (size_t)f * tb.K, k);
+      if (kreq_compatible_fail(a, in, (tb.wellknown >> k) & 1u, tb.value_int + k * 64, tb.key_nvalues[k])) ok = false;
     }
-    if (ok && P.flt.it_state[f] && P.its_fail[rq.it_state * P.S + P.flt.it_state[f]]) ok = false;
+    if (ok && P.flt.it_state[f] && tb.its_fail[sh.rq.it_state * tb.S + P.flt.it_state[f]]) ok = false;
     if (ok) return true;
   }
   return false;
 }
 
-__device__ __forceinline__ void grp_record(const DevProb& P, const DevState& S, int g, int d) {   // TopologyGroup.Record, topologygroup.go:101-105
-  i32& c = S.gcnt[(size_t)g * 64 + d]; c = c < 0 ? 1 : c + 1; S.g_reg[g] |= 1ull << d; S.g_pos[g] |= 1ull << d;
+__device__ __forceinline__ void grp_record(const Tabs& tb, int g, int d) {   // TopologyGroup.Record, topologygroup.go:101-105
+  i32& c = tb.gcnt[(size_t)g * 64 + d]; c = c < 0 ? 1 : c + 1; tb.g_reg[g] |= 1ull << d; tb.g_pos[g] |= 1ull << d;
 }
-__device__ __forceinline__ void grp_record_host(const DevProb& P, const DevState& S, int g, u32 slot) {
-  const i32 h = P.grp_hslot[g]; i32& c = S.hcnt[(size_t)slot * P.GH + h];
-  if (c <= 0) S.g_hpos[h]++;
+__device__ __forceinline__ void grp_record_host(const DevState& S, const Tabs& tb, int h, u32 slot) {
+  GA i32& c = tb.hcnt[(size_t)slot * tb.GH + h];
+  if (c <= 0) tb.g_hpos[h]++;
   c = c < 0 ? 1 : c + 1;
 }
-// Topology.Record, topology.go:120-143 (one lane)
-__device__ void topology_record(const DevProb& P, const DevState& S, const ClsL& c, const ReqOut& rq, u32 slot) {
-  for (u32 i = P.cls_sel_off[c.c]; i < P.cls_sel_off[c.c + 1]; ++i) {
-    const int g = P.sel_list[i];
-    if (!S.g_active[g]) continue;
-    if (!filter_matches(P, g, rq)) continue;                       // TopologyGroup.Counts, topologygroup.go:109-111
-    const i32 k = P.grp_key[g];
-    if (k == KS_KEY_HOSTNAME) { grp_record_host(P, S, g, slot); continue; }   // node requirement is `hostname In [own]`
-    if (!((rq.present >> k) & 1u)) continue;                       // Get() of a missing key is Exists: no values, Len != 1
-    const bool comp = (rq.complement >> k) & 1u; const u64 m = rq.mask[k];
-    if (P.grp_type[g] == 2) { for (u64 b = m; b; b &= b - 1) grp_record(P, S, g, __builtin_ctzll(b)); }     // Values(): for a complement set the excluded values
-    else if (!comp && __builtin_popcountll(m) == 1) grp_record(P, S, g, __builtin_ctzll(m));
+// Topology.Record, topology.go:120-143: lane i handles the i-th group of the class's record list
+// (distinct groups, so the lanes never touch the same counters).
+__device__ __forceinline__ void topology_record(const DevProb& P, const DevState& S, const Tabs& tb, const WaveShared& sh, const Rec& r, u32 slot, int lane) {
+  const ClsPlan& c = sh.cls;
+  if ((u32)lane >= c.nrec) return;
+  const PlanRec& pr = c.rec[lane]; const int g = pr.g;
+  if (!pr.owned_inverse) {
+    if (!tb.g_active[g]) return;
+    if (!filter_matches(P, tb, g, sh, r)) return;                        // TopologyGroup.Counts, topologygroup.go:109-111
   }
-  for (u32 i = P.cls_iown_off[c.c]; i < P.cls_iown_off[c.c + 1]; ++i) {
-    const int g = P.iown_list[i]; const i32 k = P.grp_key[g];
-    if (k == KS_KEY_HOSTNAME) { grp_record_host(P, S, g, slot); continue; }
-    if (!((rq.present >> k) & 1u)) continue;
-    for (u64 b = rq.mask[k]; b; b &= b - 1) grp_record(P, S, g, __builtin_ctzll(b));
-  }
+  if (pr.key == KS_KEY_HOSTNAME) { grp_record_host(S, tb, pr.hslot, slot); return; }   // the node requirement is `hostname In [own]`
+  const KReq q = new_req(sh, r, pr.key);
+  if (!q.present) return;                                            // Get() of a missing key is Exists: no values, Len != 1
+  if (pr.owned_inverse || pr.type == 2) { for (u64 b = q.mask; b; b &= b - 1) grp_record(tb, g, __builtin_ctzll(b)); }   // Values(): for a complement set the excluded values
+  else if (!q.complement && __builtin_popcountll(q.mask) == 1) grp_record(tb, g, __builtin_ctzll(q.mask));
 }
-
-struct WaveShared {
-  ClsL cls; ReqOut rq;
-  i64 req_new[KS_MAX_RES]; i64 cap_new[KS_MAX_RES];
-};
 
 #define WSYNC() __syncthreads()     /* single-wave workgroup: an LDS/global ordering point, not a real barrier */
 
 __device__ __forceinline__ i64 wave_max_i64(i64 v) { for (int off = 32; off > 0; off >>= 1) { const i64 o = __shfl_xor(v, off); if (o > v) v = o; } return v; }
 
-// Load the pod's class into LDS and pre-evaluate the per-pod part of every matching topology group
-// (getMatchingTopologies, topology.go:351-364; domainMinCount, topologygroup.go:184-200).
-__device__ void stage_class(const DevProb& P, const DevState& S, WaveShared& sh, u32 c, int lane) {
-  ClsL& L = sh.cls;
-  if ((u32)lane < P.K) { const u32 k = lane; L.mask[k] = P.cls.mask[(size_t)c * P.K + k]; L.gt[k] = P.cls.gt[(size_t)c * P.K + k]; L.lt[k] = P.cls.lt[(size_t)c * P.K + k]; }
-  if (lane >= 32 && (u32)lane < 32 + P.R) { const u32 r = lane - 32; L.req[r] = P.cls_requests[(size_t)c * P.R + r]; }
-  if (lane == 63) {
-    L.c = c; L.present = P.cls.present[c]; L.complement = P.cls.complement[c]; L.it_state = P.cls.it_state[c];
-    L.hn_mode = P.cls_hn_mode[c]; L.hn_off = P.cls_hn_off[c]; L.hn_cnt = P.cls_hn_off[c + 1] - P.cls_hn_off[c];
-    L.reqmask = P.cls_requests_present[c]; L.tol = P.cls_tolerated[c]; L.port_off = P.cls_port_off[c]; L.port_cnt = P.cls_port_off[c + 1] - P.cls_port_off[c];
-  }
+// Stage the pod's class plan in LDS (one coalesced copy) and evaluate the per-pod, node-independent part
+// of its topology groups (domainMinCount, topologygroup.go:184-200).
+__device__ __forceinline__ void stage_class(const Tabs& tb, WaveShared& sh, const GA ClsPlan* plans, u32 c, int lane) {
+  const GA u32x4* src = (const GA u32x4*)(plans + c); u32x4* dst = (u32x4*)&sh.cls;
+  for (u32 i = lane; i < sizeof(ClsPlan) / 16; i += 64) dst[i] = src[i];
   WSYNC();
-  const u32 ob = P.cls_own_off[c], oe = P.cls_own_off[c + 1], ib = P.cls_isel_off[c], ie = P.cls_isel_off[c + 1];
-  const u32 n = (oe - ob) + (ie - ib);
-  if ((u32)lane < n && lane < KS_MAX_TOPO) {
-    const u32 i = lane; TopoItem t;
-    u32 ent; if (i < oe - ob) { ent = P.own_list[ob + i]; t.inverse = 0; } else { ent = P.isel_list[ib + (i - (oe - ob))]; t.inverse = 1; }
-    t.g = ent & 0x7FFFFFFFu; t.self = ent >> 31; t.type = P.grp_type[t.g]; t.key = P.grp_key[t.g]; t.hslot = P.grp_hslot[t.g]; t.maxskew = P.grp_max_skew[t.g];
-    t.minc = 0; t.PD = ~0ull; t.pod_has = 0; t.reg = 0; t.pos = 0;
-    if (t.key >= 0) {
-      const int k = t.key; KReq pd = kreq_exists();
-      if ((L.present >> k) & 1u) { pd = load_req(L.present, L.complement, L.mask, L.gt, L.lt, k); t.pod_has = 1; }
-      t.PD = kreq_has_mask(pd, P.value_int + k * 64, P.key_nvalues[k]);
-      t.reg = S.g_reg[t.g]; t.pos = S.g_pos[t.g];
-      i32 mn = INT32_MAX;
-      for (u64 b = t.reg & t.PD; b; b &= b - 1) { const i32 cn = S.gcnt[(size_t)t.g * 64 + __builtin_ctzll(b)]; if (cn < mn) mn = cn; }
-      t.minc = mn;
-    }
-    L.topo[i] = t;
+  const ClsPlan& L = sh.cls;
+  if ((u32)lane < L.ntopo) {
+    const PlanTopo& t = L.topo[lane]; TopoDyn d; d.reg = tb.g_reg[t.g]; d.pos = tb.g_pos[t.g]; d.pad = 0;
+    i32 mn = INT32_MAX;
+    for (u64 b = d.reg & t.PD; b; b &= b - 1) { const i32 cn = tb.gcnt[(size_t)t.g * 64 + __builtin_ctzll(b)]; if (cn < mn) mn = cn; }
+    d.minc = mn; sh.dyn[lane] = d;
   }
-  if (lane == 0) L.ntopo = n < KS_MAX_TOPO ? (int)n : KS_MAX_TOPO;
+  if (lane >= 32 && (u32)(lane - 32) < L.nhost) sh.host_anypos[lane - 32] = tb.g_hpos[L.host[lane - 32].hslot] > 0;
   WSYNC();
 }
 
+// lower_bound over the ascending distinct Allocatable values of one resource with a 64-ary search: every
+// lane probes one pivot, __ballot narrows the interval; two rounds cover 4096 values.
+__device__ __forceinline__ u32 ge_row_index(const i64* vals, u32 n, i64 q, int lane) {
+  u32 lo = 0, hi = n;                               // answer in [lo, hi]
+  while (lo < hi) {
+    const u32 span = hi - lo, step = (span + 63) / 64;
+    const u32 idx = lo + (u32)lane * step;
+    const bool ge = idx < hi && vals[idx] >= q;
+    const u64 b = ballot64(ge);
+    const u32 npiv = (span + step - 1) / step;      // pivots actually inside [lo, hi)
+    if (!b) { lo = lo + (npiv - 1) * step + 1; continue; }
+    const u32 f = __builtin_ctzll(b);
+    if (step == 1) return lo + f;
+    hi = lo + f * step;                             // vals[hi] >= q
+    if (f > 0) lo = lo + (f - 1) * step + 1;
+  }
+  return lo;
+}
+
 // Instance-type filter (filterInstanceTypesByRequirements, node.go:137-141) on T-bit masks, one wave:
-//   alive' = alive & passTypes(changed keys) & its_types(state) & offerings & fits(requests)
-// Lane w owns word w of the mask; for every non-empty word all 64 lanes then test one type each against
-// the request vector (resources.Fits) and __ballot rebuilds the word.  Also returns, per resource, the
-// maximum Allocatable over alive' (the resource screen of later pods) in sh.cap_new.
-__device__ bool filter_types(const DevProb& P, WaveShared& sh, const i64* alloc, const u64* alive_in, u64* alive_out, u32 reqmask_new,
+//   alive' = alive & passTypes(changed keys) & its_types(state) & offerings & AND_r ge_rows[r][row(requests[r])]
+// Lane w owns word w; there is no per-type loop: resources.Fits is one precomputed row per requested resource.
+__device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, WaveShared& sh, const Rec& r, const GA u64* alive_in, GA u64* alive_out, u32 reqmask_new,
                              u32 changed_keys, bool check_offer, bool check_it, int lane) {
-  const ReqOut& rq = sh.rq;
-  i64 mx[KS_MAX_RES];
+  const GA u64* rows[KS_MAX_RES];
 #pragma unroll
-  for (int r = 0; r < KS_MAX_RES; ++r) mx[r] = INT64_MIN;
+  for (int i = 0; i < KS_MAX_RES; ++i) {
+    rows[i] = nullptr;
+    if ((reqmask_new >> i) & 1u) {
+      const u32 n = tb.ge_cnt[i];
+      const u32 idx = ge_row_index(tb.ge_vals + (size_t)i * tb.T, n, sh.req_new[i], lane);
+      if (idx >= n) { for (u32 w = lane; w < tb.TW; w += 64) alive_out[w] = 0; WSYNC(); return false; }   // nothing has that much of resource i
+      rows[i] = tb.ge_rows + ((size_t)i * tb.T + idx) * tb.TW;
+    }
+  }
   bool any = false;
-  for (u32 wbase = 0; wbase < P.TW; wbase += 64) {
+  for (u32 wbase = 0; wbase < tb.TW; wbase += 64) {
     const u32 w = wbase + lane; u64 a = 0;
-    if (w < P.TW) {
+    if (w < tb.TW) {
       a = alive_in[w];
-      for (u32 bits = changed_keys; bits && a; bits &= bits - 1) { const int k = __builtin_ctz(bits); a &= pass_types_word(P, k, load_req(rq.present, rq.complement, rq.mask, rq.gt, rq.lt, k), w); }
-      if (check_it && a) a &= P.its_types[(size_t)rq.it_state * P.TW + w];
-      if (check_offer && a) a &= offer_types_word(P, rq, w);
+#pragma unroll
+      for (int i = 0; i < KS_MAX_RES; ++i) if (rows[i]) a &= rows[i][w];
+      for (u32 bits = changed_keys; bits && a; bits &= bits - 1) { const int k = __builtin_ctz(bits); a &= pass_types_word(P, tb, k, new_req(sh, r, k), w); }
+      if (check_it && a) a &= tb.its_types[(size_t)sh.rq.it_state * tb.TW + w];
+      if (check_offer && a) a &= offer_types_word(P, tb, sh, r, w);
+      alive_out[w] = a;
     }
-    for (u64 nz = ballot64(a != 0); nz; nz &= nz - 1) {
-      const int b = __builtin_ctzll(nz);
-      const u64 aw = __shfl(a, b);
-      const u32 t = (wbase + b) * 64 + lane;
-      bool ok = (aw >> lane) & 1ull;
-      if (ok) for (u32 bits = reqmask_new; bits; bits &= bits - 1) { const int r = __builtin_ctz(bits); if (sh.req_new[r] > alloc[(size_t)r * P.T + t]) { ok = false; break; } }
-      if (ok) for (u32 r = 0; r < P.R; ++r) { const i64 al = alloc[(size_t)r * P.T + t]; if (al > mx[r]) mx[r] = al; }
-      const u64 bw = ballot64(ok);
-      if (lane == b) a = bw;
-    }
-    if (w < P.TW) alive_out[w] = a;
     if (ballot64(a != 0)) any = true;
   }
-  for (u32 r = 0; r < P.R; ++r) { const i64 v = wave_max_i64(mx[r]); if (lane == 0) sh.cap_new[r] = v; }
   WSYNC();
   return any;
 }
 
-// Write the winning node's record after Add (lane-parallel stores).
-__device__ __forceinline__ void write_record(const DevProb& P, const Rec& r, const WaveShared& sh, u32 reqmask_new, bool write_cap, int lane) {
-  if ((u32)lane < P.K) { r.mask()[lane] = sh.rq.mask[lane]; r.gt()[lane] = sh.rq.gt[lane]; r.lt()[lane] = sh.rq.lt[lane]; }
-  if (lane >= 32 && (u32)lane < 32 + P.R) { const int rr = lane - 32; r.req()[rr] = sh.req_new[rr]; if (write_cap) r.cap()[rr] = sh.cap_new[rr]; }
+// Per-resource maximum Allocatable over a node's surviving types: the (necessary) resource screen of
+// eval_node.  Recomputed lazily -- only after a candidate passed the screen but failed the filter.
+__device__ __forceinline__ void recompute_cap(const DevProb& P, const Tabs& tb, const GA u64* alive, GA i64* cap, int lane) {
+  i64 mx[KS_MAX_RES];
+#pragma unroll
+  for (int r = 0; r < KS_MAX_RES; ++r) mx[r] = INT64_MIN;
+  for (u32 t = lane; t < tb.TW * 64; t += 64) {
+    const bool on = t < tb.T && ((alive[t >> 6] >> (t & 63)) & 1ull);
+#pragma unroll
+    for (int r = 0; r < KS_MAX_RES; ++r) if ((u32)r < tb.R && on) { const i64 al = P.it_alloc[(size_t)r * tb.T + t]; if (al > mx[r]) mx[r] = al; }
+  }
+#pragma unroll
+  for (int r = 0; r < KS_MAX_RES; ++r) if ((u32)r < tb.R) { const i64 v = wave_max_i64(mx[r]); if (lane == 0) cap[r] = v; }
+  WSYNC();
+}
+
+// Write the winning node's record after Add: only what changed (lane-parallel stores).
+__device__ __forceinline__ void write_record(const Tabs& tb, const Rec& r, const WaveShared& sh, u32 reqmask_new, int lane) {
+  if ((u32)lane < tb.K && ((sh.rq.changed >> lane) & 1u)) { r.mask()[lane] = sh.rq.mask[lane]; r.gt()[lane] = sh.rq.gt[lane]; r.lt()[lane] = sh.rq.lt[lane]; }
+  if (lane >= 32 && (u32)lane < 32 + tb.R) r.req()[lane - 32] = sh.req_new[lane - 32];
   if (lane == 63) { r.present() = sh.rq.present; r.complement() = sh.rq.complement; r.it_state() = sh.rq.it_state; r.reqmask() = reqmask_new; }
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ks_dyn_lds[];
 
+template <bool FAST>
 __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevState* states, u32 lds_bytes) {
-  const DevProb& P = probs[blockIdx.x];
-  const DevState& S = states[blockIdx.x];
+  // descriptors are copied to LDS: loads from them can then be CSE'd across global stores (no aliasing)
+  __shared__ DevProb P_lds; __shared__ DevState S_lds;
   __shared__ WaveShared sh;
   const int lane = threadIdx.x;
-  const u32 NS = P.E + P.NMAX;
+  { const u32* src = (const u32*)&probs[blockIdx.x]; u32* dst = (u32*)&P_lds; for (u32 i = lane; i < sizeof(DevProb) / 4; i += 64) dst[i] = src[i]; }
+  { const u32* src = (const u32*)&states[blockIdx.x]; u32* dst = (u32*)&S_lds; for (u32 i = lane; i < sizeof(DevState) / 4; i += 64) dst[i] = src[i]; }
+  __syncthreads();
   const u64 t_start = __builtin_readcyclecounter();
+  const DevProb& P = P_lds;
+  const DevState& S = S_lds;
+  Tabs tb;
+  tb.K = P.K; tb.R = P.R; tb.T = P.T; tb.TW = P.TW; tb.GH = P.GH; tb.E = P.E; tb.S = P.S; tb.n_ct = P.n_ct; tb.wellknown = P.wellknown_mask; tb.key_zone = P.key_zone; tb.key_ct = P.key_ct;
+  tb.key_nvalues = P.key_nvalues; tb.value_int = P.value_int; tb.its_fail = P.its_fail; tb.its_inter = P.its_inter;
+  tb.q = (GA u32*)S.q; tb.lastgen = (GA u32*)S.lastgen; tb.lastlen = (GA u32*)S.lastlen; tb.pod_stage = (GA i32*)S.pod_stage; tb.pod_node = (GA i32*)S.pod_node; tb.pod_seq = (GA i32*)S.pod_seq;
+  tb.stage_cls = (const GA u32*)P.stage_cls; tb.pod_stage_off = (const GA u32*)P.pod_stage_off; tb.grp_filter_off = (const GA u32*)P.grp_filter_off;
+  tb.rec = (GA u8*)S.rec; tb.rec_stride = S.rec_stride; tb.hcnt = (GA i32*)S.hcnt; tb.n_alive = (GA u64*)S.n_alive;
+  tb.ge_rows = (const GA u64*)P.ge_rows; tb.kv_types = (const GA u64*)P.kv_types; tb.cmplx_types = (const GA u64*)P.cmplx_types; tb.nidnex_types = (const GA u64*)P.nidnex_types;
+  tb.pair_types = (const GA u64*)P.pair_types; tb.its_types = (const GA u64*)P.its_types; tb.grid = (const GA u64*)P.grid;
+  tb.gcnt = S.gcnt; tb.g_reg = S.g_reg; tb.g_pos = S.g_pos; tb.g_active = S.g_active; tb.g_hpos = S.g_hpos; tb.ge_vals = P.ge_vals; tb.ge_cnt = P.ge_cnt;
 
-  // ---- dynamic LDS: instance-type Allocatable table (if it fits in half), then the visiting-order array ----
-  const size_t alloc_bytes = (size_t)P.R * P.T * sizeof(i64);
-  const i64* alloc = P.it_alloc; u32 lds_used = 0;
-  if (alloc_bytes <= lds_bytes / 2) {
-    i64* a = (i64*)ks_dyn_lds;
-    for (u32 i = lane; i < P.R * P.T; i += 64) a[i] = P.it_alloc[i];
-    alloc = a; lds_used = (u32)((alloc_bytes + 15) & ~(size_t)15);
+  // ---------------- initialise state (global memory) ----------------
+  for (u32 i = lane; i < P.P; i += 64) { tb.q[i] = P.queue[i]; tb.lastgen[i] = 0xFFFFFFFFu; tb.lastlen[i] = 0; tb.pod_stage[i] = 0; tb.pod_node[i] = -1; tb.pod_seq[i] = -1; }
+  for (u32 e = lane; e < tb.E; e += 64) {
+    const Rec r = slot_rec(S, tb, e);
+    r.taints() = P.en_taints[e]; r.present() = P.en.present[e]; r.complement() = P.en.complement[e]; r.it_state() = P.en.it_state[e];
+    r.reqmask() = P.en_requests_present[e]; r.count() = 0;
+    for (u32 k = 0; k < tb.K; ++k) { r.mask()[k] = P.en.mask[(size_t)e * tb.K + k]; r.gt()[k] = P.en.gt[(size_t)e * tb.K + k]; r.lt()[k] = P.en.lt[(size_t)e * tb.K + k]; }
+    for (u32 rr = 0; rr < tb.R; ++rr) { r.req()[rr] = P.en_requests[(size_t)e * tb.R + rr]; r.cap()[rr] = P.en_avail[(size_t)e * tb.R + rr]; }
+    i32 head = -1; for (u32 i = P.en_port_off[e]; i < P.en_port_off[e + 1]; ++i) { S.pp_entry[i] = P.ports[i]; S.pp_next[i] = head; head = (i32)i; }
+    r.porthead() = head;
+    for (u32 h = 0; h < tb.GH; ++h) tb.hcnt[(size_t)e * tb.GH + h] = P.grph_count[(size_t)h * tb.E + e];
   }
+  for (u32 i = lane; i < P.M * tb.R; i += 64) S.remaining[i] = P.tmpl_remaining[i];
+
+  // ---------------- small hot tables: true LDS arrays in the FAST variant, global memory otherwise ----------------
+  u32 lds_used = 0;
+  if constexpr (FAST) {
+    __shared__ u32 sm_key_nvalues[KS_MAX_KEYS]; __shared__ i32 sm_value_int[KS_MAX_KEYS * 64];
+    __shared__ u8 sm_its_fail[KS_FAST_S * KS_FAST_S]; __shared__ u8 sm_its_inter[KS_FAST_S * KS_FAST_S];
+    __shared__ i32 sm_gcnt[KS_FAST_G * 64]; __shared__ u64 sm_g_reg[KS_FAST_G]; __shared__ u64 sm_g_pos[KS_FAST_G]; __shared__ u8 sm_g_active[KS_FAST_G]; __shared__ i32 sm_g_hpos[KS_FAST_G];
+    __shared__ u32 sm_ge_cnt[KS_MAX_RES];
+    for (u32 i = lane; i < tb.K; i += 64) sm_key_nvalues[i] = P.key_nvalues[i];
+    for (u32 i = lane; i < tb.K * 64; i += 64) sm_value_int[i] = P.value_int[i];
+    for (u32 i = lane; i < tb.S * tb.S; i += 64) { sm_its_fail[i] = P.its_fail[i]; sm_its_inter[i] = P.its_inter[i]; }
+    for (u32 i = lane; i < P.G * 64; i += 64) sm_gcnt[i] = P.grp_count[i];
+    for (u32 g = lane; g < P.G; g += 64) {
+      u64 reg = 0, pos = 0; for (int d = 0; d < 64; ++d) { const i32 c = P.grp_count[(size_t)g * 64 + d]; if (c >= 0) reg |= 1ull << d; if (c > 0) pos |= 1ull << d; }
+      sm_g_reg[g] = reg; sm_g_pos[g] = pos; sm_g_active[g] = P.grp_active[g];
+    }
+    for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h]; for (u32 e = 0; e < tb.E; ++e) if (P.grph_count[(size_t)h * tb.E + e] > 0) ++np; sm_g_hpos[h] = np; }
+    for (u32 i = lane; i < tb.R; i += 64) sm_ge_cnt[i] = P.ge_cnt[i];
+    i64* ge = (i64*)ks_dyn_lds;
+    for (u32 i = lane; i < tb.R * tb.T; i += 64) ge[i] = P.ge_vals[i];
+    lds_used = (u32)(((size_t)tb.R * tb.T * sizeof(i64) + 15) & ~(size_t)15);
+    tb.key_nvalues = sm_key_nvalues; tb.value_int = sm_value_int; tb.its_fail = sm_its_fail; tb.its_inter = sm_its_inter;
+    tb.gcnt = sm_gcnt; tb.g_reg = sm_g_reg; tb.g_pos = sm_g_pos; tb.g_active = sm_g_active; tb.g_hpos = sm_g_hpos; tb.ge_cnt = sm_ge_cnt; tb.ge_vals = ge;
+  } else {
+    for (u32 i = lane; i < P.G * 64; i += 64) S.gcnt[i] = P.grp_count[i];
+    for (u32 g = lane; g < P.G; g += 64) {
+      u64 reg = 0, pos = 0; for (int d = 0; d < 64; ++d) { const i32 c = P.grp_count[(size_t)g * 64 + d]; if (c >= 0) reg |= 1ull << d; if (c > 0) pos |= 1ull << d; }
+      S.g_reg[g] = reg; S.g_pos[g] = pos; S.g_active[g] = P.grp_active[g];
+    }
+    for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h]; for (u32 e = 0; e < tb.E; ++e) if (P.grph_count[(size_t)h * tb.E + e] > 0) ++np; S.g_hpos[h] = np; }
+  }
+  __threadfence_block();
+  WSYNC();
+  const GA ClsPlan* plans = (const GA ClsPlan*)P.plans;
   u32* ord = (u32*)(ks_dyn_lds + lds_used);            // ord[pos] = new-node index j, sorted in visiting order
   const u32 ord_cap = (lds_bytes - lds_used) / 4;
   bool ord_in_lds = true;
-
-  // ---------------- initialise state ----------------
-  for (u32 i = lane; i < P.P; i += 64) { S.q[i] = P.queue[i]; S.lastgen[i] = 0xFFFFFFFFu; S.lastlen[i] = 0; S.pod_stage[i] = 0; S.pod_node[i] = -1; S.pod_seq[i] = -1; }
-  for (u32 e = lane; e < P.E; e += 64) {
-    const Rec r = slot_rec(P, S, e);
-    r.taints() = P.en_taints[e]; r.present() = P.en.present[e]; r.complement() = P.en.complement[e]; r.it_state() = P.en.it_state[e];
-    r.reqmask() = P.en_requests_present[e]; r.count() = 0;
-    for (u32 k = 0; k < P.K; ++k) { r.mask()[k] = P.en.mask[(size_t)e * P.K + k]; r.gt()[k] = P.en.gt[(size_t)e * P.K + k]; r.lt()[k] = P.en.lt[(size_t)e * P.K + k]; }
-    for (u32 rr = 0; rr < P.R; ++rr) { r.req()[rr] = P.en_requests[(size_t)e * P.R + rr]; r.cap()[rr] = P.en_avail[(size_t)e * P.R + rr]; }
-    i32 head = -1; for (u32 i = P.en_port_off[e]; i < P.en_port_off[e + 1]; ++i) { S.pp_entry[i] = P.ports[i]; S.pp_next[i] = head; head = (i32)i; }
-    r.porthead() = head;
-    for (u32 h = 0; h < P.GH; ++h) S.hcnt[(size_t)e * P.GH + h] = P.grph_count[(size_t)h * P.E + e];
-  }
-  for (u32 i = lane; i < P.G * 64; i += 64) S.gcnt[i] = P.grp_count[i];
-  for (u32 g = lane; g < P.G; g += 64) {
-    u64 reg = 0, pos = 0; for (int d = 0; d < 64; ++d) { const i32 c = P.grp_count[(size_t)g * 64 + d]; if (c >= 0) reg |= 1ull << d; if (c > 0) pos |= 1ull << d; }
-    S.g_reg[g] = reg; S.g_pos[g] = pos; S.g_active[g] = P.grp_active[g];
-  }
-  for (u32 h = lane; h < P.GH; h += 64) { i32 np = P.grph_extra_pos[h]; for (u32 e = 0; e < P.E; ++e) if (P.grph_count[(size_t)h * P.E + e] > 0) ++np; S.g_hpos[h] = np; }
-  for (u32 i = lane; i < P.M * P.R; i += 64) S.remaining[i] = P.tmpl_remaining[i];
-  WSYNC();
+  // count-bucket boundaries: bstart[c] (1 <= c <= maxc+1) = first position in `ord` whose node has >= c pods
+#define BST(c) (*((c) < KS_BST_LDS ? &sh.bstart[(c)] : &S.bstart[(c)]))
 
   // wave-uniform loop state lives in registers (SGPRs)
   u32 q_head = 0, q_len = P.P, q_gen = 0, nnew = 0, seq = 0, err = 0, maxc = 0;
-  u32 pp_used = P.E ? P.en_port_off[P.E] : 0;
+  u32 pp_used = tb.E ? P.en_port_off[tb.E] : 0;
   u64 st_pops = 0, st_relax = 0, st_full = 0, st_fullfail = 0, st_ref_attempts = 0, st_ref_types = 0;
   const bool want_stats = (P.flags & KS_FLAG_STATS) != 0;
-  // S.bstart[c] (1 <= c <= maxc+1): first position in `ord` whose node has >= c pods; bstart[maxc+1] == nnew
+  u64 tp_stage = 0, tp_scan = 0, tp_full = 0, tp_commit = 0, tp_order = 0, tp_new = 0, tp_chunks = 0, tp_evalout = 0, tp_pop = 0; u64 tmark = 0;
+#define TMARK() (tmark = __builtin_readcyclecounter())
+#define TACC(x) do { const u64 now_ = __builtin_readcyclecounter(); (x) += now_ - tmark; tmark = now_; } while (0)
+  GA u64* const scratch = tb.n_alive + (size_t)P.NMAX * tb.TW;      // one spare row of the alive table
 
   // ---------------- Solve loop, scheduler.go:104-124 ----------------
   for (;;) {
     // Queue.Pop, queue.go:44-58
     if (q_len == 0) break;
-    const u32 pod = S.q[q_head];
-    if (S.lastgen[pod] == q_gen && S.lastlen[pod] == q_len) break;
+    TMARK();
+    const u32 pod = tb.q[q_head];
+    if (tb.lastgen[pod] == q_gen && tb.lastlen[pod] == q_len) break;
     q_head = (q_head + 1 == P.P) ? 0 : q_head + 1; q_len--; ++st_pops;
-    const u32 cidx = P.stage_cls[P.pod_stage_off[pod] + S.pod_stage[pod]];
-    stage_class(P, S, sh, cidx, lane);
-    const ClsL& c = sh.cls;
+    const u32 cidx = tb.stage_cls[tb.pod_stage_off[pod] + tb.pod_stage[pod]];
+    TACC(tp_pop);
+    stage_class(tb, sh, plans, cidx, lane);
+    const ClsPlan& c = sh.cls;
+    if (c.overflow) { err = (u32)(-KS_ERR_UNSUPPORTED); break; }
     bool placed = false;
+    TACC(tp_stage);
 
-    // ---- 1. existing nodes in the caller's order: first success wins (scheduler.go:176-180) ----
-    for (u32 base = 0; base < P.E && !placed; base += 64) {
-      const u32 e = base + lane; int rc = 0;
-      if (e < P.E) { NodeView v = slot_view(P, S, e); rc = eval_node(P, S, c, v, nullptr); }
-      const u64 m = ballot64(rc == 2);
-      if (!m) { if (want_stats) st_ref_attempts += min(64u, P.E - base); continue; }
-      const int win = __builtin_ctzll(m); const u32 slot = base + win;
-      if (want_stats) st_ref_attempts += win + 1;
-      if (lane == win) { NodeView v = slot_view(P, S, slot); eval_node(P, S, c, v, &sh.rq); }
-      WSYNC();
-      const Rec r = slot_rec(P, S, slot);
-      if ((u32)lane < P.R) sh.req_new[lane] = r.req()[lane] + c.req[lane];
-      const u32 rm = r.reqmask() | c.reqmask;
-      WSYNC();
-      write_record(P, r, sh, rm, false, lane);                       // commit, existingnode.go:122-129
-      if (lane == 0) {
-        topology_record(P, S, c, sh.rq, slot);
-        for (u32 i = 0; i < c.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
-        S.pod_node[pod] = (i32)slot; S.pod_seq[pod] = (i32)seq;
+    // Candidates in the reference's visiting order (scheduler.go:174-217): existing nodes in the caller's
+    // order, then open new nodes in `sort.Slice(newNodes, len(Pods))` order -- 64 per step, one per lane --
+    // then one fresh node per machine template (a single-lane "chunk").  One code path evaluates, filters
+    // and commits all three kinds.
+    u32 pos_base = 0, tm = 0;
+    while (!placed && !err) {
+      const u32 total = tb.E + nnew;
+      const bool fresh = pos_base >= total;
+      u32 slot = 0xFFFFFFFFu; u32 m_t = 0, lim = 0xFFFFFFFFu, ltypes = 0; size_t mc = 0;
+      if (!fresh) {
+        const u32 pos = pos_base + lane;
+        if (pos < total) slot = pos < tb.E ? pos : tb.E + ord[pos - tb.E];
+      } else {
+        // ---- a new node from the next template that survives the pre-checks (scheduler.go:193-213) ----
+        TMARK();
+        bool have = false;
+        for (; tm < P.M && !have; ++tm) {
+          m_t = tm; mc = (size_t)m_t * P.C + cidx; lim = P.tmpl_limit_present[m_t];
+          if (nnew >= P.NMAX) { err = (u32)(-KS_ERR_CAPACITY); break; }
+          // filterByRemainingResources, scheduler.go:293-309 (only when the provisioner has limits)
+          bool lany = false; ltypes = 0;
+          for (u32 wbase = 0; wbase < tb.TW; wbase += 64) {
+            const u32 w = wbase + lane; u64 a = 0;
+            if (w < tb.TW) a = P.tmpl_types[(size_t)m_t * tb.TW + w];
+            if (lim != 0xFFFFFFFFu) {
+              for (u64 nz = ballot64(a != 0); nz; nz &= nz - 1) {
+                const int b = __builtin_ctzll(nz); const u64 aw = __shfl(a, b); const u32 t = (wbase + b) * 64 + lane;
+                bool ok = (aw >> lane) & 1ull;
+                if (ok) for (u32 bits = lim; bits; bits &= bits - 1) { const int r = __builtin_ctz(bits); if (P.it_cap[(size_t)r * tb.T + t] > S.remaining[(size_t)m_t * tb.R + r]) { ok = false; break; } }
+                const u64 bw = ballot64(ok); if (lane == b) a = bw;
+              }
+            }
+            if (ballot64(a != 0)) lany = true;
+            if (want_stats) { u32 pc = __builtin_popcountll(a); for (int off = 32; off > 0; off >>= 1) pc += __shfl_xor(pc, off); ltypes += pc; }
+            if (w < tb.TW) scratch[w] = a & tb.grid[mc * tb.TW + w];
+          }
+          if (!lany) continue;                  // "all available instance types exceed provisioner limits" (before NewNode)
+          if (want_stats) ++st_ref_attempts;    // NewNode + node.Add is attempted for this template
+          if (!P.mc_ok[mc]) continue;           // taints / Compatible fail inside Add
+          have = true;
+        }
+        if (err) break;
+        if (!have) { TACC(tp_new); break; }     // every template failed -> relax / requeue
+        // NewNode (node.go:44-60): materialise the fresh node's record from template∩class, register its hostname
+        const u32 fs = tb.E + nnew; const Rec fr = slot_rec(S, tb, fs);
+        if ((u32)lane < tb.K) { fr.mask()[lane] = P.mc_mask[mc * tb.K + lane]; fr.gt()[lane] = P.mc_gt[mc * tb.K + lane]; fr.lt()[lane] = P.mc_lt[mc * tb.K + lane]; }
+        if (lane >= 32 && (u32)lane < 32 + tb.R) { fr.req()[lane - 32] = P.tmpl_daemon[(size_t)m_t * tb.R + lane - 32]; fr.cap()[lane - 32] = INT64_MAX; }
+        if (lane == 63) { fr.taints() = P.tmpl_taints[m_t]; fr.present() = P.mc_present[mc]; fr.complement() = P.mc_complement[mc]; fr.it_state() = P.mc_it[mc]; fr.reqmask() = P.tmpl_daemon_present[m_t]; fr.porthead() = -1; fr.count() = 0; }
+        for (u32 g = lane; g < P.G; g += 64) if (P.grp_hslot[g] >= 0) tb.hcnt[(size_t)fs * tb.GH + P.grp_hslot[g]] = tb.g_active[g] ? 0 : -1;   // Topology.Register(hostname), node.go:47
+        __threadfence_block();
+        WSYNC();
+        if (lane == 0) slot = fs;
+        TACC(tp_new);
       }
-      pp_used += c.port_cnt; ++seq; placed = true;
-      WSYNC();
-    }
 
-    // ---- 2. open new nodes in `sort.Slice(newNodes, len(Pods))` order (scheduler.go:183-190) ----
-    for (u32 base = 0; base < nnew && !placed; base += 64) {
-      const u32 pos = base + lane; u32 j = 0xFFFFFFFFu; int rc = 0;
-      if (pos < nnew) { j = ord[pos]; NodeView v = slot_view(P, S, P.E + j); rc = eval_node(P, S, c, v, nullptr); }
-      u64 m = ballot64(rc == 2);
-      const u64 reach = ballot64(rc >= 1);
-      u32 my_alive = 0;
-      if (want_stats) { if (rc >= 1) for (u32 w = 0; w < P.TW; ++w) my_alive += __builtin_popcountll(S.n_alive[(size_t)j * P.TW + w]); }
-      u32 last_lane = min(64u, nnew - base);     // lanes the reference would have visited in this chunk (all, unless one succeeds)
+      // ---- Node.Add / ExistingNode.Add up to the instance-type filter, one node per lane ----
+      Ev ev; ev.rc = 0;
+      if (slot != 0xFFFFFFFFu) eval_node(P, S, tb, sh, slot, slot < tb.E, fresh, ev, lane);
+      u64 m = ballot64(ev.rc == 2);
+      const u64 reach = ballot64(ev.rc >= 1);
+      if (!fresh) { TACC(tp_scan); ++tp_chunks; }
+      u32 my_alive = 0; u32 visited = fresh ? 0 : min(64u, total - pos_base);   // lanes the reference would have visited (all, unless one succeeds)
+      if (want_stats && !fresh && slot != 0xFFFFFFFFu && slot >= tb.E && ev.rc >= 1) for (u32 w = 0; w < tb.TW; ++w) my_alive += __builtin_popcountll(tb.n_alive[(size_t)(slot - tb.E) * tb.TW + w]);
+
       while (m) {
         const int win = __builtin_ctzll(m);
-        const u32 jw = __shfl(j, win); const u32 slot = P.E + jw;
-        if (lane == win) { NodeView v = slot_view(P, S, slot); eval_node(P, S, c, v, &sh.rq); }
-        const Rec r = slot_rec(P, S, slot);
-        if ((u32)lane < P.R) sh.req_new[lane] = r.req()[lane] + c.req[lane];
-        const u32 rm = r.reqmask() | c.reqmask;
+        const u32 sw = __shfl(slot, win); const bool ex = sw < tb.E; const u32 jw = sw - tb.E;
+        publish_eval(tb, sh, ev, win, lane);
+        const Rec r = slot_rec(S, tb, sw);
         WSYNC();
-        ++st_full;
-        const bool zc = (P.key_zone >= 0 && ((sh.rq.changed >> P.key_zone) & 1u)) || (P.key_ct >= 0 && ((sh.rq.changed >> P.key_ct) & 1u));
-        const bool itc = sh.rq.it_state != r.it_state();
-        u64* alive = S.n_alive + (size_t)jw * P.TW;
-        u64* scratch = S.n_alive + (size_t)P.NMAX * P.TW;     // one spare row
-        const bool ok = filter_types(P, sh, alloc, alive, scratch, rm, sh.rq.changed, zc, itc, lane);
-        if (!ok) { ++st_fullfail; m &= m - 1; continue; }
-        // commit, node.go:100-105
-        last_lane = win + 1;
-        for (u32 w = lane; w < P.TW; w += 64) alive[w] = scratch[w];
-        write_record(P, r, sh, rm, true, lane);
-        const u32 cnt = r.count();                                   // pods on the node before this one
-        if (lane == 0) {
-          r.count() = cnt + 1;
-          topology_record(P, S, c, sh.rq, slot);
-          for (u32 i = 0; i < c.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
-          S.pod_node[pod] = (i32)slot; S.pod_seq[pod] = (i32)seq;
+        const u32 rm = sh.rq.rm;
+        TACC(tp_evalout);
+        if (!ex) {
+          // filterInstanceTypesByRequirements (node.go:94-98): existing nodes have no instance-type step
+          ++st_full; if (want_stats && fresh) st_ref_types += ltypes;
+          GA u64* const alive = tb.n_alive + (size_t)jw * tb.TW;
+          const u32 keys = fresh ? sh.rq.topo_narrowed : sh.rq.changed;   // a fresh node's own keys are already in the grid row
+          const bool zc = (tb.key_zone >= 0 && ((keys >> tb.key_zone) & 1u)) || (tb.key_ct >= 0 && ((keys >> tb.key_ct) & 1u));
+          const bool itc = !fresh && sh.rq.it_state != sh.rq.it_before;
+          const bool ok = filter_types(P, tb, sh, r, fresh ? scratch : alive, fresh ? alive : scratch, rm, keys, zc, itc, lane);
+          TACC(tp_full);
+          if (!ok) { ++st_fullfail; if (!fresh) recompute_cap(P, tb, alive, r.cap(), lane); m &= m - 1; continue; }
+          if (!fresh) for (u32 w = lane; w < tb.TW; w += 64) alive[w] = scratch[w];
         }
-        // visiting order: the node leaves position p of bucket `cnt` for the FRONT of bucket cnt+1
-        {
-          const u32 p = base + win;
-          const u32 endc = S.bstart[cnt + 1];                        // one past the last node with `cnt` pods
+        // ---- commit: node.go:100-105 / existingnode.go:122-129 / scheduler.go:214-216 ----
+        visited = win + 1;
+        if (fresh && lim != 0xFFFFFFFFu) {          // subtractMax, scheduler.go:273-290
+          GA u64* const alive = tb.n_alive + (size_t)jw * tb.TW;
+          i64 mx[KS_MAX_RES];
+#pragma unroll
+          for (int rr = 0; rr < KS_MAX_RES; ++rr) mx[rr] = INT64_MIN;
+          for (u32 t = lane; t < tb.TW * 64; t += 64) {
+            const bool on = t < tb.T && ((alive[t >> 6] >> (t & 63)) & 1ull);
+#pragma unroll
+            for (int rr = 0; rr < KS_MAX_RES; ++rr) if ((u32)rr < tb.R && on) { const i64 cp = P.it_cap[(size_t)rr * tb.T + t]; if (cp > mx[rr]) mx[rr] = cp; }
+          }
+#pragma unroll
+          for (int rr = 0; rr < KS_MAX_RES; ++rr) if ((u32)rr < tb.R) { const i64 v = wave_max_i64(mx[rr]); if (lane == 0 && ((lim >> rr) & 1u)) S.remaining[(size_t)m_t * tb.R + rr] -= v; }
+        }
+        topology_record(P, S, tb, sh, r, sw, lane);
+        const u32 cnt = sh.rq.count;                                   // pods on the node before this one
+        WSYNC();
+        write_record(tb, r, sh, rm, lane);
+        if (lane == 0) {
+          if (!ex) r.count() = cnt + 1;
+          if (fresh) S.n_tmpl[jw] = (i32)m_t;
+          for (u32 i = 0; i < c.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
+          tb.pod_node[pod] = (i32)sw; tb.pod_seq[pod] = (i32)seq;
+        }
+        TACC(tp_commit);
+        if (!ex && !fresh) {
+          // visiting order: the node leaves position p of bucket `cnt` for the FRONT of bucket cnt+1
+          const u32 p = pos_base + win - tb.E;
+          const u32 endc = BST(cnt + 1);                             // one past the last node with `cnt` pods
           for (u32 i = p + 1; i < endc; i += 64) { const u32 ii = i + lane; u32 v = 0; if (ii < endc) v = ord[ii]; WSYNC(); if (ii < endc) ord[ii - 1] = v; }
           WSYNC();
-          if (lane == 0) { ord[endc - 1] = jw; S.bstart[cnt + 1] = endc - 1; if (cnt + 1 > maxc) S.bstart[cnt + 2] = nnew; }
+          if (lane == 0) { ord[endc - 1] = jw; BST(cnt + 1) = endc - 1; if (cnt + 1 > maxc) BST(cnt + 2) = nnew; }
           if (cnt + 1 > maxc) maxc = cnt + 1;
+        } else if (fresh) {
+          // visiting order: appended -> BACK of the count-1 bucket, i.e. position bstart[2]; everything after shifts right
+          if (ord_in_lds && nnew + 1 > ord_cap) {                     // spill the order array to global memory
+            for (u32 i = lane; i < nnew; i += 64) S.order_g[i] = ord[i];
+            WSYNC(); ord = S.order_g; ord_in_lds = false;
+          }
+          if (maxc == 0) { if (lane == 0) { BST(1) = 0; BST(2) = 1; ord[0] = jw; } maxc = 1; }
+          else {
+            const u32 ins = BST(2);
+            for (u32 hi = nnew; hi > ins; ) { const u32 lo = hi > ins + 64 ? hi - 64 : ins; const u32 ii = lo + lane; u32 v = 0; if (ii < hi) v = ord[ii]; WSYNC(); if (ii < hi) ord[ii + 1] = v; WSYNC(); hi = lo; }
+            if (lane == 0) ord[ins] = jw;
+            for (u32 cc = 2 + lane; cc <= maxc + 1; cc += 64) BST(cc) += 1;
+          }
+          nnew = jw + 1;
         }
         pp_used += c.port_cnt; ++seq; placed = true;
         WSYNC();
+        TACC(tp_order);
         break;
       }
-      if (want_stats) {
-        st_ref_attempts += last_lane;
-        u32 ty = ((u32)lane < last_lane && ((reach >> lane) & 1ull)) ? my_alive : 0;
+      if (want_stats && !fresh) {
+        st_ref_attempts += visited;
+        u32 ty = ((u32)lane < visited && ((reach >> lane) & 1ull)) ? my_alive : 0;
         for (int off = 32; off > 0; off >>= 1) ty += __shfl_xor(ty, off);
         st_ref_types += ty;
       }
-    }
-
-    // ---- 3. a new node from the first template that works (scheduler.go:193-217) ----
-    for (u32 m = 0; m < P.M && !placed && !err; ++m) {
-      const size_t mc = (size_t)m * P.C + cidx;
-      const u32 lim = P.tmpl_limit_present[m];
-      const u32 j = nnew; const u32 slot = P.E + j;
-      if (nnew >= P.NMAX) { err = (u32)(-KS_ERR_CAPACITY); break; }
-      u64* alive = S.n_alive + (size_t)j * P.TW;
-      u64* scratch = S.n_alive + (size_t)P.NMAX * P.TW;
-      // filterByRemainingResources, scheduler.go:293-309 (only when the provisioner has limits)
-      bool lany = false; u32 ltypes = 0;
-      for (u32 wbase = 0; wbase < P.TW; wbase += 64) {
-        const u32 w = wbase + lane; u64 a = 0;
-        if (w < P.TW) a = P.tmpl_types[(size_t)m * P.TW + w];
-        if (lim != 0xFFFFFFFFu) {
-          for (u64 nz = ballot64(a != 0); nz; nz &= nz - 1) {
-            const int b = __builtin_ctzll(nz); const u64 aw = __shfl(a, b); const u32 t = (wbase + b) * 64 + lane;
-            bool ok = (aw >> lane) & 1ull;
-            if (ok) for (u32 bits = lim; bits; bits &= bits - 1) { const int r = __builtin_ctz(bits); if (P.it_cap[(size_t)r * P.T + t] > S.remaining[(size_t)m * P.R + r]) { ok = false; break; } }
-            const u64 bw = ballot64(ok); if (lane == b) a = bw;
-          }
-        }
-        if (ballot64(a != 0)) lany = true;
-        if (want_stats) { u32 pc = __builtin_popcountll(a); for (int off = 32; off > 0; off >>= 1) pc += __shfl_xor(pc, off); ltypes += pc; }
-        if (w < P.TW) scratch[w] = a & P.grid[mc * P.TW + w];
-      }
-      if (!lany) continue;                      // "all available instance types exceed provisioner limits" (before NewNode)
-      WSYNC();
-      if (want_stats) ++st_ref_attempts;        // NewNode + node.Add is attempted for this template
-      if (!P.mc_ok[mc]) continue;               // taints / Compatible fail inside Add
-      // NewNode + Node.Add on the fresh node (its own requirements are already merged in mc_*)
-      int rc = 0;
-      if (lane == 0) {
-        NodeView v; v.present = P.mc_present[mc]; v.complement = P.mc_complement[mc]; v.it_state = P.mc_it[mc];
-        v.mask = P.mc_mask + mc * P.K; v.gt = P.mc_gt + mc * P.K; v.lt = P.mc_lt + mc * P.K;
-        v.taints = 0; v.porthead = -1; v.req = P.tmpl_daemon + (size_t)m * P.R; v.reqmask = P.tmpl_daemon_present[m]; v.cap = nullptr; v.slot = (i32)slot; v.existing = false; v.fresh = true;
-        rc = eval_node(P, S, c, v, &sh.rq, true);
-      }
-      rc = __shfl(rc, 0);
-      if ((u32)lane < P.R) sh.req_new[lane] = P.tmpl_daemon[(size_t)m * P.R + lane] + c.req[lane];
-      const u32 rm = P.tmpl_daemon_present[m] | c.reqmask;
-      WSYNC();
-      if (rc != 2) continue;
-      ++st_full; if (want_stats) st_ref_types += ltypes;
-      // topology may have narrowed keys beyond template∩class: re-filter those keys (+ offerings); fits again for the maxima
-      const u32 nk = sh.rq.topo_narrowed;
-      const bool zc = (P.key_zone >= 0 && ((nk >> P.key_zone) & 1u)) || (P.key_ct >= 0 && ((nk >> P.key_ct) & 1u));
-      const bool ok = filter_types(P, sh, alloc, scratch, alive, rm, nk, zc, false, lane);
-      if (!ok) { ++st_fullfail; continue; }
-      // commit the new node (scheduler.go:214-216); Topology.Register(hostname), node.go:47
-      for (u32 g = lane; g < P.G; g += 64) if (P.grp_hslot[g] >= 0) S.hcnt[(size_t)slot * P.GH + P.grp_hslot[g]] = S.g_active[g] ? 0 : -1;
-      // subtractMax, scheduler.go:273-290
-      if (lim != 0xFFFFFFFFu) {
-        i64 mx[KS_MAX_RES];
-#pragma unroll
-        for (int r = 0; r < KS_MAX_RES; ++r) mx[r] = INT64_MIN;
-        for (u32 t = lane; t < P.T; t += 64) if ((alive[t >> 6] >> (t & 63)) & 1ull) for (u32 r = 0; r < P.R; ++r) { const i64 cp = P.it_cap[(size_t)r * P.T + t]; if (cp > mx[r]) mx[r] = cp; }
-        for (u32 r = 0; r < P.R; ++r) { const i64 v = wave_max_i64(mx[r]); if (lane == 0 && ((lim >> r) & 1u)) S.remaining[(size_t)m * P.R + r] -= v; }
-      }
-      const Rec r = slot_rec(P, S, slot);
-      write_record(P, r, sh, rm, true, lane);
-      WSYNC();
-      if (lane == 0) {
-        r.taints() = P.tmpl_taints[m]; r.porthead() = -1; r.count() = 1; S.n_tmpl[j] = (i32)m;
-        topology_record(P, S, c, sh.rq, slot);
-        for (u32 i = 0; i < c.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
-        S.pod_node[pod] = (i32)slot; S.pod_seq[pod] = (i32)seq;
-      }
-      // visiting order: appended -> BACK of the count-1 bucket, i.e. position bstart[2]; everything after shifts right
-      {
-        if (ord_in_lds && nnew + 1 > ord_cap) {                       // spill the order array to global memory
-          for (u32 i = lane; i < nnew; i += 64) S.order_g[i] = ord[i];
-          WSYNC(); ord = S.order_g; ord_in_lds = false;
-        }
-        if (maxc == 0) { if (lane == 0) { S.bstart[1] = 0; S.bstart[2] = 1; ord[0] = j; } maxc = 1; }
-        else {
-          const u32 ins = S.bstart[2];
-          for (u32 hi = nnew; hi > ins; ) { const u32 lo = hi > ins + 64 ? hi - 64 : ins; const u32 ii = lo + lane; u32 v = 0; if (ii < hi) v = ord[ii]; WSYNC(); if (ii < hi) ord[ii + 1] = v; WSYNC(); hi = lo; }
-          if (lane == 0) ord[ins] = j;
-          for (u32 cc = 2 + lane; cc <= maxc + 1; cc += 64) S.bstart[cc] += 1;
-        }
-      }
-      nnew = j + 1; pp_used += c.port_cnt; ++seq; placed = true;
-      WSYNC();
+      if (!fresh) pos_base += 64;
     }
     if (err) break;
 
-    // ---- 4. failure: Preferences.Relax + Queue.Push + Topology.Update (scheduler.go:116-123) ----
+    // ---- failure: Preferences.Relax + Queue.Push + Topology.Update (scheduler.go:116-123) ----
     if (!placed) {
-      const u32 nst = P.pod_stage_off[pod + 1] - P.pod_stage_off[pod];
-      const i32 stg = S.pod_stage[pod];
+      const u32 nst = tb.pod_stage_off[pod + 1] - tb.pod_stage_off[pod];
+      const i32 stg = tb.pod_stage[pod];
       const bool relaxed = (u32)stg + 1 < nst;
       u32 tail = q_head + q_len; if (tail >= P.P) tail -= P.P;
       q_len++;
       if (lane == 0) {
-        S.q[tail] = pod;
+        tb.q[tail] = pod;
         if (relaxed) {
-          S.pod_stage[pod] = stg + 1;
-          const u32 nc = P.stage_cls[P.pod_stage_off[pod] + stg + 1];
-          for (u32 i = P.cls_own_off[nc]; i < P.cls_own_off[nc + 1]; ++i) S.g_active[P.own_list[i] & 0x7FFFFFFFu] = 1;   // Topology.Update creates the group
-        } else { S.lastlen[pod] = q_len; S.lastgen[pod] = q_gen; }
+          tb.pod_stage[pod] = stg + 1;
+          const u32 nc = tb.stage_cls[tb.pod_stage_off[pod] + stg + 1];
+          for (u32 i = P.cls_own_off[nc]; i < P.cls_own_off[nc + 1]; ++i) tb.g_active[P.own_list[i] & 0x7FFFFFFFu] = 1;   // Topology.Update creates the group
+        } else { tb.lastlen[pod] = q_len; tb.lastgen[pod] = q_gen; }
       }
       if (relaxed) { q_gen++; ++st_relax; }
+      __threadfence_block();
       WSYNC();
     }
   }
 
   // ---------------- results ----------------
   WSYNC();
-  for (u32 i = lane; i < q_len; i += 64) { u32 idx = q_head + i; if (idx >= P.P) idx -= P.P; S.unscheduled[i] = (i32)S.q[idx]; }
+  for (u32 i = lane; i < q_len; i += 64) { u32 idx = q_head + i; if (idx >= P.P) idx -= P.P; S.unscheduled[i] = (i32)tb.q[idx]; }
   for (u32 j = lane; j < nnew; j += 64) {        // de-interleave the new nodes' records into the SoA result arrays
-    const Rec r = slot_rec(P, S, P.E + j);
+    const Rec r = slot_rec(S, tb, tb.E + j);
     S.o_present[j] = r.present(); S.o_complement[j] = r.complement(); S.o_it[j] = r.it_state(); S.o_reqmask[j] = r.reqmask();
-    for (u32 k = 0; k < P.K; ++k) { S.o_mask[(size_t)j * P.K + k] = r.mask()[k]; S.o_gt[(size_t)j * P.K + k] = r.gt()[k]; S.o_lt[(size_t)j * P.K + k] = r.lt()[k]; }
-    for (u32 rr = 0; rr < P.R; ++rr) S.o_req[(size_t)j * P.R + rr] = r.req()[rr];
+    for (u32 k = 0; k < tb.K; ++k) { S.o_mask[(size_t)j * tb.K + k] = r.mask()[k]; S.o_gt[(size_t)j * tb.K + k] = r.gt()[k]; S.o_lt[(size_t)j * tb.K + k] = r.lt()[k]; }
+    for (u32 rr = 0; rr < tb.R; ++rr) S.o_req[(size_t)j * tb.R + rr] = r.req()[rr];
   }
   if (lane == 0) {
     S.out_counts[0] = nnew; S.out_counts[1] = q_len;
     S.stats[KS_STAT_POPS] = st_pops; S.stats[KS_STAT_RELAX] = st_relax; S.stats[KS_STAT_FULLCHECKS] = st_full; S.stats[KS_STAT_FULLFAILS] = st_fullfail;
     S.stats[KS_STAT_REF_ATTEMPTS] = st_ref_attempts; S.stats[KS_STAT_REF_TYPES] = st_ref_types;
     S.stats[KS_STAT_CYCLES] = __builtin_readcyclecounter() - t_start; S.stats[KS_STAT_ERR] = err;
+    S.stats[15] = tp_evalout; S.stats[16] = tp_pop;
+    S.stats[8] = tp_stage; S.stats[9] = tp_scan; S.stats[10] = tp_full; S.stats[11] = tp_commit; S.stats[12] = tp_order; S.stats[13] = tp_new; S.stats[14] = tp_chunks;
   }
 }
 
@@ -975,6 +1155,13 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   // derived tables
   TRY(dev_alloc(d, (size_t)K * 64 * TW, &h.kv_types, 0)); TRY(dev_alloc(d, (size_t)K * TW, &h.cmplx_types, 0)); TRY(dev_alloc(d, (size_t)K * TW, &h.nidnex_types, 0));
   TRY(dev_alloc(d, (size_t)64 * TW, &h.pair_types, 0));
+  {   // ascending distinct Allocatable values per resource (host sort; the rows are built on the device)
+    std::vector<i64> vals((size_t)R * T, 0); std::vector<u32> cnt(R, 0);
+    for (u32 r = 0; r < R; ++r) { std::vector<i64> v(p->it_alloc + (size_t)r * T, p->it_alloc + (size_t)(r + 1) * T); std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); cnt[r] = (u32)v.size(); std::copy(v.begin(), v.end(), vals.begin() + (size_t)r * T); }
+    const i64* dv; const u32* dc; TRY(dev_copy(d, vals.data(), vals.size(), &dv)); TRY(dev_copy(d, cnt.data(), cnt.size(), &dc)); h.ge_vals = (i64*)dv; h.ge_cnt = (u32*)dc;
+    TRY(dev_alloc(d, (size_t)R * T * TW, &h.ge_rows, 0));
+  }
+  { u8* pl = nullptr; TRY(dev_alloc(d, (size_t)C * sizeof(ClsPlan), &pl, 0)); h.plans = pl; }
   const size_t MC = (size_t)M * C;
   TRY(dev_alloc(d, MC, &h.mc_ok, 0)); TRY(dev_alloc(d, MC, &h.mc_present)); TRY(dev_alloc(d, MC, &h.mc_complement));
   TRY(dev_alloc(d, MC * K, &h.mc_mask)); TRY(dev_alloc(d, MC * K, &h.mc_gt)); TRY(dev_alloc(d, MC * K, &h.mc_lt)); TRY(dev_alloc(d, MC, &h.mc_it));
@@ -995,7 +1182,7 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   size_t pool = E ? p->en_port_off[E] : 0;
   for (u32 i = 0; i < P; ++i) { u32 mx = 0; for (u32 st = p->pod_stage_off[i]; st < p->pod_stage_off[i + 1]; ++st) { const u32 c = p->stage_cls[st]; const u32 n = p->cls_port_off[c + 1] - p->cls_port_off[c]; if (n > mx) mx = n; } pool += mx; }
   s.pp_cap = (u32)pool; TRY(dev_alloc(d, pool, &s.pp_entry)); TRY(dev_alloc(d, pool, &s.pp_next));
-  TRY(dev_alloc(d, 16, &s.stats, 0)); TRY(dev_alloc(d, 4, &s.out_counts, 0)); TRY(dev_alloc(d, P, &s.unscheduled));
+  TRY(dev_alloc(d, 32, &s.stats, 0)); TRY(dev_alloc(d, 4, &s.out_counts, 0)); TRY(dev_alloc(d, P, &s.unscheduled));
   TRY(dev_alloc(d, 1, &d->d_prob)); TRY(dev_alloc(d, 1, &d->d_state));
   HIPCHK(hipMemcpy(d->d_prob, &d->h, sizeof(DevProb), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d->d_state, &d->hs, sizeof(DevState), hipMemcpyHostToDevice));
@@ -1009,6 +1196,8 @@ static int build_static(ks_dev_problem* d, float* grid_ms) {
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   const u32 rows = h.K * 64 + 2 * h.K + 64;
   hipLaunchKernelGGL(ks_build_type_tables, dim3((rows * 64 + 255) / 256), dim3(256), 0, d->stream, h);
+  if (h.C) hipLaunchKernelGGL(ks_build_plans, dim3((h.C + 63) / 64), dim3(64), 0, d->stream, h, (ClsPlan*)h.plans);
+  hipLaunchKernelGGL(ks_build_ge_rows, dim3((u32)(((size_t)h.R * h.T * 64 + 255) / 256)), dim3(256), 0, d->stream, h);
   const size_t MC = (size_t)h.M * h.C;
   HIPCHK(hipEventRecord(e0, d->stream));
   if (MC) {
@@ -1036,9 +1225,9 @@ extern "C" int ks_feasibility_grid(ks_dev_problem* d, uint64_t* out_grid, float*
 static int download(ks_dev_problem* d, ks_result* out) {
   const DevProb& h = d->h; const DevState& s = d->hs;
   u32 counts[4]; HIPCHK(hipMemcpy(counts, s.out_counts, sizeof counts, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(out->stats, s.stats, 16 * sizeof(u64), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out->stats, s.stats, 32 * sizeof(u64), hipMemcpyDeviceToHost));
   out->n_new = counts[0]; out->n_unscheduled = counts[1];
-  if (out->stats[KS_STAT_ERR]) return fail(-(int)out->stats[KS_STAT_ERR], "device-side error (more new nodes than max_new_nodes?)");
+  if (out->stats[KS_STAT_ERR]) return fail(-(int)out->stats[KS_STAT_ERR], out->stats[KS_STAT_ERR] == (u64)(-KS_ERR_CAPACITY) ? "more new nodes than max_new_nodes" : "a pod class exceeds the kernel's per-class limits (12 touched keys / 24 topology groups / 3 hostname groups / 24 recorded groups)");
   const u32 P = h.P, K = h.K, R = h.R, TW = h.TW, N = out->n_new;
   if (P) {
     HIPCHK(hipMemcpy(out->pod_node, s.pod_node, P * sizeof(i32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out->pod_stage, s.pod_stage, P * sizeof(i32), hipMemcpyDeviceToHost));
@@ -1076,10 +1265,16 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   HIPCHK(hipEventRecord(e0, st));
   // dynamic LDS: Allocatable table + visiting-order array.  One Solve gets most of the CU's 160 KiB;
   // batched what-ifs take 64 KiB each so two workgroups share a CU.
-  const u32 lds_bytes = n == 1 ? 144u * 1024u : 64u * 1024u;
+  const u32 lds_bytes = n == 1 ? 100u * 1024u : 64u * 1024u;
+  bool fast = true;
+  for (u32 i = 0; i < n; ++i) { const DevProb& q = ds[i]->h; if (q.G > KS_FAST_G || q.GH > KS_FAST_G || q.S > KS_FAST_S || (size_t)q.R * q.T > KS_FAST_RT || (size_t)q.R * q.T * 8 + 16384 > lds_bytes) fast = false; }
   static bool attr_set = false;
-  if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)ks_pack, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
-  hipLaunchKernelGGL(ks_pack, dim3(n), dim3(64), lds_bytes, st, dp, dsv, lds_bytes);
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)ks_pack<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024)); attr_set = true;
+  }
+  if (fast) hipLaunchKernelGGL(ks_pack<true>, dim3(n), dim3(64), lds_bytes, st, dp, dsv, lds_bytes);
+  else hipLaunchKernelGGL(ks_pack<false>, dim3(n), dim3(64), lds_bytes, st, dp, dsv, lds_bytes);
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());

@@ -538,11 +538,14 @@ struct Builder {
       for (uint32_t gi : sel[l]) E.sel_list.push_back(gi); E.cls_sel_off.push_back((uint32_t)E.sel_list.size());
       for (uint32_t gi : isel[l]) E.isel_list.push_back(gi); E.cls_isel_off.push_back((uint32_t)E.isel_list.size());
       for (int g : cls_groups[c].iown) E.iown_list.push_back((uint32_t)remap[g]); E.cls_iown_off.push_back((uint32_t)E.iown_list.size());
-      // touched-key budget of the kernel (KS_MAX_TOUCH = 12)
+      // touched-key budget of the kernel (KS_MAX_TOUCH = 12, KS_MAX_HOST = 3)
       std::set<int> touched; for (uint32_t k = 0; k < K; ++k) if ((E.cls.present[c] >> k) & 1u) touched.insert((int)k);
       for (int g : cls_groups[c].own) if (groups[g]->key != ksp::kHostname) touched.insert(key_id.at(groups[g]->key));
       for (uint32_t gi : isel[l]) if (E.grp_key[gi] >= 0) touched.insert(E.grp_key[gi]);
-      if (touched.size() > 12) throw Unsupported("a pod touches more than 12 label keys");
+      if (touched.size() > 12) throw Unsupported("a pod touches more than 12 label keys (own requirements + topology keys)");
+      size_t nh = 0; for (int g : cls_groups[c].own) if (groups[g]->key == ksp::kHostname) ++nh;
+      for (uint32_t gi : isel[l]) if (E.grp_key[gi] == KS_KEY_HOSTNAME) ++nh;
+      if (nh > 3) throw Unsupported("a pod is constrained by more than 3 hostname-keyed topology groups");
     }
   }
   [[noreturn]] void key_missing(const std::string& k, const std::string& v) { throw std::logic_error("topology domain " + v + " of key " + k + " missing from the universe"); }
@@ -666,7 +669,8 @@ std::string Encoded::decode(const ks_result& r, double solve_seconds) const {
   for (uint32_t e = 0; e < NE; ++e) { o << "ENODE " << tokq(src.nodes[existing[e]].name) << " " << pods_of[e].size(); for (auto& sp : pods_of[e]) o << " " << sp.second; o << "\n"; }
   o << "UNSCHEDULED " << r.n_unscheduled; for (uint32_t i = 0; i < r.n_unscheduled; ++i) o << " " << r.unscheduled[i]; o << "\n";
   o << "STAGES " << p.P; for (uint32_t i = 0; i < p.P; ++i) o << " " << r.pod_stage[i]; o << "\n";
-  o << "STATS 9 queue_pops " << r.stats[KS_STAT_POPS] << " relaxations " << r.stats[KS_STAT_RELAX] << " full_checks " << r.stats[KS_STAT_FULLCHECKS] << " full_fails " << r.stats[KS_STAT_FULLFAILS]
+  o << "STATS 18 cyc_evalout " << r.stats[15] << " cyc_pop " << r.stats[16] << " cyc_stage " << r.stats[8] << " cyc_scan " << r.stats[9] << " cyc_full " << r.stats[10] << " cyc_commit " << r.stats[11] << " cyc_order " << r.stats[12] << " cyc_new " << r.stats[13] << " scan_chunks " << r.stats[14]
+    << " queue_pops " << r.stats[KS_STAT_POPS] << " relaxations " << r.stats[KS_STAT_RELAX] << " full_checks " << r.stats[KS_STAT_FULLCHECKS] << " full_fails " << r.stats[KS_STAT_FULLFAILS]
     << " attempts " << r.stats[KS_STAT_REF_ATTEMPTS] << " types_scanned " << r.stats[KS_STAT_REF_TYPES] << " kernel_cycles " << r.stats[KS_STAT_CYCLES]
     << " classes " << p.C << " solve_ns " << (int64_t)(solve_seconds * 1e9) << "\n";
   o << "END\n";

@@ -1,0 +1,13 @@
+import sys, time, json
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from karpenter_core_amd import scheduler as S, workloads as W
+pods = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+pr = W.config3(pods=pods)
+fp = S.FlatProblem(pr); fp.upload(0); fp.grid(want_bits=False)
+fp.solve(decode=False)
+r = fp.solve()
+print("kernel_ms", fp.kernel_ms, "nodes", len(r.new_nodes))
+st = r.stats; tot = st["kernel_cycles"]
+for k in ("cyc_pop","cyc_stage","cyc_scan","cyc_evalout","cyc_full","cyc_commit","cyc_order","cyc_new"):
+    print(f"{k:12s} {st[k]:>14d}  {100*st[k]/tot:5.1f}%  per pod {st[k]/pods:9.0f}")
+print("total cycles", tot, "per pod", tot/pods, "chunks/pod", st["scan_chunks"]/pods, "full_checks", st["full_checks"], "full_fails", st["full_fails"])
