@@ -36,6 +36,7 @@
 #define KS_MAX_TOUCH 12      // distinct narrow keys a class may touch (own requirements + topology + recorded keys)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define RL(v, l) ((u32)__builtin_amdgcn_readlane((int)(v), (l)))   /* broadcast from a wave-uniform lane: v_readlane, no LDS round trip */
 #define GA __attribute__((address_space(1)))   /* global address space: loads become global_load, not flat_load */
 typedef uint64_t u64; typedef uint32_t u32; typedef uint16_t u16; typedef int64_t i64; typedef int32_t i32; typedef uint8_t u8;
 
@@ -80,7 +81,7 @@ struct DevProb {
 // Mutable state of one Solve (device memory).
 struct DevState {
   // queue (queue.go:29-72)
-  u32* q; u32* lastlen; u32* lastgen; i32* pod_stage; i32* pod_node; i32* pod_seq;
+  u64* q; u32* lastlen; u32* lastgen; i32* pod_stage; i32* pod_node; i32* pod_seq;   // q entry: pod | class<<32 | requeued-unrelaxed<<63
   // node records (AoS, see Rec): slots [0,E) existing nodes, [E,E+NMAX) new nodes
   u8* rec; u32 rec_stride;
   i32* n_tmpl; u64* n_alive;          // new nodes only, indexed by j = slot-E; n_alive has one spare row
@@ -370,7 +371,7 @@ struct Tabs {
   u32 K, R, T, TW, GH, E, S, n_ct, wellknown; i32 key_zone, key_ct;
   // hot global arrays, typed with the global address space (pointers loaded from a descriptor in memory
   // would otherwise be generic and every access a FLAT instruction)
-  GA u32* q; GA u32* lastgen; GA u32* lastlen; GA i32* pod_stage; GA i32* pod_node; GA i32* pod_seq;
+  GA u64* q; GA u32* lastgen; GA u32* lastlen; GA i32* pod_stage; GA i32* pod_node; GA i32* pod_seq;
   const GA u32* stage_cls; const GA u32* pod_stage_off; const GA u32* grp_filter_off;
   GA u8* rec; u32 rec_stride; GA i32* hcnt; GA u64* n_alive;
   const GA u64* ge_rows; const GA u64* kv_types; const GA u64* cmplx_types; const GA u64* nidnex_types; const GA u64* pair_types; const GA u64* its_types; const GA u64* grid;
@@ -386,6 +387,7 @@ struct alignas(16) WaveShared {
   TopoDyn dyn[KS_MAX_TOPO]; i32 host_anypos[KS_MAX_HOST];
   i64 req_new[KS_MAX_RES];
   u32 bstart[KS_BST_LDS];
+  u64 prof[24];
   u64 la_mask[KS_MAX_TOUCH][64]; i32 la_gt[KS_MAX_TOUCH][64]; i32 la_lt[KS_MAX_TOUCH][64];   // per-lane requirement slots of eval_node
 };
 
@@ -553,8 +555,8 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
 // Add (sh.rq), the new request vector and the header values the commit needs.  All lanes call this.
 __device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, const Ev& ev, int win, int lane) {
   const ClsPlan& c = sh.cls; ReqOut& o = sh.rq;
-  const u32 tpres = __shfl(ev.tpres, win), tcomp = __shfl(ev.tcomp, win), tchg = __shfl(ev.tchg, win), tnar = __shfl(ev.tnar, win);
-  u32 np = __shfl(ev.present, win), nc = __shfl(ev.complement, win), changed = 0, narrowed = 0, valid = 0;
+  const u32 tpres = RL(ev.tpres, win), tcomp = RL(ev.tcomp, win), tchg = RL(ev.tchg, win), tnar = RL(ev.tnar, win);
+  u32 np = RL(ev.present, win), nc = RL(ev.complement, win), changed = 0, narrowed = 0, valid = 0;
   for (u32 i = 0; i < c.ntouch; ++i) {
     const int k = c.touch[i].key;
     if ((tpres >> i) & 1u) { np |= 1u << k; nc = ((tcomp >> i) & 1u) ? (nc | (1u << k)) : (nc & ~(1u << k)); }
@@ -563,11 +565,11 @@ __device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, con
     valid |= 1u << k;
     if (lane == 0) { o.mask[k] = sh.la_mask[i][win]; o.gt[k] = sh.la_gt[i][win]; o.lt[k] = sh.la_lt[i][win]; }
   }
-  const u32 rm = __shfl(ev.reqmask, win) | c.reqmask; const u32 cnt = __shfl(ev.count, win);
-  const i32 its = __shfl(ev.it_state, win), it0 = __shfl(ev.it0, win);
+  const u32 rm = RL(ev.reqmask, win) | c.reqmask; const u32 cnt = RL(ev.count, win);
+  const i32 its = (i32)RL((u32)ev.it_state, win), it0 = (i32)RL((u32)ev.it0, win);
   if (lane == 0) { o.present = np; o.complement = nc; o.it_state = its; o.changed = changed; o.topo_narrowed = narrowed; o.valid = valid; o.rm = rm; o.count = cnt; o.it_before = it0; }
 #pragma unroll
-  for (int i = 0; i < KS_MAX_RES; ++i) if ((u32)i < tb.R) { const i64 v = __shfl(ev.req[i], win); if (lane == 0) sh.req_new[i] = v + c.req[i]; }
+  for (int i = 0; i < KS_MAX_RES; ++i) if ((u32)i < tb.R) { const u64 x = (u64)ev.req[i]; const i64 v = (i64)(((u64)RL((u32)(x >> 32), win) << 32) | RL((u32)x, win)); if (lane == 0) sh.req_new[i] = v + c.req[i]; }
 }
 
 // The node's requirement on key k after the Add that is being committed (published entries, else the record).
@@ -645,7 +647,19 @@ __device__ __forceinline__ void topology_record(const DevProb& P, const DevState
   else if (!q.complement && __builtin_popcountll(q.mask) == 1) grp_record(tb, g, __builtin_ctzll(q.mask));
 }
 
-#define WSYNC() __syncthreads()     /* single-wave workgroup: an LDS/global ordering point, not a real barrier */
+// Synchronisation inside the single-wave workgroup.
+//   LSYNC: cross-lane hand-off through LDS.  LDS instructions of one wave execute in program order, so only
+//          the compiler must be stopped from reordering -- no instruction is emitted.
+//   GSYNC: cross-lane hand-off through GLOBAL memory: the writer's stores must have completed
+//          (s_waitcnt vmcnt(0)) before another lane's load is issued; costs a store round trip, so it is used
+//          once per pod (before the candidate scan re-reads node records) and on rare paths.
+#ifdef KS_PROBES   /* fine-grained cycle probes (tools/phase_profile.py --probes builds with -DKS_PROBES) */
+#define PROBE(i) do { const u64 now_ = __builtin_readcyclecounter(); if (lane == 0) sh.prof[(i)] += now_ - tprobe; tprobe = now_; } while (0)
+#else
+#define PROBE(i) do { (void)tprobe; } while (0)
+#endif
+#define LSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define GSYNC() __syncthreads()
 
 __device__ __forceinline__ i64 wave_max_i64(i64 v) { for (int off = 32; off > 0; off >>= 1) { const i64 o = __shfl_xor(v, off); if (o > v) v = o; } return v; }
 
@@ -654,7 +668,7 @@ __device__ __forceinline__ i64 wave_max_i64(i64 v) { for (int off = 32; off > 0;
 __device__ __forceinline__ void stage_class(const Tabs& tb, WaveShared& sh, const GA ClsPlan* plans, u32 c, int lane) {
   const GA u32x4* src = (const GA u32x4*)(plans + c); u32x4* dst = (u32x4*)&sh.cls;
   for (u32 i = lane; i < sizeof(ClsPlan) / 16; i += 64) dst[i] = src[i];
-  WSYNC();
+  LSYNC();
   const ClsPlan& L = sh.cls;
   if ((u32)lane < L.ntopo) {
     const PlanTopo& t = L.topo[lane]; TopoDyn d; d.reg = tb.g_reg[t.g]; d.pos = tb.g_pos[t.g]; d.pad = 0;
@@ -663,44 +677,55 @@ __device__ __forceinline__ void stage_class(const Tabs& tb, WaveShared& sh, cons
     d.minc = mn; sh.dyn[lane] = d;
   }
   if (lane >= 32 && (u32)(lane - 32) < L.nhost) sh.host_anypos[lane - 32] = tb.g_hpos[L.host[lane - 32].hslot] > 0;
-  WSYNC();
+  LSYNC();
 }
 
-// lower_bound over the ascending distinct Allocatable values of one resource with a 64-ary search: every
-// lane probes one pivot, __ballot narrows the interval; two rounds cover 4096 values.
-__device__ __forceinline__ u32 ge_row_index(const i64* vals, u32 n, i64 q, int lane) {
-  u32 lo = 0, hi = n;                               // answer in [lo, hi]
-  while (lo < hi) {
-    const u32 span = hi - lo, step = (span + 63) / 64;
-    const u32 idx = lo + (u32)lane * step;
-    const bool ge = idx < hi && vals[idx] >= q;
-    const u64 b = ballot64(ge);
-    const u32 npiv = (span + step - 1) / step;      // pivots actually inside [lo, hi)
-    if (!b) { lo = lo + (npiv - 1) * step + 1; continue; }
-    const u32 f = __builtin_ctzll(b);
-    if (step == 1) return lo + f;
-    hi = lo + f * step;                             // vals[hi] >= q
-    if (f > 0) lo = lo + (f - 1) * step + 1;
+// lower_bound over the ascending distinct Allocatable values of every requested resource with a 64-ary
+// search: every lane probes one pivot, __ballot narrows the interval (two rounds cover 4096 values).  All
+// resources advance together so their LDS reads overlap.  idx[r] == ge_cnt[r] means "no type has that much".
+__device__ __forceinline__ void ge_row_indices(const Tabs& tb, const WaveShared& sh, u32 reqmask, int lane, u32 (&idx)[KS_MAX_RES]) {
+  u32 lo[KS_MAX_RES], hi[KS_MAX_RES];
+#pragma unroll
+  for (int r = 0; r < KS_MAX_RES; ++r) { lo[r] = 0; hi[r] = ((reqmask >> r) & 1u) ? tb.ge_cnt[r] : 0; }
+  for (;;) {
+    bool busy = false;
+#pragma unroll
+    for (int r = 0; r < KS_MAX_RES; ++r) if (lo[r] < hi[r]) {
+      busy = true;
+      const u32 span = hi[r] - lo[r], step = (span + 63) >> 6;
+      const u32 p = lo[r] + (u32)lane * step;
+      const bool in = p < hi[r];
+      const bool ge = in && tb.ge_vals[(size_t)r * tb.T + p] >= sh.req_new[r];
+      const u64 b = ballot64(ge); const u32 npiv = __builtin_popcountll(ballot64(in));
+      if (!b) lo[r] = lo[r] + (npiv - 1) * step + 1;
+      else {
+        const u32 f = __builtin_ctzll(b);
+        if (step == 1) { lo[r] = hi[r] = lo[r] + f; }
+        else { hi[r] = lo[r] + f * step; if (f > 0) lo[r] = lo[r] + (f - 1) * step + 1; }
+      }
+    }
+    if (!busy) break;
   }
-  return lo;
+#pragma unroll
+  for (int r = 0; r < KS_MAX_RES; ++r) idx[r] = lo[r];
 }
 
 // Instance-type filter (filterInstanceTypesByRequirements, node.go:137-141) on T-bit masks, one wave:
 //   alive' = alive & passTypes(changed keys) & its_types(state) & offerings & AND_r ge_rows[r][row(requests[r])]
 // Lane w owns word w; there is no per-type loop: resources.Fits is one precomputed row per requested resource.
 __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, WaveShared& sh, const Rec& r, const GA u64* alive_in, GA u64* alive_out, u32 reqmask_new,
-                             u32 changed_keys, bool check_offer, bool check_it, int lane) {
-  const GA u64* rows[KS_MAX_RES];
+                             u32 changed_keys, bool check_offer, bool check_it, int lane, u64& tprobe) {
+  const GA u64* rows[KS_MAX_RES]; u32 ridx[KS_MAX_RES];
+  PROBE(2);
+  ge_row_indices(tb, sh, reqmask_new, lane, ridx);
+  PROBE(3);
+  bool none = false;
 #pragma unroll
   for (int i = 0; i < KS_MAX_RES; ++i) {
     rows[i] = nullptr;
-    if ((reqmask_new >> i) & 1u) {
-      const u32 n = tb.ge_cnt[i];
-      const u32 idx = ge_row_index(tb.ge_vals + (size_t)i * tb.T, n, sh.req_new[i], lane);
-      if (idx >= n) { for (u32 w = lane; w < tb.TW; w += 64) alive_out[w] = 0; WSYNC(); return false; }   // nothing has that much of resource i
-      rows[i] = tb.ge_rows + ((size_t)i * tb.T + idx) * tb.TW;
-    }
+    if ((reqmask_new >> i) & 1u) { if (ridx[i] >= tb.ge_cnt[i]) none = true; rows[i] = tb.ge_rows + ((size_t)i * tb.T + ridx[i]) * tb.TW; }
   }
+  if (none) { for (u32 w = lane; w < tb.TW; w += 64) alive_out[w] = 0; LSYNC(); return false; }   // nothing has that much of some resource
   bool any = false;
   for (u32 wbase = 0; wbase < tb.TW; wbase += 64) {
     const u32 w = wbase + lane; u64 a = 0;
@@ -715,7 +740,8 @@ __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, W
     }
     if (ballot64(a != 0)) any = true;
   }
-  WSYNC();
+  LSYNC();
+  PROBE(4);
   return any;
 }
 
@@ -732,7 +758,7 @@ __device__ __forceinline__ void recompute_cap(const DevProb& P, const Tabs& tb, 
   }
 #pragma unroll
   for (int r = 0; r < KS_MAX_RES; ++r) if ((u32)r < tb.R) { const i64 v = wave_max_i64(mx[r]); if (lane == 0) cap[r] = v; }
-  WSYNC();
+  LSYNC();
 }
 
 // Write the winning node's record after Add: only what changed (lane-parallel stores).
@@ -759,7 +785,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
   Tabs tb;
   tb.K = P.K; tb.R = P.R; tb.T = P.T; tb.TW = P.TW; tb.GH = P.GH; tb.E = P.E; tb.S = P.S; tb.n_ct = P.n_ct; tb.wellknown = P.wellknown_mask; tb.key_zone = P.key_zone; tb.key_ct = P.key_ct;
   tb.key_nvalues = P.key_nvalues; tb.value_int = P.value_int; tb.its_fail = P.its_fail; tb.its_inter = P.its_inter;
-  tb.q = (GA u32*)S.q; tb.lastgen = (GA u32*)S.lastgen; tb.lastlen = (GA u32*)S.lastlen; tb.pod_stage = (GA i32*)S.pod_stage; tb.pod_node = (GA i32*)S.pod_node; tb.pod_seq = (GA i32*)S.pod_seq;
+  tb.q = (GA u64*)S.q; tb.lastgen = (GA u32*)S.lastgen; tb.lastlen = (GA u32*)S.lastlen; tb.pod_stage = (GA i32*)S.pod_stage; tb.pod_node = (GA i32*)S.pod_node; tb.pod_seq = (GA i32*)S.pod_seq;
   tb.stage_cls = (const GA u32*)P.stage_cls; tb.pod_stage_off = (const GA u32*)P.pod_stage_off; tb.grp_filter_off = (const GA u32*)P.grp_filter_off;
   tb.rec = (GA u8*)S.rec; tb.rec_stride = S.rec_stride; tb.hcnt = (GA i32*)S.hcnt; tb.n_alive = (GA u64*)S.n_alive;
   tb.ge_rows = (const GA u64*)P.ge_rows; tb.kv_types = (const GA u64*)P.kv_types; tb.cmplx_types = (const GA u64*)P.cmplx_types; tb.nidnex_types = (const GA u64*)P.nidnex_types;
@@ -767,7 +793,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
   tb.gcnt = S.gcnt; tb.g_reg = S.g_reg; tb.g_pos = S.g_pos; tb.g_active = S.g_active; tb.g_hpos = S.g_hpos; tb.ge_vals = P.ge_vals; tb.ge_cnt = P.ge_cnt;
 
   // ---------------- initialise state (global memory) ----------------
-  for (u32 i = lane; i < P.P; i += 64) { tb.q[i] = P.queue[i]; tb.lastgen[i] = 0xFFFFFFFFu; tb.lastlen[i] = 0; tb.pod_stage[i] = 0; tb.pod_node[i] = -1; tb.pod_seq[i] = -1; }
+  for (u32 i = lane; i < P.P; i += 64) { const u32 pd = P.queue[i]; tb.q[i] = (u64)pd | ((u64)P.stage_cls[P.pod_stage_off[pd]] << 32); tb.lastgen[i] = 0xFFFFFFFFu; tb.lastlen[i] = 0; tb.pod_stage[i] = 0; tb.pod_node[i] = -1; tb.pod_seq[i] = -1; }
   for (u32 e = lane; e < tb.E; e += 64) {
     const Rec r = slot_rec(S, tb, e);
     r.taints() = P.en_taints[e]; r.present() = P.en.present[e]; r.complement() = P.en.complement[e]; r.it_state() = P.en.it_state[e];
@@ -811,9 +837,12 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
     for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h]; for (u32 e = 0; e < tb.E; ++e) if (P.grph_count[(size_t)h * tb.E + e] > 0) ++np; S.g_hpos[h] = np; }
   }
   __threadfence_block();
-  WSYNC();
+  GSYNC();
   const GA ClsPlan* plans = (const GA ClsPlan*)P.plans;
-  u32* ord = (u32*)(ks_dyn_lds + lds_used);            // ord[pos] = new-node index j, sorted in visiting order
+  u32* const ord_l = (u32*)(ks_dyn_lds + lds_used);    // ord[pos] = new-node index j, sorted in visiting order (LDS home)
+  GA u32* const ord_g = (GA u32*)S.order_g;            // ... its global-memory home once it outgrows LDS
+#define ORD_RD(i) (ord_in_lds ? ord_l[(i)] : ord_g[(i)])
+#define ORD_WR(i, v) do { if (ord_in_lds) ord_l[(i)] = (v); else ord_g[(i)] = (v); } while (0)
   const u32 ord_cap = (lds_bytes - lds_used) / 4;
   bool ord_in_lds = true;
   // count-bucket boundaries: bstart[c] (1 <= c <= maxc+1) = first position in `ord` whose node has >= c pods
@@ -828,16 +857,17 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
 #define TMARK() (tmark = __builtin_readcyclecounter())
 #define TACC(x) do { const u64 now_ = __builtin_readcyclecounter(); (x) += now_ - tmark; tmark = now_; } while (0)
   GA u64* const scratch = tb.n_alive + (size_t)P.NMAX * tb.TW;      // one spare row of the alive table
+  u64 tprobe = __builtin_readcyclecounter(); if (lane < 24) sh.prof[lane] = 0;
 
   // ---------------- Solve loop, scheduler.go:104-124 ----------------
   for (;;) {
     // Queue.Pop, queue.go:44-58
     if (q_len == 0) break;
     TMARK();
-    const u32 pod = tb.q[q_head];
-    if (tb.lastgen[pod] == q_gen && tb.lastlen[pod] == q_len) break;
+    const u64 qe = tb.q[q_head];
+    const u32 pod = (u32)qe, cidx = (u32)(qe >> 32) & 0x7FFFFFFFu;
+    if ((qe >> 63) && tb.lastgen[pod] == q_gen && tb.lastlen[pod] == q_len) break;   // only a requeued, unrelaxed pod can be stale
     q_head = (q_head + 1 == P.P) ? 0 : q_head + 1; q_len--; ++st_pops;
-    const u32 cidx = tb.stage_cls[tb.pod_stage_off[pod] + tb.pod_stage[pod]];
     TACC(tp_pop);
     stage_class(tb, sh, plans, cidx, lane);
     const ClsPlan& c = sh.cls;
@@ -849,6 +879,9 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
     // order, then open new nodes in `sort.Slice(newNodes, len(Pods))` order -- 64 per step, one per lane --
     // then one fresh node per machine template (a single-lane "chunk").  One code path evaluates, filters
     // and commits all three kinds.
+    PROBE(10);
+    GSYNC();                       // the previous pod's record / counter stores are complete before they are re-read
+    PROBE(11);
     u32 pos_base = 0, tm = 0;
     while (!placed && !err) {
       const u32 total = tb.E + nnew;
@@ -856,7 +889,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
       u32 slot = 0xFFFFFFFFu; u32 m_t = 0, lim = 0xFFFFFFFFu, ltypes = 0; size_t mc = 0;
       if (!fresh) {
         const u32 pos = pos_base + lane;
-        if (pos < total) slot = pos < tb.E ? pos : tb.E + ord[pos - tb.E];
+        if (pos < total) slot = pos < tb.E ? pos : tb.E + ORD_RD(pos - tb.E);
       } else {
         // ---- a new node from the next template that survives the pre-checks (scheduler.go:193-213) ----
         TMARK();
@@ -895,26 +928,30 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
         if (lane == 63) { fr.taints() = P.tmpl_taints[m_t]; fr.present() = P.mc_present[mc]; fr.complement() = P.mc_complement[mc]; fr.it_state() = P.mc_it[mc]; fr.reqmask() = P.tmpl_daemon_present[m_t]; fr.porthead() = -1; fr.count() = 0; }
         for (u32 g = lane; g < P.G; g += 64) if (P.grp_hslot[g] >= 0) tb.hcnt[(size_t)fs * tb.GH + P.grp_hslot[g]] = tb.g_active[g] ? 0 : -1;   // Topology.Register(hostname), node.go:47
         __threadfence_block();
-        WSYNC();
+        GSYNC();
         if (lane == 0) slot = fs;
         TACC(tp_new);
       }
 
       // ---- Node.Add / ExistingNode.Add up to the instance-type filter, one node per lane ----
+      PROBE(0);
       Ev ev; ev.rc = 0;
       if (slot != 0xFFFFFFFFu) eval_node(P, S, tb, sh, slot, slot < tb.E, fresh, ev, lane);
       u64 m = ballot64(ev.rc == 2);
       const u64 reach = ballot64(ev.rc >= 1);
+      PROBE(1);
       if (!fresh) { TACC(tp_scan); ++tp_chunks; }
       u32 my_alive = 0; u32 visited = fresh ? 0 : min(64u, total - pos_base);   // lanes the reference would have visited (all, unless one succeeds)
       if (want_stats && !fresh && slot != 0xFFFFFFFFu && slot >= tb.E && ev.rc >= 1) for (u32 w = 0; w < tb.TW; ++w) my_alive += __builtin_popcountll(tb.n_alive[(size_t)(slot - tb.E) * tb.TW + w]);
 
       while (m) {
         const int win = __builtin_ctzll(m);
-        const u32 sw = __shfl(slot, win); const bool ex = sw < tb.E; const u32 jw = sw - tb.E;
+        const u32 sw = RL(slot, win); const bool ex = sw < tb.E; const u32 jw = sw - tb.E;
+        PROBE(8);
         publish_eval(tb, sh, ev, win, lane);
         const Rec r = slot_rec(S, tb, sw);
-        WSYNC();
+        LSYNC();
+        PROBE(9);
         const u32 rm = sh.rq.rm;
         TACC(tp_evalout);
         if (!ex) {
@@ -924,7 +961,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
           const u32 keys = fresh ? sh.rq.topo_narrowed : sh.rq.changed;   // a fresh node's own keys are already in the grid row
           const bool zc = (tb.key_zone >= 0 && ((keys >> tb.key_zone) & 1u)) || (tb.key_ct >= 0 && ((keys >> tb.key_ct) & 1u));
           const bool itc = !fresh && sh.rq.it_state != sh.rq.it_before;
-          const bool ok = filter_types(P, tb, sh, r, fresh ? scratch : alive, fresh ? alive : scratch, rm, keys, zc, itc, lane);
+          const bool ok = filter_types(P, tb, sh, r, fresh ? scratch : alive, fresh ? alive : scratch, rm, keys, zc, itc, lane, tprobe);
           TACC(tp_full);
           if (!ok) { ++st_fullfail; if (!fresh) recompute_cap(P, tb, alive, r.cap(), lane); m &= m - 1; continue; }
           if (!fresh) for (u32 w = lane; w < tb.TW; w += 64) alive[w] = scratch[w];
@@ -944,9 +981,11 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
 #pragma unroll
           for (int rr = 0; rr < KS_MAX_RES; ++rr) if ((u32)rr < tb.R) { const i64 v = wave_max_i64(mx[rr]); if (lane == 0 && ((lim >> rr) & 1u)) S.remaining[(size_t)m_t * tb.R + rr] -= v; }
         }
+        PROBE(5);
         topology_record(P, S, tb, sh, r, sw, lane);
+        PROBE(6);
         const u32 cnt = sh.rq.count;                                   // pods on the node before this one
-        WSYNC();
+        LSYNC();
         write_record(tb, r, sh, rm, lane);
         if (lane == 0) {
           if (!ex) r.count() = cnt + 1;
@@ -954,32 +993,33 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
           for (u32 i = 0; i < c.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
           tb.pod_node[pod] = (i32)sw; tb.pod_seq[pod] = (i32)seq;
         }
+        PROBE(7);
         TACC(tp_commit);
         if (!ex && !fresh) {
           // visiting order: the node leaves position p of bucket `cnt` for the FRONT of bucket cnt+1
           const u32 p = pos_base + win - tb.E;
           const u32 endc = BST(cnt + 1);                             // one past the last node with `cnt` pods
-          for (u32 i = p + 1; i < endc; i += 64) { const u32 ii = i + lane; u32 v = 0; if (ii < endc) v = ord[ii]; WSYNC(); if (ii < endc) ord[ii - 1] = v; }
-          WSYNC();
-          if (lane == 0) { ord[endc - 1] = jw; BST(cnt + 1) = endc - 1; if (cnt + 1 > maxc) BST(cnt + 2) = nnew; }
+          for (u32 i = p + 1; i < endc; i += 64) { const u32 ii = i + lane; u32 v = 0; if (ii < endc) v = ORD_RD(ii); if (ord_in_lds) LSYNC(); else GSYNC(); if (ii < endc) ORD_WR(ii - 1, v); }
+          if (ord_in_lds) LSYNC(); else GSYNC();
+          if (lane == 0) { ORD_WR(endc - 1, jw); BST(cnt + 1) = endc - 1; if (cnt + 1 > maxc) BST(cnt + 2) = nnew; }
           if (cnt + 1 > maxc) maxc = cnt + 1;
         } else if (fresh) {
           // visiting order: appended -> BACK of the count-1 bucket, i.e. position bstart[2]; everything after shifts right
           if (ord_in_lds && nnew + 1 > ord_cap) {                     // spill the order array to global memory
-            for (u32 i = lane; i < nnew; i += 64) S.order_g[i] = ord[i];
-            WSYNC(); ord = S.order_g; ord_in_lds = false;
+            for (u32 i = lane; i < nnew; i += 64) ord_g[i] = ord_l[i];
+            GSYNC(); ord_in_lds = false;
           }
-          if (maxc == 0) { if (lane == 0) { BST(1) = 0; BST(2) = 1; ord[0] = jw; } maxc = 1; }
+          if (maxc == 0) { if (lane == 0) { BST(1) = 0; BST(2) = 1; ORD_WR(0, jw); } maxc = 1; }
           else {
             const u32 ins = BST(2);
-            for (u32 hi = nnew; hi > ins; ) { const u32 lo = hi > ins + 64 ? hi - 64 : ins; const u32 ii = lo + lane; u32 v = 0; if (ii < hi) v = ord[ii]; WSYNC(); if (ii < hi) ord[ii + 1] = v; WSYNC(); hi = lo; }
-            if (lane == 0) ord[ins] = jw;
+            for (u32 hi = nnew; hi > ins; ) { const u32 lo = hi > ins + 64 ? hi - 64 : ins; const u32 ii = lo + lane; u32 v = 0; if (ii < hi) v = ORD_RD(ii); if (ord_in_lds) LSYNC(); else GSYNC(); if (ii < hi) ORD_WR(ii + 1, v); if (ord_in_lds) LSYNC(); else GSYNC(); hi = lo; }
+            if (lane == 0) ORD_WR(ins, jw);
             for (u32 cc = 2 + lane; cc <= maxc + 1; cc += 64) BST(cc) += 1;
           }
           nnew = jw + 1;
         }
         pp_used += c.port_cnt; ++seq; placed = true;
-        WSYNC();
+        LSYNC();
         TACC(tp_order);
         break;
       }
@@ -1001,21 +1041,22 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
       u32 tail = q_head + q_len; if (tail >= P.P) tail -= P.P;
       q_len++;
       if (lane == 0) {
-        tb.q[tail] = pod;
+        const u32 ncls = relaxed ? tb.stage_cls[tb.pod_stage_off[pod] + stg + 1] : cidx;
+        tb.q[tail] = (u64)pod | ((u64)ncls << 32) | (relaxed ? 0ull : (1ull << 63));
         if (relaxed) {
           tb.pod_stage[pod] = stg + 1;
-          const u32 nc = tb.stage_cls[tb.pod_stage_off[pod] + stg + 1];
+          const u32 nc = ncls;
           for (u32 i = P.cls_own_off[nc]; i < P.cls_own_off[nc + 1]; ++i) tb.g_active[P.own_list[i] & 0x7FFFFFFFu] = 1;   // Topology.Update creates the group
         } else { tb.lastlen[pod] = q_len; tb.lastgen[pod] = q_gen; }
       }
       if (relaxed) { q_gen++; ++st_relax; }
       __threadfence_block();
-      WSYNC();
+      GSYNC();
     }
   }
 
   // ---------------- results ----------------
-  WSYNC();
+  GSYNC();
   for (u32 i = lane; i < q_len; i += 64) { u32 idx = q_head + i; if (idx >= P.P) idx -= P.P; S.unscheduled[i] = (i32)tb.q[idx]; }
   for (u32 j = lane; j < nnew; j += 64) {        // de-interleave the new nodes' records into the SoA result arrays
     const Rec r = slot_rec(S, tb, tb.E + j);
@@ -1029,6 +1070,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
     S.stats[KS_STAT_REF_ATTEMPTS] = st_ref_attempts; S.stats[KS_STAT_REF_TYPES] = st_ref_types;
     S.stats[KS_STAT_CYCLES] = __builtin_readcyclecounter() - t_start; S.stats[KS_STAT_ERR] = err;
     S.stats[15] = tp_evalout; S.stats[16] = tp_pop;
+    for (int i = 0; i < 14; ++i) S.stats[17 + i] = sh.prof[i];
     S.stats[8] = tp_stage; S.stats[9] = tp_scan; S.stats[10] = tp_full; S.stats[11] = tp_commit; S.stats[12] = tp_order; S.stats[13] = tp_new; S.stats[14] = tp_chunks;
   }
 }
