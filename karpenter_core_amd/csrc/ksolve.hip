@@ -371,11 +371,23 @@ struct Tabs {
   u32 K, R, T, TW, GH, E, S, n_ct, wellknown; i32 key_zone, key_ct;
   // hot global arrays, typed with the global address space (pointers loaded from a descriptor in memory
   // would otherwise be generic and every access a FLAT instruction)
-  GA u64* q; GA u32* lastgen; GA u32* lastlen; GA i32* pod_stage; GA i32* pod_node; GA i32* pod_seq;
-  const GA u32* stage_cls; const GA u32* pod_stage_off; const GA u32* grp_filter_off;
-  GA u8* rec; u32 rec_stride; GA i32* hcnt; GA u64* n_alive;
-  const GA u64* ge_rows; const GA u64* kv_types; const GA u64* cmplx_types; const GA u64* nidnex_types; const GA u64* pair_types; const GA u64* its_types; const GA u64* grid;
+  // Only what every pod step touches lives here (SGPRs are scarce: 102 per wave); cold pointers are read
+  // from the LDS descriptor at their use site through the G_* accessors below.
+  GA u64* q; GA i32* pod_node; GA i32* pod_seq;
+  GA u8* rec; u32 rec_stride; GA i32* hcnt; GA u64* n_alive; const GA u64* ge_rows;
 };
+#define G_lastgen ((GA u32*)S.lastgen)
+#define G_lastlen ((GA u32*)S.lastlen)
+#define G_pod_stage ((GA i32*)S.pod_stage)
+#define G_stage_cls ((const GA u32*)P.stage_cls)
+#define G_pod_stage_off ((const GA u32*)P.pod_stage_off)
+#define G_grp_filter_off ((const GA u32*)P.grp_filter_off)
+#define G_kv_types ((const GA u64*)P.kv_types)
+#define G_cmplx_types ((const GA u64*)P.cmplx_types)
+#define G_nidnex_types ((const GA u64*)P.nidnex_types)
+#define G_pair_types ((const GA u64*)P.pair_types)
+#define G_its_types ((const GA u64*)P.its_types)
+#define G_grid ((const GA u64*)P.grid)
 
 struct ReqOut {    // requirement set of the winning node after the pod is added (entries in `valid` only)
   u32 present, complement; i32 it_state; u32 changed; u32 topo_narrowed; u32 valid; u32 rm; u32 count; i32 it_before; u32 pad[3];
@@ -385,16 +397,19 @@ struct TopoDyn { u64 reg, pos; i32 minc; i32 pad; };
 struct alignas(16) WaveShared {
   ClsPlan cls; ReqOut rq;
   TopoDyn dyn[KS_MAX_TOPO]; i32 host_anypos[KS_MAX_HOST];
-  i64 req_new[KS_MAX_RES];
+  i64 req_new[KS_MAX_RES]; i64 low_new[KS_MAX_RES];
   u32 bstart[KS_BST_LDS];
-  u64 prof[24];
+  u64 ctr[32];          // statistics + (KS_PROBES builds) per-phase cycle counters; slot numbers = ks_result.stats[]
   u64 la_mask[KS_MAX_TOUCH][64]; i32 la_gt[KS_MAX_TOUCH][64]; i32 la_lt[KS_MAX_TOUCH][64];   // per-lane requirement slots of eval_node
 };
 
 // ---- slot record (AoS).  Offsets in bytes; stride = ks_rec_stride(R,K) ----
 //   0 u64 taints | 8 u32 present | 12 u32 complement | 16 i32 it_state | 20 u32 reqmask | 24 i32 porthead | 28 u32 count
-//   32 i64 req[R] | 32+8R i64 cap[R] | 32+16R u64 mask[K] | +8K i32 gt[K] | +4K i32 lt[K]
-__host__ __device__ inline u32 ks_rec_stride(u32 R, u32 K) { return (32 + 16 * R + 16 * K + 15) & ~15u; }
+//   32 i64 req[R] | +8R i64 cap[R] | +8R i64 low[R] | 32+24R u64 mask[K] | +8K i32 gt[K] | +4K i32 lt[K]
+//   cap: resource screen (max Allocatable over the surviving types, lazily tightened)
+//   low: the Allocatable value the last instance-type filter rounded each request up to; while the requests
+//        stay <= low the filter would select the same ge_rows, i.e. leave InstanceTypeOptions unchanged
+__host__ __device__ inline u32 ks_rec_stride(u32 R, u32 K) { return (32 + 24 * R + 16 * K + 15) & ~15u; }
 struct Rec {
   GA u8* p; u32 R, K;
   __device__ __forceinline__ GA u64& taints() const { return *(GA u64*)p; }
@@ -406,9 +421,10 @@ struct Rec {
   __device__ __forceinline__ GA u32& count() const { return *(GA u32*)(p + 28); }
   __device__ __forceinline__ GA i64* req() const { return (GA i64*)(p + 32); }
   __device__ __forceinline__ GA i64* cap() const { return (GA i64*)(p + 32 + 8 * R); }
-  __device__ __forceinline__ GA u64* mask() const { return (GA u64*)(p + 32 + 16 * R); }
-  __device__ __forceinline__ GA i32* gt() const { return (GA i32*)(p + 32 + 16 * R + 8 * K); }
-  __device__ __forceinline__ GA i32* lt() const { return (GA i32*)(p + 32 + 16 * R + 12 * K); }
+  __device__ __forceinline__ GA i64* low() const { return (GA i64*)(p + 32 + 16 * R); }
+  __device__ __forceinline__ GA u64* mask() const { return (GA u64*)(p + 32 + 24 * R); }
+  __device__ __forceinline__ GA i32* gt() const { return (GA i32*)(p + 32 + 24 * R + 8 * K); }
+  __device__ __forceinline__ GA i32* lt() const { return (GA i32*)(p + 32 + 24 * R + 12 * K); }
 };
 __device__ __forceinline__ Rec slot_rec(const DevState& S, const Tabs& tb, u32 s) { Rec r; r.p = tb.rec + (size_t)s * tb.rec_stride; r.R = tb.R; r.K = tb.K; return r; }
 __device__ __forceinline__ KReq rec_req(const Rec& r, u32 present, u32 complement, int k) {
@@ -551,25 +567,29 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
   ev.rc = fit ? 2 : 1;
 }
 
-// Publish the winning lane's evaluation (wave-uniform after the shuffles): the node's requirement set after
-// Add (sh.rq), the new request vector and the header values the commit needs.  All lanes call this.
-__device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, const Ev& ev, int win, int lane) {
+// The winning lane publishes its evaluation through LDS (it alone executes this): the node's requirement set
+// after Add (sh.rq), the new request vector, the header values the commit needs, and whether the
+// instance-type filter can change anything at all (see Rec::low).
+__device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, const Ev& ev, const Rec& r, u32 slot, bool fresh, int lane) {
   const ClsPlan& c = sh.cls; ReqOut& o = sh.rq;
-  const u32 tpres = RL(ev.tpres, win), tcomp = RL(ev.tcomp, win), tchg = RL(ev.tchg, win), tnar = RL(ev.tnar, win);
-  u32 np = RL(ev.present, win), nc = RL(ev.complement, win), changed = 0, narrowed = 0, valid = 0;
+  const u32 rm = ev.reqmask | c.reqmask;
+  i64 low[KS_MAX_RES];
+#pragma unroll
+  for (int i = 0; i < KS_MAX_RES; ++i) { low[i] = INT64_MIN; if ((u32)i < tb.R) low[i] = r.low()[i]; }
+  u32 np = ev.present, nc = ev.complement, changed = 0, narrowed = 0, valid = 0;
   for (u32 i = 0; i < c.ntouch; ++i) {
     const int k = c.touch[i].key;
-    if ((tpres >> i) & 1u) { np |= 1u << k; nc = ((tcomp >> i) & 1u) ? (nc | (1u << k)) : (nc & ~(1u << k)); }
-    if ((tchg >> i) & 1u) changed |= 1u << k;
-    if ((tnar >> i) & 1u) narrowed |= 1u << k;
+    if ((ev.tpres >> i) & 1u) { np |= 1u << k; nc = ((ev.tcomp >> i) & 1u) ? (nc | (1u << k)) : (nc & ~(1u << k)); }
+    if ((ev.tchg >> i) & 1u) changed |= 1u << k;
+    if ((ev.tnar >> i) & 1u) narrowed |= 1u << k;
     valid |= 1u << k;
-    if (lane == 0) { o.mask[k] = sh.la_mask[i][win]; o.gt[k] = sh.la_gt[i][win]; o.lt[k] = sh.la_lt[i][win]; }
+    o.mask[k] = sh.la_mask[i][lane]; o.gt[k] = sh.la_gt[i][lane]; o.lt[k] = sh.la_lt[i][lane];
   }
-  const u32 rm = RL(ev.reqmask, win) | c.reqmask; const u32 cnt = RL(ev.count, win);
-  const i32 its = (i32)RL((u32)ev.it_state, win), it0 = (i32)RL((u32)ev.it0, win);
-  if (lane == 0) { o.present = np; o.complement = nc; o.it_state = its; o.changed = changed; o.topo_narrowed = narrowed; o.valid = valid; o.rm = rm; o.count = cnt; o.it_before = it0; }
+  bool need = fresh || changed != 0 || ev.it_state != ev.it0;
 #pragma unroll
-  for (int i = 0; i < KS_MAX_RES; ++i) if ((u32)i < tb.R) { const u64 x = (u64)ev.req[i]; const i64 v = (i64)(((u64)RL((u32)(x >> 32), win) << 32) | RL((u32)x, win)); if (lane == 0) sh.req_new[i] = v + c.req[i]; }
+  for (int i = 0; i < KS_MAX_RES; ++i) if ((u32)i < tb.R) { const i64 v = ev.req[i] + c.req[i]; sh.req_new[i] = v; if (((rm >> i) & 1u) && v > low[i]) need = true; }
+  o.present = np; o.complement = nc; o.it_state = ev.it_state; o.changed = changed; o.topo_narrowed = narrowed; o.valid = valid;
+  o.rm = rm; o.count = ev.count; o.it_before = ev.it0; o.pad[0] = slot; o.pad[1] = need ? 1u : 0u;
 }
 
 // The node's requirement on key k after the Add that is being committed (published entries, else the record).
@@ -584,9 +604,9 @@ __device__ __forceinline__ KReq new_req(const WaveShared& sh, const Rec& r, int 
 __device__ __forceinline__ u64 pass_types_word(const DevProb& P, const Tabs& tb, int k, const KReq& B, u32 w) {
   const i32* vi = tb.value_int + k * 64; const u32 nv = tb.key_nvalues[k];
   u64 acc = 0;
-  for (u64 bits = kreq_has_mask(B, vi, nv); bits; bits &= bits - 1) acc |= tb.kv_types[((size_t)k * 64 + __builtin_ctzll(bits)) * tb.TW + w];
-  if (B.complement) acc |= tb.cmplx_types[(size_t)k * tb.TW + w];
-  if (kreq_nidne(B)) acc |= tb.nidnex_types[(size_t)k * tb.TW + w];
+  for (u64 bits = kreq_has_mask(B, vi, nv); bits; bits &= bits - 1) acc |= G_kv_types[((size_t)k * 64 + __builtin_ctzll(bits)) * tb.TW + w];
+  if (B.complement) acc |= G_cmplx_types[(size_t)k * tb.TW + w];
+  if (kreq_nidne(B)) acc |= G_nidnex_types[(size_t)k * tb.TW + w];
   return acc;
 }
 // hasOffering (node.go:151-159) as a T-bit mask word
@@ -598,14 +618,14 @@ __device__ __forceinline__ u64 offer_types_word(const DevProb& P, const Tabs& tb
   u64 acc = 0; const u64 cm = allowC & ((1ull << tb.n_ct) - 1);
   for (u64 zz = allowZ; zz; zz &= zz - 1) {
     const int z = __builtin_ctzll(zz); if ((u32)z * tb.n_ct >= 64) break;
-    for (u64 cb = cm; cb; cb &= cb - 1) acc |= tb.pair_types[((size_t)z * tb.n_ct + __builtin_ctzll(cb)) * tb.TW + w];
+    for (u64 cb = cm; cb; cb &= cb - 1) acc |= G_pair_types[((size_t)z * tb.n_ct + __builtin_ctzll(cb)) * tb.TW + w];
   }
   return acc;
 }
 
 // TopologyNodeFilter.MatchesRequirements, topologynodefilter.go:57-70
 __device__ __forceinline__ bool filter_matches(const DevProb& P, const Tabs& tb, int g, const WaveShared& sh, const Rec& r) {
-  const u32 b = tb.grp_filter_off[g], e = tb.grp_filter_off[g + 1];
+  const u32 b = G_grp_filter_off[g], e = G_grp_filter_off[g + 1];
   if (b == e) return true;
   for (u32 f = b; f < e; ++f) {
     bool ok = true;
@@ -654,10 +674,11 @@ __device__ __forceinline__ void topology_record(const DevProb& P, const DevState
 //          (s_waitcnt vmcnt(0)) before another lane's load is issued; costs a store round trip, so it is used
 //          once per pod (before the candidate scan re-reads node records) and on rare paths.
 #ifdef KS_PROBES   /* fine-grained cycle probes (tools/phase_profile.py --probes builds with -DKS_PROBES) */
-#define PROBE(i) do { const u64 now_ = __builtin_readcyclecounter(); if (lane == 0) sh.prof[(i)] += now_ - tprobe; tprobe = now_; } while (0)
+#define PROBE(i) do { const u64 now_ = __builtin_readcyclecounter(); if (lane == 0) sh.ctr[(i)] += now_ - tprobe; tprobe = now_; } while (0)
 #else
 #define PROBE(i) do { (void)tprobe; } while (0)
 #endif
+#define CTR(i, v) do { if (lane == 0) sh.ctr[(i)] += (v); } while (0)
 #define LSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define GSYNC() __syncthreads()
 
@@ -716,9 +737,7 @@ __device__ __forceinline__ void ge_row_indices(const Tabs& tb, const WaveShared&
 __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, WaveShared& sh, const Rec& r, const GA u64* alive_in, GA u64* alive_out, u32 reqmask_new,
                              u32 changed_keys, bool check_offer, bool check_it, int lane, u64& tprobe) {
   const GA u64* rows[KS_MAX_RES]; u32 ridx[KS_MAX_RES];
-  PROBE(2);
   ge_row_indices(tb, sh, reqmask_new, lane, ridx);
-  PROBE(3);
   bool none = false;
 #pragma unroll
   for (int i = 0; i < KS_MAX_RES; ++i) {
@@ -726,6 +745,8 @@ __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, W
     if ((reqmask_new >> i) & 1u) { if (ridx[i] >= tb.ge_cnt[i]) none = true; rows[i] = tb.ge_rows + ((size_t)i * tb.T + ridx[i]) * tb.TW; }
   }
   if (none) { for (u32 w = lane; w < tb.TW; w += 64) alive_out[w] = 0; LSYNC(); return false; }   // nothing has that much of some resource
+#pragma unroll
+  for (int i = 0; i < KS_MAX_RES; ++i) if (lane == 0 && ((reqmask_new >> i) & 1u)) sh.low_new[i] = tb.ge_vals[(size_t)i * tb.T + ridx[i]];
   bool any = false;
   for (u32 wbase = 0; wbase < tb.TW; wbase += 64) {
     const u32 w = wbase + lane; u64 a = 0;
@@ -734,14 +755,13 @@ __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, W
 #pragma unroll
       for (int i = 0; i < KS_MAX_RES; ++i) if (rows[i]) a &= rows[i][w];
       for (u32 bits = changed_keys; bits && a; bits &= bits - 1) { const int k = __builtin_ctz(bits); a &= pass_types_word(P, tb, k, new_req(sh, r, k), w); }
-      if (check_it && a) a &= tb.its_types[(size_t)sh.rq.it_state * tb.TW + w];
+      if (check_it && a) a &= G_its_types[(size_t)sh.rq.it_state * tb.TW + w];
       if (check_offer && a) a &= offer_types_word(P, tb, sh, r, w);
       alive_out[w] = a;
     }
     if (ballot64(a != 0)) any = true;
   }
   LSYNC();
-  PROBE(4);
   return any;
 }
 
@@ -785,21 +805,18 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
   Tabs tb;
   tb.K = P.K; tb.R = P.R; tb.T = P.T; tb.TW = P.TW; tb.GH = P.GH; tb.E = P.E; tb.S = P.S; tb.n_ct = P.n_ct; tb.wellknown = P.wellknown_mask; tb.key_zone = P.key_zone; tb.key_ct = P.key_ct;
   tb.key_nvalues = P.key_nvalues; tb.value_int = P.value_int; tb.its_fail = P.its_fail; tb.its_inter = P.its_inter;
-  tb.q = (GA u64*)S.q; tb.lastgen = (GA u32*)S.lastgen; tb.lastlen = (GA u32*)S.lastlen; tb.pod_stage = (GA i32*)S.pod_stage; tb.pod_node = (GA i32*)S.pod_node; tb.pod_seq = (GA i32*)S.pod_seq;
-  tb.stage_cls = (const GA u32*)P.stage_cls; tb.pod_stage_off = (const GA u32*)P.pod_stage_off; tb.grp_filter_off = (const GA u32*)P.grp_filter_off;
-  tb.rec = (GA u8*)S.rec; tb.rec_stride = S.rec_stride; tb.hcnt = (GA i32*)S.hcnt; tb.n_alive = (GA u64*)S.n_alive;
-  tb.ge_rows = (const GA u64*)P.ge_rows; tb.kv_types = (const GA u64*)P.kv_types; tb.cmplx_types = (const GA u64*)P.cmplx_types; tb.nidnex_types = (const GA u64*)P.nidnex_types;
-  tb.pair_types = (const GA u64*)P.pair_types; tb.its_types = (const GA u64*)P.its_types; tb.grid = (const GA u64*)P.grid;
+  tb.q = (GA u64*)S.q; tb.pod_node = (GA i32*)S.pod_node; tb.pod_seq = (GA i32*)S.pod_seq;
+  tb.rec = (GA u8*)S.rec; tb.rec_stride = S.rec_stride; tb.hcnt = (GA i32*)S.hcnt; tb.n_alive = (GA u64*)S.n_alive; tb.ge_rows = (const GA u64*)P.ge_rows;
   tb.gcnt = S.gcnt; tb.g_reg = S.g_reg; tb.g_pos = S.g_pos; tb.g_active = S.g_active; tb.g_hpos = S.g_hpos; tb.ge_vals = P.ge_vals; tb.ge_cnt = P.ge_cnt;
 
   // ---------------- initialise state (global memory) ----------------
-  for (u32 i = lane; i < P.P; i += 64) { const u32 pd = P.queue[i]; tb.q[i] = (u64)pd | ((u64)P.stage_cls[P.pod_stage_off[pd]] << 32); tb.lastgen[i] = 0xFFFFFFFFu; tb.lastlen[i] = 0; tb.pod_stage[i] = 0; tb.pod_node[i] = -1; tb.pod_seq[i] = -1; }
+  for (u32 i = lane; i < P.P; i += 64) { const u32 pd = P.queue[i]; tb.q[i] = (u64)pd | ((u64)P.stage_cls[P.pod_stage_off[pd]] << 32); G_lastgen[i] = 0xFFFFFFFFu; G_lastlen[i] = 0; G_pod_stage[i] = 0; tb.pod_node[i] = -1; tb.pod_seq[i] = -1; }
   for (u32 e = lane; e < tb.E; e += 64) {
     const Rec r = slot_rec(S, tb, e);
     r.taints() = P.en_taints[e]; r.present() = P.en.present[e]; r.complement() = P.en.complement[e]; r.it_state() = P.en.it_state[e];
     r.reqmask() = P.en_requests_present[e]; r.count() = 0;
     for (u32 k = 0; k < tb.K; ++k) { r.mask()[k] = P.en.mask[(size_t)e * tb.K + k]; r.gt()[k] = P.en.gt[(size_t)e * tb.K + k]; r.lt()[k] = P.en.lt[(size_t)e * tb.K + k]; }
-    for (u32 rr = 0; rr < tb.R; ++rr) { r.req()[rr] = P.en_requests[(size_t)e * tb.R + rr]; r.cap()[rr] = P.en_avail[(size_t)e * tb.R + rr]; }
+    for (u32 rr = 0; rr < tb.R; ++rr) { r.req()[rr] = P.en_requests[(size_t)e * tb.R + rr]; r.cap()[rr] = P.en_avail[(size_t)e * tb.R + rr]; r.low()[rr] = INT64_MIN; }
     i32 head = -1; for (u32 i = P.en_port_off[e]; i < P.en_port_off[e + 1]; ++i) { S.pp_entry[i] = P.ports[i]; S.pp_next[i] = head; head = (i32)i; }
     r.porthead() = head;
     for (u32 h = 0; h < tb.GH; ++h) tb.hcnt[(size_t)e * tb.GH + h] = P.grph_count[(size_t)h * tb.E + e];
@@ -851,37 +868,31 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
   // wave-uniform loop state lives in registers (SGPRs)
   u32 q_head = 0, q_len = P.P, q_gen = 0, nnew = 0, seq = 0, err = 0, maxc = 0;
   u32 pp_used = tb.E ? P.en_port_off[tb.E] : 0;
-  u64 st_pops = 0, st_relax = 0, st_full = 0, st_fullfail = 0, st_ref_attempts = 0, st_ref_types = 0;
   const bool want_stats = (P.flags & KS_FLAG_STATS) != 0;
-  u64 tp_stage = 0, tp_scan = 0, tp_full = 0, tp_commit = 0, tp_order = 0, tp_new = 0, tp_chunks = 0, tp_evalout = 0, tp_pop = 0; u64 tmark = 0;
-#define TMARK() (tmark = __builtin_readcyclecounter())
-#define TACC(x) do { const u64 now_ = __builtin_readcyclecounter(); (x) += now_ - tmark; tmark = now_; } while (0)
   GA u64* const scratch = tb.n_alive + (size_t)P.NMAX * tb.TW;      // one spare row of the alive table
-  u64 tprobe = __builtin_readcyclecounter(); if (lane < 24) sh.prof[lane] = 0;
+  u64 tprobe = __builtin_readcyclecounter(); if (lane < 32) sh.ctr[lane] = 0;
 
   // ---------------- Solve loop, scheduler.go:104-124 ----------------
   for (;;) {
     // Queue.Pop, queue.go:44-58
     if (q_len == 0) break;
-    TMARK();
+    PROBE(20);
     const u64 qe = tb.q[q_head];
     const u32 pod = (u32)qe, cidx = (u32)(qe >> 32) & 0x7FFFFFFFu;
-    if ((qe >> 63) && tb.lastgen[pod] == q_gen && tb.lastlen[pod] == q_len) break;   // only a requeued, unrelaxed pod can be stale
-    q_head = (q_head + 1 == P.P) ? 0 : q_head + 1; q_len--; ++st_pops;
-    TACC(tp_pop);
+    if ((qe >> 63) && G_lastgen[pod] == q_gen && G_lastlen[pod] == q_len) break;   // only a requeued, unrelaxed pod can be stale
+    q_head = (q_head + 1 == P.P) ? 0 : q_head + 1; q_len--; CTR(KS_STAT_POPS, 1);
+    PROBE(12);
     stage_class(tb, sh, plans, cidx, lane);
     const ClsPlan& c = sh.cls;
     if (c.overflow) { err = (u32)(-KS_ERR_UNSUPPORTED); break; }
     bool placed = false;
-    TACC(tp_stage);
+    PROBE(13);
 
     // Candidates in the reference's visiting order (scheduler.go:174-217): existing nodes in the caller's
     // order, then open new nodes in `sort.Slice(newNodes, len(Pods))` order -- 64 per step, one per lane --
     // then one fresh node per machine template (a single-lane "chunk").  One code path evaluates, filters
     // and commits all three kinds.
-    PROBE(10);
     GSYNC();                       // the previous pod's record / counter stores are complete before they are re-read
-    PROBE(11);
     u32 pos_base = 0, tm = 0;
     while (!placed && !err) {
       const u32 total = tb.E + nnew;
@@ -892,7 +903,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
         if (pos < total) slot = pos < tb.E ? pos : tb.E + ORD_RD(pos - tb.E);
       } else {
         // ---- a new node from the next template that survives the pre-checks (scheduler.go:193-213) ----
-        TMARK();
+        PROBE(20);
         bool have = false;
         for (; tm < P.M && !have; ++tm) {
           m_t = tm; mc = (size_t)m_t * P.C + cidx; lim = P.tmpl_limit_present[m_t];
@@ -912,59 +923,58 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
             }
             if (ballot64(a != 0)) lany = true;
             if (want_stats) { u32 pc = __builtin_popcountll(a); for (int off = 32; off > 0; off >>= 1) pc += __shfl_xor(pc, off); ltypes += pc; }
-            if (w < tb.TW) scratch[w] = a & tb.grid[mc * tb.TW + w];
+            if (w < tb.TW) scratch[w] = a & G_grid[mc * tb.TW + w];
           }
           if (!lany) continue;                  // "all available instance types exceed provisioner limits" (before NewNode)
-          if (want_stats) ++st_ref_attempts;    // NewNode + node.Add is attempted for this template
+          if (want_stats) CTR(KS_STAT_REF_ATTEMPTS, 1);    // NewNode + node.Add is attempted for this template
           if (!P.mc_ok[mc]) continue;           // taints / Compatible fail inside Add
           have = true;
         }
         if (err) break;
-        if (!have) { TACC(tp_new); break; }     // every template failed -> relax / requeue
+        if (!have) { PROBE(19); break; }     // every template failed -> relax / requeue
         // NewNode (node.go:44-60): materialise the fresh node's record from template∩class, register its hostname
         const u32 fs = tb.E + nnew; const Rec fr = slot_rec(S, tb, fs);
         if ((u32)lane < tb.K) { fr.mask()[lane] = P.mc_mask[mc * tb.K + lane]; fr.gt()[lane] = P.mc_gt[mc * tb.K + lane]; fr.lt()[lane] = P.mc_lt[mc * tb.K + lane]; }
-        if (lane >= 32 && (u32)lane < 32 + tb.R) { fr.req()[lane - 32] = P.tmpl_daemon[(size_t)m_t * tb.R + lane - 32]; fr.cap()[lane - 32] = INT64_MAX; }
+        if (lane >= 32 && (u32)lane < 32 + tb.R) { fr.req()[lane - 32] = P.tmpl_daemon[(size_t)m_t * tb.R + lane - 32]; fr.cap()[lane - 32] = INT64_MAX; fr.low()[lane - 32] = INT64_MIN; }
         if (lane == 63) { fr.taints() = P.tmpl_taints[m_t]; fr.present() = P.mc_present[mc]; fr.complement() = P.mc_complement[mc]; fr.it_state() = P.mc_it[mc]; fr.reqmask() = P.tmpl_daemon_present[m_t]; fr.porthead() = -1; fr.count() = 0; }
         for (u32 g = lane; g < P.G; g += 64) if (P.grp_hslot[g] >= 0) tb.hcnt[(size_t)fs * tb.GH + P.grp_hslot[g]] = tb.g_active[g] ? 0 : -1;   // Topology.Register(hostname), node.go:47
         __threadfence_block();
         GSYNC();
         if (lane == 0) slot = fs;
-        TACC(tp_new);
+        PROBE(19);
       }
 
       // ---- Node.Add / ExistingNode.Add up to the instance-type filter, one node per lane ----
-      PROBE(0);
       Ev ev; ev.rc = 0;
       if (slot != 0xFFFFFFFFu) eval_node(P, S, tb, sh, slot, slot < tb.E, fresh, ev, lane);
       u64 m = ballot64(ev.rc == 2);
       const u64 reach = ballot64(ev.rc >= 1);
-      PROBE(1);
-      if (!fresh) { TACC(tp_scan); ++tp_chunks; }
+      if (!fresh) { PROBE(14); CTR(21, 1); }
       u32 my_alive = 0; u32 visited = fresh ? 0 : min(64u, total - pos_base);   // lanes the reference would have visited (all, unless one succeeds)
       if (want_stats && !fresh && slot != 0xFFFFFFFFu && slot >= tb.E && ev.rc >= 1) for (u32 w = 0; w < tb.TW; ++w) my_alive += __builtin_popcountll(tb.n_alive[(size_t)(slot - tb.E) * tb.TW + w]);
 
       while (m) {
         const int win = __builtin_ctzll(m);
-        const u32 sw = RL(slot, win); const bool ex = sw < tb.E; const u32 jw = sw - tb.E;
-        PROBE(8);
-        publish_eval(tb, sh, ev, win, lane);
-        const Rec r = slot_rec(S, tb, sw);
+        if (lane == win) publish_eval(tb, sh, ev, slot_rec(S, tb, slot), slot, fresh, lane);
         LSYNC();
-        PROBE(9);
+        const u32 sw = sh.rq.pad[0]; const bool ex = sw < tb.E; const u32 jw = sw - tb.E;
+        const Rec r = slot_rec(S, tb, sw);
         const u32 rm = sh.rq.rm;
-        TACC(tp_evalout);
+        PROBE(15);
         if (!ex) {
           // filterInstanceTypesByRequirements (node.go:94-98): existing nodes have no instance-type step
-          ++st_full; if (want_stats && fresh) st_ref_types += ltypes;
+          CTR(KS_STAT_FULLCHECKS, 1); if (want_stats && fresh) CTR(KS_STAT_REF_TYPES, ltypes);
           GA u64* const alive = tb.n_alive + (size_t)jw * tb.TW;
           const u32 keys = fresh ? sh.rq.topo_narrowed : sh.rq.changed;   // a fresh node's own keys are already in the grid row
           const bool zc = (tb.key_zone >= 0 && ((keys >> tb.key_zone) & 1u)) || (tb.key_ct >= 0 && ((keys >> tb.key_ct) & 1u));
           const bool itc = !fresh && sh.rq.it_state != sh.rq.it_before;
-          const bool ok = filter_types(P, tb, sh, r, fresh ? scratch : alive, fresh ? alive : scratch, rm, keys, zc, itc, lane, tprobe);
-          TACC(tp_full);
-          if (!ok) { ++st_fullfail; if (!fresh) recompute_cap(P, tb, alive, r.cap(), lane); m &= m - 1; continue; }
-          if (!fresh) for (u32 w = lane; w < tb.TW; w += 64) alive[w] = scratch[w];
+          if (sh.rq.pad[1]) {     // otherwise the filter would pick the same rows as last time: InstanceTypeOptions unchanged
+            const bool ok = filter_types(P, tb, sh, r, fresh ? scratch : alive, fresh ? alive : scratch, rm, keys, zc, itc, lane, tprobe);
+            PROBE(16);
+            if (!ok) { CTR(KS_STAT_FULLFAILS, 1); if (!fresh) recompute_cap(P, tb, alive, r.cap(), lane); m &= m - 1; continue; }
+            if (!fresh) for (u32 w = lane; w < tb.TW; w += 64) alive[w] = scratch[w];
+            if ((u32)lane < tb.R && ((rm >> lane) & 1u)) r.low()[lane] = sh.low_new[lane];
+          }
         }
         // ---- commit: node.go:100-105 / existingnode.go:122-129 / scheduler.go:214-216 ----
         visited = win + 1;
@@ -981,9 +991,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
 #pragma unroll
           for (int rr = 0; rr < KS_MAX_RES; ++rr) if ((u32)rr < tb.R) { const i64 v = wave_max_i64(mx[rr]); if (lane == 0 && ((lim >> rr) & 1u)) S.remaining[(size_t)m_t * tb.R + rr] -= v; }
         }
-        PROBE(5);
         topology_record(P, S, tb, sh, r, sw, lane);
-        PROBE(6);
         const u32 cnt = sh.rq.count;                                   // pods on the node before this one
         LSYNC();
         write_record(tb, r, sh, rm, lane);
@@ -993,8 +1001,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
           for (u32 i = 0; i < c.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
           tb.pod_node[pod] = (i32)sw; tb.pod_seq[pod] = (i32)seq;
         }
-        PROBE(7);
-        TACC(tp_commit);
+        PROBE(17);
         if (!ex && !fresh) {
           // visiting order: the node leaves position p of bucket `cnt` for the FRONT of bucket cnt+1
           const u32 p = pos_base + win - tb.E;
@@ -1020,14 +1027,14 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
         }
         pp_used += c.port_cnt; ++seq; placed = true;
         LSYNC();
-        TACC(tp_order);
+        PROBE(18);
         break;
       }
       if (want_stats && !fresh) {
-        st_ref_attempts += visited;
+        CTR(KS_STAT_REF_ATTEMPTS, visited);
         u32 ty = ((u32)lane < visited && ((reach >> lane) & 1ull)) ? my_alive : 0;
         for (int off = 32; off > 0; off >>= 1) ty += __shfl_xor(ty, off);
-        st_ref_types += ty;
+        CTR(KS_STAT_REF_TYPES, ty);
       }
       if (!fresh) pos_base += 64;
     }
@@ -1035,21 +1042,21 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
 
     // ---- failure: Preferences.Relax + Queue.Push + Topology.Update (scheduler.go:116-123) ----
     if (!placed) {
-      const u32 nst = tb.pod_stage_off[pod + 1] - tb.pod_stage_off[pod];
-      const i32 stg = tb.pod_stage[pod];
+      const u32 nst = G_pod_stage_off[pod + 1] - G_pod_stage_off[pod];
+      const i32 stg = G_pod_stage[pod];
       const bool relaxed = (u32)stg + 1 < nst;
       u32 tail = q_head + q_len; if (tail >= P.P) tail -= P.P;
       q_len++;
       if (lane == 0) {
-        const u32 ncls = relaxed ? tb.stage_cls[tb.pod_stage_off[pod] + stg + 1] : cidx;
+        const u32 ncls = relaxed ? G_stage_cls[G_pod_stage_off[pod] + stg + 1] : cidx;
         tb.q[tail] = (u64)pod | ((u64)ncls << 32) | (relaxed ? 0ull : (1ull << 63));
         if (relaxed) {
-          tb.pod_stage[pod] = stg + 1;
+          G_pod_stage[pod] = stg + 1;
           const u32 nc = ncls;
           for (u32 i = P.cls_own_off[nc]; i < P.cls_own_off[nc + 1]; ++i) tb.g_active[P.own_list[i] & 0x7FFFFFFFu] = 1;   // Topology.Update creates the group
-        } else { tb.lastlen[pod] = q_len; tb.lastgen[pod] = q_gen; }
+        } else { G_lastlen[pod] = q_len; G_lastgen[pod] = q_gen; }
       }
-      if (relaxed) { q_gen++; ++st_relax; }
+      if (relaxed) { q_gen++; CTR(KS_STAT_RELAX, 1); }
       __threadfence_block();
       GSYNC();
     }
@@ -1066,12 +1073,8 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
   }
   if (lane == 0) {
     S.out_counts[0] = nnew; S.out_counts[1] = q_len;
-    S.stats[KS_STAT_POPS] = st_pops; S.stats[KS_STAT_RELAX] = st_relax; S.stats[KS_STAT_FULLCHECKS] = st_full; S.stats[KS_STAT_FULLFAILS] = st_fullfail;
-    S.stats[KS_STAT_REF_ATTEMPTS] = st_ref_attempts; S.stats[KS_STAT_REF_TYPES] = st_ref_types;
+    for (int i = 0; i < 32; ++i) S.stats[i] = sh.ctr[i];
     S.stats[KS_STAT_CYCLES] = __builtin_readcyclecounter() - t_start; S.stats[KS_STAT_ERR] = err;
-    S.stats[15] = tp_evalout; S.stats[16] = tp_pop;
-    for (int i = 0; i < 14; ++i) S.stats[17 + i] = sh.prof[i];
-    S.stats[8] = tp_stage; S.stats[9] = tp_scan; S.stats[10] = tp_full; S.stats[11] = tp_commit; S.stats[12] = tp_order; S.stats[13] = tp_new; S.stats[14] = tp_chunks;
   }
 }
 

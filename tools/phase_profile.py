@@ -10,6 +10,4 @@ print("kernel_ms", fp.kernel_ms, "nodes", len(r.new_nodes))
 st = r.stats; tot = st["kernel_cycles"]
 for k in ("cyc_pop","cyc_stage","cyc_scan","cyc_evalout","cyc_full","cyc_commit","cyc_order","cyc_new"):
     print(f"{k:12s} {st[k]:>14d}  {100*st[k]/tot:5.1f}%  per pod {st[k]/pods:9.0f}")
-names={0:"cand-select",1:"eval+ballot",2:"pre-filter",3:"ge-search",4:"rows+store",5:"post-filter",6:"topology_record",7:"write_record+misc",8:"stats/loop",9:"publish",10:"order+pop+stage",11:"GSYNC"}
-for i in range(12): print(f"prof{i:<2d} {names.get(i,''):18s} {st['prof%d'%i]/pods:9.0f}")
 print("total cycles", tot, "per pod", tot/pods, "chunks/pod", st["scan_chunks"]/pods, "full_checks", st["full_checks"], "full_fails", st["full_fails"])

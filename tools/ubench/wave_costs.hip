@@ -1,0 +1,84 @@
+// Single-wave cost model on gfx950: cycles per primitive when ONE wave64 runs alone on a CU.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef unsigned long long u64; typedef unsigned int u32;
+#define N 4096
+__global__ void k(u32* g, u64* out, int n_nodes) {
+  __shared__ u32 lds[4096];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 4096; i += 64) lds[i] = (i * 7 + 1) & 4095;
+  __syncthreads();
+  u64 t0, t1; u32 x = lane + 1; int slot = 0;
+  // 0: empty timer pair
+  t0 = __builtin_readcyclecounter(); t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 1: dependent VALU chain (v_mad)
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 64
+  for (int i = 0; i < N; ++i) x = x * 3u + 1u;
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 2: dependent 64-bit add chain
+  u64 y = x;
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 64
+  for (int i = 0; i < N; ++i) y = y + (y >> 3) + 1;
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 3: taken branches (loop not unrolled, tiny body)
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < N; ++i) { x += 1; asm volatile("" ::: "memory"); }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 4: dependent LDS reads (pointer chase)
+  u32 p = lane;
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 16
+  for (int i = 0; i < N; ++i) p = lds[p];
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 5: dependent global loads, L2/L1-resident pointer chase over n_nodes*64 dwords
+  u32 q = lane;
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 8
+  for (int i = 0; i < 1024; ++i) q = g[q] & (n_nodes * 64 - 1);
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 6: ballot + ctz + readlane chain
+  u32 z = x;
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 16
+  for (int i = 0; i < N; ++i) { u64 m = __ballot((z >> (i & 7)) & 1); int w = m ? __builtin_ctzll(m) : 0; z += __builtin_amdgcn_readlane(z, w); }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 7: divergent branch (half the lanes) with small bodies
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < N; ++i) { if ((lane + i) & 1) x = x * 5 + 1; else x = x ^ 0x55; }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 8: uniform branch skipping a block (s_cbranch) per iteration
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < N; ++i) { if (__builtin_amdgcn_readfirstlane(x + i) & 1024) { x = x * 7 + 3; y += x; } x += 2; }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 9: global store + __syncthreads (vmcnt(0)) round trip
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < 256; ++i) { g[(lane + i * 64) & 4095] = x; __syncthreads(); }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 10: independent global loads (8 in flight) then sum
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < 256; ++i) { u32 s = 0; 
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += g[(q + j * 517 + i * 64) & (n_nodes * 64 - 1)]; q += s & 63; }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  if (lane == 0) out[15] = x + y + p + q + z;
+}
+int main() {
+  const int n_nodes = 2048 * 8; u32* g; u64* out; std::vector<u32> h(n_nodes * 64);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = (u32)((i * 2654435761u) % h.size());
+  hipMalloc(&g, h.size() * 4); hipMalloc(&out, 16 * 8); hipMemcpy(g, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, g, out, n_nodes); hipDeviceSynchronize(); }
+  u64 o[16]; hipMemcpy(o, out, sizeof o, hipMemcpyDeviceToHost);
+  const char* names[] = {"timer pair", "dep v_mad x4096", "dep 64-bit add x4096", "taken branch loop x4096", "dep LDS read x4096", "dep global load (4MB chase) x1024",
+                         "ballot+ctz+readlane x4096", "divergent if/else x4096", "uniform skip branch x4096", "store+syncthreads x256", "8 indep global loads x256"};
+  const int div[] = {1, 4096, 4096, 4096, 4096, 1024, 4096, 4096, 4096, 256, 256};
+  for (int i = 0; i < 11; ++i) printf("%-36s total %8llu  per-iter %8.1f cycles\n", names[i], o[i], (double)o[i] / div[i]);
+  return 0;
+}
