@@ -46,7 +46,7 @@ extern "C" {
 #define KS_MAX_KEYS 32
 #define KS_MAX_RES 8
 #define KS_MAX_VALUES 64
-#define KS_MAX_ITSTATES 256
+#define KS_MAX_ITSTATES 65535
 #define KS_NO_BOUND_GT INT32_MIN /* "no greaterThan" */
 #define KS_NO_BOUND_LT INT32_MAX /* "no lessThan"   */
 #define KS_KEY_HOSTNAME (-2)
@@ -81,7 +81,8 @@ typedef struct ks_problem {
   uint32_t R;  /* resources                                           */
   uint32_t G;  /* topology groups (topologies first, then inverse)    */
   uint32_t GH; /* groups whose key is the hostname                    */
-  uint32_t S;  /* instance-type-key states                            */
+  uint32_t S;  /* instance-type-key states a node can be in (0 = key absent)                       */
+  uint32_t SC; /* instance-type-key requirements a pod class / topology filter can carry (0 = none) */
   uint32_t max_new_nodes; /* capacity for scheduling.Node records (<= P is always enough) */
   uint32_t flags;         /* KS_FLAG_* */
 
@@ -100,8 +101,8 @@ typedef struct ks_problem {
   const int64_t* it_cap;         /* [R*T]  Capacity (provisioner limits, scheduler.go:273-309) */
   const uint64_t* it_offer;      /* [T]    available (zone,capacity-type) pairs, types.go:106-128 */
   /* instance-type key lattice */
-  const uint8_t* its_inter;  /* [S*S] state of a∩b                                                    */
-  const uint8_t* its_fail;   /* [S*S] Requirements.Intersects error for existing=a, incoming=b         */
+  const uint16_t* its_inter; /* [S*SC] node state after intersecting node state a with pod-side req b  */
+  const uint8_t* its_fail;   /* [S*SC] Requirements.Intersects error for existing=a, incoming=b        */
   const uint8_t* its_nidne;  /* [S]   operator in {NotIn, DoesNotExist}                                */
   const uint64_t* its_types; /* [S*TW] types whose own `instance-type In [name]` passes against state s */
 

@@ -37,6 +37,11 @@
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define RL(v, l) ((u32)__builtin_amdgcn_readlane((int)(v), (l)))   /* broadcast from a wave-uniform lane: v_readlane, no LDS round trip */
+#ifdef KS_PROBES   /* fine-grained cycle probes (tools/phase_profile.py --probes builds with -DKS_PROBES) */
+#define PROBE(i) do { const u64 now_ = __builtin_readcyclecounter(); if (lane == 0) sh.ctr[(i)] += now_ - tprobe; tprobe = now_; } while (0)
+#else
+#define PROBE(i) do { (void)tprobe; } while (0)
+#endif
 #define GA __attribute__((address_space(1)))   /* global address space: loads become global_load, not flat_load */
 typedef uint64_t u64; typedef uint32_t u32; typedef uint16_t u16; typedef int64_t i64; typedef int32_t i32; typedef uint8_t u8;
 
@@ -50,10 +55,10 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 struct ReqSetsD { u32 n; const u32* present; const u32* complement; const u64* mask; const i32* gt; const i32* lt; const i32* it_state; };
 
 struct DevProb {
-  u32 P, C, T, TW, M, E, K, R, G, GH, S, NMAX, flags, n_topologies;
+  u32 P, C, T, TW, M, E, K, R, G, GH, S, SC, NMAX, flags, n_topologies;
   u32 wellknown_mask; const u32* key_nvalues; const i32* value_int; i32 key_zone, key_ct; u32 n_ct;
   const u32* it_present; const u32* it_complement; const u64* it_mask; const i64* it_alloc; const i64* it_cap; const u64* it_offer;
-  const u8* its_inter; const u8* its_fail; const u8* its_nidne; const u64* its_types;
+  const u16* its_inter; const u8* its_fail; const u8* its_nidne; const u64* its_types;
   ReqSetsD tmpl; const u64* tmpl_taints; const i64* tmpl_daemon; const u32* tmpl_daemon_present; const u64* tmpl_types;
   const u32* tmpl_limit_present; const i64* tmpl_remaining;
   ReqSetsD en; const u64* en_taints; const i64* en_avail; const i64* en_requests; const u32* en_requests_present; const u32* en_port_off;
@@ -187,8 +192,8 @@ __global__ __launch_bounds__(256) void ks_grid_mc(DevProb P) {
     P.mc_mask[idx * P.K + k] = r.mask; P.mc_gt[idx * P.K + k] = r.gt; P.mc_lt[idx * P.K + k] = r.lt;
   }
   const i32 sa = P.tmpl.it_state[m], sb = P.cls.it_state[c];
-  if (P.its_fail[sa * P.S + sb]) ok = false;
-  P.mc_it[idx] = P.its_inter[sa * P.S + sb];
+  if (P.its_fail[sa * P.SC + sb]) ok = false;
+  P.mc_it[idx] = P.its_inter[sa * P.SC + sb];
   P.mc_present[idx] = present; P.mc_complement[idx] = complement; P.mc_ok[idx] = ok ? 1 : 0;
 }
 
@@ -287,7 +292,7 @@ struct PlanTopo {    // static part of one matching topology group (getMatchingT
   u64 PD;            // podDomains.Has(value) over the key's universe
   i32 g; i32 maxskew; u8 type; u8 self; u8 pod_has; u8 hslot; u32 pad;
 };
-struct PlanRec { i32 g; i32 key; u8 type; u8 owned_inverse; u16 hslot; };   // one group Topology.Record must visit
+struct PlanRec { i32 g; i32 key; u8 type; u8 owned_inverse; u16 hslot; u8 tidx; u8 filtered; u16 pad; };   // one group Topology.Record must visit (tidx: touch entry holding its key, 0xFF none)
 struct alignas(16) ClsPlan {
   u32 c, present, complement; i32 it_state;
   u32 hn_mode, hn_off, hn_cnt, reqmask;
@@ -298,7 +303,7 @@ struct alignas(16) ClsPlan {
   PlanTopo topo[KS_MAX_TOPO];        // narrow-key items, grouped by touch entry
   PlanTopo host[KS_MAX_HOST];        // hostname-key items
   PlanRec rec[KS_MAX_REC];
-  u32 overflow; u32 pad[3];
+  u32 overflow; u32 lean_ok; u32 pad[2];   // lean_ok: Topology.Record needs nothing beyond the gathered keys (winner-lane commit possible)
 };
 static_assert(sizeof(ClsPlan) % 16 == 0, "plan records are copied with 16-byte loads");
 
@@ -357,6 +362,18 @@ __global__ __launch_bounds__(64) void ks_build_plans(DevProb P, ClsPlan* plans) 
       if (!seen) { PlanTouch& t = pl.touch[pl.ntouch]; t.key = r.key; t.own = 0; t.complement = 0; t.mask = 0; t.gt = KS_NOGT; t.lt = KS_NOLT; t.topo_begin = t.topo_end = (u8)pl.ntopo; ++pl.ntouch; }
     }
   }
+  pl.lean_ok = pl.port_cnt == 0 && !pl.overflow;
+  for (u32 i = 0; i < pl.nrec; ++i) {
+    PlanRec& r = pl.rec[i]; r.tidx = 0xFF; r.pad = 0;
+    r.filtered = (!r.owned_inverse && P.grp_filter_off[r.g] != P.grp_filter_off[r.g + 1]) ? 1 : 0;
+    for (u32 j = 0; j < pl.ntouch; ++j) if (pl.touch[j].key == r.key) r.tidx = (u8)j;
+    if (r.filtered) {   // a single empty filter term ({}: the pod has no node selector / affinity) always matches
+      const u32 fb = P.grp_filter_off[r.g], fe = P.grp_filter_off[r.g + 1];
+      bool trivial = false; for (u32 f = fb; f < fe; ++f) if (P.flt.present[f] == 0 && P.flt.it_state[f] == 0) trivial = true;
+      if (trivial) r.filtered = 0;
+    }
+    if (r.filtered || (r.key >= 0 && r.tidx == 0xFF)) pl.lean_ok = 0;
+  }
   plans[c] = pl;
 }
 
@@ -365,10 +382,10 @@ __global__ __launch_bounds__(64) void ks_build_plans(DevProb P, ClsPlan* plans) 
 // them (a generic pointer loaded from memory would become a FLAT access, and every FLAT access waits on
 // vmcnt(0) AND lgkmcnt(0), serialising all outstanding global loads).
 struct Tabs {
-  const u32* key_nvalues; const i32* value_int; const u8* its_fail; const u8* its_inter;
+  const u32* key_nvalues; const i32* value_int; const u8* its_fail; const u16* its_inter;
   i32* gcnt; u64* g_reg; u64* g_pos; u8* g_active; i32* g_hpos;
   const i64* ge_vals; const u32* ge_cnt;
-  u32 K, R, T, TW, GH, E, S, n_ct, wellknown; i32 key_zone, key_ct;
+  u32 K, R, T, TW, GH, E, S, SC, n_ct, wellknown; i32 key_zone, key_ct;
   // hot global arrays, typed with the global address space (pointers loaded from a descriptor in memory
   // would otherwise be generic and every access a FLAT instruction)
   // Only what every pod step touches lives here (SGPRs are scarce: 102 per wave); cold pointers are read
@@ -397,7 +414,7 @@ struct TopoDyn { u64 reg, pos; i32 minc; i32 pad; };
 struct alignas(16) WaveShared {
   ClsPlan cls; ReqOut rq;
   TopoDyn dyn[KS_MAX_TOPO]; i32 host_anypos[KS_MAX_HOST];
-  i64 req_new[KS_MAX_RES]; i64 low_new[KS_MAX_RES];
+  i64 req_new[KS_MAX_RES]; i64 low_new[KS_MAX_RES]; i64 room_new[KS_MAX_RES];
   u32 bstart[KS_BST_LDS];
   u64 ctr[32];          // statistics + (KS_PROBES builds) per-phase cycle counters; slot numbers = ks_result.stats[]
   u64 la_mask[KS_MAX_TOUCH][64]; i32 la_gt[KS_MAX_TOUCH][64]; i32 la_lt[KS_MAX_TOUCH][64];   // per-lane requirement slots of eval_node
@@ -405,8 +422,9 @@ struct alignas(16) WaveShared {
 
 // ---- slot record (AoS).  Offsets in bytes; stride = ks_rec_stride(R,K) ----
 //   0 u64 taints | 8 u32 present | 12 u32 complement | 16 i32 it_state | 20 u32 reqmask | 24 i32 porthead | 28 u32 count
-//   32 i64 req[R] | +8R i64 cap[R] | +8R i64 low[R] | 32+24R u64 mask[K] | +8K i32 gt[K] | +4K i32 lt[K]
-//   cap: resource screen (max Allocatable over the surviving types, lazily tightened)
+//   32 i64 room[R] | +8R i64 req[R] | +8R i64 low[R] | 32+24R u64 mask[K] | +8K i32 gt[K] | +4K i32 lt[K]
+//   room: resource screen = cap - req, cap being Available() for an existing node (exact) or the max Allocatable
+//         over the surviving types for a new one (lazily tightened); header + room[<=4] is one 64-byte line
 //   low: the Allocatable value the last instance-type filter rounded each request up to; while the requests
 //        stay <= low the filter would select the same ge_rows, i.e. leave InstanceTypeOptions unchanged
 __host__ __device__ inline u32 ks_rec_stride(u32 R, u32 K) { return (32 + 24 * R + 16 * K + 15) & ~15u; }
@@ -419,16 +437,21 @@ struct Rec {
   __device__ __forceinline__ GA u32& reqmask() const { return *(GA u32*)(p + 20); }
   __device__ __forceinline__ GA i32& porthead() const { return *(GA i32*)(p + 24); }
   __device__ __forceinline__ GA u32& count() const { return *(GA u32*)(p + 28); }
-  __device__ __forceinline__ GA i64* req() const { return (GA i64*)(p + 32); }
-  __device__ __forceinline__ GA i64* cap() const { return (GA i64*)(p + 32 + 8 * R); }
+  __device__ __forceinline__ GA i64* room() const { return (GA i64*)(p + 32); }
+  __device__ __forceinline__ GA i64* req() const { return (GA i64*)(p + 32 + 8 * R); }
   __device__ __forceinline__ GA i64* low() const { return (GA i64*)(p + 32 + 16 * R); }
   __device__ __forceinline__ GA u64* mask() const { return (GA u64*)(p + 32 + 24 * R); }
   __device__ __forceinline__ GA i32* gt() const { return (GA i32*)(p + 32 + 24 * R + 8 * K); }
   __device__ __forceinline__ GA i32* lt() const { return (GA i32*)(p + 32 + 24 * R + 12 * K); }
 };
 __device__ __forceinline__ Rec slot_rec(const DevState& S, const Tabs& tb, u32 s) { Rec r; r.p = tb.rec + (size_t)s * tb.rec_stride; r.R = tb.R; r.K = tb.K; return r; }
+// BOUNDS == false: no requirement anywhere in the problem carries Gt/Lt, so no node can ever acquire bounds;
+// the sentinels become compile-time constants and every within-bounds computation folds away.
+template <bool BOUNDS>
 __device__ __forceinline__ KReq rec_req(const Rec& r, u32 present, u32 complement, int k) {
-  KReq q; q.present = (present >> k) & 1u; q.complement = (complement >> k) & 1u; q.mask = r.mask()[k]; q.gt = r.gt()[k]; q.lt = r.lt()[k]; return q;
+  KReq q; q.present = (present >> k) & 1u; q.complement = (complement >> k) & 1u; q.mask = r.mask()[k];
+  if constexpr (BOUNDS) { q.gt = r.gt()[k]; q.lt = r.lt()[k]; } else { q.gt = KS_NOGT; q.lt = KS_NOLT; }
+  return q;
 }
 
 // HostPortUsage.validate, hostportusage.go:81-93 / entry.matches :45-57
@@ -447,6 +470,10 @@ __device__ __forceinline__ bool ports_conflict(const DevProb& P, const DevState&
 
 __device__ __forceinline__ bool kreq_differs(const KReq& x, const KReq& y) { return x.present != y.present || x.mask != y.mask || x.complement != y.complement || x.gt != y.gt || x.lt != y.lt; }
 
+// The popped pod's class scalars, hoisted into wave-uniform registers once per pod (a class field read from
+// LDS costs a ~60-cycle dependent round trip at every use inside eval_node).
+struct ClsR { u64 tol; u32 reqmask, ntouch, nhost, hn_mode, port_cnt; i32 it_state; i64 req[KS_MAX_RES]; };
+
 // Result of evaluating one node for the current pod: scalars in registers, the per-key requirements in
 // per-lane LDS slots (sh.la_*[touch index][lane]) so the algebra below is ONE dynamic loop body instead
 // of an unrolled copy per key, and so every lane can read the winner's slots directly.
@@ -454,68 +481,71 @@ struct Ev {
   int rc;                       // 0: fails before the instance-type filter; 1: reaches it but fails the resource screen; 2: passes
   u32 present, complement, count, reqmask; i32 it_state, it0;
   u32 tpres, tcomp, tchg, tnar; // per touch index: requirement present / complement after Add; changed; narrowed by topology
-  i64 req[KS_MAX_RES];          // the node's current requests
+  i64 room[KS_MAX_RES];         // the node's resource headroom (Rec::room)
 };
 
 // One attempt of Node.Add / ExistingNode.Add up to (not including) the instance-type filter
 // (node.go:62-90 / existingnode.go:77-115).  Every lane evaluates its own node.
 // `merged`: the pod's own requirements are already folded into the record (a fresh node materialised
 // from the template∩class record), only topology is evaluated on top.
-__device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, const Tabs& tb, WaveShared& sh, u32 slot, bool existing, bool merged, Ev& ev, int lane) {
+template <bool BOUNDS>
+__device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, const Tabs& tb, WaveShared& sh, u32 slot, bool existing, bool merged, Ev& ev, int lane, u64& tprobe, const ClsR& cr) {
   const ClsPlan& c = sh.cls;
   const Rec r = slot_rec(S, tb, slot);
+  PROBE(22);
   ev.rc = 0; ev.tpres = 0; ev.tcomp = 0; ev.tchg = 0; ev.tnar = 0;
   // ---- gather: header, requests/capacity, first touched key, hostname counters (independent loads) ----
   const u32x4 h0 = *(const GA u32x4*)r.p, h1 = *(const GA u32x4*)(r.p + 16);
   const u64 taints = (u64)h0.x | ((u64)h0.y << 32); const u32 present = h0.z, complement = h0.w;
   const i32 it0 = (i32)h1.x; const u32 reqmask = h1.y; const i32 porthead = (i32)h1.z;
   ev.present = present; ev.complement = complement; ev.it_state = it0; ev.it0 = it0; ev.reqmask = reqmask; ev.count = h1.w;
-  i64 cap[KS_MAX_RES];
 #pragma unroll
-  for (int i = 0; i < KS_MAX_RES; ++i) { ev.req[i] = 0; cap[i] = 0; if ((u32)i < tb.R) { ev.req[i] = r.req()[i]; cap[i] = r.cap()[i]; } }
-  const u32 ntouch = c.ntouch;
+  for (int i = 0; i < KS_MAX_RES; ++i) { ev.room[i] = 0; if ((u32)i < tb.R) ev.room[i] = r.room()[i]; }
+  const u32 ntouch = cr.ntouch;
   KReq nxt = kreq_absent();
-  if (ntouch) nxt = rec_req(r, present, complement, c.touch[0].key);
+  if (ntouch) nxt = rec_req<BOUNDS>(r, present, complement, c.touch[0].key);
   i32 hc0 = -1, hc1 = -1, hc2 = -1;
-  if (c.nhost > 0) hc0 = tb.hcnt[(size_t)slot * tb.GH + c.host[0].hslot];
-  if (c.nhost > 1) hc1 = tb.hcnt[(size_t)slot * tb.GH + c.host[1].hslot];
-  if (c.nhost > 2) hc2 = tb.hcnt[(size_t)slot * tb.GH + c.host[2].hslot];
+  if (cr.nhost > 0) hc0 = tb.hcnt[(size_t)slot * tb.GH + c.host[0].hslot];
+  if (cr.nhost > 1) hc1 = tb.hcnt[(size_t)slot * tb.GH + c.host[1].hslot];
+  if (cr.nhost > 2) hc2 = tb.hcnt[(size_t)slot * tb.GH + c.host[2].hslot];
 
   // ---- Taints.Tolerates, taints.go:28-40 ----
-  if (taints & ~c.tol) return;
+  PROBE(23);
+  if (taints & ~cr.tol) return;
   // ---- the pod's hostname requirement against the node's `hostname In [own]` ----
-  if (!merged && c.hn_mode != 0) {
+  if (!merged && cr.hn_mode != 0) {
     bool inlist = false;
     if (existing) for (u32 i = 0; i < c.hn_cnt; ++i) if (P.hn_list[c.hn_off + i] == slot) { inlist = true; break; }
-    if (c.hn_mode == 1 ? !inlist : inlist) return;
+    if (cr.hn_mode == 1 ? !inlist : inlist) return;
   }
   // ---- HostPortUsage.Validate ----
-  if (c.port_cnt && porthead >= 0 && ports_conflict(P, S, c, porthead)) return;
+  if (cr.port_cnt && porthead >= 0 && ports_conflict(P, S, c, porthead)) return;
   // ---- resources: exact for existing nodes (existingnode.go:99-103), a necessary screen for new ones ----
   bool fit = true;
 #pragma unroll
-  for (int i = 0; i < KS_MAX_RES; ++i) if (((reqmask | c.reqmask) >> i) & 1u) { if (ev.req[i] + c.req[i] > cap[i]) fit = false; }
+  for (int i = 0; i < KS_MAX_RES; ++i) if (((reqmask | cr.reqmask) >> i) & 1u) { if (cr.req[i] > ev.room[i]) fit = false; }
   if (existing && !fit) return;
-  if (!merged && c.it_state) { if (tb.its_fail[it0 * tb.S + c.it_state]) return; ev.it_state = tb.its_inter[it0 * tb.S + c.it_state]; }
+  if (!merged && cr.it_state) { if (tb.its_fail[it0 * tb.SC + cr.it_state]) return; ev.it_state = tb.its_inter[it0 * tb.SC + cr.it_state]; }
   // ---- Topology.AddRequirements on hostname-keyed groups: the node's only hostname domain is its own ----
-  for (u32 i = 0; i < c.nhost; ++i) {
+  for (u32 i = 0; i < cr.nhost; ++i) {
     const PlanTopo& t = c.host[i]; const i32 cnt = i == 0 ? hc0 : (i == 1 ? hc1 : hc2); bool ok;
     if (t.type == 0) ok = cnt >= 0 && (i64)cnt + t.self <= (i64)t.maxskew;                        // nextDomainTopologySpread, min==0 for hostname (topologygroup.go:184-188)
     else if (t.type == 2) ok = cnt == 0;                                                           // nextDomainAntiAffinity :235-243
     else ok = sh.host_anypos[i] ? (cnt > 0) : (t.self && cnt >= 0);                                // nextDomainAffinity :202-233
     if (!ok) return;
   }
+  PROBE(24);
   // ---- per touched key: Compatible + Add of the pod's own requirement (requirements.go:123-133, :87-94; one
   //      Intersection serves both), then Topology.AddRequirements (topology.go:149-167) and the Compatible + Add
   //      of its result (node.go:83-90).  The next key's node requirement is loaded while this one is processed. ----
   for (u32 i = 0; i < ntouch; ++i) {
     const PlanTouch& t = c.touch[i]; const int k = t.key;
     KReq a = nxt;
-    if (i + 1 < ntouch) nxt = rec_req(r, present, complement, c.touch[i + 1].key);
+    if (i + 1 < ntouch) nxt = rec_req<BOUNDS>(r, present, complement, c.touch[i + 1].key);
     const KReq orig = a;
     const i32* vi = tb.value_int + k * 64; const u32 nv = tb.key_nvalues[k];
     if (t.own && !merged) {
-      KReq b; b.present = true; b.complement = t.complement; b.mask = t.mask; b.gt = t.gt; b.lt = t.lt;
+      KReq b; b.present = true; b.complement = t.complement; b.mask = t.mask; b.gt = BOUNDS ? t.gt : KS_NOGT; b.lt = BOUNDS ? t.lt : KS_NOLT;
       if (!a.present) { if (!((tb.wellknown >> k) & 1u) && !kreq_nidne(b)) return; a = b; }     // "label does not have known values"
       else {
         const KReq mg = kreq_intersect(b, a, vi, nv);
@@ -542,7 +572,7 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
           options = d.reg & tt.PD & d.pos;
           if (!options && tt.self) {
             KReq pd = kreq_exists();
-            if (tt.pod_has) { pd.present = true; pd.complement = t.complement; pd.mask = t.mask; pd.gt = t.gt; pd.lt = t.lt; }
+            if (tt.pod_has) { pd.present = true; pd.complement = t.complement; pd.mask = t.mask; pd.gt = BOUNDS ? t.gt : KS_NOGT; pd.lt = BOUNDS ? t.lt : KS_NOLT; }
             const u64 I = kreq_has_mask(kreq_intersect(pd, nd, vi, nv), vi, nv);
             const u64 x = d.reg & I, y = d.reg & tt.PD;
             if (x) options |= x & (~x + 1);
@@ -562,20 +592,22 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
     if (a.present) ev.tpres |= 1u << i;
     if (a.complement) ev.tcomp |= 1u << i;
     if (kreq_differs(a, orig)) ev.tchg |= 1u << i;
-    sh.la_mask[i][lane] = a.mask; sh.la_gt[i][lane] = a.gt; sh.la_lt[i][lane] = a.lt;
+    sh.la_mask[i][lane] = a.mask; if constexpr (BOUNDS) { sh.la_gt[i][lane] = a.gt; sh.la_lt[i][lane] = a.lt; }
   }
   ev.rc = fit ? 2 : 1;
+  PROBE(25);
 }
 
 // The winning lane publishes its evaluation through LDS (it alone executes this): the node's requirement set
 // after Add (sh.rq), the new request vector, the header values the commit needs, and whether the
 // instance-type filter can change anything at all (see Rec::low).
+template <bool BOUNDS>
 __device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, const Ev& ev, const Rec& r, u32 slot, bool fresh, int lane) {
   const ClsPlan& c = sh.cls; ReqOut& o = sh.rq;
   const u32 rm = ev.reqmask | c.reqmask;
-  i64 low[KS_MAX_RES];
+  i64 low[KS_MAX_RES], req[KS_MAX_RES];
 #pragma unroll
-  for (int i = 0; i < KS_MAX_RES; ++i) { low[i] = INT64_MIN; if ((u32)i < tb.R) low[i] = r.low()[i]; }
+  for (int i = 0; i < KS_MAX_RES; ++i) { low[i] = INT64_MIN; req[i] = 0; if ((u32)i < tb.R) { low[i] = r.low()[i]; req[i] = r.req()[i]; } }
   u32 np = ev.present, nc = ev.complement, changed = 0, narrowed = 0, valid = 0;
   for (u32 i = 0; i < c.ntouch; ++i) {
     const int k = c.touch[i].key;
@@ -583,11 +615,11 @@ __device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, con
     if ((ev.tchg >> i) & 1u) changed |= 1u << k;
     if ((ev.tnar >> i) & 1u) narrowed |= 1u << k;
     valid |= 1u << k;
-    o.mask[k] = sh.la_mask[i][lane]; o.gt[k] = sh.la_gt[i][lane]; o.lt[k] = sh.la_lt[i][lane];
+    o.mask[k] = sh.la_mask[i][lane]; if constexpr (BOUNDS) { o.gt[k] = sh.la_gt[i][lane]; o.lt[k] = sh.la_lt[i][lane]; } else { o.gt[k] = KS_NOGT; o.lt[k] = KS_NOLT; }
   }
   bool need = fresh || changed != 0 || ev.it_state != ev.it0;
 #pragma unroll
-  for (int i = 0; i < KS_MAX_RES; ++i) if ((u32)i < tb.R) { const i64 v = ev.req[i] + c.req[i]; sh.req_new[i] = v; if (((rm >> i) & 1u) && v > low[i]) need = true; }
+  for (int i = 0; i < KS_MAX_RES; ++i) if ((u32)i < tb.R) { const i64 v = req[i] + c.req[i]; sh.req_new[i] = v; sh.room_new[i] = ev.room[i] - c.req[i]; if (((rm >> i) & 1u) && v > low[i]) need = true; }
   o.present = np; o.complement = nc; o.it_state = ev.it_state; o.changed = changed; o.topo_narrowed = narrowed; o.valid = valid;
   o.rm = rm; o.count = ev.count; o.it_before = ev.it0; o.pad[0] = slot; o.pad[1] = need ? 1u : 0u;
 }
@@ -636,7 +668,7 @@ __device__ __forceinline__ bool filter_matches(const DevProb& P, const Tabs& tb,
       const KReq in = load_req(fp, fc, P.flt.mask + (size_t)f * tb.K, P.flt.gt + (size_t)f * tb.K, P.flt.lt + (size_t)f * tb.K, k);
       if (kreq_compatible_fail(a, in, (tb.wellknown >> k) & 1u, tb.value_int + k * 64, tb.key_nvalues[k])) ok = false;
     }
-    if (ok && P.flt.it_state[f] && tb.its_fail[sh.rq.it_state * tb.S + P.flt.it_state[f]]) ok = false;
+    if (ok && P.flt.it_state[f] && tb.its_fail[sh.rq.it_state * tb.SC + P.flt.it_state[f]]) ok = false;
     if (ok) return true;
   }
   return false;
@@ -673,11 +705,6 @@ __device__ __forceinline__ void topology_record(const DevProb& P, const DevState
 //   GSYNC: cross-lane hand-off through GLOBAL memory: the writer's stores must have completed
 //          (s_waitcnt vmcnt(0)) before another lane's load is issued; costs a store round trip, so it is used
 //          once per pod (before the candidate scan re-reads node records) and on rare paths.
-#ifdef KS_PROBES   /* fine-grained cycle probes (tools/phase_profile.py --probes builds with -DKS_PROBES) */
-#define PROBE(i) do { const u64 now_ = __builtin_readcyclecounter(); if (lane == 0) sh.ctr[(i)] += now_ - tprobe; tprobe = now_; } while (0)
-#else
-#define PROBE(i) do { (void)tprobe; } while (0)
-#endif
 #define CTR(i, v) do { if (lane == 0) sh.ctr[(i)] += (v); } while (0)
 #define LSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define GSYNC() __syncthreads()
@@ -767,7 +794,7 @@ __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, W
 
 // Per-resource maximum Allocatable over a node's surviving types: the (necessary) resource screen of
 // eval_node.  Recomputed lazily -- only after a candidate passed the screen but failed the filter.
-__device__ __forceinline__ void recompute_cap(const DevProb& P, const Tabs& tb, const GA u64* alive, GA i64* cap, int lane) {
+__device__ __forceinline__ void recompute_cap(const DevProb& P, const Tabs& tb, const GA u64* alive, const Rec& rec, int lane) {
   i64 mx[KS_MAX_RES];
 #pragma unroll
   for (int r = 0; r < KS_MAX_RES; ++r) mx[r] = INT64_MIN;
@@ -777,20 +804,21 @@ __device__ __forceinline__ void recompute_cap(const DevProb& P, const Tabs& tb, 
     for (int r = 0; r < KS_MAX_RES; ++r) if ((u32)r < tb.R && on) { const i64 al = P.it_alloc[(size_t)r * tb.T + t]; if (al > mx[r]) mx[r] = al; }
   }
 #pragma unroll
-  for (int r = 0; r < KS_MAX_RES; ++r) if ((u32)r < tb.R) { const i64 v = wave_max_i64(mx[r]); if (lane == 0) cap[r] = v; }
+  for (int r = 0; r < KS_MAX_RES; ++r) if ((u32)r < tb.R) { const i64 v = wave_max_i64(mx[r]); if (lane == 0) rec.room()[r] = v - rec.req()[r]; }
   LSYNC();
 }
 
 // Write the winning node's record after Add: only what changed (lane-parallel stores).
+template <bool BOUNDS>
 __device__ __forceinline__ void write_record(const Tabs& tb, const Rec& r, const WaveShared& sh, u32 reqmask_new, int lane) {
-  if ((u32)lane < tb.K && ((sh.rq.changed >> lane) & 1u)) { r.mask()[lane] = sh.rq.mask[lane]; r.gt()[lane] = sh.rq.gt[lane]; r.lt()[lane] = sh.rq.lt[lane]; }
-  if (lane >= 32 && (u32)lane < 32 + tb.R) r.req()[lane - 32] = sh.req_new[lane - 32];
+  if ((u32)lane < tb.K && ((sh.rq.changed >> lane) & 1u)) { r.mask()[lane] = sh.rq.mask[lane]; if constexpr (BOUNDS) { r.gt()[lane] = sh.rq.gt[lane]; r.lt()[lane] = sh.rq.lt[lane]; } }
+  if (lane >= 32 && (u32)lane < 32 + tb.R) { r.req()[lane - 32] = sh.req_new[lane - 32]; r.room()[lane - 32] = sh.room_new[lane - 32]; }
   if (lane == 63) { r.present() = sh.rq.present; r.complement() = sh.rq.complement; r.it_state() = sh.rq.it_state; r.reqmask() = reqmask_new; }
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ks_dyn_lds[];
 
-template <bool FAST>
+template <bool FAST, bool BOUNDS>
 __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevState* states, u32 lds_bytes) {
   // descriptors are copied to LDS: loads from them can then be CSE'd across global stores (no aliasing)
   __shared__ DevProb P_lds; __shared__ DevState S_lds;
@@ -803,7 +831,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
   const DevProb& P = P_lds;
   const DevState& S = S_lds;
   Tabs tb;
-  tb.K = P.K; tb.R = P.R; tb.T = P.T; tb.TW = P.TW; tb.GH = P.GH; tb.E = P.E; tb.S = P.S; tb.n_ct = P.n_ct; tb.wellknown = P.wellknown_mask; tb.key_zone = P.key_zone; tb.key_ct = P.key_ct;
+  tb.K = P.K; tb.R = P.R; tb.T = P.T; tb.TW = P.TW; tb.GH = P.GH; tb.E = P.E; tb.S = P.S; tb.SC = P.SC; tb.n_ct = P.n_ct; tb.wellknown = P.wellknown_mask; tb.key_zone = P.key_zone; tb.key_ct = P.key_ct;
   tb.key_nvalues = P.key_nvalues; tb.value_int = P.value_int; tb.its_fail = P.its_fail; tb.its_inter = P.its_inter;
   tb.q = (GA u64*)S.q; tb.pod_node = (GA i32*)S.pod_node; tb.pod_seq = (GA i32*)S.pod_seq;
   tb.rec = (GA u8*)S.rec; tb.rec_stride = S.rec_stride; tb.hcnt = (GA i32*)S.hcnt; tb.n_alive = (GA u64*)S.n_alive; tb.ge_rows = (const GA u64*)P.ge_rows;
@@ -816,7 +844,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
     r.taints() = P.en_taints[e]; r.present() = P.en.present[e]; r.complement() = P.en.complement[e]; r.it_state() = P.en.it_state[e];
     r.reqmask() = P.en_requests_present[e]; r.count() = 0;
     for (u32 k = 0; k < tb.K; ++k) { r.mask()[k] = P.en.mask[(size_t)e * tb.K + k]; r.gt()[k] = P.en.gt[(size_t)e * tb.K + k]; r.lt()[k] = P.en.lt[(size_t)e * tb.K + k]; }
-    for (u32 rr = 0; rr < tb.R; ++rr) { r.req()[rr] = P.en_requests[(size_t)e * tb.R + rr]; r.cap()[rr] = P.en_avail[(size_t)e * tb.R + rr]; r.low()[rr] = INT64_MIN; }
+    for (u32 rr = 0; rr < tb.R; ++rr) { r.req()[rr] = P.en_requests[(size_t)e * tb.R + rr]; r.room()[rr] = P.en_avail[(size_t)e * tb.R + rr] - P.en_requests[(size_t)e * tb.R + rr]; r.low()[rr] = INT64_MIN; }
     i32 head = -1; for (u32 i = P.en_port_off[e]; i < P.en_port_off[e + 1]; ++i) { S.pp_entry[i] = P.ports[i]; S.pp_next[i] = head; head = (i32)i; }
     r.porthead() = head;
     for (u32 h = 0; h < tb.GH; ++h) tb.hcnt[(size_t)e * tb.GH + h] = P.grph_count[(size_t)h * tb.E + e];
@@ -827,12 +855,13 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
   u32 lds_used = 0;
   if constexpr (FAST) {
     __shared__ u32 sm_key_nvalues[KS_MAX_KEYS]; __shared__ i32 sm_value_int[KS_MAX_KEYS * 64];
-    __shared__ u8 sm_its_fail[KS_FAST_S * KS_FAST_S]; __shared__ u8 sm_its_inter[KS_FAST_S * KS_FAST_S];
+    __shared__ u8 sm_its_fail[KS_FAST_S * KS_FAST_S]; __shared__ u16 sm_its_inter[KS_FAST_S * KS_FAST_S];
     __shared__ i32 sm_gcnt[KS_FAST_G * 64]; __shared__ u64 sm_g_reg[KS_FAST_G]; __shared__ u64 sm_g_pos[KS_FAST_G]; __shared__ u8 sm_g_active[KS_FAST_G]; __shared__ i32 sm_g_hpos[KS_FAST_G];
     __shared__ u32 sm_ge_cnt[KS_MAX_RES];
     for (u32 i = lane; i < tb.K; i += 64) sm_key_nvalues[i] = P.key_nvalues[i];
     for (u32 i = lane; i < tb.K * 64; i += 64) sm_value_int[i] = P.value_int[i];
-    for (u32 i = lane; i < tb.S * tb.S; i += 64) { sm_its_fail[i] = P.its_fail[i]; sm_its_inter[i] = P.its_inter[i]; }
+    // SC == 1: no class / filter constrains the instance-type key, the tables are never read
+    if (tb.SC > 1) for (u32 i = lane; i < tb.S * tb.SC; i += 64) { sm_its_fail[i] = P.its_fail[i]; sm_its_inter[i] = P.its_inter[i]; }
     for (u32 i = lane; i < P.G * 64; i += 64) sm_gcnt[i] = P.grp_count[i];
     for (u32 g = lane; g < P.G; g += 64) {
       u64 reg = 0, pos = 0; for (int d = 0; d < 64; ++d) { const i32 c = P.grp_count[(size_t)g * 64 + d]; if (c >= 0) reg |= 1ull << d; if (c > 0) pos |= 1ull << d; }
@@ -885,6 +914,9 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
     stage_class(tb, sh, plans, cidx, lane);
     const ClsPlan& c = sh.cls;
     if (c.overflow) { err = (u32)(-KS_ERR_UNSUPPORTED); break; }
+    ClsR cr; cr.tol = c.tol; cr.reqmask = c.reqmask; cr.ntouch = c.ntouch; cr.nhost = c.nhost; cr.hn_mode = c.hn_mode; cr.port_cnt = c.port_cnt; cr.it_state = c.it_state;
+#pragma unroll
+    for (int i = 0; i < KS_MAX_RES; ++i) cr.req[i] = c.req[i];
     bool placed = false;
     PROBE(13);
 
@@ -935,7 +967,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
         // NewNode (node.go:44-60): materialise the fresh node's record from template∩class, register its hostname
         const u32 fs = tb.E + nnew; const Rec fr = slot_rec(S, tb, fs);
         if ((u32)lane < tb.K) { fr.mask()[lane] = P.mc_mask[mc * tb.K + lane]; fr.gt()[lane] = P.mc_gt[mc * tb.K + lane]; fr.lt()[lane] = P.mc_lt[mc * tb.K + lane]; }
-        if (lane >= 32 && (u32)lane < 32 + tb.R) { fr.req()[lane - 32] = P.tmpl_daemon[(size_t)m_t * tb.R + lane - 32]; fr.cap()[lane - 32] = INT64_MAX; fr.low()[lane - 32] = INT64_MIN; }
+        if (lane >= 32 && (u32)lane < 32 + tb.R) { fr.req()[lane - 32] = P.tmpl_daemon[(size_t)m_t * tb.R + lane - 32]; fr.room()[lane - 32] = INT64_MAX / 2; fr.low()[lane - 32] = INT64_MIN; }
         if (lane == 63) { fr.taints() = P.tmpl_taints[m_t]; fr.present() = P.mc_present[mc]; fr.complement() = P.mc_complement[mc]; fr.it_state() = P.mc_it[mc]; fr.reqmask() = P.tmpl_daemon_present[m_t]; fr.porthead() = -1; fr.count() = 0; }
         for (u32 g = lane; g < P.G; g += 64) if (P.grp_hslot[g] >= 0) tb.hcnt[(size_t)fs * tb.GH + P.grp_hslot[g]] = tb.g_active[g] ? 0 : -1;   // Topology.Register(hostname), node.go:47
         __threadfence_block();
@@ -946,7 +978,8 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
 
       // ---- Node.Add / ExistingNode.Add up to the instance-type filter, one node per lane ----
       Ev ev; ev.rc = 0;
-      if (slot != 0xFFFFFFFFu) eval_node(P, S, tb, sh, slot, slot < tb.E, fresh, ev, lane);
+      if (slot != 0xFFFFFFFFu) eval_node<BOUNDS>(P, S, tb, sh, slot, slot < tb.E, fresh, ev, lane, tprobe, cr);
+      PROBE(26);
       u64 m = ballot64(ev.rc == 2);
       const u64 reach = ballot64(ev.rc >= 1);
       if (!fresh) { PROBE(14); CTR(21, 1); }
@@ -955,7 +988,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
 
       while (m) {
         const int win = __builtin_ctzll(m);
-        if (lane == win) publish_eval(tb, sh, ev, slot_rec(S, tb, slot), slot, fresh, lane);
+        if (lane == win) publish_eval<BOUNDS>(tb, sh, ev, slot_rec(S, tb, slot), slot, fresh, lane);
         LSYNC();
         const u32 sw = sh.rq.pad[0]; const bool ex = sw < tb.E; const u32 jw = sw - tb.E;
         const Rec r = slot_rec(S, tb, sw);
@@ -971,7 +1004,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
           if (sh.rq.pad[1]) {     // otherwise the filter would pick the same rows as last time: InstanceTypeOptions unchanged
             const bool ok = filter_types(P, tb, sh, r, fresh ? scratch : alive, fresh ? alive : scratch, rm, keys, zc, itc, lane, tprobe);
             PROBE(16);
-            if (!ok) { CTR(KS_STAT_FULLFAILS, 1); if (!fresh) recompute_cap(P, tb, alive, r.cap(), lane); m &= m - 1; continue; }
+            if (!ok) { CTR(KS_STAT_FULLFAILS, 1); if (!fresh) recompute_cap(P, tb, alive, r, lane); m &= m - 1; continue; }
             if (!fresh) for (u32 w = lane; w < tb.TW; w += 64) alive[w] = scratch[w];
             if ((u32)lane < tb.R && ((rm >> lane) & 1u)) r.low()[lane] = sh.low_new[lane];
           }
@@ -994,7 +1027,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
         topology_record(P, S, tb, sh, r, sw, lane);
         const u32 cnt = sh.rq.count;                                   // pods on the node before this one
         LSYNC();
-        write_record(tb, r, sh, rm, lane);
+        write_record<BOUNDS>(tb, r, sh, rm, lane);
         if (lane == 0) {
           if (!ex) r.count() = cnt + 1;
           if (fresh) S.n_tmpl[jw] = (i32)m_t;
@@ -1099,6 +1132,7 @@ struct ks_dev_problem {
   std::vector<void*> allocs;
   hipStream_t stream = nullptr;
   bool tables_built = false;
+  bool any_bounds = false;       // some requirement carries Gt/Lt -> the BOUNDS kernel variant
   u32 pp_cap = 0;
 };
 
@@ -1121,6 +1155,7 @@ template <typename T> static int dev_alloc(ks_dev_problem* d, size_t n, T** dst,
 
 static int copy_reqsets(ks_dev_problem* d, const ks_reqsets& s, u32 n, u32 K, ReqSetsD* out) {
   out->n = n;
+  for (size_t i = 0; i < (size_t)n * K; ++i) if (s.gt[i] != KS_NO_BOUND_GT || s.lt[i] != KS_NO_BOUND_LT) d->any_bounds = true;
   TRY(dev_copy(d, s.present, n, &out->present)); TRY(dev_copy(d, s.complement, n, &out->complement));
   TRY(dev_copy(d, s.mask, (size_t)n * K, &out->mask)); TRY(dev_copy(d, s.gt, (size_t)n * K, &out->gt)); TRY(dev_copy(d, s.lt, (size_t)n * K, &out->lt));
   TRY(dev_copy(d, s.it_state, n, &out->it_state)); return KS_OK;
@@ -1137,7 +1172,7 @@ static int validate(const ks_problem* p) {
   if (!p) return fail(KS_ERR_INVALID, "null problem");
   if (p->K > KS_MAX_KEYS) return fail(KS_ERR_UNSUPPORTED, "more than 32 narrow label keys");
   if (p->R > KS_MAX_RES || p->R < 3) return fail(KS_ERR_INVALID, "R must be in [3,8]");
-  if (p->S == 0 || p->S > KS_MAX_ITSTATES) return fail(KS_ERR_INVALID, "S must be in [1,256]");
+  if (p->S == 0 || p->S > KS_MAX_ITSTATES || p->SC == 0 || p->SC > KS_MAX_ITSTATES) return fail(KS_ERR_INVALID, "S and SC must be in [1,65535]");
   if (p->M == 0) return fail(KS_ERR_INVALID, "no provisioners found");   // provisioner.go:278-280
   if (p->T == 0) return fail(KS_ERR_INVALID, "no instance types");
   if (p->max_new_nodes == 0 && p->P) return fail(KS_ERR_INVALID, "max_new_nodes == 0");
@@ -1163,7 +1198,7 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   struct Guard { ks_dev_problem* d; bool ok = false; ~Guard() { if (!ok) ks_problem_free(d); } } guard{d};
   HIPCHK(hipStreamCreate(&d->stream));
   DevProb& h = d->h;
-  h.P = p->P; h.C = p->C; h.T = p->T; h.TW = (p->T + 63) / 64; h.M = p->M; h.E = p->E; h.K = p->K; h.R = p->R; h.G = p->G; h.GH = p->GH; h.S = p->S;
+  h.P = p->P; h.C = p->C; h.T = p->T; h.TW = (p->T + 63) / 64; h.M = p->M; h.E = p->E; h.K = p->K; h.R = p->R; h.G = p->G; h.GH = p->GH; h.S = p->S; h.SC = p->SC;
   h.NMAX = p->max_new_nodes ? p->max_new_nodes : 1; h.flags = p->flags; h.n_topologies = p->n_topologies;
   h.wellknown_mask = p->wellknown_mask; h.key_zone = p->key_zone; h.key_ct = p->key_ct; h.n_ct = p->n_ct;
   const u32 K = h.K, R = h.R, T = h.T, TW = h.TW, C = h.C, M = h.M, E = h.E, G = h.G, P = h.P;
@@ -1171,7 +1206,7 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   TRY(dev_copy(d, p->it_present, T, &h.it_present)); TRY(dev_copy(d, p->it_complement, T, &h.it_complement));
   TRY(dev_copy(d, p->it_mask, (size_t)K * T, &h.it_mask)); TRY(dev_copy(d, p->it_alloc, (size_t)R * T, &h.it_alloc));
   TRY(dev_copy(d, p->it_cap, (size_t)R * T, &h.it_cap)); TRY(dev_copy(d, p->it_offer, T, &h.it_offer));
-  TRY(dev_copy(d, p->its_inter, (size_t)h.S * h.S, &h.its_inter)); TRY(dev_copy(d, p->its_fail, (size_t)h.S * h.S, &h.its_fail));
+  TRY(dev_copy(d, p->its_inter, (size_t)h.S * h.SC, &h.its_inter)); TRY(dev_copy(d, p->its_fail, (size_t)h.S * h.SC, &h.its_fail));
   TRY(dev_copy(d, p->its_nidne, h.S, &h.its_nidne)); TRY(dev_copy(d, p->its_types, (size_t)h.S * TW, &h.its_types));
   TRY(copy_reqsets(d, p->tmpl, M, K, &h.tmpl)); TRY(dev_copy(d, p->tmpl_taints, M, &h.tmpl_taints));
   TRY(dev_copy(d, p->tmpl_daemon, (size_t)M * R, &h.tmpl_daemon)); TRY(dev_copy(d, p->tmpl_daemon_present, M, &h.tmpl_daemon_present));
@@ -1312,14 +1347,13 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   // batched what-ifs take 64 KiB each so two workgroups share a CU.
   const u32 lds_bytes = n == 1 ? 100u * 1024u : 64u * 1024u;
   bool fast = true;
-  for (u32 i = 0; i < n; ++i) { const DevProb& q = ds[i]->h; if (q.G > KS_FAST_G || q.GH > KS_FAST_G || q.S > KS_FAST_S || (size_t)q.R * q.T > KS_FAST_RT || (size_t)q.R * q.T * 8 + 16384 > lds_bytes) fast = false; }
+  for (u32 i = 0; i < n; ++i) { const DevProb& q = ds[i]->h; if (q.G > KS_FAST_G || q.GH > KS_FAST_G || (q.SC > 1 && (size_t)q.S * q.SC > KS_FAST_S * KS_FAST_S) || (size_t)q.R * q.T > KS_FAST_RT || (size_t)q.R * q.T * 8 + 16384 > lds_bytes) fast = false; }
   static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)ks_pack<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024)); attr_set = true;
-  }
-  if (fast) hipLaunchKernelGGL(ks_pack<true>, dim3(n), dim3(64), lds_bytes, st, dp, dsv, lds_bytes);
-  else hipLaunchKernelGGL(ks_pack<false>, dim3(n), dim3(64), lds_bytes, st, dp, dsv, lds_bytes);
+  bool bounds = false; for (u32 i = 0; i < n; ++i) bounds = bounds || ds[i]->any_bounds;
+  typedef void (*pack_fn)(const DevProb*, const DevState*, u32);
+  static const pack_fn variants[4] = {ks_pack<false, false>, ks_pack<false, true>, ks_pack<true, false>, ks_pack<true, true>};
+  if (!attr_set) { for (int i = 0; i < 4; ++i) HIPCHK(hipFuncSetAttribute((const void*)variants[i], hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024)); attr_set = true; }
+  hipLaunchKernelGGL(variants[(fast ? 2 : 0) + (bounds ? 1 : 0)], dim3(n), dim3(64), lds_bytes, st, dp, dsv, lds_bytes);
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());

@@ -115,7 +115,8 @@ struct Builder {
   std::map<std::string, std::set<std::string>> domains;   // topology domain universe, provisioner.go:267-276
   std::map<std::string, int> hostname_to_existing;
   std::vector<std::unique_ptr<Group>> groups; std::map<std::string, int> topo_by_id, inverse_by_id;   // creation order; inverse flagged
-  std::vector<Requirement> it_reqs; std::map<std::string, int> it_state_id;   // instance-type states (index 0 = absent)
+  std::vector<Requirement> it_reqs; std::map<std::string, int> it_state_id;   // node-side instance-type states (index 0 = absent)
+  std::vector<Requirement> it_cols; std::map<std::string, int> it_col_id;     // pod-side instance-type requirements (classes, topology filters; 0 = none)
   std::set<std::string> batch_uids;
   std::map<std::string, const ksp::StateNode*> node_by_name;
   bool toleratePreferNoSchedule = false;
@@ -200,18 +201,23 @@ struct Builder {
   // ---------- requirement encoding ----------
   int it_state_of(const Requirement& r) {
     std::string id = r.identity(); auto it = it_state_id.find(id); if (it != it_state_id.end()) return it->second;
-    if (it_reqs.size() >= KS_MAX_ITSTATES) throw Unsupported("more than 255 distinct instance-type requirements (closure)");
+    if (it_reqs.size() >= KS_MAX_ITSTATES) throw Unsupported("more than 65534 distinct instance-type requirements (closure)");
     int s = (int)it_reqs.size(); it_reqs.push_back(r); it_state_id[id] = s; return s;
   }
+  int it_col_of(const Requirement& r) {
+    std::string id = r.identity(); auto it = it_col_id.find(id); if (it != it_col_id.end()) return it->second;
+    if (it_cols.size() >= KS_MAX_ITSTATES) throw Unsupported("more than 65534 distinct pod-side instance-type requirements");
+    int s = (int)it_cols.size(); it_cols.push_back(r); it_col_id[id] = s; return s;
+  }
   // Appends one requirement set; returns its index.  `hn` receives the hostname requirement if any.
-  uint32_t push_reqs(ReqSetsStore& st, const Requirements& rs, const Requirement** hn, bool allow_hostname) {
+  uint32_t push_reqs(ReqSetsStore& st, const Requirements& rs, const Requirement** hn, bool allow_hostname, bool pod_side) {
     uint32_t idx = st.n++; st.present.push_back(0); st.complement.push_back(0); st.it_state.push_back(0);
     st.mask.resize((size_t)st.n * K, 0); st.gt.resize((size_t)st.n * K, KS_NO_BOUND_GT); st.lt.resize((size_t)st.n * K, KS_NO_BOUND_LT);
     if (hn) *hn = nullptr;
     for (auto& kv : rs.m) {
       const Requirement& r = kv.second;
       if (kv.first == ksp::kHostname) { if (!allow_hostname) throw Unsupported("hostname requirement outside a pod spec"); if (hn) *hn = &kv.second; continue; }
-      if (kv.first == ksp::kInstanceType) { st.it_state[idx] = it_state_of(r); continue; }
+      if (kv.first == ksp::kInstanceType) { st.it_state[idx] = pod_side ? it_col_of(r) : it_state_of(r); continue; }
       int k = key_of(kv.first, false); if (k < 0) throw std::logic_error("key missing from universe: " + kv.first);
       st.present[idx] |= 1u << k; if (r.complement) st.complement[idx] |= 1u << k;
       uint64_t m = 0; for (auto& v : r.values) { int vid = value_id(k, v); if (vid < 0) throw std::logic_error("value missing from universe: " + v); m |= 1ull << vid; }
@@ -284,7 +290,7 @@ struct Builder {
       Requirements rs; rs.Add(Requirements::FromExprs(p.requirements));   // NewMachineTemplate, machinetemplate.go:46-62
       StrMap labels = p.labels; labels[ksp::kProvisionerName] = p.name; rs.Add(Requirements::FromLabels(labels));
       tmpl_reqs.push_back(rs);
-      push_reqs(E.tmpl, rs, nullptr, false);
+      push_reqs(E.tmpl, rs, nullptr, false, false);
       E.tmpl_taints.push_back(taint_mask(p.taints));
       for (int idx : p.instance_types) { if (idx < 0 || (uint32_t)idx >= T) throw ksp::Error("instance type index out of range"); E.tmpl_types[(size_t)m * TW + idx / 64] |= 1ull << (idx % 64); }
       // topology domain universe, provisioner.go:267-276
@@ -318,7 +324,7 @@ struct Builder {
       const auto& n = pr.nodes[E.existing[e]];
       Requirements full = Requirements::FromLabels(n.labels);
       Requirements hostless; for (auto& kv : full.m) if (kv.first != ksp::kHostname) hostless.m.emplace(kv.first, kv.second);
-      push_reqs(E.en, restrict_to_known_keys(hostless), nullptr, false);
+      push_reqs(E.en, restrict_to_known_keys(hostless), nullptr, false, false);
       E.en_taints.push_back(taint_mask(n.taints));
       res_vec(n.available, E.en_avail, nullptr);
       // daemons that should still land on this node, scheduler.go:229-240 + existingnode.go:41-53
@@ -472,7 +478,7 @@ struct Builder {
     for (int g : st.sg.iown) { sig += std::to_string(g); sig += ','; } sig += '\4';
     auto it = class_by_sig.find(sig); if (it != class_by_sig.end()) return it->second;
     const Requirement* hn = nullptr;
-    uint32_t c = push_reqs(E.cls, st.reqs, &hn, true);
+    uint32_t c = push_reqs(E.cls, st.reqs, &hn, true, true);
     uint8_t mode = 0;
     if (hn) {
       if (hn->greaterThan || hn->lessThan) throw Unsupported("Gt/Lt on kubernetes.io/hostname");
@@ -508,7 +514,7 @@ struct Builder {
       E.grp_type.push_back((uint8_t)g.type); E.grp_max_skew.push_back(g.max_skew); E.grp_active.push_back(g.active ? 1 : 0);
       if (!g.filter.always) for (auto& t : g.filter.terms) {
         for (auto& kv : t.m) if (kv.first == ksp::kHostname) throw Unsupported("topology node filter on hostname");
-        push_reqs(E.flt, t, nullptr, false);
+        push_reqs(E.flt, t, nullptr, false, true);
       }
       E.grp_filter_off.push_back(E.flt.n);
       if (g.key == ksp::kHostname) {
@@ -552,26 +558,48 @@ struct Builder {
 
   // ---------- instance-type-key lattice ----------
   void encode_it_states() {
-    // closure under intersection
+    // Node states are closed under intersection with every pod-side requirement (a node only ever narrows its
+    // instance-type requirement by a class's, node.go:79 / existingnode.go:102); it_state_of appends while we iterate.
     if (it_reqs.empty()) it_reqs.push_back(Requirement());   // state 0 placeholder ("absent")
-    for (size_t a = 1; a < it_reqs.size(); ++a) for (size_t b = 1; b < it_reqs.size(); ++b) it_state_of(it_reqs[a].Intersection(it_reqs[b]));
-    // (it_state_of appends; the loops above run until no new state appears because size() grows)
+    if (it_cols.empty()) it_cols.push_back(Requirement());
+    const uint32_t SC = (uint32_t)it_cols.size();
+    for (size_t a = 1; a < it_reqs.size(); ++a) for (uint32_t b = 1; b < SC; ++b) it_state_of(it_cols[b].Intersection(it_reqs[a]));
+    for (uint32_t b = 1; b < SC; ++b) it_state_of(it_cols[b]);      // absent ∩ b = b
+    for (size_t a = 1; a < it_reqs.size(); ++a) for (uint32_t b = 1; b < SC; ++b) it_state_of(it_cols[b].Intersection(it_reqs[a]));
     const uint32_t S = (uint32_t)it_reqs.size();
-    E.its_inter.assign((size_t)S * S, 0); E.its_fail.assign((size_t)S * S, 0); E.its_nidne.assign(S, 0); E.its_types.assign((size_t)S * TW, 0);
-    for (uint32_t a = 0; a < S; ++a) for (uint32_t b = 0; b < S; ++b) {
+    E.its_inter.assign((size_t)S * SC, 0); E.its_fail.assign((size_t)S * SC, 0); E.its_nidne.assign(S, 0); E.its_types.assign((size_t)S * TW, 0);
+    for (uint32_t a = 0; a < S; ++a) for (uint32_t b = 0; b < SC; ++b) {
       uint32_t r; bool fail = false;
-      if (a == 0) r = b; else if (b == 0) r = a;
-      else { Requirement x = it_reqs[b].Intersection(it_reqs[a]); r = (uint32_t)it_state_id.at(x.identity()); fail = x.Len() == 0 && !(it_reqs[b].IsNotInOrDoesNotExist() && it_reqs[a].IsNotInOrDoesNotExist()); }
-      E.its_inter[(size_t)a * S + b] = (uint8_t)r; E.its_fail[(size_t)a * S + b] = fail ? 1 : 0;
+      if (b == 0) r = a; else if (a == 0) r = (uint32_t)it_state_id.at(it_cols[b].identity());
+      else { Requirement x = it_cols[b].Intersection(it_reqs[a]); r = (uint32_t)it_state_id.at(x.identity()); fail = x.Len() == 0 && !(it_cols[b].IsNotInOrDoesNotExist() && it_reqs[a].IsNotInOrDoesNotExist()); }
+      E.its_inter[(size_t)a * SC + b] = (uint16_t)r; E.its_fail[(size_t)a * SC + b] = fail ? 1 : 0;
     }
     for (uint32_t s = 1; s < S; ++s) E.its_nidne[s] = it_reqs[s].IsNotInOrDoesNotExist() ? 1 : 0;
-    for (uint32_t s = 0; s < S; ++s) for (uint32_t t = 0; t < T; ++t) {
-      bool pass = true;
-      if (s != 0) { auto it = it_requirements[t].m.find(ksp::kInstanceType);
-        if (it != it_requirements[t].m.end()) { const Requirement& a = it->second; Requirement x = a.Intersection(it_reqs[s]); if (x.Len() == 0 && !(it_reqs[s].IsNotInOrDoesNotExist() && a.IsNotInOrDoesNotExist())) pass = false; } }
-      if (pass) E.its_types[(size_t)s * TW + t / 64] |= 1ull << (t % 64);
+    // its_types[s]: types whose own instance-type requirement intersects state s.  Types with the usual
+    // `instance-type In [name]` are resolved through a name index (|values| work per state, not T).
+    std::map<std::string, std::vector<uint32_t>> by_name; std::vector<uint32_t> general; std::vector<uint64_t> simple(TW, 0), unconstrained(TW, 0);
+    for (uint32_t t = 0; t < T; ++t) {
+      auto it = it_requirements[t].m.find(ksp::kInstanceType);
+      if (it == it_requirements[t].m.end()) { unconstrained[t / 64] |= 1ull << (t % 64); continue; }
+      const Requirement& a = it->second;
+      if (!a.complement && a.values.size() == 1 && !a.greaterThan && !a.lessThan) { by_name[*a.values.begin()].push_back(t); simple[t / 64] |= 1ull << (t % 64); }
+      else general.push_back(t);
     }
-    E.it_states = it_reqs; E.prob.S = S;
+    for (uint32_t s = 0; s < S; ++s) {
+      uint64_t* row = &E.its_types[(size_t)s * TW];
+      for (uint32_t w = 0; w < TW; ++w) row[w] = unconstrained[w];
+      const Requirement& q = it_reqs[s];
+      if (s == 0) { for (uint32_t w = 0; w < TW; ++w) row[w] |= simple[w]; for (uint32_t t : general) row[t / 64] |= 1ull << (t % 64); continue; }
+      if (!q.greaterThan && !q.lessThan) {
+        if (q.complement) { for (uint32_t w = 0; w < TW; ++w) row[w] |= simple[w]; for (auto& v : q.values) { auto f = by_name.find(v); if (f != by_name.end()) for (uint32_t t : f->second) row[t / 64] &= ~(1ull << (t % 64)); } }
+        else for (auto& v : q.values) { auto f = by_name.find(v); if (f != by_name.end()) for (uint32_t t : f->second) row[t / 64] |= 1ull << (t % 64); }
+      } else for (auto& kv : by_name) if (q.Has(kv.first)) for (uint32_t t : kv.second) row[t / 64] |= 1ull << (t % 64);
+      for (uint32_t t : general) {
+        const Requirement& a = it_requirements[t].m.find(ksp::kInstanceType)->second; Requirement x = a.Intersection(q);
+        if (!(x.Len() == 0 && !(q.IsNotInOrDoesNotExist() && a.IsNotInOrDoesNotExist()))) row[t / 64] |= 1ull << (t % 64);
+      }
+    }
+    E.it_states = it_reqs; E.prob.S = S; E.prob.SC = SC;
   }
 
   void finish() {
@@ -597,7 +625,7 @@ struct Builder {
   void run() {
     collect_universes();
     encode_instance_types();
-    it_reqs.push_back(Requirement());            // it-state 0 == key absent
+    it_reqs.push_back(Requirement()); it_cols.push_back(Requirement());   // state / column 0 == key absent
     encode_templates();
     encode_existing();
     collect_taints();
@@ -669,7 +697,7 @@ std::string Encoded::decode(const ks_result& r, double solve_seconds) const {
   for (uint32_t e = 0; e < NE; ++e) { o << "ENODE " << tokq(src.nodes[existing[e]].name) << " " << pods_of[e].size(); for (auto& sp : pods_of[e]) o << " " << sp.second; o << "\n"; }
   o << "UNSCHEDULED " << r.n_unscheduled; for (uint32_t i = 0; i < r.n_unscheduled; ++i) o << " " << r.unscheduled[i]; o << "\n";
   o << "STAGES " << p.P; for (uint32_t i = 0; i < p.P; ++i) o << " " << r.pod_stage[i]; o << "\n";
-  o << "STATS 18 cyc_pop " << r.stats[12] << " cyc_stage " << r.stats[13] << " cyc_scan " << r.stats[14] << " cyc_evalout " << r.stats[15] << " cyc_full " << r.stats[16]
+  o << "STATS 23 p22 " << r.stats[22] << " p23 " << r.stats[23] << " p24 " << r.stats[24] << " p25 " << r.stats[25] << " p26 " << r.stats[26] << " cyc_pop " << r.stats[12] << " cyc_stage " << r.stats[13] << " cyc_scan " << r.stats[14] << " cyc_evalout " << r.stats[15] << " cyc_full " << r.stats[16]
     << " cyc_commit " << r.stats[17] << " cyc_order " << r.stats[18] << " cyc_new " << r.stats[19] << " scan_chunks " << r.stats[21]
     << " queue_pops " << r.stats[KS_STAT_POPS] << " relaxations " << r.stats[KS_STAT_RELAX] << " full_checks " << r.stats[KS_STAT_FULLCHECKS] << " full_fails " << r.stats[KS_STAT_FULLFAILS]
     << " attempts " << r.stats[KS_STAT_REF_ATTEMPTS] << " types_scanned " << r.stats[KS_STAT_REF_TYPES] << " kernel_cycles " << r.stats[KS_STAT_CYCLES]

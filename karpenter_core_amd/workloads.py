@@ -231,7 +231,7 @@ def cluster_snapshot(existing: int = 2048, sizes: int = 50, seed: int = 45):
     return its, prov, nodes, bound
 
 
-def whatif(its, prov, nodes, bound, candidates: List[int]) -> Problem:
+def whatif(its, prov, nodes, bound, candidates: List[int], with_cluster_pods: bool = True) -> Problem:
     """simulateScheduling (deprovisioning/helpers.go:42-115): candidate nodes leave the state-node list,
     their pods become the pending batch; the cluster still holds the bound pods (excluded by UID,
     topology.go:66-70,249)."""
@@ -240,21 +240,23 @@ def whatif(its, prov, nodes, bound, candidates: List[int]) -> Problem:
                     daemonset_requests=n.daemonset_requests, host_ports=n.host_ports, in_state=(i not in cand))
           for i, n in enumerate(nodes)]
     pods = [p for i in candidates for p in bound[i]]
+    # the bound pods only matter to countDomains / inverse anti-affinity; a snapshot whose pods carry no
+    # topology terms can skip listing them (nothing would be counted)
     cps = [ClusterPod(uid=p.uid, namespace=p.namespace, node_name=nodes[i].name, labels=p.labels)
-           for i in range(len(nodes)) for p in bound[i]]
+           for i in range(len(nodes)) for p in bound[i]] if with_cluster_pods else []
     return Problem(instance_types=its, provisioners=[prov], pods=pods, nodes=ns, cluster_pods=cps,
                    extra_well_known=fake.EXTRA_WELL_KNOWN, simulation_mode=True)
 
 
-def config4(whatifs: int = 512, existing: int = 2048, sizes: int = 50, seed: int = 45) -> List[Problem]:
+def config4(whatifs: int = 512, existing: int = 2048, sizes: int = 50, seed: int = 45, with_cluster_pods: bool = False) -> List[Problem]:
     """512 what-ifs: half are multi-node prefixes (multinodeconsolidation.go:86-90), half singletons
     (singlenodeconsolidation.go:54)."""
     its, prov, nodes, bound = cluster_snapshot(existing, sizes, seed)
     out = []
     half = whatifs // 2
     for i in range(half):
-        out.append(whatif(its, prov, nodes, bound, list(range(0, i + 1))))          # prefix [0..i]
+        out.append(whatif(its, prov, nodes, bound, list(range(0, i + 1)), with_cluster_pods))          # prefix [0..i]
     rs = np.random.RandomState(seed + 1)
     for _ in range(whatifs - half):
-        out.append(whatif(its, prov, nodes, bound, [int(rs.randint(existing))]))      # singleton
+        out.append(whatif(its, prov, nodes, bound, [int(rs.randint(existing))], with_cluster_pods))      # singleton
     return out

@@ -69,6 +69,39 @@ def test_whatifs_single_and_batched():
         assert S.solve_problem(p).canonical() == w
 
 
+def test_existing_nodes_with_instance_type_selectors():
+    """> 255 distinct instance-type labels on existing nodes (one node-side state each) against pods that select
+    instance types with In / NotIn / a spread filtered by an instance-type node selector (pod-side columns)."""
+    from karpenter_core_amd.model import (Container, Expr, LabelSelector, Pod, TopologySpreadConstraint, DO_NOT_SCHEDULE,
+                                          LABEL_INSTANCE_TYPE, LABEL_ZONE)
+    its, prov, nodes, bound = W.cluster_snapshot(existing=400, sizes=20, seed=9)
+    base = W.whatif(its, prov, nodes, bound, list(range(0, 12)))
+    rs = np.random.RandomState(5)
+    names = sorted({n.labels[LABEL_INSTANCE_TYPE] for n in nodes})
+    assert len(names) > 255
+    # NotIn sets are drawn from a small pool: every subset of distinct NotIn requirements is a distinct node state
+    notin = [[names[j] for j in rs.choice(len(names), size=40, replace=False)] for _ in range(3)]
+    extra = []
+    for i in range(120):
+        pick = [names[j] for j in rs.choice(len(names), size=3, replace=False)]
+        kind = i % 4
+        c = [Container(requests={"cpu": "250m", "memory": "256Mi"} if i % 3 else {"cpu": "6", "memory": "20Gi"})]
+        if kind == 0:
+            extra.append(Pod(uid=f"sel-{i:04d}", labels={"app": "x"}, containers=c, node_selector={LABEL_INSTANCE_TYPE: pick[0]}))
+        elif kind == 1:
+            extra.append(Pod(uid=f"sel-{i:04d}", labels={"app": "x"}, containers=c, required_affinity=[[Expr(LABEL_INSTANCE_TYPE, "In", pick)]]))
+        elif kind == 2:
+            extra.append(Pod(uid=f"sel-{i:04d}", labels={"app": "x"}, containers=c, required_affinity=[[Expr(LABEL_INSTANCE_TYPE, "NotIn", notin[i % 3])]]))
+        else:
+            extra.append(Pod(uid=f"sel-{i:04d}", labels={"app": "y"}, containers=c, required_affinity=[[Expr(LABEL_INSTANCE_TYPE, "NotIn", notin[i % 2][:1])]],
+                             spread=[TopologySpreadConstraint(1, LABEL_ZONE, DO_NOT_SCHEDULE, LabelSelector({"app": "y"}))]))
+    base.pods = base.pods + extra
+    want = assert_same(base)
+    first_sel = len(base.pods) - len(extra)
+    sel_on_existing = [u for v in want["existing"].values() for u in v if u >= first_sel]
+    assert sel_on_existing and want["new_nodes"]
+
+
 def test_feasibility_grid_matches_first_pod_option_lists():
     # grid[m][c] must equal the InstanceTypeOptions of a fresh node that receives one pod of class c
     pr = W.config2(pods=120, sizes=6, seed=9)

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""BASELINE config #4: N independent consolidation what-if Solve()s over one cluster snapshot, solved in ONE
+launch (one single-wave workgroup per what-if).  Reports aggregate decisions/s and checks a sample of the
+what-ifs bit-for-bit against the CPU oracle."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from karpenter_core_amd import scheduler as S, workloads as W
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--whatifs", type=int, default=512)
+ap.add_argument("--existing", type=int, default=2048)
+ap.add_argument("--sizes", type=int, default=50)
+ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--check", type=int, default=4)
+a = ap.parse_args()
+t0 = time.time()
+probs = W.config4(a.whatifs, a.existing, a.sizes)
+t1 = time.time()
+flats = [S.FlatProblem(p) for p in probs]
+for f in flats:
+    f.upload(0)
+t2 = time.time()
+pods = sum(f.dims["P"] for f in flats)
+S.solve_batch(flats, decode=False)                      # warm-up (also builds the static tables)
+ms = []
+for _ in range(a.steps):
+    _, kms, wms = S.solve_batch(flats, decode=False)
+    ms.append((kms, wms))
+kms = sorted(m[0] for m in ms)[len(ms) // 2]; wms = sorted(m[1] for m in ms)[len(ms) // 2]
+ok = None
+if a.check:
+    from oracle import oracle_py
+    res, _, _ = S.solve_batch(flats[:a.check] + flats[-a.check:], decode=True)
+    ok = all(r.canonical() == oracle_py.solve(p).canonical() for r, p in zip(res, probs[:a.check] + probs[-a.check:]))
+print(json.dumps({"workload": f"config #4: {a.whatifs} what-ifs over {a.existing} existing nodes, {len(probs[0].instance_types)} instance types",
+                  "whatifs": a.whatifs, "pod_decisions": pods, "largest_whatif_pods": max(f.dims["P"] for f in flats),
+                  "kernel_ms": kms, "wall_ms": wms, "decisions_per_s": pods / (wms / 1e3), "whatifs_per_s": a.whatifs / (wms / 1e3),
+                  "generate_s": t1 - t0, "flatten_upload_s": t2 - t1, "oracle_spot_check": ok}))

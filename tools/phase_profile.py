@@ -10,4 +10,5 @@ print("kernel_ms", fp.kernel_ms, "nodes", len(r.new_nodes))
 st = r.stats; tot = st["kernel_cycles"]
 for k in ("cyc_pop","cyc_stage","cyc_scan","cyc_evalout","cyc_full","cyc_commit","cyc_order","cyc_new"):
     print(f"{k:12s} {st[k]:>14d}  {100*st[k]/tot:5.1f}%  per pod {st[k]/pods:9.0f}")
+for k,n in (("p22","to eval start"),("p23","gather loads"),("p24","taints..host topo"),("p25","touch loop"),("p26","after eval")): print(f"{k} {n:20s} {st.get(k,0)/pods:9.0f}")
 print("total cycles", tot, "per pod", tot/pods, "chunks/pod", st["scan_chunks"]/pods, "full_checks", st["full_checks"], "full_fails", st["full_fails"])
