@@ -37,6 +37,11 @@
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define RL(v, l) ((u32)__builtin_amdgcn_readlane((int)(v), (l)))   /* broadcast from a wave-uniform lane: v_readlane, no LDS round trip */
+/* a value the program knows to be wave-uniform but the compiler cannot (it came out of LDS / global memory): move it to
+   SGPRs so that branches on it are scalar branches and address arithmetic is scalar */
+#define UF(x) ((u32)__builtin_amdgcn_readfirstlane((int)(x)))
+#define UF64(x) ((u64)UF((u32)(u64)(x)) | ((u64)UF((u32)((u64)(x) >> 32)) << 32))
+#define RL64(v, l) ((u64)RL((u32)(u64)(v), (l)) | ((u64)RL((u32)((u64)(v) >> 32), (l)) << 32))
 #ifdef KS_PROBES   /* fine-grained cycle probes (tools/phase_profile.py --probes builds with -DKS_PROBES) */
 #define PROBE(i) do { const u64 now_ = __builtin_readcyclecounter(); if (lane == 0) sh.ctr[(i)] += now_ - tprobe; tprobe = now_; } while (0)
 #else
@@ -281,6 +286,9 @@ __global__ __launch_bounds__(256) void ks_grid_types(DevProb P, u32 chunks) {
 #define KS_MAX_HOST 3
 #define KS_MAX_REC 24
 #define KS_BST_LDS 1024
+#ifndef KS_FIRST_WIDTH
+#define KS_FIRST_WIDTH 64    // candidates evaluated in a pod's first step (measured: a narrower first step is a wash -- the 11-15 % of pods that need a second step pay a whole extra evaluation)
+#endif
 #define KS_FAST_G 64        // FAST variant: topology groups (and hostname groups) whose counters live in LDS
 #define KS_FAST_S 16        // FAST variant: instance-type-key states
 #define KS_FAST_RT 6144     // FAST variant: R*T sorted Allocatable values in LDS (48 KiB)
@@ -303,7 +311,8 @@ struct alignas(16) ClsPlan {
   PlanTopo topo[KS_MAX_TOPO];        // narrow-key items, grouped by touch entry
   PlanTopo host[KS_MAX_HOST];        // hostname-key items
   PlanRec rec[KS_MAX_REC];
-  u32 overflow; u32 lean_ok; u32 pad[2];   // lean_ok: Topology.Record needs nothing beyond the gathered keys (winner-lane commit possible)
+  u32 overflow; u32 eq; u64 tkeys;         // tkeys: touch[i].key packed 5 bits each, so the per-key bit arithmetic of the commit needs no LDS reads
+                                           // eq: evaluation-equivalence id (ks_link_plans), 0 = none
 };
 static_assert(sizeof(ClsPlan) % 16 == 0, "plan records are copied with 16-byte loads");
 
@@ -362,7 +371,6 @@ __global__ __launch_bounds__(64) void ks_build_plans(DevProb P, ClsPlan* plans) 
       if (!seen) { PlanTouch& t = pl.touch[pl.ntouch]; t.key = r.key; t.own = 0; t.complement = 0; t.mask = 0; t.gt = KS_NOGT; t.lt = KS_NOLT; t.topo_begin = t.topo_end = (u8)pl.ntopo; ++pl.ntouch; }
     }
   }
-  pl.lean_ok = pl.port_cnt == 0 && !pl.overflow;
   for (u32 i = 0; i < pl.nrec; ++i) {
     PlanRec& r = pl.rec[i]; r.tidx = 0xFF; r.pad = 0;
     r.filtered = (!r.owned_inverse && P.grp_filter_off[r.g] != P.grp_filter_off[r.g + 1]) ? 1 : 0;
@@ -372,9 +380,33 @@ __global__ __launch_bounds__(64) void ks_build_plans(DevProb P, ClsPlan* plans) 
       bool trivial = false; for (u32 f = fb; f < fe; ++f) if (P.flt.present[f] == 0 && P.flt.it_state[f] == 0) trivial = true;
       if (trivial) r.filtered = 0;
     }
-    if (r.filtered || (r.key >= 0 && r.tidx == 0xFF)) pl.lean_ok = 0;
   }
+  pl.tkeys = 0; for (u32 j = 0; j < pl.ntouch; ++j) pl.tkeys |= (u64)(u32)pl.touch[j].key << (5 * j);
+  pl.eq = 0;
   plans[c] = pl;
+}
+
+// Two classes are evaluation-equivalent when Node.Add reads exactly the same inputs for both and neither
+// consults the topology (they may still differ in the groups Topology.Record updates, e.g. replicas that
+// differ only in labels).  For a run of equivalent pods the fit bitmap of one candidate step stays valid:
+// only the node that just received a pod changed, and it moved behind the rest of its count bucket.
+__device__ inline bool ks_plan_eval_eligible(const ClsPlan& p) { return !p.overflow && p.ntopo == 0 && p.nhost == 0 && p.port_cnt == 0 && p.hn_mode == 0; }
+__global__ __launch_bounds__(64) void ks_link_plans(ClsPlan* plans, u32 C, u32 R) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const ClsPlan& me = plans[c];
+  if (!ks_plan_eval_eligible(me)) return;
+  u32 eq = c + 1;
+  for (u32 o = 0; o < c; ++o) {
+    const ClsPlan& p = plans[o];
+    if (!ks_plan_eval_eligible(p) || p.present != me.present || p.complement != me.complement || p.it_state != me.it_state || p.reqmask != me.reqmask ||
+        p.tol != me.tol || p.ntouch != me.ntouch || p.tkeys != me.tkeys) continue;
+    bool same = true;
+    for (u32 r = 0; r < R && same; ++r) same = p.req[r] == me.req[r];
+    for (u32 i = 0; i < me.ntouch && same; ++i) { const PlanTouch &a = p.touch[i], &b = me.touch[i]; same = a.mask == b.mask && a.gt == b.gt && a.lt == b.lt && a.own == b.own && a.complement == b.complement; }
+    if (same) { eq = o + 1; break; }
+  }
+  plans[c].eq = eq;   // the first equivalent class represents the set (no other thread reads this field)
 }
 
 // Hot, small tables and scalars of one Solve, held in registers.  In the FAST kernel variant every
@@ -406,15 +438,20 @@ struct Tabs {
 #define G_its_types ((const GA u64*)P.its_types)
 #define G_grid ((const GA u64*)P.grid)
 
-struct ReqOut {    // requirement set of the winning node after the pod is added (entries in `valid` only)
-  u32 present, complement; i32 it_state; u32 changed; u32 topo_narrowed; u32 valid; u32 rm; u32 count; i32 it_before; u32 pad[3];
+struct ReqOut {    // per-key requirement of the winning node after the pod is added (entries in Pub::valid only)
   u64 mask[KS_MAX_KEYS]; i32 gt[KS_MAX_KEYS]; i32 lt[KS_MAX_KEYS];
+};
+// The winner's evaluation, broadcast to the whole wave with v_readlane: wave-uniform registers, so the
+// filter and the commit branch on scalars instead of waiting on LDS round trips.
+struct Pub {
+  u32 slot, present, complement, changed, narrowed, valid, rm, count; i32 it_state, it_before; bool need;
+  i64 req_new[KS_MAX_RES], room_new[KS_MAX_RES];
 };
 struct TopoDyn { u64 reg, pos; i32 minc; i32 pad; };
 struct alignas(16) WaveShared {
   ClsPlan cls; ReqOut rq;
   TopoDyn dyn[KS_MAX_TOPO]; i32 host_anypos[KS_MAX_HOST];
-  i64 req_new[KS_MAX_RES]; i64 low_new[KS_MAX_RES]; i64 room_new[KS_MAX_RES];
+  i64 low_new[KS_MAX_RES];
   u32 bstart[KS_BST_LDS];
   u64 ctr[32];          // statistics + (KS_PROBES builds) per-phase cycle counters; slot numbers = ks_result.stats[]
   u64 la_mask[KS_MAX_TOUCH][64]; i32 la_gt[KS_MAX_TOUCH][64]; i32 la_lt[KS_MAX_TOUCH][64];   // per-lane requirement slots of eval_node
@@ -472,7 +509,7 @@ __device__ __forceinline__ bool kreq_differs(const KReq& x, const KReq& y) { ret
 
 // The popped pod's class scalars, hoisted into wave-uniform registers once per pod (a class field read from
 // LDS costs a ~60-cycle dependent round trip at every use inside eval_node).
-struct ClsR { u64 tol; u32 reqmask, ntouch, nhost, hn_mode, port_cnt; i32 it_state; i64 req[KS_MAX_RES]; };
+struct ClsR { u64 tol, tkeys; u32 reqmask, ntouch, nhost, hn_mode, port_cnt, eq; i32 it_state; i64 req[KS_MAX_RES]; };
 
 // Result of evaluating one node for the current pod: scalars in registers, the per-key requirements in
 // per-lane LDS slots (sh.la_*[touch index][lane]) so the algebra below is ONE dynamic loop body instead
@@ -482,6 +519,7 @@ struct Ev {
   u32 present, complement, count, reqmask; i32 it_state, it0;
   u32 tpres, tcomp, tchg, tnar; // per touch index: requirement present / complement after Add; changed; narrowed by topology
   i64 room[KS_MAX_RES];         // the node's resource headroom (Rec::room)
+  i64 req[KS_MAX_RES], low[KS_MAX_RES];   // Rec::req / Rec::low, fetched with the rest so the winner publishes without another round trip
 };
 
 // One attempt of Node.Add / ExistingNode.Add up to (not including) the instance-type filter
@@ -500,14 +538,14 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
   const i32 it0 = (i32)h1.x; const u32 reqmask = h1.y; const i32 porthead = (i32)h1.z;
   ev.present = present; ev.complement = complement; ev.it_state = it0; ev.it0 = it0; ev.reqmask = reqmask; ev.count = h1.w;
 #pragma unroll
-  for (int i = 0; i < KS_MAX_RES; ++i) { ev.room[i] = 0; if ((u32)i < tb.R) ev.room[i] = r.room()[i]; }
+  for (int i = 0; i < KS_MAX_RES; ++i) { ev.room[i] = 0; ev.req[i] = 0; ev.low[i] = INT64_MIN; if ((u32)i < tb.R) { ev.room[i] = r.room()[i]; ev.req[i] = r.req()[i]; ev.low[i] = r.low()[i]; } }
   const u32 ntouch = cr.ntouch;
   KReq nxt = kreq_absent();
-  if (ntouch) nxt = rec_req<BOUNDS>(r, present, complement, c.touch[0].key);
+  if (ntouch) nxt = rec_req<BOUNDS>(r, present, complement, (int)((u32)cr.tkeys & 31u));
   i32 hc0 = -1, hc1 = -1, hc2 = -1;
-  if (cr.nhost > 0) hc0 = tb.hcnt[(size_t)slot * tb.GH + c.host[0].hslot];
-  if (cr.nhost > 1) hc1 = tb.hcnt[(size_t)slot * tb.GH + c.host[1].hslot];
-  if (cr.nhost > 2) hc2 = tb.hcnt[(size_t)slot * tb.GH + c.host[2].hslot];
+  if (cr.nhost > 0) hc0 = tb.hcnt[(size_t)slot * tb.GH + UF(c.host[0].hslot)];
+  if (cr.nhost > 1) hc1 = tb.hcnt[(size_t)slot * tb.GH + UF(c.host[1].hslot)];
+  if (cr.nhost > 2) hc2 = tb.hcnt[(size_t)slot * tb.GH + UF(c.host[2].hslot)];
 
   // ---- Taints.Tolerates, taints.go:28-40 ----
   PROBE(23);
@@ -528,10 +566,11 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
   if (!merged && cr.it_state) { if (tb.its_fail[it0 * tb.SC + cr.it_state]) return; ev.it_state = tb.its_inter[it0 * tb.SC + cr.it_state]; }
   // ---- Topology.AddRequirements on hostname-keyed groups: the node's only hostname domain is its own ----
   for (u32 i = 0; i < cr.nhost; ++i) {
-    const PlanTopo& t = c.host[i]; const i32 cnt = i == 0 ? hc0 : (i == 1 ? hc1 : hc2); bool ok;
+    const PlanTopo& th = c.host[i]; const i32 cnt = i == 0 ? hc0 : (i == 1 ? hc1 : hc2); bool ok;
+    struct { u32 type, self; i32 maxskew; } t; { const u32 f = UF(*(const u32*)&th.type); t.type = f & 0xFF; t.self = (f >> 8) & 0xFF; t.maxskew = (i32)UF(th.maxskew); }
     if (t.type == 0) ok = cnt >= 0 && (i64)cnt + t.self <= (i64)t.maxskew;                        // nextDomainTopologySpread, min==0 for hostname (topologygroup.go:184-188)
     else if (t.type == 2) ok = cnt == 0;                                                           // nextDomainAntiAffinity :235-243
-    else ok = sh.host_anypos[i] ? (cnt > 0) : (t.self && cnt >= 0);                                // nextDomainAffinity :202-233
+    else ok = UF(sh.host_anypos[i]) ? (cnt > 0) : (t.self && cnt >= 0);                                // nextDomainAffinity :202-233
     if (!ok) return;
   }
   PROBE(24);
@@ -539,9 +578,11 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
   //      Intersection serves both), then Topology.AddRequirements (topology.go:149-167) and the Compatible + Add
   //      of its result (node.go:83-90).  The next key's node requirement is loaded while this one is processed. ----
   for (u32 i = 0; i < ntouch; ++i) {
-    const PlanTouch& t = c.touch[i]; const int k = t.key;
+    const PlanTouch& tl = c.touch[i]; const int k = (int)((u32)(cr.tkeys >> (5 * i)) & 31u);
+    struct { u64 mask; i32 gt, lt; u32 own, complement, topo_begin, topo_end; } t;
+    { const u32 f = UF(*(const u32*)&tl.own); t.own = f & 0xFF; t.complement = (f >> 8) & 0xFF; t.topo_begin = (f >> 16) & 0xFF; t.topo_end = f >> 24; t.mask = tl.mask; t.gt = tl.gt; t.lt = tl.lt; }
     KReq a = nxt;
-    if (i + 1 < ntouch) nxt = rec_req<BOUNDS>(r, present, complement, c.touch[i + 1].key);
+    if (i + 1 < ntouch) nxt = rec_req<BOUNDS>(r, present, complement, (int)((u32)(cr.tkeys >> (5 * (i + 1))) & 31u));
     const KReq orig = a;
     const i32* vi = tb.value_int + k * 64; const u32 nv = tb.key_nvalues[k];
     if (t.own && !merged) {
@@ -558,8 +599,10 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
       const KReq nd = before.present ? before : kreq_exists();
       const u64 ND = kreq_has_mask(nd, vi, nv);
       u64 dom = ~0ull;
-      for (int j = t.topo_begin; j < t.topo_end; ++j) {
-        const PlanTopo& tt = c.topo[j]; const TopoDyn& d = sh.dyn[j]; u64 options = 0;
+      for (u32 j = t.topo_begin; j < t.topo_end; ++j) {
+        const PlanTopo& tg = c.topo[j]; const TopoDyn& d = sh.dyn[j]; u64 options = 0;
+        struct { u64 PD; i32 g, maxskew; u32 type, self, pod_has; } tt;
+        { const u32 f = UF(*(const u32*)&tg.type); tt.type = f & 0xFF; tt.self = (f >> 8) & 0xFF; tt.pod_has = (f >> 16) & 0xFF; tt.g = (i32)UF(tg.g); tt.maxskew = (i32)UF(tg.maxskew); tt.PD = tg.PD; }
         if (tt.type == 0) {                                       // spread: nextDomainTopologySpread :155-182
           i32 best = INT32_MAX; int bestv = -1;
           for (u64 bits = d.reg & ND; bits; bits &= bits - 1) {
@@ -598,36 +641,56 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
   PROBE(25);
 }
 
-// The winning lane publishes its evaluation through LDS (it alone executes this): the node's requirement set
-// after Add (sh.rq), the new request vector, the header values the commit needs, and whether the
-// instance-type filter can change anything at all (see Rec::low).
+// Synchronisation inside the single-wave workgroup.
+//   LSYNC: cross-lane hand-off through LDS.  LDS instructions of one wave execute in program order, so only
+//          the compiler must be stopped from reordering -- no instruction is emitted.
+//   GSYNC: cross-lane hand-off through GLOBAL memory: the writer's stores must have completed
+//          (s_waitcnt vmcnt(0)) before another lane's load is issued; costs a store round trip, so it is used
+//          once per pod (before the candidate scan re-reads node records) and on rare paths.
+#define CTR(i, v) do { if (lane == 0) sh.ctr[(i)] += (v); } while (0)
+#define LSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define GSYNC() __syncthreads()
+
+// Publish the winning lane's evaluation: scalars by v_readlane into wave-uniform registers (Pub), the per-key
+// requirements by one parallel LDS copy (lane i moves touch entry i).  Also decides whether the instance-type
+// filter can change anything at all (see Rec::low).
 template <bool BOUNDS>
-__device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, const Ev& ev, const Rec& r, u32 slot, bool fresh, int lane) {
-  const ClsPlan& c = sh.cls; ReqOut& o = sh.rq;
-  const u32 rm = ev.reqmask | c.reqmask;
-  i64 low[KS_MAX_RES], req[KS_MAX_RES];
-#pragma unroll
-  for (int i = 0; i < KS_MAX_RES; ++i) { low[i] = INT64_MIN; req[i] = 0; if ((u32)i < tb.R) { low[i] = r.low()[i]; req[i] = r.req()[i]; } }
-  u32 np = ev.present, nc = ev.complement, changed = 0, narrowed = 0, valid = 0;
-  for (u32 i = 0; i < c.ntouch; ++i) {
-    const int k = c.touch[i].key;
-    if ((ev.tpres >> i) & 1u) { np |= 1u << k; nc = ((ev.tcomp >> i) & 1u) ? (nc | (1u << k)) : (nc & ~(1u << k)); }
-    if ((ev.tchg >> i) & 1u) changed |= 1u << k;
-    if ((ev.tnar >> i) & 1u) narrowed |= 1u << k;
-    valid |= 1u << k;
-    o.mask[k] = sh.la_mask[i][lane]; if constexpr (BOUNDS) { o.gt[k] = sh.la_gt[i][lane]; o.lt[k] = sh.la_lt[i][lane]; } else { o.gt[k] = KS_NOGT; o.lt[k] = KS_NOLT; }
+__device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, const Ev& ev, u32 slot, bool fresh, int lane, int win, const ClsR& cr, Pub& p) {
+  p.slot = RL(slot, win);
+  const u32 tpres = RL(ev.tpres, win), tcomp = RL(ev.tcomp, win), tchg = RL(ev.tchg, win), tnar = RL(ev.tnar, win);
+  u32 np = RL(ev.present, win), nc = RL(ev.complement, win), changed = 0, narrowed = 0, valid = 0;
+  for (u32 i = 0; i < cr.ntouch; ++i) {
+    const u32 kb = 1u << ((u32)(cr.tkeys >> (5 * i)) & 31u);
+    if ((tpres >> i) & 1u) { np |= kb; nc = ((tcomp >> i) & 1u) ? (nc | kb) : (nc & ~kb); }
+    if ((tchg >> i) & 1u) changed |= kb;
+    if ((tnar >> i) & 1u) narrowed |= kb;
+    valid |= kb;
   }
-  bool need = fresh || changed != 0 || ev.it_state != ev.it0;
+  if ((u32)lane < cr.ntouch) {
+    const u32 k = (u32)(cr.tkeys >> (5 * lane)) & 31u;
+    sh.rq.mask[k] = sh.la_mask[lane][win];
+    if constexpr (BOUNDS) { sh.rq.gt[k] = sh.la_gt[lane][win]; sh.rq.lt[k] = sh.la_lt[lane][win]; } else { sh.rq.gt[k] = KS_NOGT; sh.rq.lt[k] = KS_NOLT; }
+  }
+  p.present = np; p.complement = nc; p.changed = changed; p.narrowed = narrowed; p.valid = valid;
+  p.it_state = (i32)RL(ev.it_state, win); p.it_before = (i32)RL(ev.it0, win); p.count = RL(ev.count, win);
+  p.rm = RL(ev.reqmask, win) | cr.reqmask;
+  bool need = fresh || changed != 0 || p.it_state != p.it_before;
 #pragma unroll
-  for (int i = 0; i < KS_MAX_RES; ++i) if ((u32)i < tb.R) { const i64 v = req[i] + c.req[i]; sh.req_new[i] = v; sh.room_new[i] = ev.room[i] - c.req[i]; if (((rm >> i) & 1u) && v > low[i]) need = true; }
-  o.present = np; o.complement = nc; o.it_state = ev.it_state; o.changed = changed; o.topo_narrowed = narrowed; o.valid = valid;
-  o.rm = rm; o.count = ev.count; o.it_before = ev.it0; o.pad[0] = slot; o.pad[1] = need ? 1u : 0u;
+  for (int i = 0; i < KS_MAX_RES; ++i) {
+    p.req_new[i] = 0; p.room_new[i] = 0;
+    if ((u32)i < tb.R) {
+      const i64 v = (i64)RL64(ev.req[i], win) + cr.req[i]; p.req_new[i] = v; p.room_new[i] = (i64)RL64(ev.room[i], win) - cr.req[i];
+      if (((p.rm >> i) & 1u) && v > (i64)RL64(ev.low[i], win)) need = true;
+    }
+  }
+  p.need = need;
+  LSYNC();
 }
 
 // The node's requirement on key k after the Add that is being committed (published entries, else the record).
-__device__ __forceinline__ KReq new_req(const WaveShared& sh, const Rec& r, int k) {
-  const ReqOut& o = sh.rq; KReq q; q.present = (o.present >> k) & 1u; q.complement = (o.complement >> k) & 1u;
-  if ((o.valid >> k) & 1u) { q.mask = o.mask[k]; q.gt = o.gt[k]; q.lt = o.lt[k]; } else { q.mask = r.mask()[k]; q.gt = r.gt()[k]; q.lt = r.lt()[k]; }
+__device__ __forceinline__ KReq new_req(const Pub& pb, const WaveShared& sh, const Rec& r, int k) {
+  const ReqOut& o = sh.rq; KReq q; q.present = (pb.present >> k) & 1u; q.complement = (pb.complement >> k) & 1u;
+  if ((pb.valid >> k) & 1u) { q.mask = o.mask[k]; q.gt = o.gt[k]; q.lt = o.lt[k]; } else { q.mask = r.mask()[k]; q.gt = r.gt()[k]; q.lt = r.lt()[k]; }
   return q;
 }
 
@@ -642,10 +705,10 @@ __device__ __forceinline__ u64 pass_types_word(const DevProb& P, const Tabs& tb,
   return acc;
 }
 // hasOffering (node.go:151-159) as a T-bit mask word
-__device__ __forceinline__ u64 offer_types_word(const DevProb& P, const Tabs& tb, const WaveShared& sh, const Rec& r, u32 w) {
+__device__ __forceinline__ u64 offer_types_word(const DevProb& P, const Tabs& tb, const Pub& pb, const WaveShared& sh, const Rec& r, u32 w) {
   u64 allowZ = ~0ull, allowC = ~0ull;
-  if (tb.key_zone >= 0 && ((sh.rq.present >> tb.key_zone) & 1u)) allowZ = kreq_has_mask(new_req(sh, r, tb.key_zone), tb.value_int + tb.key_zone * 64, tb.key_nvalues[tb.key_zone]);
-  if (tb.key_ct >= 0 && ((sh.rq.present >> tb.key_ct) & 1u)) allowC = kreq_has_mask(new_req(sh, r, tb.key_ct), tb.value_int + tb.key_ct * 64, tb.key_nvalues[tb.key_ct]);
+  if (tb.key_zone >= 0 && ((pb.present >> tb.key_zone) & 1u)) allowZ = kreq_has_mask(new_req(pb, sh, r, tb.key_zone), tb.value_int + tb.key_zone * 64, tb.key_nvalues[tb.key_zone]);
+  if (tb.key_ct >= 0 && ((pb.present >> tb.key_ct) & 1u)) allowC = kreq_has_mask(new_req(pb, sh, r, tb.key_ct), tb.value_int + tb.key_ct * 64, tb.key_nvalues[tb.key_ct]);
   if (tb.n_ct == 0) return ~0ull;
   u64 acc = 0; const u64 cm = allowC & ((1ull << tb.n_ct) - 1);
   for (u64 zz = allowZ; zz; zz &= zz - 1) {
@@ -656,7 +719,7 @@ __device__ __forceinline__ u64 offer_types_word(const DevProb& P, const Tabs& tb
 }
 
 // TopologyNodeFilter.MatchesRequirements, topologynodefilter.go:57-70
-__device__ __forceinline__ bool filter_matches(const DevProb& P, const Tabs& tb, int g, const WaveShared& sh, const Rec& r) {
+__device__ __forceinline__ bool filter_matches(const DevProb& P, const Tabs& tb, int g, const Pub& pb, const WaveShared& sh, const Rec& r) {
   const u32 b = G_grp_filter_off[g], e = G_grp_filter_off[g + 1];
   if (b == e) return true;
   for (u32 f = b; f < e; ++f) {
@@ -664,11 +727,11 @@ __device__ __forceinline__ bool filter_matches(const DevProb& P, const Tabs& tb,
     const u32 fp = P.flt.present[f], fc = P.flt.complement[f];
     for (u32 bits = fp; bits && ok; bits &= bits - 1) {
       const int k = __builtin_ctz(bits);
-      const KReq a = new_req(sh, r, k);
+      const KReq a = new_req(pb, sh, r, k);
       const KReq in = load_req(fp, fc, P.flt.mask + (size_t)f * tb.K, P.flt.gt + (size_t)f * tb.K, P.flt.lt + (size_t)f * tb.K, k);
       if (kreq_compatible_fail(a, in, (tb.wellknown >> k) & 1u, tb.value_int + k * 64, tb.key_nvalues[k])) ok = false;
     }
-    if (ok && P.flt.it_state[f] && tb.its_fail[sh.rq.it_state * tb.SC + P.flt.it_state[f]]) ok = false;
+    if (ok && P.flt.it_state[f] && tb.its_fail[pb.it_state * tb.SC + P.flt.it_state[f]]) ok = false;
     if (ok) return true;
   }
   return false;
@@ -684,38 +747,29 @@ __device__ __forceinline__ void grp_record_host(const DevState& S, const Tabs& t
 }
 // Topology.Record, topology.go:120-143: lane i handles the i-th group of the class's record list
 // (distinct groups, so the lanes never touch the same counters).
-__device__ __forceinline__ void topology_record(const DevProb& P, const DevState& S, const Tabs& tb, const WaveShared& sh, const Rec& r, u32 slot, int lane) {
+__device__ __forceinline__ void topology_record(const DevProb& P, const DevState& S, const Tabs& tb, const Pub& pb, const WaveShared& sh, const Rec& r, u32 slot, int lane) {
   const ClsPlan& c = sh.cls;
   if ((u32)lane >= c.nrec) return;
   const PlanRec& pr = c.rec[lane]; const int g = pr.g;
   if (!pr.owned_inverse) {
     if (!tb.g_active[g]) return;
-    if (!filter_matches(P, tb, g, sh, r)) return;                        // TopologyGroup.Counts, topologygroup.go:109-111
+    if (pr.filtered && !filter_matches(P, tb, g, pb, sh, r)) return;         // TopologyGroup.Counts, topologygroup.go:109-111 (filtered == 0: no filter, or one that matches every node)
   }
   if (pr.key == KS_KEY_HOSTNAME) { grp_record_host(S, tb, pr.hslot, slot); return; }   // the node requirement is `hostname In [own]`
-  const KReq q = new_req(sh, r, pr.key);
+  const KReq q = new_req(pb, sh, r, pr.key);
   if (!q.present) return;                                            // Get() of a missing key is Exists: no values, Len != 1
   if (pr.owned_inverse || pr.type == 2) { for (u64 b = q.mask; b; b &= b - 1) grp_record(tb, g, __builtin_ctzll(b)); }   // Values(): for a complement set the excluded values
   else if (!q.complement && __builtin_popcountll(q.mask) == 1) grp_record(tb, g, __builtin_ctzll(q.mask));
 }
 
-// Synchronisation inside the single-wave workgroup.
-//   LSYNC: cross-lane hand-off through LDS.  LDS instructions of one wave execute in program order, so only
-//          the compiler must be stopped from reordering -- no instruction is emitted.
-//   GSYNC: cross-lane hand-off through GLOBAL memory: the writer's stores must have completed
-//          (s_waitcnt vmcnt(0)) before another lane's load is issued; costs a store round trip, so it is used
-//          once per pod (before the candidate scan re-reads node records) and on rare paths.
-#define CTR(i, v) do { if (lane == 0) sh.ctr[(i)] += (v); } while (0)
-#define LSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#define GSYNC() __syncthreads()
-
 __device__ __forceinline__ i64 wave_max_i64(i64 v) { for (int off = 32; off > 0; off >>= 1) { const i64 o = __shfl_xor(v, off); if (o > v) v = o; } return v; }
 
 // Stage the pod's class plan in LDS (one coalesced copy) and evaluate the per-pod, node-independent part
 // of its topology groups (domainMinCount, topologygroup.go:184-200).
-__device__ __forceinline__ void stage_class(const Tabs& tb, WaveShared& sh, const GA ClsPlan* plans, u32 c, int lane) {
-  const GA u32x4* src = (const GA u32x4*)(plans + c); u32x4* dst = (u32x4*)&sh.cls;
-  for (u32 i = lane; i < sizeof(ClsPlan) / 16; i += 64) dst[i] = src[i];
+// The plan itself reaches LDS from registers: it was prefetched while the previous pod was being placed.
+constexpr u32 KS_PLAN_V = sizeof(ClsPlan) / 16;
+static_assert(KS_PLAN_V <= 128, "a class plan is prefetched as two 16-byte registers per lane");
+__device__ __forceinline__ void stage_class(const Tabs& tb, WaveShared& sh, int lane) {
   LSYNC();
   const ClsPlan& L = sh.cls;
   if ((u32)lane < L.ntopo) {
@@ -731,7 +785,7 @@ __device__ __forceinline__ void stage_class(const Tabs& tb, WaveShared& sh, cons
 // lower_bound over the ascending distinct Allocatable values of every requested resource with a 64-ary
 // search: every lane probes one pivot, __ballot narrows the interval (two rounds cover 4096 values).  All
 // resources advance together so their LDS reads overlap.  idx[r] == ge_cnt[r] means "no type has that much".
-__device__ __forceinline__ void ge_row_indices(const Tabs& tb, const WaveShared& sh, u32 reqmask, int lane, u32 (&idx)[KS_MAX_RES]) {
+__device__ __forceinline__ void ge_row_indices(const Tabs& tb, const Pub& pb, u32 reqmask, int lane, u32 (&idx)[KS_MAX_RES]) {
   u32 lo[KS_MAX_RES], hi[KS_MAX_RES];
 #pragma unroll
   for (int r = 0; r < KS_MAX_RES; ++r) { lo[r] = 0; hi[r] = ((reqmask >> r) & 1u) ? tb.ge_cnt[r] : 0; }
@@ -743,7 +797,7 @@ __device__ __forceinline__ void ge_row_indices(const Tabs& tb, const WaveShared&
       const u32 span = hi[r] - lo[r], step = (span + 63) >> 6;
       const u32 p = lo[r] + (u32)lane * step;
       const bool in = p < hi[r];
-      const bool ge = in && tb.ge_vals[(size_t)r * tb.T + p] >= sh.req_new[r];
+      const bool ge = in && tb.ge_vals[(size_t)r * tb.T + p] >= pb.req_new[r];
       const u64 b = ballot64(ge); const u32 npiv = __builtin_popcountll(ballot64(in));
       if (!b) lo[r] = lo[r] + (npiv - 1) * step + 1;
       else {
@@ -761,31 +815,36 @@ __device__ __forceinline__ void ge_row_indices(const Tabs& tb, const WaveShared&
 // Instance-type filter (filterInstanceTypesByRequirements, node.go:137-141) on T-bit masks, one wave:
 //   alive' = alive & passTypes(changed keys) & its_types(state) & offerings & AND_r ge_rows[r][row(requests[r])]
 // Lane w owns word w; there is no per-type loop: resources.Fits is one precomputed row per requested resource.
-__device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, WaveShared& sh, const Rec& r, const GA u64* alive_in, GA u64* alive_out, u32 reqmask_new,
-                             u32 changed_keys, bool check_offer, bool check_it, int lane, u64& tprobe) {
+__device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, const Pub& pb, WaveShared& sh, const Rec& r, const GA u64* alive_in, GA u64* alive_out, u32 reqmask_new,
+                             u32 changed_keys, bool check_offer, bool check_it, int lane, u64& tprobe, u64& word) {   // alive_out == nullptr (TW <= 64 only): the result stays in `word`
   const GA u64* rows[KS_MAX_RES]; u32 ridx[KS_MAX_RES];
-  ge_row_indices(tb, sh, reqmask_new, lane, ridx);
+  ge_row_indices(tb, pb, reqmask_new, lane, ridx);
   bool none = false;
 #pragma unroll
   for (int i = 0; i < KS_MAX_RES; ++i) {
     rows[i] = nullptr;
     if ((reqmask_new >> i) & 1u) { if (ridx[i] >= tb.ge_cnt[i]) none = true; rows[i] = tb.ge_rows + ((size_t)i * tb.T + ridx[i]) * tb.TW; }
   }
-  if (none) { for (u32 w = lane; w < tb.TW; w += 64) alive_out[w] = 0; LSYNC(); return false; }   // nothing has that much of some resource
+  word = 0;
+  if (none) { if (alive_out) for (u32 w = lane; w < tb.TW; w += 64) alive_out[w] = 0; LSYNC(); return false; }   // nothing has that much of some resource
 #pragma unroll
   for (int i = 0; i < KS_MAX_RES; ++i) if (lane == 0 && ((reqmask_new >> i) & 1u)) sh.low_new[i] = tb.ge_vals[(size_t)i * tb.T + ridx[i]];
   bool any = false;
   for (u32 wbase = 0; wbase < tb.TW; wbase += 64) {
     const u32 w = wbase + lane; u64 a = 0;
     if (w < tb.TW) {
+      // every load below is independent of the others: one memory round trip, not one per term
       a = alive_in[w];
 #pragma unroll
       for (int i = 0; i < KS_MAX_RES; ++i) if (rows[i]) a &= rows[i][w];
-      for (u32 bits = changed_keys; bits && a; bits &= bits - 1) { const int k = __builtin_ctz(bits); a &= pass_types_word(P, tb, k, new_req(sh, r, k), w); }
-      if (check_it && a) a &= G_its_types[(size_t)sh.rq.it_state * tb.TW + w];
-      if (check_offer && a) a &= offer_types_word(P, tb, sh, r, w);
-      alive_out[w] = a;
+      u64 x = ~0ull;
+      for (u32 bits = changed_keys; bits; bits &= bits - 1) { const int k = __builtin_ctz(bits); x &= pass_types_word(P, tb, k, new_req(pb, sh, r, k), w); }
+      if (check_it) x &= G_its_types[(size_t)pb.it_state * tb.TW + w];
+      if (check_offer) x &= offer_types_word(P, tb, pb, sh, r, w);
+      a &= x;
+      if (alive_out) alive_out[w] = a;
     }
+    if (wbase == 0) word = a;
     if (ballot64(a != 0)) any = true;
   }
   LSYNC();
@@ -810,10 +869,15 @@ __device__ __forceinline__ void recompute_cap(const DevProb& P, const Tabs& tb, 
 
 // Write the winning node's record after Add: only what changed (lane-parallel stores).
 template <bool BOUNDS>
-__device__ __forceinline__ void write_record(const Tabs& tb, const Rec& r, const WaveShared& sh, u32 reqmask_new, int lane) {
-  if ((u32)lane < tb.K && ((sh.rq.changed >> lane) & 1u)) { r.mask()[lane] = sh.rq.mask[lane]; if constexpr (BOUNDS) { r.gt()[lane] = sh.rq.gt[lane]; r.lt()[lane] = sh.rq.lt[lane]; } }
-  if (lane >= 32 && (u32)lane < 32 + tb.R) { r.req()[lane - 32] = sh.req_new[lane - 32]; r.room()[lane - 32] = sh.room_new[lane - 32]; }
-  if (lane == 63) { r.present() = sh.rq.present; r.complement() = sh.rq.complement; r.it_state() = sh.rq.it_state; r.reqmask() = reqmask_new; }
+__device__ __forceinline__ void write_record(const Tabs& tb, const Rec& r, const Pub& pb, const WaveShared& sh, u32 reqmask_new, int lane) {
+  if ((u32)lane < tb.K && ((pb.changed >> lane) & 1u)) { r.mask()[lane] = sh.rq.mask[lane]; if constexpr (BOUNDS) { r.gt()[lane] = sh.rq.gt[lane]; r.lt()[lane] = sh.rq.lt[lane]; } }
+  if (lane >= 32 && (u32)lane < 32 + tb.R) {
+    i64 rq = 0, ro = 0;
+#pragma unroll
+    for (int i = 0; i < KS_MAX_RES; ++i) if (lane - 32 == i) { rq = pb.req_new[i]; ro = pb.room_new[i]; }
+    r.req()[lane - 32] = rq; r.room()[lane - 32] = ro;
+  }
+  if (lane == 63) { r.present() = pb.present; r.complement() = pb.complement; r.it_state() = pb.it_state; r.reqmask() = reqmask_new; }
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ks_dyn_lds[];
@@ -831,10 +895,11 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
   const DevProb& P = P_lds;
   const DevState& S = S_lds;
   Tabs tb;
-  tb.K = P.K; tb.R = P.R; tb.T = P.T; tb.TW = P.TW; tb.GH = P.GH; tb.E = P.E; tb.S = P.S; tb.SC = P.SC; tb.n_ct = P.n_ct; tb.wellknown = P.wellknown_mask; tb.key_zone = P.key_zone; tb.key_ct = P.key_ct;
+  tb.K = UF(P.K); tb.R = UF(P.R); tb.T = UF(P.T); tb.TW = UF(P.TW); tb.GH = UF(P.GH); tb.E = UF(P.E); tb.S = UF(P.S); tb.SC = UF(P.SC); tb.n_ct = UF(P.n_ct); tb.wellknown = UF(P.wellknown_mask); tb.key_zone = (i32)UF(P.key_zone); tb.key_ct = (i32)UF(P.key_ct);
   tb.key_nvalues = P.key_nvalues; tb.value_int = P.value_int; tb.its_fail = P.its_fail; tb.its_inter = P.its_inter;
-  tb.q = (GA u64*)S.q; tb.pod_node = (GA i32*)S.pod_node; tb.pod_seq = (GA i32*)S.pod_seq;
-  tb.rec = (GA u8*)S.rec; tb.rec_stride = S.rec_stride; tb.hcnt = (GA i32*)S.hcnt; tb.n_alive = (GA u64*)S.n_alive; tb.ge_rows = (const GA u64*)P.ge_rows;
+  tb.q = (GA u64*)UF64((u64)S.q); tb.pod_node = (GA i32*)UF64((u64)S.pod_node); tb.pod_seq = (GA i32*)UF64((u64)S.pod_seq);
+  tb.rec = (GA u8*)UF64((u64)S.rec); tb.rec_stride = UF(S.rec_stride); tb.hcnt = (GA i32*)UF64((u64)S.hcnt); tb.n_alive = (GA u64*)UF64((u64)S.n_alive); tb.ge_rows = (const GA u64*)UF64((u64)P.ge_rows);
+  const u32 nP = UF(P.P), nM = UF(P.M), nC = UF(P.C), nG = UF(P.G), nMAX = UF(P.NMAX);
   tb.gcnt = S.gcnt; tb.g_reg = S.g_reg; tb.g_pos = S.g_pos; tb.g_active = S.g_active; tb.g_hpos = S.g_hpos; tb.ge_vals = P.ge_vals; tb.ge_cnt = P.ge_cnt;
 
   // ---------------- initialise state (global memory) ----------------
@@ -884,7 +949,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
   }
   __threadfence_block();
   GSYNC();
-  const GA ClsPlan* plans = (const GA ClsPlan*)P.plans;
+  const GA ClsPlan* plans = (const GA ClsPlan*)UF64((u64)P.plans);
   u32* const ord_l = (u32*)(ks_dyn_lds + lds_used);    // ord[pos] = new-node index j, sorted in visiting order (LDS home)
   GA u32* const ord_g = (GA u32*)S.order_g;            // ... its global-memory home once it outgrows LDS
 #define ORD_RD(i) (ord_in_lds ? ord_l[(i)] : ord_g[(i)])
@@ -895,28 +960,45 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
 #define BST(c) (*((c) < KS_BST_LDS ? &sh.bstart[(c)] : &S.bstart[(c)]))
 
   // wave-uniform loop state lives in registers (SGPRs)
-  u32 q_head = 0, q_len = P.P, q_gen = 0, nnew = 0, seq = 0, err = 0, maxc = 0;
+  u32 q_head = 0, q_len = nP, q_gen = 0, nnew = 0, seq = 0, err = 0, maxc = 0;
   u32 pp_used = tb.E ? P.en_port_off[tb.E] : 0;
-  const bool want_stats = (P.flags & KS_FLAG_STATS) != 0;
-  GA u64* const scratch = tb.n_alive + (size_t)P.NMAX * tb.TW;      // one spare row of the alive table
+  const bool want_stats = (UF(P.flags) & KS_FLAG_STATS) != 0;
+  GA u64* const scratch = tb.n_alive + (size_t)nMAX * tb.TW;      // one spare row of the alive table
   u64 tprobe = __builtin_readcyclecounter(); if (lane < 32) sh.ctr[lane] = 0;
+  u64 qe_a = 0, qe_b = 0; u32x4 pf0 = {0, 0, 0, 0}, pf1 = {0, 0, 0, 0}; bool pf_ok = false;
+  // Fit-bitmap reuse across a run of evaluation-equivalent pods (ks_link_plans): every lane keeps its last
+  // evaluation (ev, slot, the sh.la_* slots); r_mask = lanes that passed and have not been used, valid for lanes
+  // below r_lim (the rest of the winner's count bucket); r_removed = nodes that left the step's window since.
+  Ev ev; ev.rc = 0; u32 slot = 0xFFFFFFFFu;
+  bool r_valid = false; u32 r_eq = 0, r_base = 0, r_removed = 0, r_lim = 0; u64 r_mask = 0;
 
   // ---------------- Solve loop, scheduler.go:104-124 ----------------
   for (;;) {
     // Queue.Pop, queue.go:44-58
     if (q_len == 0) break;
     PROBE(20);
-    const u64 qe = tb.q[q_head];
+#ifdef KS_PROBES
+    const u64 t_pod = __builtin_readcyclecounter();
+#endif
+    // The queue entry and the class plan of this pod were requested one pod ago (qe_a, pf0/pf1), the entry after
+    // it two pods ago (qe_b); a Push invalidates the pipeline (the pushed entry may be one of the prefetched slots).
+    if (!pf_ok) {
+      qe_a = tb.q[q_head]; qe_b = tb.q[(q_head + 1 == nP) ? 0 : q_head + 1];
+      const GA u32x4* src = (const GA u32x4*)(plans + ((u32)(qe_a >> 32) & 0x7FFFFFFFu));
+      pf0 = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) pf1 = src[lane + 64];
+    }
+    const u64 qe = UF64(qe_a);
     const u32 pod = (u32)qe, cidx = (u32)(qe >> 32) & 0x7FFFFFFFu;
-    if ((qe >> 63) && G_lastgen[pod] == q_gen && G_lastlen[pod] == q_len) break;   // only a requeued, unrelaxed pod can be stale
-    q_head = (q_head + 1 == P.P) ? 0 : q_head + 1; q_len--; CTR(KS_STAT_POPS, 1);
+    if ((qe >> 63) && UF(G_lastgen[pod]) == q_gen && UF(G_lastlen[pod]) == q_len) break;   // only a requeued, unrelaxed pod can be stale
+    q_head = (q_head + 1 == nP) ? 0 : q_head + 1; q_len--; CTR(KS_STAT_POPS, 1);
     PROBE(12);
-    stage_class(tb, sh, plans, cidx, lane);
+    { u32x4* dst = (u32x4*)&sh.cls; dst[lane] = pf0; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = pf1; }
+    stage_class(tb, sh, lane);
     const ClsPlan& c = sh.cls;
-    if (c.overflow) { err = (u32)(-KS_ERR_UNSUPPORTED); break; }
-    ClsR cr; cr.tol = c.tol; cr.reqmask = c.reqmask; cr.ntouch = c.ntouch; cr.nhost = c.nhost; cr.hn_mode = c.hn_mode; cr.port_cnt = c.port_cnt; cr.it_state = c.it_state;
+    if (UF(c.overflow)) { err = (u32)(-KS_ERR_UNSUPPORTED); break; }
+    ClsR cr; cr.tol = UF64(c.tol); cr.reqmask = UF(c.reqmask); cr.ntouch = UF(c.ntouch); cr.nhost = UF(c.nhost); cr.hn_mode = UF(c.hn_mode); cr.port_cnt = UF(c.port_cnt); cr.it_state = (i32)UF(c.it_state); cr.tkeys = UF64(c.tkeys); cr.eq = UF(c.eq);
 #pragma unroll
-    for (int i = 0; i < KS_MAX_RES; ++i) cr.req[i] = c.req[i];
+    for (int i = 0; i < KS_MAX_RES; ++i) cr.req[i] = (i64)UF64(c.req[i]);
     bool placed = false;
     PROBE(13);
 
@@ -925,21 +1007,37 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
     // then one fresh node per machine template (a single-lane "chunk").  One code path evaluates, filters
     // and commits all three kinds.
     GSYNC();                       // the previous pod's record / counter stores are complete before they are re-read
-    u32 pos_base = 0, tm = 0;
+    {   // (after the barrier: its vmcnt(0) would otherwise wait for these loads) request the next pod's plan and the queue entry after it (every slot of q always holds a valid class index)
+      qe_a = qe_b; qe_b = tb.q[(q_head + 1 == nP) ? 0 : q_head + 1];
+      const GA u32x4* src = (const GA u32x4*)(plans + ((u32)(qe_a >> 32) & 0x7FFFFFFFu));
+      pf0 = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) pf1 = src[lane + 64];
+      pf_ok = true;
+    }
+    u32 pos_base = 0, tm = 0, width = KS_FIRST_WIDTH;
+    bool reuse = r_valid && !want_stats && cr.eq != 0 && cr.eq == r_eq;
+    if (cr.eq != 0) CTR(8, 1);
+    r_valid = reuse;               // any other path re-evaluates (or moves nodes in ways the window does not track)
     while (!placed && !err) {
       const u32 total = tb.E + nnew;
-      const bool fresh = pos_base >= total;
-      u32 slot = 0xFFFFFFFFu; u32 m_t = 0, lim = 0xFFFFFFFFu, ltypes = 0; size_t mc = 0;
+      const bool fresh = !reuse && pos_base >= total;
+      u32 m_t = 0, lim = 0xFFFFFFFFu, ltypes = 0; size_t mc = 0;
+      u64 m = 0, reach = 0;
+      if (reuse) {
+        // the kept evaluations are still exact: no node of the window changed except the ones taken out of it
+        pos_base = r_base - r_removed;
+        m = r_mask & (r_lim >= 64 ? ~0ull : ((1ull << r_lim) - 1ull));
+      } else {
+      slot = 0xFFFFFFFFu;
       if (!fresh) {
         const u32 pos = pos_base + lane;
-        if (pos < total) slot = pos < tb.E ? pos : tb.E + ORD_RD(pos - tb.E);
+        if ((u32)lane < width && pos < total) slot = pos < tb.E ? pos : tb.E + ORD_RD(pos - tb.E);
       } else {
         // ---- a new node from the next template that survives the pre-checks (scheduler.go:193-213) ----
         PROBE(20);
         bool have = false;
-        for (; tm < P.M && !have; ++tm) {
-          m_t = tm; mc = (size_t)m_t * P.C + cidx; lim = P.tmpl_limit_present[m_t];
-          if (nnew >= P.NMAX) { err = (u32)(-KS_ERR_CAPACITY); break; }
+        for (; tm < nM && !have; ++tm) {
+          m_t = tm; mc = (size_t)m_t * nC + cidx; lim = UF(P.tmpl_limit_present[m_t]);
+          if (nnew >= nMAX) { err = (u32)(-KS_ERR_CAPACITY); break; }
           // filterByRemainingResources, scheduler.go:293-309 (only when the provisioner has limits)
           bool lany = false; ltypes = 0;
           for (u32 wbase = 0; wbase < tb.TW; wbase += 64) {
@@ -959,7 +1057,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
           }
           if (!lany) continue;                  // "all available instance types exceed provisioner limits" (before NewNode)
           if (want_stats) CTR(KS_STAT_REF_ATTEMPTS, 1);    // NewNode + node.Add is attempted for this template
-          if (!P.mc_ok[mc]) continue;           // taints / Compatible fail inside Add
+          if (!UF(P.mc_ok[mc])) continue;           // taints / Compatible fail inside Add
           have = true;
         }
         if (err) break;
@@ -969,7 +1067,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
         if ((u32)lane < tb.K) { fr.mask()[lane] = P.mc_mask[mc * tb.K + lane]; fr.gt()[lane] = P.mc_gt[mc * tb.K + lane]; fr.lt()[lane] = P.mc_lt[mc * tb.K + lane]; }
         if (lane >= 32 && (u32)lane < 32 + tb.R) { fr.req()[lane - 32] = P.tmpl_daemon[(size_t)m_t * tb.R + lane - 32]; fr.room()[lane - 32] = INT64_MAX / 2; fr.low()[lane - 32] = INT64_MIN; }
         if (lane == 63) { fr.taints() = P.tmpl_taints[m_t]; fr.present() = P.mc_present[mc]; fr.complement() = P.mc_complement[mc]; fr.it_state() = P.mc_it[mc]; fr.reqmask() = P.tmpl_daemon_present[m_t]; fr.porthead() = -1; fr.count() = 0; }
-        for (u32 g = lane; g < P.G; g += 64) if (P.grp_hslot[g] >= 0) tb.hcnt[(size_t)fs * tb.GH + P.grp_hslot[g]] = tb.g_active[g] ? 0 : -1;   // Topology.Register(hostname), node.go:47
+        for (u32 g = lane; g < nG; g += 64) if (P.grp_hslot[g] >= 0) tb.hcnt[(size_t)fs * tb.GH + P.grp_hslot[g]] = tb.g_active[g] ? 0 : -1;   // Topology.Register(hostname), node.go:47
         __threadfence_block();
         GSYNC();
         if (lane == 0) slot = fs;
@@ -977,35 +1075,38 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
       }
 
       // ---- Node.Add / ExistingNode.Add up to the instance-type filter, one node per lane ----
-      Ev ev; ev.rc = 0;
+      ev.rc = 0;
       if (slot != 0xFFFFFFFFu) eval_node<BOUNDS>(P, S, tb, sh, slot, slot < tb.E, fresh, ev, lane, tprobe, cr);
       PROBE(26);
-      u64 m = ballot64(ev.rc == 2);
-      const u64 reach = ballot64(ev.rc >= 1);
+      m = ballot64(ev.rc == 2);
+      reach = ballot64(ev.rc >= 1);
+      }
       if (!fresh) { PROBE(14); CTR(21, 1); }
-      u32 my_alive = 0; u32 visited = fresh ? 0 : min(64u, total - pos_base);   // lanes the reference would have visited (all, unless one succeeds)
+      u32 my_alive = 0; u32 visited = fresh ? 0 : min(width, total - pos_base);   // lanes the reference would have visited (all, unless one succeeds)
       if (want_stats && !fresh && slot != 0xFFFFFFFFu && slot >= tb.E && ev.rc >= 1) for (u32 w = 0; w < tb.TW; ++w) my_alive += __builtin_popcountll(tb.n_alive[(size_t)(slot - tb.E) * tb.TW + w]);
 
       while (m) {
         const int win = __builtin_ctzll(m);
-        if (lane == win) publish_eval<BOUNDS>(tb, sh, ev, slot_rec(S, tb, slot), slot, fresh, lane);
-        LSYNC();
-        const u32 sw = sh.rq.pad[0]; const bool ex = sw < tb.E; const u32 jw = sw - tb.E;
+        Pub pb; publish_eval<BOUNDS>(tb, sh, ev, slot, fresh, lane, win, cr, pb);
+        const u32 sw = pb.slot; const bool ex = sw < tb.E; const u32 jw = sw - tb.E;
         const Rec r = slot_rec(S, tb, sw);
-        const u32 rm = sh.rq.rm;
+        const u32 rm = pb.rm;
         PROBE(15);
         if (!ex) {
           // filterInstanceTypesByRequirements (node.go:94-98): existing nodes have no instance-type step
           CTR(KS_STAT_FULLCHECKS, 1); if (want_stats && fresh) CTR(KS_STAT_REF_TYPES, ltypes);
           GA u64* const alive = tb.n_alive + (size_t)jw * tb.TW;
-          const u32 keys = fresh ? sh.rq.topo_narrowed : sh.rq.changed;   // a fresh node's own keys are already in the grid row
+          const u32 keys = fresh ? pb.narrowed : pb.changed;   // a fresh node's own keys are already in the grid row
           const bool zc = (tb.key_zone >= 0 && ((keys >> tb.key_zone) & 1u)) || (tb.key_ct >= 0 && ((keys >> tb.key_ct) & 1u));
-          const bool itc = !fresh && sh.rq.it_state != sh.rq.it_before;
-          if (sh.rq.pad[1]) {     // otherwise the filter would pick the same rows as last time: InstanceTypeOptions unchanged
-            const bool ok = filter_types(P, tb, sh, r, fresh ? scratch : alive, fresh ? alive : scratch, rm, keys, zc, itc, lane, tprobe);
+          const bool itc = !fresh && pb.it_state != pb.it_before;
+          if (pb.need) {     // otherwise the filter would pick the same rows as last time: InstanceTypeOptions unchanged
+            const bool inreg = !fresh && tb.TW <= 64;   // the surviving-type word stays in a register: no scratch round trip
+            u64 aw;
+            const bool ok = filter_types(P, tb, pb, sh, r, fresh ? scratch : alive, fresh ? alive : (inreg ? (GA u64*)nullptr : scratch), rm, keys, zc, itc, lane, tprobe, aw);
             PROBE(16);
             if (!ok) { CTR(KS_STAT_FULLFAILS, 1); if (!fresh) recompute_cap(P, tb, alive, r, lane); m &= m - 1; continue; }
-            if (!fresh) for (u32 w = lane; w < tb.TW; w += 64) alive[w] = scratch[w];
+            if (inreg) { if ((u32)lane < tb.TW) alive[lane] = aw; }
+            else if (!fresh) for (u32 w = lane; w < tb.TW; w += 64) alive[w] = scratch[w];
             if ((u32)lane < tb.R && ((rm >> lane) & 1u)) r.low()[lane] = sh.low_new[lane];
           }
         }
@@ -1024,25 +1125,33 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
 #pragma unroll
           for (int rr = 0; rr < KS_MAX_RES; ++rr) if ((u32)rr < tb.R) { const i64 v = wave_max_i64(mx[rr]); if (lane == 0 && ((lim >> rr) & 1u)) S.remaining[(size_t)m_t * tb.R + rr] -= v; }
         }
-        topology_record(P, S, tb, sh, r, sw, lane);
-        const u32 cnt = sh.rq.count;                                   // pods on the node before this one
+        topology_record(P, S, tb, pb, sh, r, sw, lane);
+        const u32 cnt = pb.count;                                   // pods on the node before this one
         LSYNC();
-        write_record<BOUNDS>(tb, r, sh, rm, lane);
+        write_record<BOUNDS>(tb, r, pb, sh, rm, lane);
         if (lane == 0) {
           if (!ex) r.count() = cnt + 1;
           if (fresh) S.n_tmpl[jw] = (i32)m_t;
-          for (u32 i = 0; i < c.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
+          for (u32 i = 0; i < cr.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
           tb.pod_node[pod] = (i32)sw; tb.pod_seq[pod] = (i32)seq;
         }
         PROBE(17);
         if (!ex && !fresh) {
           // visiting order: the node leaves position p of bucket `cnt` for the FRONT of bucket cnt+1
           const u32 p = pos_base + win - tb.E;
-          const u32 endc = BST(cnt + 1);                             // one past the last node with `cnt` pods
+          const u32 endc = UF(BST(cnt + 1));                         // one past the last node with `cnt` pods
           for (u32 i = p + 1; i < endc; i += 64) { const u32 ii = i + lane; u32 v = 0; if (ii < endc) v = ORD_RD(ii); if (ord_in_lds) LSYNC(); else GSYNC(); if (ii < endc) ORD_WR(ii - 1, v); }
           if (ord_in_lds) LSYNC(); else GSYNC();
           if (lane == 0) { ORD_WR(endc - 1, jw); BST(cnt + 1) = endc - 1; if (cnt + 1 > maxc) BST(cnt + 2) = nnew; }
           if (cnt + 1 > maxc) maxc = cnt + 1;
+          // keep the step's remaining fit bits for the next pod if it is evaluation-equivalent: valid for the lanes
+          // whose nodes share the winner's count bucket (they now precede it in the visiting order)
+          if (reuse) { r_mask = m & (m - 1); ++r_removed; CTR(11, 1); }
+          else if (cr.eq != 0 && !want_stats) {
+            CTR(10, 1);
+            const u32 lim_abs = tb.E + endc;                          // one past the bucket, in this step's coordinates
+            r_valid = true; r_eq = cr.eq; r_mask = m & (m - 1); r_base = pos_base; r_removed = 1; r_lim = lim_abs > pos_base ? min(64u, lim_abs - pos_base) : 0;
+          }
         } else if (fresh) {
           // visiting order: appended -> BACK of the count-1 bucket, i.e. position bstart[2]; everything after shifts right
           if (ord_in_lds && nnew + 1 > ord_cap) {                     // spill the order array to global memory
@@ -1051,35 +1160,39 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
           }
           if (maxc == 0) { if (lane == 0) { BST(1) = 0; BST(2) = 1; ORD_WR(0, jw); } maxc = 1; }
           else {
-            const u32 ins = BST(2);
+            const u32 ins = UF(BST(2));
             for (u32 hi = nnew; hi > ins; ) { const u32 lo = hi > ins + 64 ? hi - 64 : ins; const u32 ii = lo + lane; u32 v = 0; if (ii < hi) v = ORD_RD(ii); if (ord_in_lds) LSYNC(); else GSYNC(); if (ii < hi) ORD_WR(ii + 1, v); if (ord_in_lds) LSYNC(); else GSYNC(); hi = lo; }
             if (lane == 0) ORD_WR(ins, jw);
             for (u32 cc = 2 + lane; cc <= maxc + 1; cc += 64) BST(cc) += 1;
           }
           nnew = jw + 1;
         }
-        pp_used += c.port_cnt; ++seq; placed = true;
+        pp_used += cr.port_cnt; ++seq; placed = true;
         LSYNC();
         PROBE(18);
         break;
       }
+      if (reuse && !placed) { CTR(9, 1); reuse = false; r_valid = false; pos_base = 0; continue; }   // window exhausted: evaluate from the top
       if (want_stats && !fresh) {
         CTR(KS_STAT_REF_ATTEMPTS, visited);
         u32 ty = ((u32)lane < visited && ((reach >> lane) & 1ull)) ? my_alive : 0;
         for (int off = 32; off > 0; off >>= 1) ty += __shfl_xor(ty, off);
         CTR(KS_STAT_REF_TYPES, ty);
       }
-      if (!fresh) pos_base += 64;
+      if (!fresh) { pos_base += width; width = 64; }
     }
     if (err) break;
+#ifdef KS_PROBES
+    { const u32 kind = cr.nhost ? 2 : (c.ntopo ? 1 : 0); CTR(27 + kind, __builtin_readcyclecounter() - t_pod); if (kind) CTR(29 + kind, 1); }
+#endif
 
     // ---- failure: Preferences.Relax + Queue.Push + Topology.Update (scheduler.go:116-123) ----
     if (!placed) {
-      const u32 nst = G_pod_stage_off[pod + 1] - G_pod_stage_off[pod];
-      const i32 stg = G_pod_stage[pod];
+      const u32 nst = UF(G_pod_stage_off[pod + 1] - G_pod_stage_off[pod]);
+      const i32 stg = (i32)UF(G_pod_stage[pod]);
       const bool relaxed = (u32)stg + 1 < nst;
-      u32 tail = q_head + q_len; if (tail >= P.P) tail -= P.P;
-      q_len++;
+      u32 tail = q_head + q_len; if (tail >= nP) tail -= nP;
+      q_len++; pf_ok = false;
       if (lane == 0) {
         const u32 ncls = relaxed ? G_stage_cls[G_pod_stage_off[pod] + stg + 1] : cidx;
         tb.q[tail] = (u64)pod | ((u64)ncls << 32) | (relaxed ? 0ull : (1ull << 63));
@@ -1097,7 +1210,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
 
   // ---------------- results ----------------
   GSYNC();
-  for (u32 i = lane; i < q_len; i += 64) { u32 idx = q_head + i; if (idx >= P.P) idx -= P.P; S.unscheduled[i] = (i32)tb.q[idx]; }
+  for (u32 i = lane; i < q_len; i += 64) { u32 idx = q_head + i; if (idx >= nP) idx -= nP; S.unscheduled[i] = (i32)tb.q[idx]; }
   for (u32 j = lane; j < nnew; j += 64) {        // de-interleave the new nodes' records into the SoA result arrays
     const Rec r = slot_rec(S, tb, tb.E + j);
     S.o_present[j] = r.present(); S.o_complement[j] = r.complement(); S.o_it[j] = r.it_state(); S.o_reqmask[j] = r.reqmask();
@@ -1277,6 +1390,7 @@ static int build_static(ks_dev_problem* d, float* grid_ms) {
   const u32 rows = h.K * 64 + 2 * h.K + 64;
   hipLaunchKernelGGL(ks_build_type_tables, dim3((rows * 64 + 255) / 256), dim3(256), 0, d->stream, h);
   if (h.C) hipLaunchKernelGGL(ks_build_plans, dim3((h.C + 63) / 64), dim3(64), 0, d->stream, h, (ClsPlan*)h.plans);
+  if (h.C) hipLaunchKernelGGL(ks_link_plans, dim3((h.C + 63) / 64), dim3(64), 0, d->stream, (ClsPlan*)h.plans, h.C, h.R);
   hipLaunchKernelGGL(ks_build_ge_rows, dim3((u32)(((size_t)h.R * h.T * 64 + 255) / 256)), dim3(256), 0, d->stream, h);
   const size_t MC = (size_t)h.M * h.C;
   HIPCHK(hipEventRecord(e0, d->stream));

@@ -12,3 +12,6 @@ for k in ("cyc_pop","cyc_stage","cyc_scan","cyc_evalout","cyc_full","cyc_commit"
     print(f"{k:12s} {st[k]:>14d}  {100*st[k]/tot:5.1f}%  per pod {st[k]/pods:9.0f}")
 for k,n in (("p22","to eval start"),("p23","gather loads"),("p24","taints..host topo"),("p25","touch loop"),("p26","after eval")): print(f"{k} {n:20s} {st.get(k,0)/pods:9.0f}")
 print("total cycles", tot, "per pod", tot/pods, "chunks/pod", st["scan_chunks"]/pods, "full_checks", st["full_checks"], "full_fails", st["full_fails"])
+n1, n2 = st.get("n_kind1",0), st.get("n_kind2",0); n0 = st["queue_pops"] - n1 - n2
+for nm, cy, n in (("no topology in eval", st.get("cyc_kind0",0), n0), ("narrow-key topology", st.get("cyc_kind1",0), n1), ("hostname topology", st.get("cyc_kind2",0), n2)): print("%-22s pops %7d  cycles/pop %8.0f  share %4.1f%%" % (nm, n, cy/max(n,1), 100*cy/tot))
+print("eq-eligible pods %d, window seeds %d, reuse hits %d, exhausted %d" % (st.get("eq_pods",0), st.get("reuse_seeds",0), st.get("reuse_hits",0), st.get("reuse_exhausted",0)))
