@@ -443,9 +443,11 @@ struct ReqOut {    // per-key requirement of the winning node after the pod is a
 };
 // The winner's evaluation, broadcast to the whole wave with v_readlane: wave-uniform registers, so the
 // filter and the commit branch on scalars instead of waiting on LDS round trips.
-struct Pub {
+// RM: compile-time bound on the resource count (4 in the LEAN kernel variant, KS_MAX_RES otherwise) -- every loop over
+// resources is fully unrolled, so the bound is paid in instructions and registers whether or not R reaches it.
+template <int RM> struct PubT {
   u32 slot, present, complement, changed, narrowed, valid, rm, count; i32 it_state, it_before; bool need;
-  i64 req_new[KS_MAX_RES], room_new[KS_MAX_RES];
+  i64 req_new[RM], room_new[RM];
 };
 struct TopoDyn { u64 reg, pos; i32 minc; i32 pad; };
 struct alignas(16) WaveShared {
@@ -509,25 +511,25 @@ __device__ __forceinline__ bool kreq_differs(const KReq& x, const KReq& y) { ret
 
 // The popped pod's class scalars, hoisted into wave-uniform registers once per pod (a class field read from
 // LDS costs a ~60-cycle dependent round trip at every use inside eval_node).
-struct ClsR { u64 tol, tkeys; u32 reqmask, ntouch, nhost, hn_mode, port_cnt, eq; i32 it_state; i64 req[KS_MAX_RES]; };
+template <int RM> struct ClsRT { u64 tol, tkeys; u32 reqmask, ntouch, nhost, hn_mode, port_cnt, eq; i32 it_state; i64 req[RM]; };
 
 // Result of evaluating one node for the current pod: scalars in registers, the per-key requirements in
 // per-lane LDS slots (sh.la_*[touch index][lane]) so the algebra below is ONE dynamic loop body instead
 // of an unrolled copy per key, and so every lane can read the winner's slots directly.
-struct Ev {
+template <int RM> struct EvT {
   int rc;                       // 0: fails before the instance-type filter; 1: reaches it but fails the resource screen; 2: passes
   u32 present, complement, count, reqmask; i32 it_state, it0;
   u32 tpres, tcomp, tchg, tnar; // per touch index: requirement present / complement after Add; changed; narrowed by topology
-  i64 room[KS_MAX_RES];         // the node's resource headroom (Rec::room)
-  i64 req[KS_MAX_RES], low[KS_MAX_RES];   // Rec::req / Rec::low, fetched with the rest so the winner publishes without another round trip
+  i64 room[RM];                 // the node's resource headroom (Rec::room)
+  i64 req[RM], low[RM];           // Rec::req / Rec::low, fetched with the rest so the winner publishes without another round trip
 };
 
 // One attempt of Node.Add / ExistingNode.Add up to (not including) the instance-type filter
 // (node.go:62-90 / existingnode.go:77-115).  Every lane evaluates its own node.
 // `merged`: the pod's own requirements are already folded into the record (a fresh node materialised
 // from the template∩class record), only topology is evaluated on top.
-template <bool BOUNDS>
-__device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, const Tabs& tb, WaveShared& sh, u32 slot, bool existing, bool merged, Ev& ev, int lane, u64& tprobe, const ClsR& cr) {
+template <bool BOUNDS, bool LEAN, int RM>
+__device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, const Tabs& tb, WaveShared& sh, u32 slot, bool existing, bool merged, EvT<RM>& ev, int lane, u64& tprobe, const ClsRT<RM>& cr) {
   const ClsPlan& c = sh.cls;
   const Rec r = slot_rec(S, tb, slot);
   PROBE(22);
@@ -538,7 +540,7 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
   const i32 it0 = (i32)h1.x; const u32 reqmask = h1.y; const i32 porthead = (i32)h1.z;
   ev.present = present; ev.complement = complement; ev.it_state = it0; ev.it0 = it0; ev.reqmask = reqmask; ev.count = h1.w;
 #pragma unroll
-  for (int i = 0; i < KS_MAX_RES; ++i) { ev.room[i] = 0; ev.req[i] = 0; ev.low[i] = INT64_MIN; if ((u32)i < tb.R) { ev.room[i] = r.room()[i]; ev.req[i] = r.req()[i]; ev.low[i] = r.low()[i]; } }
+  for (int i = 0; i < RM; ++i) { ev.room[i] = 0; ev.req[i] = 0; ev.low[i] = INT64_MIN; if ((u32)i < tb.R) { ev.room[i] = r.room()[i]; ev.req[i] = r.req()[i]; ev.low[i] = r.low()[i]; } }
   const u32 ntouch = cr.ntouch;
   KReq nxt = kreq_absent();
   if (ntouch) nxt = rec_req<BOUNDS>(r, present, complement, (int)((u32)cr.tkeys & 31u));
@@ -551,19 +553,19 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
   PROBE(23);
   if (taints & ~cr.tol) return;
   // ---- the pod's hostname requirement against the node's `hostname In [own]` ----
-  if (!merged && cr.hn_mode != 0) {
+  if (!LEAN && !merged && cr.hn_mode != 0) {
     bool inlist = false;
     if (existing) for (u32 i = 0; i < c.hn_cnt; ++i) if (P.hn_list[c.hn_off + i] == slot) { inlist = true; break; }
     if (cr.hn_mode == 1 ? !inlist : inlist) return;
   }
   // ---- HostPortUsage.Validate ----
-  if (cr.port_cnt && porthead >= 0 && ports_conflict(P, S, c, porthead)) return;
+  if (!LEAN && cr.port_cnt && porthead >= 0 && ports_conflict(P, S, c, porthead)) return;
   // ---- resources: exact for existing nodes (existingnode.go:99-103), a necessary screen for new ones ----
   bool fit = true;
 #pragma unroll
-  for (int i = 0; i < KS_MAX_RES; ++i) if (((reqmask | cr.reqmask) >> i) & 1u) { if (cr.req[i] > ev.room[i]) fit = false; }
+  for (int i = 0; i < RM; ++i) if (((reqmask | cr.reqmask) >> i) & 1u) { if (cr.req[i] > ev.room[i]) fit = false; }
   if (existing && !fit) return;
-  if (!merged && cr.it_state) { if (tb.its_fail[it0 * tb.SC + cr.it_state]) return; ev.it_state = tb.its_inter[it0 * tb.SC + cr.it_state]; }
+  if (!LEAN && !merged && cr.it_state) { if (tb.its_fail[it0 * tb.SC + cr.it_state]) return; ev.it_state = tb.its_inter[it0 * tb.SC + cr.it_state]; }
   // ---- Topology.AddRequirements on hostname-keyed groups: the node's only hostname domain is its own ----
   for (u32 i = 0; i < cr.nhost; ++i) {
     const PlanTopo& th = c.host[i]; const i32 cnt = i == 0 ? hc0 : (i == 1 ? hc1 : hc2); bool ok;
@@ -654,8 +656,8 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
 // Publish the winning lane's evaluation: scalars by v_readlane into wave-uniform registers (Pub), the per-key
 // requirements by one parallel LDS copy (lane i moves touch entry i).  Also decides whether the instance-type
 // filter can change anything at all (see Rec::low).
-template <bool BOUNDS>
-__device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, const Ev& ev, u32 slot, bool fresh, int lane, int win, const ClsR& cr, Pub& p) {
+template <bool BOUNDS, int RM>
+__device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, const EvT<RM>& ev, u32 slot, bool fresh, int lane, int win, const ClsRT<RM>& cr, PubT<RM>& p) {
   p.slot = RL(slot, win);
   const u32 tpres = RL(ev.tpres, win), tcomp = RL(ev.tcomp, win), tchg = RL(ev.tchg, win), tnar = RL(ev.tnar, win);
   u32 np = RL(ev.present, win), nc = RL(ev.complement, win), changed = 0, narrowed = 0, valid = 0;
@@ -676,7 +678,7 @@ __device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, con
   p.rm = RL(ev.reqmask, win) | cr.reqmask;
   bool need = fresh || changed != 0 || p.it_state != p.it_before;
 #pragma unroll
-  for (int i = 0; i < KS_MAX_RES; ++i) {
+  for (int i = 0; i < RM; ++i) {
     p.req_new[i] = 0; p.room_new[i] = 0;
     if ((u32)i < tb.R) {
       const i64 v = (i64)RL64(ev.req[i], win) + cr.req[i]; p.req_new[i] = v; p.room_new[i] = (i64)RL64(ev.room[i], win) - cr.req[i];
@@ -688,7 +690,8 @@ __device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, con
 }
 
 // The node's requirement on key k after the Add that is being committed (published entries, else the record).
-__device__ __forceinline__ KReq new_req(const Pub& pb, const WaveShared& sh, const Rec& r, int k) {
+template <class PUB>
+__device__ __forceinline__ KReq new_req(const PUB& pb, const WaveShared& sh, const Rec& r, int k) {
   const ReqOut& o = sh.rq; KReq q; q.present = (pb.present >> k) & 1u; q.complement = (pb.complement >> k) & 1u;
   if ((pb.valid >> k) & 1u) { q.mask = o.mask[k]; q.gt = o.gt[k]; q.lt = o.lt[k]; } else { q.mask = r.mask()[k]; q.gt = r.gt()[k]; q.lt = r.lt()[k]; }
   return q;
@@ -705,7 +708,8 @@ __device__ __forceinline__ u64 pass_types_word(const DevProb& P, const Tabs& tb,
   return acc;
 }
 // hasOffering (node.go:151-159) as a T-bit mask word
-__device__ __forceinline__ u64 offer_types_word(const DevProb& P, const Tabs& tb, const Pub& pb, const WaveShared& sh, const Rec& r, u32 w) {
+template <class PUB>
+__device__ __forceinline__ u64 offer_types_word(const DevProb& P, const Tabs& tb, const PUB& pb, const WaveShared& sh, const Rec& r, u32 w) {
   u64 allowZ = ~0ull, allowC = ~0ull;
   if (tb.key_zone >= 0 && ((pb.present >> tb.key_zone) & 1u)) allowZ = kreq_has_mask(new_req(pb, sh, r, tb.key_zone), tb.value_int + tb.key_zone * 64, tb.key_nvalues[tb.key_zone]);
   if (tb.key_ct >= 0 && ((pb.present >> tb.key_ct) & 1u)) allowC = kreq_has_mask(new_req(pb, sh, r, tb.key_ct), tb.value_int + tb.key_ct * 64, tb.key_nvalues[tb.key_ct]);
@@ -719,7 +723,8 @@ __device__ __forceinline__ u64 offer_types_word(const DevProb& P, const Tabs& tb
 }
 
 // TopologyNodeFilter.MatchesRequirements, topologynodefilter.go:57-70
-__device__ __forceinline__ bool filter_matches(const DevProb& P, const Tabs& tb, int g, const Pub& pb, const WaveShared& sh, const Rec& r) {
+template <class PUB>
+__device__ __forceinline__ bool filter_matches(const DevProb& P, const Tabs& tb, int g, const PUB& pb, const WaveShared& sh, const Rec& r) {
   const u32 b = G_grp_filter_off[g], e = G_grp_filter_off[g + 1];
   if (b == e) return true;
   for (u32 f = b; f < e; ++f) {
@@ -747,7 +752,8 @@ __device__ __forceinline__ void grp_record_host(const DevState& S, const Tabs& t
 }
 // Topology.Record, topology.go:120-143: lane i handles the i-th group of the class's record list
 // (distinct groups, so the lanes never touch the same counters).
-__device__ __forceinline__ void topology_record(const DevProb& P, const DevState& S, const Tabs& tb, const Pub& pb, const WaveShared& sh, const Rec& r, u32 slot, int lane) {
+template <class PUB>
+__device__ __forceinline__ void topology_record(const DevProb& P, const DevState& S, const Tabs& tb, const PUB& pb, const WaveShared& sh, const Rec& r, u32 slot, int lane) {
   const ClsPlan& c = sh.cls;
   if ((u32)lane >= c.nrec) return;
   const PlanRec& pr = c.rec[lane]; const int g = pr.g;
@@ -785,14 +791,15 @@ __device__ __forceinline__ void stage_class(const Tabs& tb, WaveShared& sh, int 
 // lower_bound over the ascending distinct Allocatable values of every requested resource with a 64-ary
 // search: every lane probes one pivot, __ballot narrows the interval (two rounds cover 4096 values).  All
 // resources advance together so their LDS reads overlap.  idx[r] == ge_cnt[r] means "no type has that much".
-__device__ __forceinline__ void ge_row_indices(const Tabs& tb, const Pub& pb, u32 reqmask, int lane, u32 (&idx)[KS_MAX_RES]) {
-  u32 lo[KS_MAX_RES], hi[KS_MAX_RES];
+template <int RM>
+__device__ __forceinline__ void ge_row_indices(const Tabs& tb, const PubT<RM>& pb, u32 reqmask, int lane, u32 (&idx)[RM]) {
+  u32 lo[RM], hi[RM];
 #pragma unroll
-  for (int r = 0; r < KS_MAX_RES; ++r) { lo[r] = 0; hi[r] = ((reqmask >> r) & 1u) ? tb.ge_cnt[r] : 0; }
+  for (int r = 0; r < RM; ++r) { lo[r] = 0; hi[r] = ((reqmask >> r) & 1u) ? tb.ge_cnt[r] : 0; }
   for (;;) {
     bool busy = false;
 #pragma unroll
-    for (int r = 0; r < KS_MAX_RES; ++r) if (lo[r] < hi[r]) {
+    for (int r = 0; r < RM; ++r) if (lo[r] < hi[r]) {
       busy = true;
       const u32 span = hi[r] - lo[r], step = (span + 63) >> 6;
       const u32 p = lo[r] + (u32)lane * step;
@@ -809,26 +816,27 @@ __device__ __forceinline__ void ge_row_indices(const Tabs& tb, const Pub& pb, u3
     if (!busy) break;
   }
 #pragma unroll
-  for (int r = 0; r < KS_MAX_RES; ++r) idx[r] = lo[r];
+  for (int r = 0; r < RM; ++r) idx[r] = lo[r];
 }
 
 // Instance-type filter (filterInstanceTypesByRequirements, node.go:137-141) on T-bit masks, one wave:
 //   alive' = alive & passTypes(changed keys) & its_types(state) & offerings & AND_r ge_rows[r][row(requests[r])]
 // Lane w owns word w; there is no per-type loop: resources.Fits is one precomputed row per requested resource.
-__device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, const Pub& pb, WaveShared& sh, const Rec& r, const GA u64* alive_in, GA u64* alive_out, u32 reqmask_new,
+template <int RM>
+__device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, const PubT<RM>& pb, WaveShared& sh, const Rec& r, const GA u64* alive_in, GA u64* alive_out, u32 reqmask_new,
                              u32 changed_keys, bool check_offer, bool check_it, int lane, u64& tprobe, u64& word) {   // alive_out == nullptr (TW <= 64 only): the result stays in `word`
-  const GA u64* rows[KS_MAX_RES]; u32 ridx[KS_MAX_RES];
+  const GA u64* rows[RM]; u32 ridx[RM];
   ge_row_indices(tb, pb, reqmask_new, lane, ridx);
   bool none = false;
 #pragma unroll
-  for (int i = 0; i < KS_MAX_RES; ++i) {
+  for (int i = 0; i < RM; ++i) {
     rows[i] = nullptr;
     if ((reqmask_new >> i) & 1u) { if (ridx[i] >= tb.ge_cnt[i]) none = true; rows[i] = tb.ge_rows + ((size_t)i * tb.T + ridx[i]) * tb.TW; }
   }
   word = 0;
   if (none) { if (alive_out) for (u32 w = lane; w < tb.TW; w += 64) alive_out[w] = 0; LSYNC(); return false; }   // nothing has that much of some resource
 #pragma unroll
-  for (int i = 0; i < KS_MAX_RES; ++i) if (lane == 0 && ((reqmask_new >> i) & 1u)) sh.low_new[i] = tb.ge_vals[(size_t)i * tb.T + ridx[i]];
+  for (int i = 0; i < RM; ++i) if (lane == 0 && ((reqmask_new >> i) & 1u)) sh.low_new[i] = tb.ge_vals[(size_t)i * tb.T + ridx[i]];
   bool any = false;
   for (u32 wbase = 0; wbase < tb.TW; wbase += 64) {
     const u32 w = wbase + lane; u64 a = 0;
@@ -836,7 +844,7 @@ __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, c
       // every load below is independent of the others: one memory round trip, not one per term
       a = alive_in[w];
 #pragma unroll
-      for (int i = 0; i < KS_MAX_RES; ++i) if (rows[i]) a &= rows[i][w];
+      for (int i = 0; i < RM; ++i) if (rows[i]) a &= rows[i][w];
       u64 x = ~0ull;
       for (u32 bits = changed_keys; bits; bits &= bits - 1) { const int k = __builtin_ctz(bits); x &= pass_types_word(P, tb, k, new_req(pb, sh, r, k), w); }
       if (check_it) x &= G_its_types[(size_t)pb.it_state * tb.TW + w];
@@ -853,28 +861,29 @@ __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, c
 
 // Per-resource maximum Allocatable over a node's surviving types: the (necessary) resource screen of
 // eval_node.  Recomputed lazily -- only after a candidate passed the screen but failed the filter.
+template <int RM>
 __device__ __forceinline__ void recompute_cap(const DevProb& P, const Tabs& tb, const GA u64* alive, const Rec& rec, int lane) {
-  i64 mx[KS_MAX_RES];
+  i64 mx[RM];
 #pragma unroll
-  for (int r = 0; r < KS_MAX_RES; ++r) mx[r] = INT64_MIN;
+  for (int r = 0; r < RM; ++r) mx[r] = INT64_MIN;
   for (u32 t = lane; t < tb.TW * 64; t += 64) {
     const bool on = t < tb.T && ((alive[t >> 6] >> (t & 63)) & 1ull);
 #pragma unroll
-    for (int r = 0; r < KS_MAX_RES; ++r) if ((u32)r < tb.R && on) { const i64 al = P.it_alloc[(size_t)r * tb.T + t]; if (al > mx[r]) mx[r] = al; }
+    for (int r = 0; r < RM; ++r) if ((u32)r < tb.R && on) { const i64 al = P.it_alloc[(size_t)r * tb.T + t]; if (al > mx[r]) mx[r] = al; }
   }
 #pragma unroll
-  for (int r = 0; r < KS_MAX_RES; ++r) if ((u32)r < tb.R) { const i64 v = wave_max_i64(mx[r]); if (lane == 0) rec.room()[r] = v - rec.req()[r]; }
+  for (int r = 0; r < RM; ++r) if ((u32)r < tb.R) { const i64 v = wave_max_i64(mx[r]); if (lane == 0) rec.room()[r] = v - rec.req()[r]; }
   LSYNC();
 }
 
 // Write the winning node's record after Add: only what changed (lane-parallel stores).
-template <bool BOUNDS>
-__device__ __forceinline__ void write_record(const Tabs& tb, const Rec& r, const Pub& pb, const WaveShared& sh, u32 reqmask_new, int lane) {
+template <bool BOUNDS, int RM>
+__device__ __forceinline__ void write_record(const Tabs& tb, const Rec& r, const PubT<RM>& pb, const WaveShared& sh, u32 reqmask_new, int lane) {
   if ((u32)lane < tb.K && ((pb.changed >> lane) & 1u)) { r.mask()[lane] = sh.rq.mask[lane]; if constexpr (BOUNDS) { r.gt()[lane] = sh.rq.gt[lane]; r.lt()[lane] = sh.rq.lt[lane]; } }
   if (lane >= 32 && (u32)lane < 32 + tb.R) {
     i64 rq = 0, ro = 0;
 #pragma unroll
-    for (int i = 0; i < KS_MAX_RES; ++i) if (lane - 32 == i) { rq = pb.req_new[i]; ro = pb.room_new[i]; }
+    for (int i = 0; i < RM; ++i) if (lane - 32 == i) { rq = pb.req_new[i]; ro = pb.room_new[i]; }
     r.req()[lane - 32] = rq; r.room()[lane - 32] = ro;
   }
   if (lane == 63) { r.present() = pb.present; r.complement() = pb.complement; r.it_state() = pb.it_state; r.reqmask() = reqmask_new; }
@@ -882,8 +891,13 @@ __device__ __forceinline__ void write_record(const Tabs& tb, const Rec& r, const
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ks_dyn_lds[];
 
-template <bool FAST, bool BOUNDS>
+// LEAN: no class has host ports, a hostname selector or an instance-type requirement, no provisioner has limits,
+// R <= 4 and no statistics are requested -- the code for all of that (and half of every unrolled resource loop) is
+// compiled out.  One wave issues ~1 instruction per 5 cycles, so instructions, not bytes, are what a Solve costs.
+template <bool FAST, bool BOUNDS, bool LEAN>
 __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevState* states, u32 lds_bytes) {
+  constexpr int RM = LEAN ? 4 : KS_MAX_RES;
+  using ClsR = ClsRT<RM>; using Ev = EvT<RM>; using Pub = PubT<RM>;
   // descriptors are copied to LDS: loads from them can then be CSE'd across global stores (no aliasing)
   __shared__ DevProb P_lds; __shared__ DevState S_lds;
   __shared__ WaveShared sh;
@@ -962,7 +976,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
   // wave-uniform loop state lives in registers (SGPRs)
   u32 q_head = 0, q_len = nP, q_gen = 0, nnew = 0, seq = 0, err = 0, maxc = 0;
   u32 pp_used = tb.E ? P.en_port_off[tb.E] : 0;
-  const bool want_stats = (UF(P.flags) & KS_FLAG_STATS) != 0;
+  const bool want_stats = !LEAN && (UF(P.flags) & KS_FLAG_STATS) != 0;
   GA u64* const scratch = tb.n_alive + (size_t)nMAX * tb.TW;      // one spare row of the alive table
   u64 tprobe = __builtin_readcyclecounter(); if (lane < 32) sh.ctr[lane] = 0;
   u64 qe_a = 0, qe_b = 0; u32x4 pf0 = {0, 0, 0, 0}, pf1 = {0, 0, 0, 0}; bool pf_ok = false;
@@ -998,7 +1012,8 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
     if (UF(c.overflow)) { err = (u32)(-KS_ERR_UNSUPPORTED); break; }
     ClsR cr; cr.tol = UF64(c.tol); cr.reqmask = UF(c.reqmask); cr.ntouch = UF(c.ntouch); cr.nhost = UF(c.nhost); cr.hn_mode = UF(c.hn_mode); cr.port_cnt = UF(c.port_cnt); cr.it_state = (i32)UF(c.it_state); cr.tkeys = UF64(c.tkeys); cr.eq = UF(c.eq);
 #pragma unroll
-    for (int i = 0; i < KS_MAX_RES; ++i) cr.req[i] = (i64)UF64(c.req[i]);
+    for (int i = 0; i < RM; ++i) cr.req[i] = (i64)UF64(c.req[i]);
+    if constexpr (LEAN) { cr.port_cnt = 0; cr.hn_mode = 0; cr.it_state = 0; }
     bool placed = false;
     PROBE(13);
 
@@ -1037,6 +1052,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
         bool have = false;
         for (; tm < nM && !have; ++tm) {
           m_t = tm; mc = (size_t)m_t * nC + cidx; lim = UF(P.tmpl_limit_present[m_t]);
+          if constexpr (LEAN) lim = 0xFFFFFFFFu;
           if (nnew >= nMAX) { err = (u32)(-KS_ERR_CAPACITY); break; }
           // filterByRemainingResources, scheduler.go:293-309 (only when the provisioner has limits)
           bool lany = false; ltypes = 0;
@@ -1076,7 +1092,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
 
       // ---- Node.Add / ExistingNode.Add up to the instance-type filter, one node per lane ----
       ev.rc = 0;
-      if (slot != 0xFFFFFFFFu) eval_node<BOUNDS>(P, S, tb, sh, slot, slot < tb.E, fresh, ev, lane, tprobe, cr);
+      if (slot != 0xFFFFFFFFu) eval_node<BOUNDS, LEAN, RM>(P, S, tb, sh, slot, slot < tb.E, fresh, ev, lane, tprobe, cr);
       PROBE(26);
       m = ballot64(ev.rc == 2);
       reach = ballot64(ev.rc >= 1);
@@ -1087,7 +1103,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
 
       while (m) {
         const int win = __builtin_ctzll(m);
-        Pub pb; publish_eval<BOUNDS>(tb, sh, ev, slot, fresh, lane, win, cr, pb);
+        Pub pb; publish_eval<BOUNDS, RM>(tb, sh, ev, slot, fresh, lane, win, cr, pb);
         const u32 sw = pb.slot; const bool ex = sw < tb.E; const u32 jw = sw - tb.E;
         const Rec r = slot_rec(S, tb, sw);
         const u32 rm = pb.rm;
@@ -1104,7 +1120,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
             u64 aw;
             const bool ok = filter_types(P, tb, pb, sh, r, fresh ? scratch : alive, fresh ? alive : (inreg ? (GA u64*)nullptr : scratch), rm, keys, zc, itc, lane, tprobe, aw);
             PROBE(16);
-            if (!ok) { CTR(KS_STAT_FULLFAILS, 1); if (!fresh) recompute_cap(P, tb, alive, r, lane); m &= m - 1; continue; }
+            if (!ok) { CTR(KS_STAT_FULLFAILS, 1); if (!fresh) recompute_cap<RM>(P, tb, alive, r, lane); m &= m - 1; continue; }
             if (inreg) { if ((u32)lane < tb.TW) alive[lane] = aw; }
             else if (!fresh) for (u32 w = lane; w < tb.TW; w += 64) alive[w] = scratch[w];
             if ((u32)lane < tb.R && ((rm >> lane) & 1u)) r.low()[lane] = sh.low_new[lane];
@@ -1114,21 +1130,21 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
         visited = win + 1;
         if (fresh && lim != 0xFFFFFFFFu) {          // subtractMax, scheduler.go:273-290
           GA u64* const alive = tb.n_alive + (size_t)jw * tb.TW;
-          i64 mx[KS_MAX_RES];
+          i64 mx[RM];
 #pragma unroll
-          for (int rr = 0; rr < KS_MAX_RES; ++rr) mx[rr] = INT64_MIN;
+          for (int rr = 0; rr < RM; ++rr) mx[rr] = INT64_MIN;
           for (u32 t = lane; t < tb.TW * 64; t += 64) {
             const bool on = t < tb.T && ((alive[t >> 6] >> (t & 63)) & 1ull);
 #pragma unroll
-            for (int rr = 0; rr < KS_MAX_RES; ++rr) if ((u32)rr < tb.R && on) { const i64 cp = P.it_cap[(size_t)rr * tb.T + t]; if (cp > mx[rr]) mx[rr] = cp; }
+            for (int rr = 0; rr < RM; ++rr) if ((u32)rr < tb.R && on) { const i64 cp = P.it_cap[(size_t)rr * tb.T + t]; if (cp > mx[rr]) mx[rr] = cp; }
           }
 #pragma unroll
-          for (int rr = 0; rr < KS_MAX_RES; ++rr) if ((u32)rr < tb.R) { const i64 v = wave_max_i64(mx[rr]); if (lane == 0 && ((lim >> rr) & 1u)) S.remaining[(size_t)m_t * tb.R + rr] -= v; }
+          for (int rr = 0; rr < RM; ++rr) if ((u32)rr < tb.R) { const i64 v = wave_max_i64(mx[rr]); if (lane == 0 && ((lim >> rr) & 1u)) S.remaining[(size_t)m_t * tb.R + rr] -= v; }
         }
         topology_record(P, S, tb, pb, sh, r, sw, lane);
         const u32 cnt = pb.count;                                   // pods on the node before this one
         LSYNC();
-        write_record<BOUNDS>(tb, r, pb, sh, rm, lane);
+        write_record<BOUNDS, RM>(tb, r, pb, sh, rm, lane);
         if (lane == 0) {
           if (!ex) r.count() = cnt + 1;
           if (fresh) S.n_tmpl[jw] = (i32)m_t;
@@ -1246,6 +1262,7 @@ struct ks_dev_problem {
   hipStream_t stream = nullptr;
   bool tables_built = false;
   bool any_bounds = false;       // some requirement carries Gt/Lt -> the BOUNDS kernel variant
+  bool lean_ok = false;          // none of the rarely used features is present -> the LEAN kernel variant (see ks_pack)
   u32 pp_cap = 0;
 };
 
@@ -1315,6 +1332,12 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   h.NMAX = p->max_new_nodes ? p->max_new_nodes : 1; h.flags = p->flags; h.n_topologies = p->n_topologies;
   h.wellknown_mask = p->wellknown_mask; h.key_zone = p->key_zone; h.key_ct = p->key_ct; h.n_ct = p->n_ct;
   const u32 K = h.K, R = h.R, T = h.T, TW = h.TW, C = h.C, M = h.M, E = h.E, G = h.G, P = h.P;
+  {   // LEAN kernel variant eligibility (see ks_pack)
+    bool lean = R <= 4 && h.SC == 1 && !(p->flags & KS_FLAG_STATS);
+    for (u32 m = 0; m < M && lean; ++m) lean = p->tmpl_limit_present[m] == 0xFFFFFFFFu || p->tmpl_limit_present[m] == 0;
+    for (u32 c = 0; c < C && lean; ++c) lean = p->cls_hn_mode[c] == 0 && p->cls_port_off[c + 1] == p->cls_port_off[c];
+    d->lean_ok = lean;
+  }
   TRY(dev_copy(d, p->key_nvalues, K, &h.key_nvalues)); TRY(dev_copy(d, p->value_int, (size_t)K * 64, &h.value_int));
   TRY(dev_copy(d, p->it_present, T, &h.it_present)); TRY(dev_copy(d, p->it_complement, T, &h.it_complement));
   TRY(dev_copy(d, p->it_mask, (size_t)K * T, &h.it_mask)); TRY(dev_copy(d, p->it_alloc, (size_t)R * T, &h.it_alloc));
@@ -1464,10 +1487,13 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   for (u32 i = 0; i < n; ++i) { const DevProb& q = ds[i]->h; if (q.G > KS_FAST_G || q.GH > KS_FAST_G || (q.SC > 1 && (size_t)q.S * q.SC > KS_FAST_S * KS_FAST_S) || (size_t)q.R * q.T > KS_FAST_RT || (size_t)q.R * q.T * 8 + 16384 > lds_bytes) fast = false; }
   static bool attr_set = false;
   bool bounds = false; for (u32 i = 0; i < n; ++i) bounds = bounds || ds[i]->any_bounds;
+  bool lean = true; for (u32 i = 0; i < n; ++i) lean = lean && ds[i]->lean_ok;
+  if (getenv("KS_NO_LEAN")) lean = false;      // test hook: run the general variant on a problem the LEAN one would take
   typedef void (*pack_fn)(const DevProb*, const DevState*, u32);
-  static const pack_fn variants[4] = {ks_pack<false, false>, ks_pack<false, true>, ks_pack<true, false>, ks_pack<true, true>};
-  if (!attr_set) { for (int i = 0; i < 4; ++i) HIPCHK(hipFuncSetAttribute((const void*)variants[i], hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024)); attr_set = true; }
-  hipLaunchKernelGGL(variants[(fast ? 2 : 0) + (bounds ? 1 : 0)], dim3(n), dim3(64), lds_bytes, st, dp, dsv, lds_bytes);
+  static const pack_fn variants[8] = {ks_pack<false, false, false>, ks_pack<false, true, false>, ks_pack<true, false, false>, ks_pack<true, true, false>,
+                                      ks_pack<false, false, true>, ks_pack<false, true, true>, ks_pack<true, false, true>, ks_pack<true, true, true>};
+  if (!attr_set) { for (int i = 0; i < 8; ++i) HIPCHK(hipFuncSetAttribute((const void*)variants[i], hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024)); attr_set = true; }
+  hipLaunchKernelGGL(variants[(lean ? 4 : 0) + (fast ? 2 : 0) + (bounds ? 1 : 0)], dim3(n), dim3(64), lds_bytes, st, dp, dsv, lds_bytes);
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());

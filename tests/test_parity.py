@@ -56,6 +56,14 @@ def test_config5_full_constraint_set(pods, seed):
     assert_same(W.config5(pods=pods, sizes=10, seed=seed))
 
 
+def test_general_kernel_variant_on_lean_problems(monkeypatch):
+    """Problems without ports / hostname selectors / limits / instance-type selectors normally run the LEAN kernel
+    variant; KS_NO_LEAN forces the general one, which must give the same bits."""
+    monkeypatch.setenv("KS_NO_LEAN", "1")
+    assert_same(W.config3(pods=700, sizes=10, seed=7))
+    assert_same(W.config1(pods=400, types=20, seed=3))
+
+
 def test_whatifs_single_and_batched():
     its, prov, nodes, bound = W.cluster_snapshot(existing=96, sizes=8, seed=45)
     probs = [W.whatif(its, prov, nodes, bound, list(range(0, i + 1))) for i in range(6)] + \
