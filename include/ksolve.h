@@ -58,6 +58,7 @@ extern "C" {
 #define KS_ERR_UNSUPPORTED (-2) /* feature outside the supported encoding */
 #define KS_ERR_DEVICE (-3)      /* HIP failure / no gfx950 device: the library never falls back to a CPU path */
 #define KS_ERR_CAPACITY (-4)    /* more new nodes than max_new_nodes */
+#define KS_ERR_INTERNAL (-5)    /* device-side watchdog: the pack loop did not terminate within its step bound */
 
 /* A family of requirement sets (reference scheduling.Requirements), n sets x K keys, SoA. */
 typedef struct ks_reqsets {

@@ -43,7 +43,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define UF64(x) ((u64)UF((u32)(u64)(x)) | ((u64)UF((u32)((u64)(x) >> 32)) << 32))
 #define RL64(v, l) ((u64)RL((u32)(u64)(v), (l)) | ((u64)RL((u32)((u64)(v) >> 32), (l)) << 32))
 #ifdef KS_PROBES   /* fine-grained cycle probes (tools/phase_profile.py --probes builds with -DKS_PROBES) */
-#define PROBE(i) do { const u64 now_ = __builtin_readcyclecounter(); if (lane == 0) sh.ctr[(i)] += now_ - tprobe; tprobe = now_; } while (0)
+#define PROBE(i) do { const u64 now_ = __builtin_readcyclecounter(); if (lane == 0 && wv == 0) ls.ctr[(i)] += now_ - tprobe; tprobe = now_; } while (0)
 #else
 #define PROBE(i) do { (void)tprobe; } while (0)
 #endif
@@ -60,7 +60,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 struct ReqSetsD { u32 n; const u32* present; const u32* complement; const u64* mask; const i32* gt; const i32* lt; const i32* it_state; };
 
 struct DevProb {
-  u32 P, C, T, TW, M, E, K, R, G, GH, S, SC, NMAX, flags, n_topologies;
+  u32 P, C, T, TW, M, E, K, R, G, GH, S, SC, NMAX, flags, n_topologies, ge_max;   // ge_max: largest ge_cnt[r]
   u32 wellknown_mask; const u32* key_nvalues; const i32* value_int; i32 key_zone, key_ct; u32 n_ct;
   const u32* it_present; const u32* it_complement; const u64* it_mask; const i64* it_alloc; const i64* it_cap; const u64* it_offer;
   const u16* its_inter; const u8* its_fail; const u8* its_nidne; const u64* its_types;
@@ -311,6 +311,7 @@ struct alignas(16) ClsPlan {
   PlanTopo topo[KS_MAX_TOPO];        // narrow-key items, grouped by touch entry
   PlanTopo host[KS_MAX_HOST];        // hostname-key items
   PlanRec rec[KS_MAX_REC];
+  u64 tmask, rmask;                        // groups (bit g & 63) the evaluation reads / Topology.Record may update: round speculation (ks_pack) needs them disjoint
   u32 overflow; u32 eq; u64 tkeys;         // tkeys: touch[i].key packed 5 bits each, so the per-key bit arithmetic of the commit needs no LDS reads
                                            // eq: evaluation-equivalence id (ks_link_plans), 0 = none
 };
@@ -382,6 +383,10 @@ __global__ __launch_bounds__(64) void ks_build_plans(DevProb P, ClsPlan* plans) 
     }
   }
   pl.tkeys = 0; for (u32 j = 0; j < pl.ntouch; ++j) pl.tkeys |= (u64)(u32)pl.touch[j].key << (5 * j);
+  pl.tmask = 0; pl.rmask = 0;
+  for (u32 j = 0; j < pl.ntopo; ++j) pl.tmask |= 1ull << (pl.topo[j].g & 63);
+  for (u32 j = 0; j < pl.nhost; ++j) pl.tmask |= 1ull << (pl.host[j].g & 63);
+  for (u32 j = 0; j < pl.nrec; ++j) pl.rmask |= 1ull << (pl.rec[j].g & 63);
   pl.eq = 0;
   plans[c] = pl;
 }
@@ -417,7 +422,7 @@ struct Tabs {
   const u32* key_nvalues; const i32* value_int; const u8* its_fail; const u16* its_inter;
   i32* gcnt; u64* g_reg; u64* g_pos; u8* g_active; i32* g_hpos;
   const i64* ge_vals; const u32* ge_cnt;
-  u32 K, R, T, TW, GH, E, S, SC, n_ct, wellknown; i32 key_zone, key_ct;
+  u32 K, R, T, TW, GH, E, S, SC, n_ct, wellknown, ge_stride; i32 key_zone, key_ct;
   // hot global arrays, typed with the global address space (pointers loaded from a descriptor in memory
   // would otherwise be generic and every access a FLAT instruction)
   // Only what every pod step touches lives here (SGPRs are scarce: 102 per wave); cold pointers are read
@@ -450,13 +455,23 @@ template <int RM> struct PubT {
   i64 req_new[RM], room_new[RM];
 };
 struct TopoDyn { u64 reg, pos; i32 minc; i32 pad; };
-struct alignas(16) WaveShared {
+struct alignas(16) WaveShared {      // one per wave of the workgroup
   ClsPlan cls; ReqOut rq;
   TopoDyn dyn[KS_MAX_TOPO]; i32 host_anypos[KS_MAX_HOST];
   i64 low_new[KS_MAX_RES];
+  u64 la_mask[KS_MAX_TOUCH][64];                                                            // per-lane requirement slots of eval_node
+};
+struct WaveBounds { i32 la_gt[KS_MAX_TOUCH][64]; i32 la_lt[KS_MAX_TOUCH][64]; };            // ... their Gt/Lt halves (BOUNDS variants only)
+struct LeaderShared {                // owned by wave 0, which carries the Solve's sequential state
   u32 bstart[KS_BST_LDS];
   u64 ctr[32];          // statistics + (KS_PROBES builds) per-phase cycle counters; slot numbers = ks_result.stats[]
-  u64 la_mask[KS_MAX_TOUCH][64]; i32 la_gt[KS_MAX_TOUCH][64]; i32 la_lt[KS_MAX_TOUCH][64];   // per-lane requirement slots of eval_node
+};
+#define KS_MAX_WAVES 8
+struct RoundCtl {                    // round speculation hand-off between the leader and the other waves
+  u32 mode, n, nnew, seq0, n_ok, ord_in_lds, pad0, pad1;
+  u64 qe[KS_MAX_WAVES], m[KS_MAX_WAVES], T[KS_MAX_WAVES], R[KS_MAX_WAVES];
+  u32 elig[KS_MAX_WAVES], win[KS_MAX_WAVES], fail[KS_MAX_WAVES];
+  u32 cnt[64];
 };
 
 // ---- slot record (AoS).  Offsets in bytes; stride = ks_rec_stride(R,K) ----
@@ -529,10 +544,9 @@ template <int RM> struct EvT {
 // `merged`: the pod's own requirements are already folded into the record (a fresh node materialised
 // from the template∩class record), only topology is evaluated on top.
 template <bool BOUNDS, bool LEAN, int RM>
-__device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, const Tabs& tb, WaveShared& sh, u32 slot, bool existing, bool merged, EvT<RM>& ev, int lane, u64& tprobe, const ClsRT<RM>& cr) {
+__device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, const Tabs& tb, WaveShared& sh, WaveBounds& wb, u32 slot, bool existing, bool merged, EvT<RM>& ev, int lane, u64& tprobe, const ClsRT<RM>& cr) {
   const ClsPlan& c = sh.cls;
   const Rec r = slot_rec(S, tb, slot);
-  PROBE(22);
   ev.rc = 0; ev.tpres = 0; ev.tcomp = 0; ev.tchg = 0; ev.tnar = 0;
   // ---- gather: header, requests/capacity, first touched key, hostname counters (independent loads) ----
   const u32x4 h0 = *(const GA u32x4*)r.p, h1 = *(const GA u32x4*)(r.p + 16);
@@ -550,7 +564,6 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
   if (cr.nhost > 2) hc2 = tb.hcnt[(size_t)slot * tb.GH + UF(c.host[2].hslot)];
 
   // ---- Taints.Tolerates, taints.go:28-40 ----
-  PROBE(23);
   if (taints & ~cr.tol) return;
   // ---- the pod's hostname requirement against the node's `hostname In [own]` ----
   if (!LEAN && !merged && cr.hn_mode != 0) {
@@ -575,7 +588,6 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
     else ok = UF(sh.host_anypos[i]) ? (cnt > 0) : (t.self && cnt >= 0);                                // nextDomainAffinity :202-233
     if (!ok) return;
   }
-  PROBE(24);
   // ---- per touched key: Compatible + Add of the pod's own requirement (requirements.go:123-133, :87-94; one
   //      Intersection serves both), then Topology.AddRequirements (topology.go:149-167) and the Compatible + Add
   //      of its result (node.go:83-90).  The next key's node requirement is loaded while this one is processed. ----
@@ -637,10 +649,9 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
     if (a.present) ev.tpres |= 1u << i;
     if (a.complement) ev.tcomp |= 1u << i;
     if (kreq_differs(a, orig)) ev.tchg |= 1u << i;
-    sh.la_mask[i][lane] = a.mask; if constexpr (BOUNDS) { sh.la_gt[i][lane] = a.gt; sh.la_lt[i][lane] = a.lt; }
+    sh.la_mask[i][lane] = a.mask; if constexpr (BOUNDS) { wb.la_gt[i][lane] = a.gt; wb.la_lt[i][lane] = a.lt; }
   }
   ev.rc = fit ? 2 : 1;
-  PROBE(25);
 }
 
 // Synchronisation inside the single-wave workgroup.
@@ -649,15 +660,16 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
 //   GSYNC: cross-lane hand-off through GLOBAL memory: the writer's stores must have completed
 //          (s_waitcnt vmcnt(0)) before another lane's load is issued; costs a store round trip, so it is used
 //          once per pod (before the candidate scan re-reads node records) and on rare paths.
-#define CTR(i, v) do { if (lane == 0) sh.ctr[(i)] += (v); } while (0)
+//   __syncthreads(): hand-off between the waves of a multi-wave workgroup (speculation rounds).
+#define CTR(i, v) do { if (lane == 0 && wv == 0) ls.ctr[(i)] += (v); } while (0)
 #define LSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#define GSYNC() __syncthreads()
+#define GSYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")   /* wave-local: only wave 0 runs the sequential path */
 
 // Publish the winning lane's evaluation: scalars by v_readlane into wave-uniform registers (Pub), the per-key
 // requirements by one parallel LDS copy (lane i moves touch entry i).  Also decides whether the instance-type
 // filter can change anything at all (see Rec::low).
 template <bool BOUNDS, int RM>
-__device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, const EvT<RM>& ev, u32 slot, bool fresh, int lane, int win, const ClsRT<RM>& cr, PubT<RM>& p) {
+__device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, const WaveBounds& wb, const EvT<RM>& ev, u32 slot, bool fresh, int lane, int win, const ClsRT<RM>& cr, PubT<RM>& p) {
   p.slot = RL(slot, win);
   const u32 tpres = RL(ev.tpres, win), tcomp = RL(ev.tcomp, win), tchg = RL(ev.tchg, win), tnar = RL(ev.tnar, win);
   u32 np = RL(ev.present, win), nc = RL(ev.complement, win), changed = 0, narrowed = 0, valid = 0;
@@ -671,7 +683,7 @@ __device__ __forceinline__ void publish_eval(const Tabs& tb, WaveShared& sh, con
   if ((u32)lane < cr.ntouch) {
     const u32 k = (u32)(cr.tkeys >> (5 * lane)) & 31u;
     sh.rq.mask[k] = sh.la_mask[lane][win];
-    if constexpr (BOUNDS) { sh.rq.gt[k] = sh.la_gt[lane][win]; sh.rq.lt[k] = sh.la_lt[lane][win]; } else { sh.rq.gt[k] = KS_NOGT; sh.rq.lt[k] = KS_NOLT; }
+    if constexpr (BOUNDS) { sh.rq.gt[k] = wb.la_gt[lane][win]; sh.rq.lt[k] = wb.la_lt[lane][win]; } else { sh.rq.gt[k] = KS_NOGT; sh.rq.lt[k] = KS_NOLT; }
   }
   p.present = np; p.complement = nc; p.changed = changed; p.narrowed = narrowed; p.valid = valid;
   p.it_state = (i32)RL(ev.it_state, win); p.it_before = (i32)RL(ev.it0, win); p.count = RL(ev.count, win);
@@ -742,17 +754,23 @@ __device__ __forceinline__ bool filter_matches(const DevProb& P, const Tabs& tb,
   return false;
 }
 
+// ATOMIC: several waves commit pods of one speculation round at the same time; two of them may count into the same
+// domain.  max(c, 0) is idempotent and the increments commute, so the result does not depend on the interleaving.
+template <bool ATOMIC>
 __device__ __forceinline__ void grp_record(const Tabs& tb, int g, int d) {   // TopologyGroup.Record, topologygroup.go:101-105
-  i32& c = tb.gcnt[(size_t)g * 64 + d]; c = c < 0 ? 1 : c + 1; tb.g_reg[g] |= 1ull << d; tb.g_pos[g] |= 1ull << d;
+  i32& c = tb.gcnt[(size_t)g * 64 + d];
+  if constexpr (ATOMIC) { atomicMax(&c, 0); atomicAdd(&c, 1); atomicOr((unsigned long long*)&tb.g_reg[g], 1ull << d); atomicOr((unsigned long long*)&tb.g_pos[g], 1ull << d); }
+  else { c = c < 0 ? 1 : c + 1; tb.g_reg[g] |= 1ull << d; tb.g_pos[g] |= 1ull << d; }
 }
+template <bool ATOMIC>
 __device__ __forceinline__ void grp_record_host(const DevState& S, const Tabs& tb, int h, u32 slot) {
-  GA i32& c = tb.hcnt[(size_t)slot * tb.GH + h];
-  if (c <= 0) tb.g_hpos[h]++;
+  GA i32& c = tb.hcnt[(size_t)slot * tb.GH + h];      // one node receives at most one pod per round: no contention on its counters
+  if (c <= 0) { if constexpr (ATOMIC) atomicAdd(&tb.g_hpos[h], 1); else tb.g_hpos[h]++; }
   c = c < 0 ? 1 : c + 1;
 }
 // Topology.Record, topology.go:120-143: lane i handles the i-th group of the class's record list
 // (distinct groups, so the lanes never touch the same counters).
-template <class PUB>
+template <bool ATOMIC, class PUB>
 __device__ __forceinline__ void topology_record(const DevProb& P, const DevState& S, const Tabs& tb, const PUB& pb, const WaveShared& sh, const Rec& r, u32 slot, int lane) {
   const ClsPlan& c = sh.cls;
   if ((u32)lane >= c.nrec) return;
@@ -761,11 +779,11 @@ __device__ __forceinline__ void topology_record(const DevProb& P, const DevState
     if (!tb.g_active[g]) return;
     if (pr.filtered && !filter_matches(P, tb, g, pb, sh, r)) return;         // TopologyGroup.Counts, topologygroup.go:109-111 (filtered == 0: no filter, or one that matches every node)
   }
-  if (pr.key == KS_KEY_HOSTNAME) { grp_record_host(S, tb, pr.hslot, slot); return; }   // the node requirement is `hostname In [own]`
+  if (pr.key == KS_KEY_HOSTNAME) { grp_record_host<ATOMIC>(S, tb, pr.hslot, slot); return; }   // the node requirement is `hostname In [own]`
   const KReq q = new_req(pb, sh, r, pr.key);
   if (!q.present) return;                                            // Get() of a missing key is Exists: no values, Len != 1
-  if (pr.owned_inverse || pr.type == 2) { for (u64 b = q.mask; b; b &= b - 1) grp_record(tb, g, __builtin_ctzll(b)); }   // Values(): for a complement set the excluded values
-  else if (!q.complement && __builtin_popcountll(q.mask) == 1) grp_record(tb, g, __builtin_ctzll(q.mask));
+  if (pr.owned_inverse || pr.type == 2) { for (u64 b = q.mask; b; b &= b - 1) grp_record<ATOMIC>(tb, g, __builtin_ctzll(b)); }   // Values(): for a complement set the excluded values
+  else if (!q.complement && __builtin_popcountll(q.mask) == 1) grp_record<ATOMIC>(tb, g, __builtin_ctzll(q.mask));
 }
 
 __device__ __forceinline__ i64 wave_max_i64(i64 v) { for (int off = 32; off > 0; off >>= 1) { const i64 o = __shfl_xor(v, off); if (o > v) v = o; } return v; }
@@ -804,7 +822,7 @@ __device__ __forceinline__ void ge_row_indices(const Tabs& tb, const PubT<RM>& p
       const u32 span = hi[r] - lo[r], step = (span + 63) >> 6;
       const u32 p = lo[r] + (u32)lane * step;
       const bool in = p < hi[r];
-      const bool ge = in && tb.ge_vals[(size_t)r * tb.T + p] >= pb.req_new[r];
+      const bool ge = in && tb.ge_vals[(size_t)r * tb.ge_stride + p] >= pb.req_new[r];
       const u64 b = ballot64(ge); const u32 npiv = __builtin_popcountll(ballot64(in));
       if (!b) lo[r] = lo[r] + (npiv - 1) * step + 1;
       else {
@@ -836,7 +854,7 @@ __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, c
   word = 0;
   if (none) { if (alive_out) for (u32 w = lane; w < tb.TW; w += 64) alive_out[w] = 0; LSYNC(); return false; }   // nothing has that much of some resource
 #pragma unroll
-  for (int i = 0; i < RM; ++i) if (lane == 0 && ((reqmask_new >> i) & 1u)) sh.low_new[i] = tb.ge_vals[(size_t)i * tb.T + ridx[i]];
+  for (int i = 0; i < RM; ++i) if (lane == 0 && ((reqmask_new >> i) & 1u)) sh.low_new[i] = tb.ge_vals[(size_t)i * tb.ge_stride + ridx[i]];
   bool any = false;
   for (u32 wbase = 0; wbase < tb.TW; wbase += 64) {
     const u32 w = wbase + lane; u64 a = 0;
@@ -894,16 +912,18 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ks_dyn_lds[];
 // LEAN: no class has host ports, a hostname selector or an instance-type requirement, no provisioner has limits,
 // R <= 4 and no statistics are requested -- the code for all of that (and half of every unrolled resource loop) is
 // compiled out.  One wave issues ~1 instruction per 5 cycles, so instructions, not bytes, are what a Solve costs.
-template <bool FAST, bool BOUNDS, bool LEAN>
-__global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevState* states, u32 lds_bytes) {
+template <bool FAST, bool BOUNDS, bool LEAN, int NW>
+__global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const DevState* states, u32 lds_bytes) {
   constexpr int RM = LEAN ? 4 : KS_MAX_RES;
   using ClsR = ClsRT<RM>; using Ev = EvT<RM>; using Pub = PubT<RM>;
+  static_assert(NW >= 1 && NW <= KS_MAX_WAVES, "wave count");
   // descriptors are copied to LDS: loads from them can then be CSE'd across global stores (no aliasing)
   __shared__ DevProb P_lds; __shared__ DevState S_lds;
-  __shared__ WaveShared sh;
-  const int lane = threadIdx.x;
-  { const u32* src = (const u32*)&probs[blockIdx.x]; u32* dst = (u32*)&P_lds; for (u32 i = lane; i < sizeof(DevProb) / 4; i += 64) dst[i] = src[i]; }
-  { const u32* src = (const u32*)&states[blockIdx.x]; u32* dst = (u32*)&S_lds; for (u32 i = lane; i < sizeof(DevState) / 4; i += 64) dst[i] = src[i]; }
+  __shared__ WaveShared shw[NW]; __shared__ WaveBounds wbs[BOUNDS ? NW : 1]; __shared__ LeaderShared ls; __shared__ RoundCtl rc;
+  const int lane = threadIdx.x & 63; const u32 wv = NW > 1 ? UF(threadIdx.x >> 6) : 0u;
+  WaveShared& sh = shw[wv]; WaveBounds& wb = wbs[BOUNDS ? wv : 0];
+  { const u32* src = (const u32*)&probs[blockIdx.x]; u32* dst = (u32*)&P_lds; for (u32 i = threadIdx.x; i < sizeof(DevProb) / 4; i += 64 * NW) dst[i] = src[i]; }
+  { const u32* src = (const u32*)&states[blockIdx.x]; u32* dst = (u32*)&S_lds; for (u32 i = threadIdx.x; i < sizeof(DevState) / 4; i += 64 * NW) dst[i] = src[i]; }
   __syncthreads();
   const u64 t_start = __builtin_readcyclecounter();
   const DevProb& P = P_lds;
@@ -914,9 +934,10 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
   tb.q = (GA u64*)UF64((u64)S.q); tb.pod_node = (GA i32*)UF64((u64)S.pod_node); tb.pod_seq = (GA i32*)UF64((u64)S.pod_seq);
   tb.rec = (GA u8*)UF64((u64)S.rec); tb.rec_stride = UF(S.rec_stride); tb.hcnt = (GA i32*)UF64((u64)S.hcnt); tb.n_alive = (GA u64*)UF64((u64)S.n_alive); tb.ge_rows = (const GA u64*)UF64((u64)P.ge_rows);
   const u32 nP = UF(P.P), nM = UF(P.M), nC = UF(P.C), nG = UF(P.G), nMAX = UF(P.NMAX);
-  tb.gcnt = S.gcnt; tb.g_reg = S.g_reg; tb.g_pos = S.g_pos; tb.g_active = S.g_active; tb.g_hpos = S.g_hpos; tb.ge_vals = P.ge_vals; tb.ge_cnt = P.ge_cnt;
+  tb.gcnt = S.gcnt; tb.g_reg = S.g_reg; tb.g_pos = S.g_pos; tb.g_active = S.g_active; tb.g_hpos = S.g_hpos; tb.ge_vals = P.ge_vals; tb.ge_cnt = P.ge_cnt; tb.ge_stride = tb.T;
 
-  // ---------------- initialise state (global memory) ----------------
+  // ---------------- initialise state (global memory); wave 0 alone, it is a one-off ----------------
+  if (wv == 0) {
   for (u32 i = lane; i < P.P; i += 64) { const u32 pd = P.queue[i]; tb.q[i] = (u64)pd | ((u64)P.stage_cls[P.pod_stage_off[pd]] << 32); G_lastgen[i] = 0xFFFFFFFFu; G_lastlen[i] = 0; G_pod_stage[i] = 0; tb.pod_node[i] = -1; tb.pod_seq[i] = -1; }
   for (u32 e = lane; e < tb.E; e += 64) {
     const Rec r = slot_rec(S, tb, e);
@@ -929,6 +950,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
     for (u32 h = 0; h < tb.GH; ++h) tb.hcnt[(size_t)e * tb.GH + h] = P.grph_count[(size_t)h * tb.E + e];
   }
   for (u32 i = lane; i < P.M * tb.R; i += 64) S.remaining[i] = P.tmpl_remaining[i];
+  }
 
   // ---------------- small hot tables: true LDS arrays in the FAST variant, global memory otherwise ----------------
   u32 lds_used = 0;
@@ -937,6 +959,9 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
     __shared__ u8 sm_its_fail[KS_FAST_S * KS_FAST_S]; __shared__ u16 sm_its_inter[KS_FAST_S * KS_FAST_S];
     __shared__ i32 sm_gcnt[KS_FAST_G * 64]; __shared__ u64 sm_g_reg[KS_FAST_G]; __shared__ u64 sm_g_pos[KS_FAST_G]; __shared__ u8 sm_g_active[KS_FAST_G]; __shared__ i32 sm_g_hpos[KS_FAST_G];
     __shared__ u32 sm_ge_cnt[KS_MAX_RES];
+    i64* ge = (i64*)ks_dyn_lds;
+    const u32 gs = UF(P.ge_max);            // the Allocatable ladders are stored with the longest one's stride
+    if (wv == 0) {
     for (u32 i = lane; i < tb.K; i += 64) sm_key_nvalues[i] = P.key_nvalues[i];
     for (u32 i = lane; i < tb.K * 64; i += 64) sm_value_int[i] = P.value_int[i];
     // SC == 1: no class / filter constrains the instance-type key, the tables are never read
@@ -948,12 +973,12 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
     }
     for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h]; for (u32 e = 0; e < tb.E; ++e) if (P.grph_count[(size_t)h * tb.E + e] > 0) ++np; sm_g_hpos[h] = np; }
     for (u32 i = lane; i < tb.R; i += 64) sm_ge_cnt[i] = P.ge_cnt[i];
-    i64* ge = (i64*)ks_dyn_lds;
-    for (u32 i = lane; i < tb.R * tb.T; i += 64) ge[i] = P.ge_vals[i];
-    lds_used = (u32)(((size_t)tb.R * tb.T * sizeof(i64) + 15) & ~(size_t)15);
+    for (u32 r = 0; r < tb.R; ++r) for (u32 i = lane; i < gs; i += 64) ge[(size_t)r * gs + i] = i < P.ge_cnt[r] ? P.ge_vals[(size_t)r * tb.T + i] : INT64_MAX;
+    }
+    lds_used = (u32)(((size_t)tb.R * gs * sizeof(i64) + 15) & ~(size_t)15);
     tb.key_nvalues = sm_key_nvalues; tb.value_int = sm_value_int; tb.its_fail = sm_its_fail; tb.its_inter = sm_its_inter;
-    tb.gcnt = sm_gcnt; tb.g_reg = sm_g_reg; tb.g_pos = sm_g_pos; tb.g_active = sm_g_active; tb.g_hpos = sm_g_hpos; tb.ge_cnt = sm_ge_cnt; tb.ge_vals = ge;
-  } else {
+    tb.gcnt = sm_gcnt; tb.g_reg = sm_g_reg; tb.g_pos = sm_g_pos; tb.g_active = sm_g_active; tb.g_hpos = sm_g_hpos; tb.ge_cnt = sm_ge_cnt; tb.ge_vals = ge; tb.ge_stride = gs;
+  } else if (wv == 0) {
     for (u32 i = lane; i < P.G * 64; i += 64) S.gcnt[i] = P.grp_count[i];
     for (u32 g = lane; g < P.G; g += 64) {
       u64 reg = 0, pos = 0; for (int d = 0; d < 64; ++d) { const i32 c = P.grp_count[(size_t)g * 64 + d]; if (c >= 0) reg |= 1ull << d; if (c > 0) pos |= 1ull << d; }
@@ -961,8 +986,9 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
     }
     for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h]; for (u32 e = 0; e < tb.E; ++e) if (P.grph_count[(size_t)h * tb.E + e] > 0) ++np; S.g_hpos[h] = np; }
   }
+  if (wv == 0 && lane < 32) ls.ctr[lane] = 0;
   __threadfence_block();
-  GSYNC();
+  __syncthreads();
   const GA ClsPlan* plans = (const GA ClsPlan*)UF64((u64)P.plans);
   u32* const ord_l = (u32*)(ks_dyn_lds + lds_used);    // ord[pos] = new-node index j, sorted in visiting order (LDS home)
   GA u32* const ord_g = (GA u32*)S.order_g;            // ... its global-memory home once it outgrows LDS
@@ -971,25 +997,65 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
   const u32 ord_cap = (lds_bytes - lds_used) / 4;
   bool ord_in_lds = true;
   // count-bucket boundaries: bstart[c] (1 <= c <= maxc+1) = first position in `ord` whose node has >= c pods
-#define BST(c) (*((c) < KS_BST_LDS ? &sh.bstart[(c)] : &S.bstart[(c)]))
+#define BST(c) (*((c) < KS_BST_LDS ? &ls.bstart[(c)] : &S.bstart[(c)]))
 
-  // wave-uniform loop state lives in registers (SGPRs)
+  // The Solve's sequential state lives in wave 0's registers (SGPRs); the other waves of the workgroup only take
+  // part in speculation rounds (below) and otherwise wait at the barriers.
   u32 q_head = 0, q_len = nP, q_gen = 0, nnew = 0, seq = 0, err = 0, maxc = 0;
   u32 pp_used = tb.E ? P.en_port_off[tb.E] : 0;
   const bool want_stats = !LEAN && (UF(P.flags) & KS_FLAG_STATS) != 0;
   GA u64* const scratch = tb.n_alive + (size_t)nMAX * tb.TW;      // one spare row of the alive table
-  u64 tprobe = __builtin_readcyclecounter(); if (lane < 32) sh.ctr[lane] = 0;
+  u64 tprobe = __builtin_readcyclecounter();
   u64 qe_a = 0, qe_b = 0; u32x4 pf0 = {0, 0, 0, 0}, pf1 = {0, 0, 0, 0}; bool pf_ok = false;
   // Fit-bitmap reuse across a run of evaluation-equivalent pods (ks_link_plans): every lane keeps its last
   // evaluation (ev, slot, the sh.la_* slots); r_mask = lanes that passed and have not been used, valid for lanes
   // below r_lim (the rest of the winner's count bucket); r_removed = nodes that left the step's window since.
   Ev ev; ev.rc = 0; u32 slot = 0xFFFFFFFFu;
   bool r_valid = false; u32 r_eq = 0, r_base = 0, r_removed = 0, r_lim = 0; u64 r_mask = 0;
+  bool done = false; u32 seq_credit = 0, iters = 0;
 
   // ---------------- Solve loop, scheduler.go:104-124 ----------------
   for (;;) {
+    u32 mode = 1;   // 0 done, 1 one pod sequentially (wave 0), 2 speculation round
+    if constexpr (NW > 1) {
+      if (wv == 0) {
+        if (++iters > 8u * nP + 4096u) err = (u32)(-KS_ERR_INTERNAL);      // watchdog: a Solve needs at most a few steps per pod
+#ifdef KS_CHECK   /* debug builds: the visiting order must list every new node once, by nondecreasing pod count, inside its bucket */
+        if (!err) {
+          GSYNC();
+          u32 bad = 0;
+          for (u32 i = lane; i < nnew; i += 64) {
+            const u32 j = ORD_RD(i);
+            if (j >= nnew) { bad = 1; continue; }
+            const u32 cc = slot_rec(S, tb, tb.E + j).count();
+            if (cc == 0 || cc > maxc) { bad = 3; continue; }
+            if (i + 1 < nnew) { const u32 j2 = ORD_RD(i + 1); if (j2 < nnew && slot_rec(S, tb, tb.E + j2).count() < cc) bad = 2; }
+            if (i < BST(cc) || i >= BST(cc + 1)) bad = 4;
+          }
+          const u64 bb = ballot64(bad != 0);
+          if (bb) err = 100u + RL(bad, __builtin_ctzll(bb));
+        }
+#endif
+        if (done || err || q_len == 0) mode = 0;
+        else if (seq_credit == 0 && q_len >= 2) {
+          // the next NW queue entries, up to the first requeued one (its staleness test needs the sequential state)
+          const u32 cap = min((u32)NW, q_len); u64 e = 0;
+          if ((u32)lane < cap) { u32 idx = q_head + lane; if (idx >= nP) idx -= nP; e = tb.q[idx]; }
+          const u64 rq_bits = ballot64((u32)lane < cap && (e >> 63) != 0);
+          const u32 rn = rq_bits ? (u32)__builtin_ctzll(rq_bits) : cap;
+          if (rn >= 2) { mode = 2; if ((u32)lane < rn) rc.qe[lane] = e; if (lane == 0) { rc.n = rn; rc.nnew = nnew; rc.seq0 = seq; rc.ord_in_lds = ord_in_lds ? 1u : 0u; } }
+        }
+        if (mode == 1 && seq_credit) --seq_credit;
+        if (lane == 0) rc.mode = mode;
+      }
+      __syncthreads();
+      mode = UF(rc.mode);
+      if (mode == 0) break;
+    }
+    if (mode == 1) {
+    if (wv == 0) do {
     // Queue.Pop, queue.go:44-58
-    if (q_len == 0) break;
+    if (q_len == 0) { done = true; break; }
     PROBE(20);
 #ifdef KS_PROBES
     const u64 t_pod = __builtin_readcyclecounter();
@@ -1003,7 +1069,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
     }
     const u64 qe = UF64(qe_a);
     const u32 pod = (u32)qe, cidx = (u32)(qe >> 32) & 0x7FFFFFFFu;
-    if ((qe >> 63) && UF(G_lastgen[pod]) == q_gen && UF(G_lastlen[pod]) == q_len) break;   // only a requeued, unrelaxed pod can be stale
+    if ((qe >> 63) && UF(G_lastgen[pod]) == q_gen && UF(G_lastlen[pod]) == q_len) { done = true; break; }   // only a requeued, unrelaxed pod can be stale
     q_head = (q_head + 1 == nP) ? 0 : q_head + 1; q_len--; CTR(KS_STAT_POPS, 1);
     PROBE(12);
     { u32x4* dst = (u32x4*)&sh.cls; dst[lane] = pf0; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = pf1; }
@@ -1092,7 +1158,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
 
       // ---- Node.Add / ExistingNode.Add up to the instance-type filter, one node per lane ----
       ev.rc = 0;
-      if (slot != 0xFFFFFFFFu) eval_node<BOUNDS, LEAN, RM>(P, S, tb, sh, slot, slot < tb.E, fresh, ev, lane, tprobe, cr);
+      if (slot != 0xFFFFFFFFu) eval_node<BOUNDS, LEAN, RM>(P, S, tb, sh, wb, slot, slot < tb.E, fresh, ev, lane, tprobe, cr);
       PROBE(26);
       m = ballot64(ev.rc == 2);
       reach = ballot64(ev.rc >= 1);
@@ -1103,7 +1169,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
 
       while (m) {
         const int win = __builtin_ctzll(m);
-        Pub pb; publish_eval<BOUNDS, RM>(tb, sh, ev, slot, fresh, lane, win, cr, pb);
+        Pub pb; publish_eval<BOUNDS, RM>(tb, sh, wb, ev, slot, fresh, lane, win, cr, pb);
         const u32 sw = pb.slot; const bool ex = sw < tb.E; const u32 jw = sw - tb.E;
         const Rec r = slot_rec(S, tb, sw);
         const u32 rm = pb.rm;
@@ -1141,7 +1207,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
 #pragma unroll
           for (int rr = 0; rr < RM; ++rr) if ((u32)rr < tb.R) { const i64 v = wave_max_i64(mx[rr]); if (lane == 0 && ((lim >> rr) & 1u)) S.remaining[(size_t)m_t * tb.R + rr] -= v; }
         }
-        topology_record(P, S, tb, pb, sh, r, sw, lane);
+        topology_record<(NW > 1)>(P, S, tb, pb, sh, r, sw, lane);
         const u32 cnt = pb.count;                                   // pods on the node before this one
         LSYNC();
         write_record<BOUNDS, RM>(tb, r, pb, sh, rm, lane);
@@ -1222,9 +1288,136 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
       __threadfence_block();
       GSYNC();
     }
+    } while (0);
+    if constexpr (NW == 1) { if (done || err) break; }
+    continue;
+    }
+
+    // =====================================================================================================
+    // Speculation round.  Up to NW queued pods are evaluated, one per wave, against the SAME snapshot of the
+    // first 64 candidates in visiting order; the leader then assigns nodes from the fit bitmaps alone:
+    //   pod k takes u = the first candidate that accepted it and was not taken earlier in the round, provided
+    //   (a) no earlier pod of the round records into a topology group pod k's evaluation reads (tmask/rmask),
+    //   (b) no earlier winner that had accepted pod k precedes u in the visiting order as it now is -- a winner
+    //       from the new nodes went to the FRONT of its next count bucket (so it precedes u iff cnt+1 <= cnt(u)),
+    //       an existing node keeps its place.
+    // Nodes that rejected pod k stay rejecting (a commit only narrows a node), untouched nodes keep their bit.
+    // The first pod that breaks a rule ends the round and simply opens the next one (or goes sequential).
+    // oracle/oracle.cpp Scheduler::solve_spec restates these rules over the reference algorithm and checks every
+    // prediction (tests/test_speculation_rules.py).
+    // =====================================================================================================
+    if constexpr (NW > 1) {
+      const u32 rn = UF(rc.n);
+      const bool ord_lds_r = UF(rc.ord_in_lds) != 0;
+      u32 pod_w = 0; ClsR cr;
+      // ---- P1: evaluate ----
+      if (wv < rn) {
+        const u64 qe = UF64(rc.qe[wv]);
+        pod_w = (u32)qe; const u32 cidx = (u32)(qe >> 32) & 0x7FFFFFFFu;
+        { const GA u32x4* src = (const GA u32x4*)(plans + cidx); u32x4* dst = (u32x4*)&sh.cls; dst[lane] = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = src[lane + 64]; }
+        stage_class(tb, sh, lane);
+        const ClsPlan& c = sh.cls;
+        cr.tol = UF64(c.tol); cr.reqmask = UF(c.reqmask); cr.ntouch = UF(c.ntouch); cr.nhost = UF(c.nhost); cr.hn_mode = UF(c.hn_mode); cr.port_cnt = UF(c.port_cnt); cr.it_state = (i32)UF(c.it_state); cr.tkeys = UF64(c.tkeys); cr.eq = UF(c.eq);
+#pragma unroll
+        for (int i = 0; i < RM; ++i) cr.req[i] = (i64)UF64(c.req[i]);
+        if constexpr (LEAN) { cr.port_cnt = 0; cr.hn_mode = 0; cr.it_state = 0; }
+        const u32 total = tb.E + UF(rc.nnew);
+        slot = 0xFFFFFFFFu;
+        if ((u32)lane < total) slot = (u32)lane < tb.E ? (u32)lane : tb.E + (ord_lds_r ? ord_l[lane - tb.E] : ord_g[lane - tb.E]);
+        ev.rc = 0; ev.count = 0;
+        if (slot != 0xFFFFFFFFu) eval_node<BOUNDS, LEAN, RM>(P, S, tb, sh, wb, slot, slot < tb.E, false, ev, lane, tprobe, cr);
+        const u64 m = ballot64(ev.rc == 2);
+        if (lane == 0) { rc.m[wv] = m; rc.T[wv] = c.tmask; rc.R[wv] = c.rmask; rc.elig[wv] = (!c.overflow && cr.port_cnt == 0) ? 1u : 0u; }
+        if (wv == 0) rc.cnt[lane] = ev.count;
+      }
+      __syncthreads();
+      // ---- P2: the leader resolves the round ----
+      if (wv == 0) {
+        u32 my_win = 0, my_cnt = 0, n_ok = 0; u64 taken = 0, rall = 0;
+        for (u32 k = 0; k < rn; ++k) {
+          if (!UF(rc.elig[k])) break;
+          const u64 mk = UF64(rc.m[k]);
+          if (UF64(rc.T[k]) & rall) break;
+          const u64 cand = mk & ~taken; if (!cand) break;
+          const u32 u = (u32)__builtin_ctzll(cand); const u32 cu = UF(rc.cnt[u]);
+          bool bad = false;
+          if ((u32)lane < k && ((mk >> my_win) & 1ull)) bad = my_win < tb.E ? (my_win < u) : (u >= tb.E && my_cnt + 1 <= cu);
+          if (ballot64(bad)) break;
+          if ((u32)lane == k) { my_win = u; my_cnt = cu; }
+          if (lane == 0) rc.win[k] = u;
+          taken |= 1ull << u; rall |= UF64(rc.R[k]); n_ok = k + 1;
+        }
+        if (lane == 0) rc.n_ok = n_ok;
+      }
+      __syncthreads();
+      // ---- P3: publish the assigned candidate, run the instance-type filter ----
+      const u32 n_ok = UF(rc.n_ok);
+      Pub pb; u64 aw = 0; bool filtered = false;
+      if (wv < n_ok) {
+        const int win = (int)UF(rc.win[wv]);
+        publish_eval<BOUNDS, RM>(tb, sh, wb, ev, slot, false, lane, win, cr, pb);
+        bool failed = false;
+        if (pb.slot >= tb.E && pb.need) {
+          const Rec r = slot_rec(S, tb, pb.slot);
+          const GA u64* const alive = tb.n_alive + (size_t)(pb.slot - tb.E) * tb.TW;
+          const u32 keys = pb.changed;
+          const bool zc = (tb.key_zone >= 0 && ((keys >> tb.key_zone) & 1u)) || (tb.key_ct >= 0 && ((keys >> tb.key_ct) & 1u));
+          failed = !filter_types(P, tb, pb, sh, r, alive, (GA u64*)nullptr, pb.rm, keys, zc, pb.it_state != pb.it_before, lane, tprobe, aw);
+          filtered = true;
+        }
+        if (lane == 0) rc.fail[wv] = failed ? 1u : 0u;
+      }
+      __syncthreads();
+      // ---- P4: commit everything before the first failed filter; the leader moves the winners in the visiting order ----
+      u32 n_commit = n_ok;
+      { const u64 fb = ballot64((u32)lane < n_ok && rc.fail[lane & (KS_MAX_WAVES - 1)] != 0); if (fb) n_commit = (u32)__builtin_ctzll(fb); }
+      if (wv < n_commit) {
+        const u32 sw = pb.slot; const bool ex = sw < tb.E;
+        const Rec r = slot_rec(S, tb, sw);
+        if (filtered) {
+          GA u64* const alive = tb.n_alive + (size_t)(sw - tb.E) * tb.TW;
+          if ((u32)lane < tb.TW) alive[lane] = aw;
+          if ((u32)lane < tb.R && ((pb.rm >> lane) & 1u)) r.low()[lane] = sh.low_new[lane];
+        }
+        topology_record<true>(P, S, tb, pb, sh, r, sw, lane);
+        LSYNC();
+        write_record<BOUNDS, RM>(tb, r, pb, sh, pb.rm, lane);
+        if (lane == 0) { if (!ex) r.count() = pb.count + 1; tb.pod_node[pod_w] = (i32)sw; tb.pod_seq[pod_w] = (i32)(UF(rc.seq0) + wv); }
+      }
+      if (wv == 0) {
+        u32 moved_before = 0;      // bit j: winner j was a new node (it left its place in the window)
+        for (u32 k = 0; k < n_commit; ++k) {
+          const u32 u = UF(rc.win[k]);
+          if (u >= tb.E) {
+            CTR(KS_STAT_FULLCHECKS, 1);
+            // Where is the node now?  An earlier winner that stood before it in its OWN count bucket left a gap and went
+            // behind it (front of the next bucket): one place to the left.  A winner from a lower bucket was re-inserted
+            // at the front of a bucket that is still before (or is) this node's: no net shift.  Winners behind it: none.
+            const u32 cnt = UF(rc.cnt[u]);
+            u32 shift = 0; for (u32 j = 0; j < k; ++j) { const u32 wj = UF(rc.win[j]); if (((moved_before >> j) & 1u) && wj < u && UF(rc.cnt[wj]) == cnt) ++shift; }
+            const u32 p = u - shift - tb.E;
+            const u32 jw = UF(ORD_RD(p));
+            const u32 endc = UF(BST(cnt + 1));
+            for (u32 i = p + 1; i < endc; i += 64) { const u32 ii = i + lane; u32 v = 0; if (ii < endc) v = ORD_RD(ii); if (ord_in_lds) LSYNC(); else GSYNC(); if (ii < endc) ORD_WR(ii - 1, v); }
+            if (ord_in_lds) LSYNC(); else GSYNC();
+            if (lane == 0) { ORD_WR(endc - 1, jw); BST(cnt + 1) = endc - 1; if (cnt + 1 > maxc) BST(cnt + 2) = nnew; }
+            if (cnt + 1 > maxc) maxc = cnt + 1;
+            LSYNC();
+            moved_before |= 1u << k;
+          }
+        }
+        q_head += n_commit; if (q_head >= nP) q_head -= nP;
+        q_len -= n_commit; seq += n_commit; CTR(KS_STAT_POPS, n_commit); CTR(21, 1);
+        pf_ok = false; r_valid = false;
+        if (n_commit == 0) seq_credit = 1;            // the head pod needs more than the window offers: take it sequentially
+        else if (n_commit == 1) seq_credit = 3;       // little to win here: spare a few rounds' overhead
+      }
+      __syncthreads();
+    }
   }
 
   // ---------------- results ----------------
+  if (wv != 0) return;
   GSYNC();
   for (u32 i = lane; i < q_len; i += 64) { u32 idx = q_head + i; if (idx >= nP) idx -= nP; S.unscheduled[i] = (i32)tb.q[idx]; }
   for (u32 j = lane; j < nnew; j += 64) {        // de-interleave the new nodes' records into the SoA result arrays
@@ -1235,7 +1428,7 @@ __global__ __launch_bounds__(64) void ks_pack(const DevProb* probs, const DevSta
   }
   if (lane == 0) {
     S.out_counts[0] = nnew; S.out_counts[1] = q_len;
-    for (int i = 0; i < 32; ++i) S.stats[i] = sh.ctr[i];
+    for (int i = 0; i < 32; ++i) S.stats[i] = ls.ctr[i];
     S.stats[KS_STAT_CYCLES] = __builtin_readcyclecounter() - t_start; S.stats[KS_STAT_ERR] = err;
   }
 }
@@ -1375,6 +1568,7 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
     std::vector<i64> vals((size_t)R * T, 0); std::vector<u32> cnt(R, 0);
     for (u32 r = 0; r < R; ++r) { std::vector<i64> v(p->it_alloc + (size_t)r * T, p->it_alloc + (size_t)(r + 1) * T); std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); cnt[r] = (u32)v.size(); std::copy(v.begin(), v.end(), vals.begin() + (size_t)r * T); }
     const i64* dv; const u32* dc; TRY(dev_copy(d, vals.data(), vals.size(), &dv)); TRY(dev_copy(d, cnt.data(), cnt.size(), &dc)); h.ge_vals = (i64*)dv; h.ge_cnt = (u32*)dc;
+    h.ge_max = 1; for (u32 r = 0; r < R; ++r) h.ge_max = std::max(h.ge_max, cnt[r]);
     TRY(dev_alloc(d, (size_t)R * T * TW, &h.ge_rows, 0));
   }
   { u8* pl = nullptr; TRY(dev_alloc(d, (size_t)C * sizeof(ClsPlan), &pl, 0)); h.plans = pl; }
@@ -1444,7 +1638,10 @@ static int download(ks_dev_problem* d, ks_result* out) {
   u32 counts[4]; HIPCHK(hipMemcpy(counts, s.out_counts, sizeof counts, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(out->stats, s.stats, 32 * sizeof(u64), hipMemcpyDeviceToHost));
   out->n_new = counts[0]; out->n_unscheduled = counts[1];
-  if (out->stats[KS_STAT_ERR]) return fail(-(int)out->stats[KS_STAT_ERR], out->stats[KS_STAT_ERR] == (u64)(-KS_ERR_CAPACITY) ? "more new nodes than max_new_nodes" : "a pod class exceeds the kernel's per-class limits (12 touched keys / 24 topology groups / 3 hostname groups / 24 recorded groups)");
+  if (out->stats[KS_STAT_ERR]) return fail(-(int)out->stats[KS_STAT_ERR], out->stats[KS_STAT_ERR] == (u64)(-KS_ERR_CAPACITY) ? "more new nodes than max_new_nodes" :
+                                           out->stats[KS_STAT_ERR] == (u64)(-KS_ERR_INTERNAL) ? "pack kernel watchdog: step bound exceeded" :
+                                           out->stats[KS_STAT_ERR] >= 100 ? "pack kernel self-check failed (KS_CHECK build): visiting order inconsistent" :
+                                           "a pod class exceeds the kernel's per-class limits (12 touched keys / 24 topology groups / 3 hostname groups / 24 recorded groups)");
   const u32 P = h.P, K = h.K, R = h.R, TW = h.TW, N = out->n_new;
   if (P) {
     HIPCHK(hipMemcpy(out->pod_node, s.pod_node, P * sizeof(i32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out->pod_stage, s.pod_stage, P * sizeof(i32), hipMemcpyDeviceToHost));
@@ -1484,16 +1681,28 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   // batched what-ifs take 64 KiB each so two workgroups share a CU.
   const u32 lds_bytes = n == 1 ? 100u * 1024u : 64u * 1024u;
   bool fast = true;
-  for (u32 i = 0; i < n; ++i) { const DevProb& q = ds[i]->h; if (q.G > KS_FAST_G || q.GH > KS_FAST_G || (q.SC > 1 && (size_t)q.S * q.SC > KS_FAST_S * KS_FAST_S) || (size_t)q.R * q.T > KS_FAST_RT || (size_t)q.R * q.T * 8 + 16384 > lds_bytes) fast = false; }
+  for (u32 i = 0; i < n; ++i) { const DevProb& q = ds[i]->h; if (q.G > KS_FAST_G || q.GH > KS_FAST_G || (q.SC > 1 && (size_t)q.S * q.SC > KS_FAST_S * KS_FAST_S) || (size_t)q.R * q.ge_max > KS_FAST_RT || (size_t)q.R * q.ge_max * 8 + 8192 > lds_bytes) fast = false; }
   static bool attr_set = false;
   bool bounds = false; for (u32 i = 0; i < n; ++i) bounds = bounds || ds[i]->any_bounds;
   bool lean = true; for (u32 i = 0; i < n; ++i) lean = lean && ds[i]->lean_ok;
   if (getenv("KS_NO_LEAN")) lean = false;      // test hook: run the general variant on a problem the LEAN one would take
   typedef void (*pack_fn)(const DevProb*, const DevState*, u32);
-  static const pack_fn variants[8] = {ks_pack<false, false, false>, ks_pack<false, true, false>, ks_pack<true, false, false>, ks_pack<true, true, false>,
-                                      ks_pack<false, false, true>, ks_pack<false, true, true>, ks_pack<true, false, true>, ks_pack<true, true, true>};
+  static const pack_fn variants[8] = {ks_pack<false, false, false, 1>, ks_pack<false, true, false, 1>, ks_pack<true, false, false, 1>, ks_pack<true, true, false, 1>,
+                                      ks_pack<false, false, true, 1>, ks_pack<false, true, true, 1>, ks_pack<true, false, true, 1>, ks_pack<true, true, true, 1>};
   if (!attr_set) { for (int i = 0; i < 8; ++i) HIPCHK(hipFuncSetAttribute((const void*)variants[i], hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024)); attr_set = true; }
-  hipLaunchKernelGGL(variants[(lean ? 4 : 0) + (fast ? 2 : 0) + (bounds ? 1 : 0)], dim3(n), dim3(64), lds_bytes, st, dp, dsv, lds_bytes);
+  // A single Solve whose problem takes the LEAN, FAST, no-bounds kernel gets 8 waves: waves 1..7 join wave 0 for the
+  // speculation rounds (see ks_pack).  T <= 4096 keeps a node's surviving-type mask in one register per lane.
+  bool multi = n == 1 && lean && fast && !bounds && ds[0]->h.TW <= 64 && !getenv("KS_ONE_WAVE");
+  if (multi) {
+    const u32 lds_mw = 44u * 1024u;
+    if ((size_t)ds[0]->h.R * ds[0]->h.ge_max * 8 + 8192 > lds_mw) multi = false;
+    else {
+      static bool attr_mw = false;
+      if (!attr_mw) { HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024)); attr_mw = true; }
+      hipLaunchKernelGGL((ks_pack<true, false, true, 8>), dim3(1), dim3(512), lds_mw, st, dp, dsv, lds_mw);
+    }
+  }
+  if (!multi) hipLaunchKernelGGL(variants[(lean ? 4 : 0) + (fast ? 2 : 0) + (bounds ? 1 : 0)], dim3(n), dim3(64), lds_bytes, st, dp, dsv, lds_bytes);
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());

@@ -758,6 +758,119 @@ struct Scheduler {
     unscheduled.assign(queue.begin(), queue.end());
     for (auto& n : new_nodes) n->requirements.m.erase(hostnameKey);   // FinalizeScheduling, node.go:111-115
   }
+  // ------------------------------------------------------------------------------------------------
+  // Round-speculation model check (tests only).  The HIP kernel evaluates up to W queued pods against ONE
+  // snapshot of the nodes (the first 64 candidates in visiting order), then a resolver picks each pod's node
+  // from the fit bitmaps with the rules below, without re-evaluating.  This restates those rules on top of the
+  // sequential algorithm and checks every prediction against what add() then really does.
+  //   out[0] pods placed through a prediction, out[1] rounds, out[2] pods handled sequentially,
+  //   out[3] rule violations (must be 0), out[4] predictions cut by the topology rule, out[5] cut by the order rule
+  // ------------------------------------------------------------------------------------------------
+  bool dry_new(const Node& m, PodState& ps) {
+    ksp::Pod& pod = ps.spec;
+    if (!taints_tolerates(m.tmpl->taints, pod)) return false;
+    if (!m.ports.validate(pod, nullptr)) return false;
+    Reqs nodeReqs = m.requirements; Reqs podReqs = new_pod_requirements(pod);
+    if (!reqs_compatible(cx, nodeReqs, podReqs)) return false;
+    nodeReqs.add_all(podReqs);
+    Reqs topoReqs;
+    if (!topo.add_requirements(podReqs, nodeReqs, pod, &topoReqs)) return false;
+    if (!reqs_compatible(cx, nodeReqs, topoReqs)) return false;
+    nodeReqs.add_all(topoReqs);
+    ResList requests = res_merge(m.requests, requests_for_pods({&pod}));
+    return !filter_types(m.options, nodeReqs, requests).empty();
+  }
+  bool dry_existing(const ExistingNode& n, PodState& ps) {
+    ksp::Pod& pod = ps.spec;
+    if (!taints_tolerates(n.taints, pod)) return false;
+    if (!n.ports.validate(pod, nullptr)) return false;
+    ResList requests = res_merge(n.requests, requests_for_pods({&pod}));
+    if (!res_fits(requests, n.available)) return false;
+    Reqs nodeReqs = n.requirements; Reqs podReqs = new_pod_requirements(pod);
+    if (!reqs_compatible(cx, nodeReqs, podReqs)) return false;
+    nodeReqs.add_all(podReqs);
+    Reqs topoReqs;
+    if (!topo.add_requirements(podReqs, nodeReqs, pod, &topoReqs)) return false;
+    return reqs_compatible(cx, nodeReqs, topoReqs);
+  }
+  void solve_spec(int W, long long* out) {
+    std::vector<int> q(pods.size()); for (size_t i = 0; i < pods.size(); ++i) q[i] = (int)i;
+    std::vector<ResList> rq(pods.size()); for (size_t i = 0; i < pods.size(); ++i) rq[i] = requests_for_pods({&pods[i].spec});
+    auto get = [](const ResList& r, const char* k) { auto it = r.find(k); return it == r.end() ? (int64_t)0 : it->second; };
+    std::sort(q.begin(), q.end(), [&](int a, int b) {
+      int64_t ca = get(rq[a], "cpu"), cb = get(rq[b], "cpu"); if (ca != cb) return ca > cb;
+      int64_t ma = get(rq[a], "memory"), mb = get(rq[b], "memory"); if (ma != mb) return ma > mb;
+      if (pods[a].spec.creation_ts != pods[b].spec.creation_ts) return pods[a].spec.creation_ts < pods[b].spec.creation_ts;
+      return pods[a].spec.uid < pods[b].spec.uid;
+    });
+    std::deque<int> queue(q.begin(), q.end());
+    std::unordered_map<int, size_t> lastLen;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    auto sequential_step = [&]() -> bool {   // one iteration of solve(); false == stop
+      int pi = queue.front();
+      auto ll = lastLen.find(pi);
+      if (ll != lastLen.end() && ll->second == queue.size()) return false;
+      queue.pop_front(); st.queue_pops++;
+      PodState& ps = pods[pi];
+      if (add(ps)) return true;
+      bool relaxed = relax(ps.spec);
+      queue.push_back(pi);
+      if (relaxed) { lastLen.clear(); ps.stage++; st.relaxations++; topo.update(ps.spec); } else lastLen[pi] = queue.size();
+      return true;
+    };
+    while (!queue.empty()) {
+      // ---- snapshot: the first 64 candidates in visiting order ----
+      std::stable_sort(new_nodes.begin(), new_nodes.end(), [](const std::unique_ptr<Node>& a, const std::unique_ptr<Node>& b) { return a->pods.size() < b->pods.size(); });
+      const size_t E = existing.size(), total = E + new_nodes.size(), nc = std::min<size_t>(64, total);
+      std::vector<size_t> cnt(nc, 0); for (size_t i = 0; i < nc; ++i) if (i >= E) cnt[i] = new_nodes[i - E]->pods.size();
+      std::vector<Node*> snapN(nc, nullptr); std::vector<ExistingNode*> snapE(nc, nullptr);
+      for (size_t i = 0; i < nc; ++i) { if (i < E) snapE[i] = existing[i].get(); else snapN[i] = new_nodes[i - E].get(); }
+      // ---- pods of the round: never-requeued queue entries only ----
+      size_t n = 0; while (n < (size_t)W && n < queue.size() && lastLen.find(queue[n]) == lastLen.end()) ++n;
+      std::vector<uint64_t> m(n, 0); std::vector<std::set<const TopologyGroup*>> T(n), R(n);
+      Stats keep = st;
+      for (size_t k = 0; k < n; ++k) {
+        PodState& ps = pods[queue[k]];
+        for (size_t i = 0; i < nc; ++i) if (i < E ? dry_existing(*snapE[i], ps) : dry_new(*snapN[i], ps)) m[k] |= 1ull << i;
+        if (!topo.inert) {
+          for (auto& tc : topo.topologies) { if (tc->owners.count(ps.spec.uid)) T[k].insert(tc.get()); if (tg_selects(*tc, ps.spec)) R[k].insert(tc.get()); }
+          for (auto& tc : topo.inverse) { if (tg_selects(*tc, ps.spec)) T[k].insert(tc.get()); if (tc->owners.count(ps.spec.uid)) R[k].insert(tc.get()); }
+        }
+      }
+      st = keep;
+      // ---- resolver ----
+      std::vector<int> win; uint64_t taken = 0; std::set<const TopologyGroup*> Rall;
+      for (size_t k = 0; k < n; ++k) {
+        bool topo_hit = false; for (auto* g : T[k]) if (Rall.count(g)) topo_hit = true;
+        if (topo_hit) { out[4]++; break; }
+        const uint64_t cand = m[k] & ~taken; if (!cand) break;
+        const int u = __builtin_ctzll(cand);
+        bool ok = true;
+        for (int wj : win) if ((m[k] >> wj) & 1ull) {         // an earlier winner that accepted this pod at the snapshot: does it precede u now?
+          if ((size_t)wj < E) { if (wj < u) ok = false; }     // existing nodes keep their place
+          else if ((size_t)u >= E && cnt[wj] + 1 <= cnt[u]) ok = false;   // it moved to the front of bucket cnt+1
+        }
+        if (!ok) { out[5]++; break; }
+        win.push_back(u); taken |= 1ull << u; for (auto* g : R[k]) Rall.insert(g);
+      }
+      if (win.empty()) { out[2]++; if (!sequential_step()) break; continue; }
+      out[1]++;
+      // ---- commit the predictions through the real algorithm and compare ----
+      for (size_t k = 0; k < win.size(); ++k) {
+        int pi = queue.front(); queue.pop_front(); st.queue_pops++;
+        PodState& ps = pods[pi];
+        const size_t before_nodes = new_nodes.size();
+        bool placed = add(ps);
+        bool match = placed && new_nodes.size() == before_nodes;
+        if (match) { const int u = win[k]; match = (size_t)u < E ? (!snapE[u]->pods.empty() && snapE[u]->pods.back() == ps.index) : (!snapN[u]->pods.empty() && snapN[u]->pods.back() == ps.index); }
+        if (!match) { out[3]++; fprintf(stderr, "speculation rule violated: pod %d (round position %zu) predicted candidate %d\n", pi, k, win[k]); }
+        if (!placed) { bool relaxed = relax(ps.spec); queue.push_back(pi); if (relaxed) { lastLen.clear(); ps.stage++; st.relaxations++; topo.update(ps.spec); } else lastLen[pi] = queue.size(); break; }
+        out[0]++;
+      }
+    }
+    unscheduled.assign(queue.begin(), queue.end());
+    for (auto& n : new_nodes) n->requirements.m.erase(hostnameKey);
+  }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -888,6 +1001,19 @@ int ko_solve(const char* ksp_text, size_t len, int flags, char** out_text) {
   } catch (const std::exception& e) { *out_text = strdup(e.what()); oracle::g_in = nullptr; return -1; }
 }
 void ko_free(char* p) { free(p); }
+
+// Model check of the kernel's round speculation (see Scheduler::solve_spec): solves through predictions, returns the
+// KSR1 text (must equal ko_solve's) and the counters.
+int ko_solve_spec(const char* ksp_text, size_t len, int W, long long* counters, char** out_text) {
+  oracle::Interner in; oracle::g_in = &in;
+  try {
+    ksp::Problem pr = ksp::Parser(ksp_text, len).parse();
+    auto s = oracle::build(pr, false);
+    s->solve_spec(W, counters);
+    std::string r = oracle::result_text(*s, 0.0);
+    *out_text = strdup(r.c_str()); oracle::g_in = nullptr; return 0;
+  } catch (const std::exception& e) { *out_text = strdup(e.what()); oracle::g_in = nullptr; return -1; }
+}
 
 // Requirement algebra probes for the reference truth tables.  A requirement is given as
 // "<op> <nvals> <val>*"; the result of Intersection is rendered "c=<0|1> vals=[a,b] gt=<n|-> lt=<n|->".
