@@ -463,6 +463,7 @@ struct alignas(16) WaveShared {      // one per wave of the workgroup
 };
 struct WaveBounds { i32 la_gt[KS_MAX_TOUCH][64]; i32 la_lt[KS_MAX_TOUCH][64]; };            // ... their Gt/Lt halves (BOUNDS variants only)
 struct LeaderShared {                // owned by wave 0, which carries the Solve's sequential state
+  u32 hard[8];          // 256-bit hashed set of classes whose last pod found nothing in the first candidate window (heuristic only)
   u32 bstart[KS_BST_LDS];
   u64 ctr[32];          // statistics + (KS_PROBES builds) per-phase cycle counters; slot numbers = ks_result.stats[]
 };
@@ -987,6 +988,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h]; for (u32 e = 0; e < tb.E; ++e) if (P.grph_count[(size_t)h * tb.E + e] > 0) ++np; S.g_hpos[h] = np; }
   }
   if (wv == 0 && lane < 32) ls.ctr[lane] = 0;
+  if (wv == 0 && lane < 8) ls.hard[lane] = 0;
   __threadfence_block();
   __syncthreads();
   const GA ClsPlan* plans = (const GA ClsPlan*)UF64((u64)P.plans);
@@ -1039,10 +1041,13 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         if (done || err || q_len == 0) mode = 0;
         else if (seq_credit == 0 && q_len >= 2) {
           // the next NW queue entries, up to the first requeued one (its staleness test needs the sequential state)
-          const u32 cap = min((u32)NW, q_len); u64 e = 0;
+          const u32 cap = min((u32)NW - 1u, q_len); u64 e = 0;
           if ((u32)lane < cap) { u32 idx = q_head + lane; if (idx >= nP) idx -= nP; e = tb.q[idx]; }
           const u64 rq_bits = ballot64((u32)lane < cap && (e >> 63) != 0);
-          const u32 rn = rq_bits ? (u32)__builtin_ctzll(rq_bits) : cap;
+          u32 rn = rq_bits ? (u32)__builtin_ctzll(rq_bits) : cap;
+          // a class whose last pod had to look past the window (or open a node) will most likely do so again: a round
+          // would evaluate it for nothing -- take it sequentially right away
+          { const u32 c0 = RL((u32)(e >> 32), 0) & 0x7FFFFFFFu; if ((UF(ls.hard[(c0 >> 5) & 7u]) >> (c0 & 31u)) & 1u) rn = 0; }
           if (rn >= 2) { mode = 2; if ((u32)lane < rn) rc.qe[lane] = e; if (lane == 0) { rc.n = rn; rc.nnew = nnew; rc.seq0 = seq; rc.ord_in_lds = ord_in_lds ? 1u : 0u; } }
         }
         if (mode == 1 && seq_credit) --seq_credit;
@@ -1096,7 +1101,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     }
     u32 pos_base = 0, tm = 0, width = KS_FIRST_WIDTH;
     bool reuse = r_valid && !want_stats && cr.eq != 0 && cr.eq == r_eq;
-    if (cr.eq != 0) CTR(8, 1);
+    if (NW == 1 && cr.eq != 0) CTR(8, 1);
     r_valid = reuse;               // any other path re-evaluates (or moves nodes in ways the window does not track)
     while (!placed && !err) {
       const u32 total = tb.E + nnew;
@@ -1228,9 +1233,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           if (cnt + 1 > maxc) maxc = cnt + 1;
           // keep the step's remaining fit bits for the next pod if it is evaluation-equivalent: valid for the lanes
           // whose nodes share the winner's count bucket (they now precede it in the visiting order)
-          if (reuse) { r_mask = m & (m - 1); ++r_removed; CTR(11, 1); }
+          if (reuse) { r_mask = m & (m - 1); ++r_removed; if (NW == 1) CTR(11, 1); }
           else if (cr.eq != 0 && !want_stats) {
-            CTR(10, 1);
+            if (NW == 1) CTR(10, 1);
             const u32 lim_abs = tb.E + endc;                          // one past the bucket, in this step's coordinates
             r_valid = true; r_eq = cr.eq; r_mask = m & (m - 1); r_base = pos_base; r_removed = 1; r_lim = lim_abs > pos_base ? min(64u, lim_abs - pos_base) : 0;
           }
@@ -1250,11 +1255,12 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           nnew = jw + 1;
         }
         pp_used += cr.port_cnt; ++seq; placed = true;
+        if constexpr (NW > 1) { if (lane == 0) { const u32 hb = 1u << (cidx & 31u); if (fresh || (!reuse && pos_base != 0)) ls.hard[(cidx >> 5) & 7u] |= hb; else ls.hard[(cidx >> 5) & 7u] &= ~hb; } }
         LSYNC();
         PROBE(18);
         break;
       }
-      if (reuse && !placed) { CTR(9, 1); reuse = false; r_valid = false; pos_base = 0; continue; }   // window exhausted: evaluate from the top
+      if (reuse && !placed) { if (NW == 1) CTR(9, 1); reuse = false; r_valid = false; pos_base = 0; continue; }   // window exhausted: evaluate from the top
       if (want_stats && !fresh) {
         CTR(KS_STAT_REF_ATTEMPTS, visited);
         u32 ty = ((u32)lane < visited && ((reach >> lane) & 1ull)) ? my_alive : 0;
@@ -1265,7 +1271,8 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     }
     if (err) break;
 #ifdef KS_PROBES
-    { const u32 kind = cr.nhost ? 2 : (c.ntopo ? 1 : 0); CTR(27 + kind, __builtin_readcyclecounter() - t_pod); if (kind) CTR(29 + kind, 1); }
+    if (NW == 1) { const u32 kind = cr.nhost ? 2 : (c.ntopo ? 1 : 0); CTR(27 + kind, __builtin_readcyclecounter() - t_pod); if (kind) CTR(29 + kind, 1); }
+    else { CTR(28, __builtin_readcyclecounter() - t_pod); CTR(30, 1); }
 #endif
 
     // ---- failure: Preferences.Relax + Queue.Push + Topology.Update (scheduler.go:116-123) ----
@@ -1307,12 +1314,17 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     // prediction (tests/test_speculation_rules.py).
     // =====================================================================================================
     if constexpr (NW > 1) {
+      // wave 0 coordinates (resolver, visiting-order moves, queue); waves 1..NW-1 each take round pod k = wave - 1
       const u32 rn = UF(rc.n);
+#ifdef KS_PROBES
+      const u64 t_round = __builtin_readcyclecounter();
+#endif
       const bool ord_lds_r = UF(rc.ord_in_lds) != 0;
+      const u32 kw = wv - 1;                 // this wave's pod within the round (wave 0: none)
       u32 pod_w = 0; ClsR cr;
       // ---- P1: evaluate ----
-      if (wv < rn) {
-        const u64 qe = UF64(rc.qe[wv]);
+      if (wv != 0 && kw < rn) {
+        const u64 qe = UF64(rc.qe[kw]);
         pod_w = (u32)qe; const u32 cidx = (u32)(qe >> 32) & 0x7FFFFFFFu;
         { const GA u32x4* src = (const GA u32x4*)(plans + cidx); u32x4* dst = (u32x4*)&sh.cls; dst[lane] = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = src[lane + 64]; }
         stage_class(tb, sh, lane);
@@ -1327,34 +1339,48 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         ev.rc = 0; ev.count = 0;
         if (slot != 0xFFFFFFFFu) eval_node<BOUNDS, LEAN, RM>(P, S, tb, sh, wb, slot, slot < tb.E, false, ev, lane, tprobe, cr);
         const u64 m = ballot64(ev.rc == 2);
-        if (lane == 0) { rc.m[wv] = m; rc.T[wv] = c.tmask; rc.R[wv] = c.rmask; rc.elig[wv] = (!c.overflow && cr.port_cnt == 0) ? 1u : 0u; }
-        if (wv == 0) rc.cnt[lane] = ev.count;
+        if (lane == 0) { rc.m[kw] = m; rc.T[kw] = c.tmask; rc.R[kw] = c.rmask; rc.elig[kw] = (!c.overflow && cr.port_cnt == 0) ? 1u : 0u; }
+        if (kw == 0) rc.cnt[lane] = ev.count;
       }
       __syncthreads();
-      // ---- P2: the leader resolves the round ----
+#ifdef KS_PROBES
+      u64 t_ph = __builtin_readcyclecounter(); CTR(22, t_ph - t_round);
+#endif
+      // ---- P2: the leader resolves the round (lane k holds pod k's bitmap and masks, lane u candidate u's pod count) ----
+      u32 mv_p = 0, mv_cnt = 0, mv_maxc = 0; bool mv_done = false;     // leader lane k: the move made for round pod k (undo record)
+      u32 my_win = 0, my_cnt = 0;
       if (wv == 0) {
-        u32 my_win = 0, my_cnt = 0, n_ok = 0; u64 taken = 0, rall = 0;
+        const u32 li = lane & (KS_MAX_WAVES - 1);
+        const u64 m_l = rc.m[li], t_l = rc.T[li], r_l = rc.R[li]; const u32 e_l = rc.elig[li], c_l = rc.cnt[lane];
+        u32 n_ok = 0; u64 taken = 0, rall = 0;
         for (u32 k = 0; k < rn; ++k) {
-          if (!UF(rc.elig[k])) break;
-          const u64 mk = UF64(rc.m[k]);
-          if (UF64(rc.T[k]) & rall) break;
+          if (!RL(e_l, k)) break;
+          const u64 mk = RL64(m_l, k);
+          if (RL64(t_l, k) & rall) break;
           const u64 cand = mk & ~taken; if (!cand) break;
-          const u32 u = (u32)__builtin_ctzll(cand); const u32 cu = UF(rc.cnt[u]);
+          const u32 u = (u32)__builtin_ctzll(cand); const u32 cu = RL(c_l, u);
           bool bad = false;
           if ((u32)lane < k && ((mk >> my_win) & 1ull)) bad = my_win < tb.E ? (my_win < u) : (u >= tb.E && my_cnt + 1 <= cu);
           if (ballot64(bad)) break;
           if ((u32)lane == k) { my_win = u; my_cnt = cu; }
-          if (lane == 0) rc.win[k] = u;
-          taken |= 1ull << u; rall |= UF64(rc.R[k]); n_ok = k + 1;
+          taken |= 1ull << u; rall |= RL64(r_l, k); n_ok = k + 1;
         }
+#ifdef KS_CHECK   /* debug builds cut rounds short at pseudo-random places: a cut pod is simply retried, so results must not change, and the undo path gets exercised */
+        rc.pad0 = ((iters * 2654435761u) >> 29) < 3u ? ((iters >> 3) & 3u) : 0xFFu;
+#endif
+        if ((u32)lane < n_ok) rc.win[lane] = my_win;
         if (lane == 0) rc.n_ok = n_ok;
       }
       __syncthreads();
-      // ---- P3: publish the assigned candidate, run the instance-type filter ----
+#ifdef KS_PROBES
+      { const u64 t2 = __builtin_readcyclecounter(); CTR(23, t2 - t_ph); t_ph = t2; }
+#endif
+      // ---- P3: workers publish their assigned candidate and run the instance-type filter; meanwhile the leader moves the
+      //      winners in the visiting order (speculatively: a failed filter -- 2 in 10 000 -- undoes the moves behind it) ----
       const u32 n_ok = UF(rc.n_ok);
       Pub pb; u64 aw = 0; bool filtered = false;
-      if (wv < n_ok) {
-        const int win = (int)UF(rc.win[wv]);
+      if (wv != 0 && kw < n_ok) {
+        const int win = (int)UF(rc.win[kw]);
         publish_eval<BOUNDS, RM>(tb, sh, wb, ev, slot, false, lane, win, cr, pb);
         bool failed = false;
         if (pb.slot >= tb.E && pb.need) {
@@ -1365,13 +1391,39 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           failed = !filter_types(P, tb, pb, sh, r, alive, (GA u64*)nullptr, pb.rm, keys, zc, pb.it_state != pb.it_before, lane, tprobe, aw);
           filtered = true;
         }
-        if (lane == 0) rc.fail[wv] = failed ? 1u : 0u;
+        if (lane == 0) rc.fail[kw] = failed ? 1u : 0u;
+      }
+      if (wv == 0) {
+        for (u32 k = 0; k < n_ok; ++k) {
+          const u32 u = RL(my_win, k);
+          if (u < tb.E) continue;                       // existing nodes keep their place
+          // Where is the node now?  An earlier winner that stood before it in its OWN count bucket left a gap and went
+          // behind it (front of the next bucket): one place to the left.  A winner from a lower bucket was re-inserted
+          // at the front of a bucket that is still before (or is) this node's: no net shift.  Winners behind it: none.
+          const u32 cnt = RL(my_cnt, k);
+          const u32 shift = (u32)__builtin_popcountll(ballot64((u32)lane < k && my_win >= tb.E && my_win < u && my_cnt == cnt));
+          const u32 p = u - shift - tb.E;
+          const u32 jw = UF(ORD_RD(p));
+          const u32 endc = UF(BST(cnt + 1));
+          for (u32 i = p + 1; i < endc; i += 64) { const u32 ii = i + lane; u32 v = 0; if (ii < endc) v = ORD_RD(ii); if (ord_in_lds) LSYNC(); else GSYNC(); if (ii < endc) ORD_WR(ii - 1, v); }
+          if (ord_in_lds) LSYNC(); else GSYNC();
+          if ((u32)lane == k) { mv_p = p; mv_cnt = cnt; mv_maxc = maxc; mv_done = true; }
+          if (lane == 0) { ORD_WR(endc - 1, jw); BST(cnt + 1) = endc - 1; if (cnt + 1 > maxc) BST(cnt + 2) = nnew; }
+          if (cnt + 1 > maxc) maxc = cnt + 1;
+          if (ord_in_lds) LSYNC(); else GSYNC();
+        }
       }
       __syncthreads();
-      // ---- P4: commit everything before the first failed filter; the leader moves the winners in the visiting order ----
+#ifdef KS_PROBES
+      { const u64 t2 = __builtin_readcyclecounter(); CTR(24, t2 - t_ph); t_ph = t2; }
+#endif
+      // ---- P4: commit everything before the first failed filter ----
       u32 n_commit = n_ok;
       { const u64 fb = ballot64((u32)lane < n_ok && rc.fail[lane & (KS_MAX_WAVES - 1)] != 0); if (fb) n_commit = (u32)__builtin_ctzll(fb); }
-      if (wv < n_commit) {
+#ifdef KS_CHECK
+      n_commit = min(n_commit, UF(rc.pad0));
+#endif
+      if (wv != 0 && kw < n_commit) {
         const u32 sw = pb.slot; const bool ex = sw < tb.E;
         const Rec r = slot_rec(S, tb, sw);
         if (filtered) {
@@ -1382,35 +1434,30 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         topology_record<true>(P, S, tb, pb, sh, r, sw, lane);
         LSYNC();
         write_record<BOUNDS, RM>(tb, r, pb, sh, pb.rm, lane);
-        if (lane == 0) { if (!ex) r.count() = pb.count + 1; tb.pod_node[pod_w] = (i32)sw; tb.pod_seq[pod_w] = (i32)(UF(rc.seq0) + wv); }
+        if (lane == 0) { if (!ex) r.count() = pb.count + 1; tb.pod_node[pod_w] = (i32)sw; tb.pod_seq[pod_w] = (i32)(UF(rc.seq0) + kw); }
       }
       if (wv == 0) {
-        u32 moved_before = 0;      // bit j: winner j was a new node (it left its place in the window)
-        for (u32 k = 0; k < n_commit; ++k) {
-          const u32 u = UF(rc.win[k]);
-          if (u >= tb.E) {
-            CTR(KS_STAT_FULLCHECKS, 1);
-            // Where is the node now?  An earlier winner that stood before it in its OWN count bucket left a gap and went
-            // behind it (front of the next bucket): one place to the left.  A winner from a lower bucket was re-inserted
-            // at the front of a bucket that is still before (or is) this node's: no net shift.  Winners behind it: none.
-            const u32 cnt = UF(rc.cnt[u]);
-            u32 shift = 0; for (u32 j = 0; j < k; ++j) { const u32 wj = UF(rc.win[j]); if (((moved_before >> j) & 1u) && wj < u && UF(rc.cnt[wj]) == cnt) ++shift; }
-            const u32 p = u - shift - tb.E;
-            const u32 jw = UF(ORD_RD(p));
-            const u32 endc = UF(BST(cnt + 1));
-            for (u32 i = p + 1; i < endc; i += 64) { const u32 ii = i + lane; u32 v = 0; if (ii < endc) v = ORD_RD(ii); if (ord_in_lds) LSYNC(); else GSYNC(); if (ii < endc) ORD_WR(ii - 1, v); }
-            if (ord_in_lds) LSYNC(); else GSYNC();
-            if (lane == 0) { ORD_WR(endc - 1, jw); BST(cnt + 1) = endc - 1; if (cnt + 1 > maxc) BST(cnt + 2) = nnew; }
-            if (cnt + 1 > maxc) maxc = cnt + 1;
-            LSYNC();
-            moved_before |= 1u << k;
-          }
+        // undo, last first, the moves made for pods that do not commit after all: the node sits at the front of its
+        // new bucket (later moves into that bucket were undone before it); it returns to position p of the old one
+        for (u32 k = n_ok; k > n_commit; --k) {
+          if (!RL((u32)mv_done, k - 1)) continue;
+          const u32 p = RL(mv_p, k - 1), cnt = RL(mv_cnt, k - 1);
+          const u32 at = UF(BST(cnt + 1));                         // == endc - 1 of the move
+          const u32 jw = UF(ORD_RD(at));
+          for (u32 hi = at; hi > p; ) { const u32 lo = hi > p + 64 ? hi - 64 : p; const u32 ii = lo + lane; u32 v = 0; if (ii < hi) v = ORD_RD(ii); if (ord_in_lds) LSYNC(); else GSYNC(); if (ii < hi) ORD_WR(ii + 1, v); if (ord_in_lds) LSYNC(); else GSYNC(); hi = lo; }
+          if (lane == 0) { ORD_WR(p, jw); BST(cnt + 1) = at + 1; }
+          maxc = RL(mv_maxc, k - 1);
+          if (ord_in_lds) LSYNC(); else GSYNC();
         }
         q_head += n_commit; if (q_head >= nP) q_head -= nP;
         q_len -= n_commit; seq += n_commit; CTR(KS_STAT_POPS, n_commit); CTR(21, 1);
+        CTR(KS_STAT_FULLCHECKS, (u32)__builtin_popcountll(ballot64((u32)lane < n_commit && my_win >= tb.E)));
+#ifdef KS_PROBES
+        CTR(8, rn); CTR(9, 1); CTR(10, n_commit); CTR(11, n_ok); CTR(27, __builtin_readcyclecounter() - t_round); CTR(25, __builtin_readcyclecounter() - t_ph);
+#endif
         pf_ok = false; r_valid = false;
+        if ((u32)lane < n_commit) { const u32 ck = (u32)(rc.qe[lane & (KS_MAX_WAVES - 1)] >> 32) & 0x7FFFFFFFu; atomicAnd(&ls.hard[(ck >> 5) & 7u], ~(1u << (ck & 31u))); }
         if (n_commit == 0) seq_credit = 1;            // the head pod needs more than the window offers: take it sequentially
-        else if (n_commit == 1) seq_credit = 3;       // little to win here: spare a few rounds' overhead
       }
       __syncthreads();
     }

@@ -15,3 +15,9 @@ print("total cycles", tot, "per pod", tot/pods, "chunks/pod", st["scan_chunks"]/
 n1, n2 = st.get("n_kind1",0), st.get("n_kind2",0); n0 = st["queue_pops"] - n1 - n2
 for nm, cy, n in (("no topology in eval", st.get("cyc_kind0",0), n0), ("narrow-key topology", st.get("cyc_kind1",0), n1), ("hostname topology", st.get("cyc_kind2",0), n2)): print("%-22s pops %7d  cycles/pop %8.0f  share %4.1f%%" % (nm, n, cy/max(n,1), 100*cy/tot))
 print("eq-eligible pods %d, window seeds %d, reuse hits %d, exhausted %d" % (st.get("eq_pods",0), st.get("reuse_seeds",0), st.get("reuse_hits",0), st.get("reuse_exhausted",0)))
+if not os.environ.get("KS_ONE_WAVE"):
+    print("multi-wave: rounds %d, pods offered %d, assigned %d, committed %d (%.2f per round); round cycles %.0f each; sequential pods %d at %.0f cycles" % (
+        st.get("reuse_exhausted",0), st.get("eq_pods",0), st.get("reuse_hits",0), st.get("reuse_seeds",0), st.get("reuse_seeds",0)/max(st.get("reuse_exhausted",0),1),
+        st.get("cyc_kind0",0)/max(st.get("reuse_exhausted",0),1), st.get("n_kind1",0), st.get("cyc_kind1",0)/max(st.get("n_kind1",0),1)))
+    nr = max(st.get("reuse_exhausted",0),1)
+    print("round phases (leader clock, cycles/round): evaluate %.0f  resolve %.0f  publish+filter %.0f  commit+moves %.0f" % (st.get("p22",0)/nr, st.get("p23",0)/nr, st.get("p24",0)/nr, st.get("p25",0)/nr))
