@@ -470,6 +470,7 @@ struct LeaderShared {                // owned by wave 0, which carries the Solve
 #define KS_MAX_WAVES 8
 struct RoundCtl {                    // round speculation hand-off between the leader and the other waves
   u32 mode, n, nnew, seq0, n_ok, ord_in_lds, pad0, pad1;
+  u32 cmd, scan_base, scan_total, scan_cidx;     // scan-ahead service of the sequential path (waves 1.. evaluate the windows after the leader's)
   u64 qe[KS_MAX_WAVES], m[KS_MAX_WAVES], T[KS_MAX_WAVES], R[KS_MAX_WAVES];
   u32 elig[KS_MAX_WAVES], win[KS_MAX_WAVES], fail[KS_MAX_WAVES];
   u32 cnt[64];
@@ -1108,6 +1109,13 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       const bool fresh = !reuse && pos_base >= total;
       u32 m_t = 0, lim = 0xFFFFFFFFu, ltypes = 0; size_t mc = 0;
       u64 m = 0, reach = 0;
+      // Scan ahead: while wave 0 evaluates this window, waves 1..NW-1 evaluate the NW-1 windows after it for the same pod;
+      // if this window has no candidate the leader jumps straight to the first window that has one.
+      const bool scanning = NW > 1 && !reuse && !fresh && pos_base + 64 < total;
+      if constexpr (NW > 1) if (scanning) {
+        if (lane == 0) { rc.scan_base = pos_base + 64; rc.scan_total = total; rc.scan_cidx = cidx; rc.ord_in_lds = ord_in_lds ? 1u : 0u; rc.cmd = 1; }
+        __syncthreads();
+      }
       if (reuse) {
         // the kept evaluations are still exact: no node of the window changed except the ones taken out of it
         pos_base = r_base - r_removed;
@@ -1167,6 +1175,15 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       PROBE(26);
       m = ballot64(ev.rc == 2);
       reach = ballot64(ev.rc >= 1);
+      }
+      if constexpr (NW > 1) if (scanning) {
+        __syncthreads();
+        if (m == 0) {
+          const u32 ns = min((u32)NW - 1u, (total - (pos_base + 64) + 63) / 64);       // windows the helpers covered
+          const u64 hm = (u32)lane < ns ? rc.m[lane & (KS_MAX_WAVES - 1)] : 0ull;
+          const u64 hb = ballot64(hm != 0);
+          pos_base += 64 * (hb ? (u32)__builtin_ctzll(hb) : ns);                          // the loop's own `+= width` completes the jump
+        }
       }
       if (!fresh) { PROBE(14); CTR(21, 1); }
       u32 my_alive = 0; u32 visited = fresh ? 0 : min(width, total - pos_base);   // lanes the reference would have visited (all, unless one succeeds)
@@ -1297,6 +1314,40 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     }
     } while (0);
     if constexpr (NW == 1) { if (done || err) break; }
+    else {
+      if (wv == 0) { if (lane == 0) rc.cmd = 0; __syncthreads(); }        // release the scan-ahead helpers
+      else {
+        bool staged = false; ClsR cr;
+        for (;;) {
+          __syncthreads();
+          if (UF(rc.cmd) == 0) break;
+          const u32 base = UF(rc.scan_base) + 64u * (wv - 1), total = UF(rc.scan_total);
+          u64 m = 0;
+          if (base < total) {
+            if (!staged) {      // once per pod: nothing the evaluation reads changes while the leader looks for a node
+              const u32 cidx = UF(rc.scan_cidx);
+              { const GA u32x4* src = (const GA u32x4*)(plans + cidx); u32x4* dst = (u32x4*)&sh.cls; dst[lane] = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = src[lane + 64]; }
+              stage_class(tb, sh, lane);
+              const ClsPlan& c = sh.cls;
+              cr.tol = UF64(c.tol); cr.reqmask = UF(c.reqmask); cr.ntouch = UF(c.ntouch); cr.nhost = UF(c.nhost); cr.hn_mode = UF(c.hn_mode); cr.port_cnt = UF(c.port_cnt); cr.it_state = (i32)UF(c.it_state); cr.tkeys = UF64(c.tkeys); cr.eq = UF(c.eq);
+#pragma unroll
+              for (int i = 0; i < RM; ++i) cr.req[i] = (i64)UF64(c.req[i]);
+              if constexpr (LEAN) { cr.port_cnt = 0; cr.hn_mode = 0; cr.it_state = 0; }
+              staged = true;
+            }
+            const bool ol = UF(rc.ord_in_lds) != 0;
+            const u32 pos = base + lane;
+            slot = 0xFFFFFFFFu;
+            if (pos < total) slot = pos < tb.E ? pos : tb.E + (ol ? ord_l[pos - tb.E] : ord_g[pos - tb.E]);
+            ev.rc = 0;
+            if (slot != 0xFFFFFFFFu) eval_node<BOUNDS, LEAN, RM>(P, S, tb, sh, wb, slot, slot < tb.E, false, ev, lane, tprobe, cr);
+            m = ballot64(ev.rc == 2);
+          }
+          if (lane == 0) rc.m[wv - 1] = m;
+          __syncthreads();
+        }
+      }
+    }
     continue;
     }
 
