@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--sizes", type=int, default=50, help="ladder sizes; instance types = sizes*40")
     ap.add_argument("--cpu-sample-pods", type=int, default=10_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--whatifs", type=int, default=64, help="size of the untimed-setup consolidation what-if batch leg (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,6 +124,13 @@ def main():
     mean_kernel_s = statistics.mean(kernel_ms) / 1e3
     achieved = abytes / mean_kernel_s / 1e9
     grid_bytes = dims["C"] * (8 * dims["R"] + 16 * dims["K"] + 16) + dims["T"] * (8 * dims["R"] + 16 * dims["K"] + 8) + dims["M"] * dims["C"] * TW * 8
+    traffic = None          # HBM bytes per ks_pack launch from the committed rocprofv3 --pmc passes of this same command
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_hbm_pmc.json")))["ks_pack_per_launch"]
+        if dims["P"] == 100_000 and dims["T"] == 2000:
+            traffic = pmc["hbm_bytes_fetch_x2"]
+    except Exception:
+        pass
     out = {
         "metric": "pod-placement decisions/sec (Solve())", "value": value, "unit": "decisions/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -135,13 +143,29 @@ def main():
         "p50_solve_latency_ms": statistics.median(lat_ms),
         "kernel_ms_mean": statistics.mean(kernel_ms), "prep_seconds_untimed": prep_s,
         "roofline": {"kernel": "ks_pack", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": abytes,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/r01_bench_hbm_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" if traffic else None,
+                     "algorithmic_bytes_per_launch": abytes,
                      "ref_attempts": st["attempts"], "ref_types_scanned": st["types_scanned"],
-                     "note": "one Solve() is a serial dependency chain executed by ONE workgroup (1 of 256 CUs); it is latency-bound, "
-                             "the HBM fraction is reported for completeness (see DESIGN.md)"},
+                     "note": "one Solve() is a serial dependency chain executed by ONE 8-wave workgroup (1 of 256 CUs); it is bound by "
+                             "instruction issue and dependent-access latency, the HBM fraction is reported for completeness (see DESIGN.md)"},
         "grid": {"kernel": "ks_grid_mc+ks_grid_types", "ms": grid_ms, "algorithmic_bytes": grid_bytes,
                  "achieved_GBs": grid_bytes / (grid_ms / 1e3) / 1e9 if grid_ms else None},
     }
+    if args.whatifs and world == 1:
+        # BASELINE configs[3] shape, bounded: independent consolidation what-ifs over one 2048-node snapshot, ONE launch,
+        # one single-wave workgroup per what-if (what fills the other 255 CUs; untimed setup, timed solve_batch).
+        probs = W.config4(args.whatifs, 2048, args.sizes)
+        flats = [S.FlatProblem(p) for p in probs]
+        for f in flats:
+            f.upload(local_rank)
+        S.solve_batch(flats, decode=False)
+        runs = [S.solve_batch(flats, decode=False)[1:] for _ in range(3)]
+        kms, wms = sorted(r[0] for r in runs)[1], sorted(r[1] for r in runs)[1]
+        wpods = sum(f.dims["P"] for f in flats)
+        out["whatif_batch"] = {"workload": f"{args.whatifs} consolidation what-ifs over 2048 existing nodes / {dims['T']} instance types "
+                                           "(BASELINE configs[3] shape, bounded sample)", "whatifs": args.whatifs, "decisions": wpods,
+                               "kernel_ms": kms, "wall_ms": wms, "decisions_per_s_kernel": wpods / (kms / 1e3),
+                               "decisions_per_s_wall": wpods / (wms / 1e3), "whatifs_per_s_wall": args.whatifs / (wms / 1e3)}
     if not args.no_cpu_baseline:
         from oracle import oracle_py
         sample = W.config3(pods=args.cpu_sample_pods, sizes=args.sizes, seed=44)

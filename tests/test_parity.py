@@ -64,6 +64,14 @@ def test_general_kernel_variant_on_lean_problems(monkeypatch):
     assert_same(W.config1(pods=400, types=20, seed=3))
 
 
+def test_single_wave_kernel_on_a_multi_wave_problem(monkeypatch):
+    """A single LEAN Solve normally runs the 8-wave kernel (speculation rounds + scan-ahead); KS_ONE_WAVE forces the
+    single-wave variant (the one batches use), which must give the same bits."""
+    monkeypatch.setenv("KS_ONE_WAVE", "1")
+    assert_same(W.config3(pods=3500, sizes=20, seed=44))
+    assert_same(W.config2(pods=2000, sizes=10, seed=43))
+
+
 def test_whatifs_single_and_batched():
     its, prov, nodes, bound = W.cluster_snapshot(existing=96, sizes=8, seed=45)
     probs = [W.whatif(its, prov, nodes, bound, list(range(0, i + 1))) for i in range(6)] + \

@@ -3,7 +3,7 @@
 # traffic counters in their own passes (never combined with tracing domains other than --kernel-trace).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_$1; mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --whatifs 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py $ARGS > $OUT/bench_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- python $R/bench.py $ARGS > $OUT/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- python $R/bench.py $ARGS > $OUT/bench_write.log 2>&1
