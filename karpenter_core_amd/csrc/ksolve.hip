@@ -105,6 +105,7 @@ struct DevState {
   u64* pp_entry; i32* pp_next; u32 pp_cap;
   // outputs
   u64* stats; u32* out_counts;   // out_counts: [0]=n_new [1]=n_unscheduled
+  u64* batch_meta;               // batched launches: [0]=n_new [1]=n_unscheduled [2..33]=stats of this problem in one batch-wide array (one read-back)
   i32* unscheduled;
   u32* o_present; u32* o_complement; u64* o_mask; i32* o_gt; i32* o_lt; i32* o_it; i64* o_req; u32* o_reqmask;
 };
@@ -471,7 +472,7 @@ struct LeaderShared {                // owned by wave 0, which carries the Solve
 struct RoundCtl {                    // round speculation hand-off between the leader and the other waves
   u32 mode, n, nnew, seq0, n_ok, ord_in_lds, pad0, pad1;
   u32 cmd, scan_base, scan_total, scan_cidx;     // scan-ahead service of the sequential path (waves 1.. evaluate the windows after the leader's)
-  u64 qe[KS_MAX_WAVES], m[KS_MAX_WAVES], T[KS_MAX_WAVES], R[KS_MAX_WAVES];
+  u64 qe[2 * KS_MAX_WAVES], m[KS_MAX_WAVES], T[KS_MAX_WAVES], R[KS_MAX_WAVES];   // qe: this round's pods and the ones after them (plan prefetch)
   u32 elig[KS_MAX_WAVES], win[KS_MAX_WAVES], fail[KS_MAX_WAVES];
   u32 cnt[64];
 };
@@ -1016,6 +1017,8 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
   Ev ev; ev.rc = 0; u32 slot = 0xFFFFFFFFu;
   bool r_valid = false; u32 r_eq = 0, r_base = 0, r_removed = 0, r_lim = 0; u64 r_mask = 0;
   bool done = false; u32 seq_credit = 0, iters = 0;
+  u64 pq_e = 0; bool pq_ok = false;      // leader: the next 2*(NW-1) queue entries, requested at the end of the previous step
+  u32 wpf_cidx = 0xFFFFFFFFu;            // workers: class whose plan sits prefetched in pf0/pf1
 
   // ---------------- Solve loop, scheduler.go:104-124 ----------------
   for (;;) {
@@ -1042,14 +1045,14 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         if (done || err || q_len == 0) mode = 0;
         else if (seq_credit == 0 && q_len >= 2) {
           // the next NW queue entries, up to the first requeued one (its staleness test needs the sequential state)
-          const u32 cap = min((u32)NW - 1u, q_len); u64 e = 0;
-          if ((u32)lane < cap) { u32 idx = q_head + lane; if (idx >= nP) idx -= nP; e = tb.q[idx]; }
+          const u32 cap = min((u32)NW - 1u, q_len); u64 e = pq_e;
+          if (!pq_ok) { u32 idx = q_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; e = (u32)lane < 2u * (NW - 1) ? tb.q[idx] : 0ull; }
           const u64 rq_bits = ballot64((u32)lane < cap && (e >> 63) != 0);
           u32 rn = rq_bits ? (u32)__builtin_ctzll(rq_bits) : cap;
           // a class whose last pod had to look past the window (or open a node) will most likely do so again: a round
           // would evaluate it for nothing -- take it sequentially right away
           { const u32 c0 = RL((u32)(e >> 32), 0) & 0x7FFFFFFFu; if ((UF(ls.hard[(c0 >> 5) & 7u]) >> (c0 & 31u)) & 1u) rn = 0; }
-          if (rn >= 2) { mode = 2; if ((u32)lane < rn) rc.qe[lane] = e; if (lane == 0) { rc.n = rn; rc.nnew = nnew; rc.seq0 = seq; rc.ord_in_lds = ord_in_lds ? 1u : 0u; } }
+          if (rn >= 2) { mode = 2; if ((u32)lane < 2u * (NW - 1)) rc.qe[lane] = e; if (lane == 0) { rc.n = rn; rc.nnew = nnew; rc.seq0 = seq; rc.ord_in_lds = ord_in_lds ? 1u : 0u; } }
         }
         if (mode == 1 && seq_credit) --seq_credit;
         if (lane == 0) rc.mode = mode;
@@ -1315,7 +1318,11 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     } while (0);
     if constexpr (NW == 1) { if (done || err) break; }
     else {
-      if (wv == 0) { if (lane == 0) rc.cmd = 0; __syncthreads(); }        // release the scan-ahead helpers
+      if (wv == 0) {
+        if (lane == 0) rc.cmd = 0;
+        { u32 idx = q_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; pq_e = (u32)lane < 2u * (NW - 1) ? tb.q[idx] : 0ull; pq_ok = true; }   // for the next planning step
+        __syncthreads();                                                   // release the scan-ahead helpers
+      }
       else {
         bool staged = false; ClsR cr;
         for (;;) {
@@ -1377,7 +1384,8 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       if (wv != 0 && kw < rn) {
         const u64 qe = UF64(rc.qe[kw]);
         pod_w = (u32)qe; const u32 cidx = (u32)(qe >> 32) & 0x7FFFFFFFu;
-        { const GA u32x4* src = (const GA u32x4*)(plans + cidx); u32x4* dst = (u32x4*)&sh.cls; dst[lane] = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = src[lane + 64]; }
+        if (wpf_cidx != cidx) { const GA u32x4* src = (const GA u32x4*)(plans + cidx); pf0 = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) pf1 = src[lane + 64]; wpf_cidx = cidx; }   // else: requested during the last round's commit
+        { u32x4* dst = (u32x4*)&sh.cls; dst[lane] = pf0; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = pf1; }
         stage_class(tb, sh, lane);
         const ClsPlan& c = sh.cls;
         cr.tol = UF64(c.tol); cr.reqmask = UF(c.reqmask); cr.ntouch = UF(c.ntouch); cr.nhost = UF(c.nhost); cr.hn_mode = UF(c.hn_mode); cr.port_cnt = UF(c.port_cnt); cr.it_state = (i32)UF(c.it_state); cr.tkeys = UF64(c.tkeys); cr.eq = UF(c.eq);
@@ -1487,6 +1495,10 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         write_record<BOUNDS, RM>(tb, r, pb, sh, pb.rm, lane);
         if (lane == 0) { if (!ex) r.count() = pb.count + 1; tb.pod_node[pod_w] = (i32)sw; tb.pod_seq[pod_w] = (i32)(UF(rc.seq0) + kw); }
       }
+      if (wv != 0) {     // the pod this wave evaluates next round (if a round follows): request its class plan now
+        const u32 cn = (u32)(UF64(rc.qe[(n_commit + kw) & (2 * KS_MAX_WAVES - 1)]) >> 32) & 0x7FFFFFFFu;
+        if (cn != wpf_cidx) { const GA u32x4* src = (const GA u32x4*)(plans + cn); pf0 = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) pf1 = src[lane + 64]; wpf_cidx = cn; }
+      }
       if (wv == 0) {
         // undo, last first, the moves made for pods that do not commit after all: the node sits at the front of its
         // new bucket (later moves into that bucket were undone before it); it returns to position p of the old one
@@ -1507,6 +1519,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         CTR(8, rn); CTR(9, 1); CTR(10, n_commit); CTR(11, n_ok); CTR(27, __builtin_readcyclecounter() - t_round); CTR(25, __builtin_readcyclecounter() - t_ph);
 #endif
         pf_ok = false; r_valid = false;
+        { u32 idx = q_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; pq_e = (u32)lane < 2u * (NW - 1) ? tb.q[idx] : 0ull; pq_ok = true; }   // for the next planning step
         if ((u32)lane < n_commit) { const u32 ck = (u32)(rc.qe[lane & (KS_MAX_WAVES - 1)] >> 32) & 0x7FFFFFFFu; atomicAnd(&ls.hard[(ck >> 5) & 7u], ~(1u << (ck & 31u))); }
         if (n_commit == 0) seq_credit = 1;            // the head pod needs more than the window offers: take it sequentially
       }
@@ -1528,6 +1541,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     S.out_counts[0] = nnew; S.out_counts[1] = q_len;
     for (int i = 0; i < 32; ++i) S.stats[i] = ls.ctr[i];
     S.stats[KS_STAT_CYCLES] = __builtin_readcyclecounter() - t_start; S.stats[KS_STAT_ERR] = err;
+    if (S.batch_meta) { S.batch_meta[0] = nnew; S.batch_meta[1] = q_len; for (int i = 0; i < 32; ++i) S.batch_meta[2 + i] = S.stats[i]; }
   }
 }
 
@@ -1731,6 +1745,66 @@ extern "C" int ks_feasibility_grid(ks_dev_problem* d, uint64_t* out_grid, float*
   return KS_OK;
 }
 
+// Batched read-back: one descriptor per problem, one block copies that problem's result arrays into a contiguous blob
+// (segments in the order of ks_gather_layout), so the host needs three transfers per batch instead of ~16 per problem.
+struct GatherDesc { u64 off; u32 P, K, R, TW, N, pad; };
+struct GatherSeg { const void* src; u64 bytes; };
+__device__ __host__ inline u64 ks_pad8(u64 b) { return (b + 7) & ~7ull; }
+__global__ __launch_bounds__(256) void ks_gather(const DevState* states, const GatherDesc* descs, u8* blob) {
+  const DevState& s = states[blockIdx.x]; const GatherDesc g = descs[blockIdx.x];
+  const u64 P = g.P, N = g.N, K = g.K, R = g.R, TW = g.TW;
+  const GatherSeg segs[14] = {{s.pod_node, P * 4}, {s.pod_stage, P * 4}, {s.pod_seq, P * 4}, {s.unscheduled, P * 4}, {s.n_tmpl, N * 4}, {s.n_alive, N * TW * 8},
+                              {s.o_req, N * R * 8}, {s.o_reqmask, N * 4}, {s.o_present, N * 4}, {s.o_complement, N * 4}, {s.o_mask, N * K * 8}, {s.o_gt, N * K * 4},
+                              {s.o_lt, N * K * 4}, {s.o_it, N * 4}};
+  u64 off = g.off;
+  for (int i = 0; i < 14; ++i) {
+    const u32* src = (const u32*)segs[i].src; u32* dst = (u32*)(blob + off);
+    for (u64 j = threadIdx.x; j < segs[i].bytes / 4; j += blockDim.x) dst[j] = src[j];
+    off += ks_pad8(segs[i].bytes);
+  }
+}
+static u64 ks_gather_bytes(u64 P, u64 K, u64 R, u64 TW, u64 N) {
+  return 4 * ks_pad8(P * 4) + ks_pad8(N * 4) + ks_pad8(N * TW * 8) + ks_pad8(N * R * 8) + 3 * ks_pad8(N * 4) + ks_pad8(N * K * 8) + 2 * ks_pad8(N * K * 4) + ks_pad8(N * 4);
+}
+static int ks_stats_error(const u64* stats) {
+  if (!stats[KS_STAT_ERR]) return KS_OK;
+  return fail(-(int)stats[KS_STAT_ERR], stats[KS_STAT_ERR] == (u64)(-KS_ERR_CAPACITY) ? "more new nodes than max_new_nodes" :
+              stats[KS_STAT_ERR] == (u64)(-KS_ERR_INTERNAL) ? "pack kernel watchdog: step bound exceeded" :
+              stats[KS_STAT_ERR] >= 100 ? "pack kernel self-check failed (KS_CHECK build): visiting order inconsistent" :
+              "a pod class exceeds the kernel's per-class limits (12 touched keys / 24 topology groups / 3 hostname groups / 24 recorded groups)");
+}
+static int download_batch(ks_dev_problem* const* ds, u32 n, const DevState* dsv, const u64* d_meta, ks_result* const* outs) {
+  std::vector<u64> meta((size_t)n * 34);
+  HIPCHK(hipMemcpy(meta.data(), d_meta, meta.size() * sizeof(u64), hipMemcpyDeviceToHost));
+  std::vector<GatherDesc> descs(n); u64 total = 0;
+  for (u32 i = 0; i < n; ++i) {
+    const DevProb& h = ds[i]->h; ks_result* out = outs[i];
+    out->n_new = (u32)meta[(size_t)i * 34]; out->n_unscheduled = (u32)meta[(size_t)i * 34 + 1];
+    memcpy(out->stats, &meta[(size_t)i * 34 + 2], 32 * sizeof(u64));
+    TRY(ks_stats_error(out->stats));
+    descs[i] = GatherDesc{total, h.P, h.K, h.R, h.TW, out->n_new, 0};
+    total += ks_gather_bytes(h.P, h.K, h.R, h.TW, out->n_new);
+  }
+  GatherDesc* d_desc = nullptr; u8* d_blob = nullptr;
+  HIPCHK(hipMalloc((void**)&d_desc, n * sizeof(GatherDesc))); HIPCHK(hipMalloc((void**)&d_blob, total ? total : 8));
+  HIPCHK(hipMemcpy(d_desc, descs.data(), n * sizeof(GatherDesc), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ks_gather, dim3(n), dim3(256), 0, ds[0]->stream, dsv, d_desc, d_blob);
+  std::vector<u8> blob(total ? total : 8);
+  HIPCHK(hipMemcpyAsync(blob.data(), d_blob, total ? total : 8, hipMemcpyDeviceToHost, ds[0]->stream));
+  HIPCHK(hipStreamSynchronize(ds[0]->stream));
+  hipFree(d_desc); hipFree(d_blob);
+  for (u32 i = 0; i < n; ++i) {
+    const DevProb& h = ds[i]->h; ks_result* out = outs[i]; const u64 P = h.P, K = h.K, R = h.R, TW = h.TW, N = out->n_new;
+    const u8* p = blob.data() + descs[i].off;
+    auto take = [&](void* dst, u64 bytes) { if (bytes) memcpy(dst, p, bytes); p += ks_pad8(bytes); };
+    take(out->pod_node, P * 4); take(out->pod_stage, P * 4); take(out->pod_seq, P * 4); take(out->unscheduled, P * 4);
+    take(out->node_tmpl, N * 4); take(out->node_types, N * TW * 8); take(out->node_requests, N * R * 8); take(out->node_requests_present, N * 4);
+    take(out->node_present, N * 4); take(out->node_complement, N * 4); take(out->node_mask, N * K * 8); take(out->node_gt, N * K * 4); take(out->node_lt, N * K * 4);
+    take(out->node_it_state, N * 4);
+  }
+  return KS_OK;
+}
+
 static int download(ks_dev_problem* d, ks_result* out) {
   const DevProb& h = d->h; const DevState& s = d->hs;
   u32 counts[4]; HIPCHK(hipMemcpy(counts, s.out_counts, sizeof counts, hipMemcpyDeviceToHost));
@@ -1766,9 +1840,11 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   for (u32 i = 0; i < n; ++i) { if (ds[i]->device != device) return fail(KS_ERR_INVALID, "batch spans devices"); if (!ds[i]->tables_built) TRY(build_static(ds[i], nullptr)); }
   std::vector<DevProb> hp(n); std::vector<DevState> hs(n);
   for (u32 i = 0; i < n; ++i) { hp[i] = ds[i]->h; hs[i] = ds[i]->hs; }
-  DevProb* dp = nullptr; DevState* dsv = nullptr;
+  DevProb* dp = nullptr; DevState* dsv = nullptr; u64* d_meta = nullptr;
   if (n == 1) { dp = ds[0]->d_prob; dsv = ds[0]->d_state; }
   else {
+    HIPCHK(hipMalloc((void**)&d_meta, (size_t)n * 34 * sizeof(u64)));
+    for (u32 i = 0; i < n; ++i) hs[i].batch_meta = d_meta + (size_t)i * 34;
     HIPCHK(hipMalloc((void**)&dp, n * sizeof(DevProb))); HIPCHK(hipMalloc((void**)&dsv, n * sizeof(DevState)));
     HIPCHK(hipMemcpy(dp, hp.data(), n * sizeof(DevProb), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dsv, hs.data(), n * sizeof(DevState), hipMemcpyHostToDevice));
   }
@@ -1806,9 +1882,10 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   HIPCHK(hipGetLastError());
   if (kernel_ms) HIPCHK(hipEventElapsedTime(kernel_ms, e0, e1));
   hipEventDestroy(e0); hipEventDestroy(e1);
-  if (n > 1) { hipFree(dp); hipFree(dsv); }
-  for (u32 i = 0; i < n; ++i) TRY(download(ds[i], outs[i]));
-  return KS_OK;
+  int rc = KS_OK;
+  if (n > 1) { rc = download_batch(ds, n, dsv, d_meta, outs); hipFree(dp); hipFree(dsv); hipFree(d_meta); }
+  else rc = download(ds[0], outs[0]);
+  return rc;
 }
 
 extern "C" int ks_solve_dev(ks_dev_problem* d, ks_result* out, float* kernel_ms) {
