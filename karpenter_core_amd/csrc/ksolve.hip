@@ -470,9 +470,11 @@ struct LeaderShared {                // owned by wave 0, which carries the Solve
 };
 #define KS_MAX_WAVES 8
 struct RoundCtl {                    // round speculation hand-off between the leader and the other waves
-  u32 mode, n, nnew, seq0, n_ok, ord_in_lds, pad0, pad1;
+  u32 mode2[2], n, nnew, seq0, n_ok, ord_in_lds, pad0;   // mode2: double-buffered by step parity (the leader may plan the next step before a slow wave has read this one's)
   u32 cmd, scan_base, scan_total, scan_cidx;     // scan-ahead service of the sequential path (waves 1.. evaluate the windows after the leader's)
-  u64 qe[2 * KS_MAX_WAVES], m[KS_MAX_WAVES], T[KS_MAX_WAVES], R[KS_MAX_WAVES];   // qe: this round's pods and the ones after them (plan prefetch)
+  u64 qe[2][2 * KS_MAX_WAVES];   // this round's pods and the ones after them (plan prefetch); double-buffered: the leader plans the next step while workers still read
+  u32 par, pad2;
+  u64 m[KS_MAX_WAVES], T[KS_MAX_WAVES], R[KS_MAX_WAVES];
   u32 elig[KS_MAX_WAVES], win[KS_MAX_WAVES], fail[KS_MAX_WAVES];
   u32 cnt[64];
 };
@@ -1021,13 +1023,34 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
   u32 wpf_cidx = 0xFFFFFFFFu;            // workers: class whose plan sits prefetched in pf0/pf1
 
   // ---------------- Solve loop, scheduler.go:104-124 ----------------
+  // Planning (wave 0): what the next step of the loop is -- 0 done, 1 one pod sequentially, 2 speculation round.  It runs at
+  // the END of a step, so the barrier that ends the step also publishes the plan.
+  u32 plan_par = 0, stepc = 0;     // stepc: loop iterations started (every wave counts them alike)
+  auto plan = [&]() {
+        u32 mode = 1; const u32 wpar = plan_par ^ 1u;
+        if (++iters > 8u * nP + 4096u) err = (u32)(-KS_ERR_INTERNAL);      // watchdog: a Solve needs at most a few steps per pod
+        if (done || err || q_len == 0) mode = 0;
+        else if (seq_credit == 0 && q_len >= 2) {
+          // the next NW queue entries, up to the first requeued one (its staleness test needs the sequential state)
+          const u32 cap = min((u32)NW - 1u, q_len); u64 e = pq_e;
+          if (!pq_ok) { u32 idx = q_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; e = (u32)lane < 2u * (NW - 1) ? tb.q[idx] : 0ull; }
+          const u64 rq_bits = ballot64((u32)lane < cap && (e >> 63) != 0);
+          u32 rn = rq_bits ? (u32)__builtin_ctzll(rq_bits) : cap;
+          // a class whose last pod had to look past the window (or open a node) will most likely do so again: a round
+          // would evaluate it for nothing -- take it sequentially right away
+          { const u32 c0 = RL((u32)(e >> 32), 0) & 0x7FFFFFFFu; if ((UF(ls.hard[(c0 >> 5) & 7u]) >> (c0 & 31u)) & 1u) rn = 0; }
+          if (rn >= 2) { mode = 2; if ((u32)lane < 2u * (NW - 1)) rc.qe[wpar][lane] = e; if (lane == 0) { rc.par = wpar; rc.n = rn; rc.nnew = nnew; rc.seq0 = seq; rc.ord_in_lds = ord_in_lds ? 1u : 0u; } }
+        }
+        if (mode == 1 && seq_credit) --seq_credit;
+        if (mode == 2) plan_par = wpar;
+        if (lane == 0) rc.mode2[stepc & 1u] = mode;
+  };
+  if constexpr (NW > 1) { if (wv == 0) plan(); __syncthreads(); }
   for (;;) {
     u32 mode = 1;   // 0 done, 1 one pod sequentially (wave 0), 2 speculation round
-    if constexpr (NW > 1) {
-      if (wv == 0) {
-        if (++iters > 8u * nP + 4096u) err = (u32)(-KS_ERR_INTERNAL);      // watchdog: a Solve needs at most a few steps per pod
+    if constexpr (NW > 1) { mode = UF(rc.mode2[stepc & 1u]); ++stepc; if (mode == 0) break; }
 #ifdef KS_CHECK   /* debug builds: the visiting order must list every new node once, by nondecreasing pod count, inside its bucket */
-        if (!err) {
+    if (NW > 1 && wv == 0 && !err) {
           GSYNC();
           u32 bad = 0;
           for (u32 i = lane; i < nnew; i += 64) {
@@ -1040,27 +1063,8 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           }
           const u64 bb = ballot64(bad != 0);
           if (bb) err = 100u + RL(bad, __builtin_ctzll(bb));
-        }
-#endif
-        if (done || err || q_len == 0) mode = 0;
-        else if (seq_credit == 0 && q_len >= 2) {
-          // the next NW queue entries, up to the first requeued one (its staleness test needs the sequential state)
-          const u32 cap = min((u32)NW - 1u, q_len); u64 e = pq_e;
-          if (!pq_ok) { u32 idx = q_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; e = (u32)lane < 2u * (NW - 1) ? tb.q[idx] : 0ull; }
-          const u64 rq_bits = ballot64((u32)lane < cap && (e >> 63) != 0);
-          u32 rn = rq_bits ? (u32)__builtin_ctzll(rq_bits) : cap;
-          // a class whose last pod had to look past the window (or open a node) will most likely do so again: a round
-          // would evaluate it for nothing -- take it sequentially right away
-          { const u32 c0 = RL((u32)(e >> 32), 0) & 0x7FFFFFFFu; if ((UF(ls.hard[(c0 >> 5) & 7u]) >> (c0 & 31u)) & 1u) rn = 0; }
-          if (rn >= 2) { mode = 2; if ((u32)lane < 2u * (NW - 1)) rc.qe[lane] = e; if (lane == 0) { rc.n = rn; rc.nnew = nnew; rc.seq0 = seq; rc.ord_in_lds = ord_in_lds ? 1u : 0u; } }
-        }
-        if (mode == 1 && seq_credit) --seq_credit;
-        if (lane == 0) rc.mode = mode;
-      }
-      __syncthreads();
-      mode = UF(rc.mode);
-      if (mode == 0) break;
     }
+#endif
     if (mode == 1) {
     if (wv == 0) do {
     // Queue.Pop, queue.go:44-58
@@ -1320,8 +1324,8 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     else {
       if (wv == 0) {
         if (lane == 0) rc.cmd = 0;
-        { u32 idx = q_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; pq_e = (u32)lane < 2u * (NW - 1) ? tb.q[idx] : 0ull; pq_ok = true; }   // for the next planning step
-        __syncthreads();                                                   // release the scan-ahead helpers
+        pq_ok = false; plan();
+        __syncthreads();                                                   // release the scan-ahead helpers; publishes the plan
       }
       else {
         bool staged = false; ClsR cr;
@@ -1373,7 +1377,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     // =====================================================================================================
     if constexpr (NW > 1) {
       // wave 0 coordinates (resolver, visiting-order moves, queue); waves 1..NW-1 each take round pod k = wave - 1
-      const u32 rn = UF(rc.n);
+      const u32 rn = UF(rc.n), par = UF(rc.par), seq0 = UF(rc.seq0);
 #ifdef KS_PROBES
       const u64 t_round = __builtin_readcyclecounter();
 #endif
@@ -1382,7 +1386,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       u32 pod_w = 0; ClsR cr;
       // ---- P1: evaluate ----
       if (wv != 0 && kw < rn) {
-        const u64 qe = UF64(rc.qe[kw]);
+        const u64 qe = UF64(rc.qe[par][kw]);
         pod_w = (u32)qe; const u32 cidx = (u32)(qe >> 32) & 0x7FFFFFFFu;
         if (wpf_cidx != cidx) { const GA u32x4* src = (const GA u32x4*)(plans + cidx); pf0 = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) pf1 = src[lane + 64]; wpf_cidx = cidx; }   // else: requested during the last round's commit
         { u32x4* dst = (u32x4*)&sh.cls; dst[lane] = pf0; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = pf1; }
@@ -1493,13 +1497,14 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         topology_record<true>(P, S, tb, pb, sh, r, sw, lane);
         LSYNC();
         write_record<BOUNDS, RM>(tb, r, pb, sh, pb.rm, lane);
-        if (lane == 0) { if (!ex) r.count() = pb.count + 1; tb.pod_node[pod_w] = (i32)sw; tb.pod_seq[pod_w] = (i32)(UF(rc.seq0) + kw); }
+        if (lane == 0) { if (!ex) r.count() = pb.count + 1; tb.pod_node[pod_w] = (i32)sw; tb.pod_seq[pod_w] = (i32)(seq0 + kw); }
       }
       if (wv != 0) {     // the pod this wave evaluates next round (if a round follows): request its class plan now
-        const u32 cn = (u32)(UF64(rc.qe[(n_commit + kw) & (2 * KS_MAX_WAVES - 1)]) >> 32) & 0x7FFFFFFFu;
+        const u32 cn = (u32)(UF64(rc.qe[par][(n_commit + kw) & (2 * KS_MAX_WAVES - 1)]) >> 32) & 0x7FFFFFFFu;
         if (cn != wpf_cidx) { const GA u32x4* src = (const GA u32x4*)(plans + cn); pf0 = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) pf1 = src[lane + 64]; wpf_cidx = cn; }
       }
       if (wv == 0) {
+        { u32 idx = q_head + n_commit + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; pq_e = (u32)lane < 2u * (NW - 1) ? tb.q[idx] : 0ull; pq_ok = true; }   // the entries the next plan looks at
         // undo, last first, the moves made for pods that do not commit after all: the node sits at the front of its
         // new bucket (later moves into that bucket were undone before it); it returns to position p of the old one
         for (u32 k = n_ok; k > n_commit; --k) {
@@ -1519,9 +1524,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         CTR(8, rn); CTR(9, 1); CTR(10, n_commit); CTR(11, n_ok); CTR(27, __builtin_readcyclecounter() - t_round); CTR(25, __builtin_readcyclecounter() - t_ph);
 #endif
         pf_ok = false; r_valid = false;
-        { u32 idx = q_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; pq_e = (u32)lane < 2u * (NW - 1) ? tb.q[idx] : 0ull; pq_ok = true; }   // for the next planning step
-        if ((u32)lane < n_commit) { const u32 ck = (u32)(rc.qe[lane & (KS_MAX_WAVES - 1)] >> 32) & 0x7FFFFFFFu; atomicAnd(&ls.hard[(ck >> 5) & 7u], ~(1u << (ck & 31u))); }
+        if ((u32)lane < n_commit) { const u32 ck = (u32)(rc.qe[par][lane & (KS_MAX_WAVES - 1)] >> 32) & 0x7FFFFFFFu; atomicAnd(&ls.hard[(ck >> 5) & 7u], ~(1u << (ck & 31u))); }
         if (n_commit == 0) seq_credit = 1;            // the head pod needs more than the window offers: take it sequentially
+        plan();
       }
       __syncthreads();
     }
