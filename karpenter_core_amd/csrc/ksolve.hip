@@ -1025,6 +1025,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
   // ---------------- Solve loop, scheduler.go:104-124 ----------------
   // Planning (wave 0): what the next step of the loop is -- 0 done, 1 one pod sequentially, 2 speculation round.  It runs at
   // the END of a step, so the barrier that ends the step also publishes the plan.
+  u32 last_commit = NW - 1;
   u32 plan_par = 0, stepc = 0;     // stepc: loop iterations started (every wave counts them alike)
   auto plan = [&]() {
         u32 mode = 1; const u32 wpar = plan_par ^ 1u;
@@ -1032,7 +1033,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         if (done || err || q_len == 0) mode = 0;
         else if (seq_credit == 0 && q_len >= 2) {
           // the next NW queue entries, up to the first requeued one (its staleness test needs the sequential state)
-          const u32 cap = min((u32)NW - 1u, q_len); u64 e = pq_e;
+          // offer two more pods than the last round committed: waves that evaluate pods the round will cut anyway only
+          // take issue slots from the ones that matter (two waves share a SIMD)
+          const u32 cap = min(min((u32)NW - 1u, q_len), last_commit + 2u); u64 e = pq_e;
           if (!pq_ok) { u32 idx = q_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; e = (u32)lane < 2u * (NW - 1) ? tb.q[idx] : 0ull; }
           const u64 rq_bits = ballot64((u32)lane < cap && (e >> 63) != 0);
           u32 rn = rq_bits ? (u32)__builtin_ctzll(rq_bits) : cap;
@@ -1526,6 +1529,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         pf_ok = false; r_valid = false;
         if ((u32)lane < n_commit) { const u32 ck = (u32)(rc.qe[par][lane & (KS_MAX_WAVES - 1)] >> 32) & 0x7FFFFFFFu; atomicAnd(&ls.hard[(ck >> 5) & 7u], ~(1u << (ck & 31u))); }
         if (n_commit == 0) seq_credit = 1;            // the head pod needs more than the window offers: take it sequentially
+        last_commit = n_commit;
         plan();
       }
       __syncthreads();
