@@ -101,6 +101,9 @@ typedef struct ks_problem {
   const int64_t* it_alloc;       /* [R*T]  Allocatable() = Capacity - Overhead.Total(), types.go:87-102 */
   const int64_t* it_cap;         /* [R*T]  Capacity (provisioner limits, scheduler.go:273-309) */
   const uint64_t* it_offer;      /* [T]    available (zone,capacity-type) pairs, types.go:106-128 */
+  const double* it_price;        /* [T*NP] Offering.Price of available pair p (NP = key_nvalues[key_zone] * n_ct; the highest one if a pair is offered
+                                    twice): read by the consolidation price stage only (ks_price_filter_dev); may be NULL */
+  int32_t ct_spot, ct_ondemand;  /* value ids of "spot" / "on-demand" in the capacity-type key's universe, or -1 */
   /* instance-type key lattice */
   const uint16_t* its_inter; /* [S*SC] node state after intersecting node state a with pod-side req b  */
   const uint8_t* its_fail;   /* [S*SC] Requirements.Intersects error for existing=a, incoming=b        */
@@ -219,6 +222,16 @@ int ks_solve_batch(const ks_problem* const* p, uint32_t n, ks_result* const* out
 /* The static pod-class x instance-type feasibility grid for fresh nodes of every template:
  * out_grid[(m*C + c)*TW + w].  Exposed for parity tests and roofline measurement. */
 int ks_feasibility_grid(ks_dev_problem* d, uint64_t* out_grid, float* kernel_ms);
+
+/* Consolidation price stage on results that are still on the device (deprovisioning/helpers.go:148-157 filterByPrice over
+ * :292-315 worstLaunchPrice; callers consolidation.go:238 and multinodeconsolidation.go:164): for problem i, of new node
+ * node[i]'s InstanceTypeOptions (as left by the last ks_solve*_dev of ds[i]) keep the types whose worst launch price under
+ * that node's zone / capacity-type requirements is < max_price[i].  out_types[i] receives ceil(T/64) words, out_counts[i]
+ * the number of types kept.  spot_only[i] != 0 prices node i as if its capacity-type requirement had already been narrowed
+ * to In [spot] (computeConsolidation does that before multi-node consolidation filters again, consolidation.go:262-265);
+ * spot_only may be NULL.  One launch for the whole batch. */
+int ks_price_filter_dev(ks_dev_problem* const* ds, uint32_t n, const uint32_t* node, const double* max_price,
+                        const uint32_t* spot_only, uint64_t* const* out_types, uint32_t* out_counts);
 
 /* ---- requirement-algebra probes (one key); the same device functions the kernels use ---- */
 typedef struct ks_req1 { uint64_t mask; int32_t gt, lt; uint8_t present, complement; } ks_req1;

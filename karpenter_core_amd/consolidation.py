@@ -80,3 +80,209 @@ def gpu_solve_many(problems: List[Problem]) -> List[SolveResult]:
     finally:
         for f in flats:
             f.close()
+
+
+# =====================================================================================================
+# Consolidation decisions on top of the batched what-ifs.
+#
+# The reference runs ONE simulateScheduling per probe: ceil(log2 N) dependent Solves for multi-node
+# consolidation's binary search (multinodeconsolidation.go:74-114), up to N sequential ones for single-node
+# consolidation's first-success scan (singlenodeconsolidation.go:43-78).  Here every prefix / every singleton
+# is solved in ONE ks_solve_batch launch, the price stage (filterByPrice over worstLaunchPrice,
+# helpers.go:148-157,292-315) runs on the device over the results while they are still there, and the
+# reference's control flow is replayed over the per-what-if commands.  Validation (validation.go: TTL wait,
+# re-simulation) and events need the live cluster and stay in Go.
+# =====================================================================================================
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+from .model import (InstanceType, LABEL_CAPACITY_TYPE, LABEL_INSTANCE_TYPE, LABEL_ZONE, Provisioner, RequirementOut,
+                    StateNode)
+
+ACTION_DO_NOTHING, ACTION_DELETE, ACTION_REPLACE = "do-nothing", "delete", "replace"   # deprovisioning/types.go actions
+CAPACITY_TYPE_SPOT, CAPACITY_TYPE_ON_DEMAND = "spot", "on-demand"
+
+
+@dataclass
+class Snapshot:
+    """What candidateNodes / simulateScheduling read from the cluster (helpers.go:42-115, 165-230)."""
+    instance_types: List[InstanceType]
+    provisioner: Provisioner
+    nodes: List[StateNode]
+    bound: List[list]                      # pods bound to each node
+
+
+@dataclass
+class CandidateNode:
+    """deprovisioning CandidateNode (types.go): the node plus what pricing reads."""
+    index: int
+    name: str
+    instance_type: str
+    capacity_type: str
+    zone: str
+
+
+@dataclass
+class Command:
+    """deprovisioning Command as far as the decision goes: action, nodesToRemove, the replacement node's options."""
+    action: str = ACTION_DO_NOTHING
+    nodes_to_remove: List[str] = field(default_factory=list)
+    replacement_types: List[str] = field(default_factory=list)                 # replacementNodes[0].InstanceTypeOptions
+    replacement_requirements: Dict[str, tuple] = field(default_factory=dict)  # ... .Requirements (canonical tuples)
+
+    def canonical(self):
+        return (self.action, tuple(self.nodes_to_remove), tuple(self.replacement_types), tuple(sorted(self.replacement_requirements.items())))
+
+
+def candidate(snapshot: Snapshot, i: int) -> CandidateNode:
+    lab = snapshot.nodes[i].labels
+    return CandidateNode(i, snapshot.nodes[i].name, lab[LABEL_INSTANCE_TYPE], lab[LABEL_CAPACITY_TYPE], lab[LABEL_ZONE])
+
+
+def _offering_price(it: InstanceType, capacity_type: str, zone: str) -> Optional[float]:
+    for o in it.offerings:                 # Offerings.Get, cloudprovider/types.go:117-124 (availability is not consulted)
+        if o.capacity_type == capacity_type and o.zone == zone:
+            return o.price
+    return None
+
+
+def get_node_prices(types: Dict[str, InstanceType], cands: Sequence[CandidateNode]) -> float:
+    """getNodePrices, consolidation.go:277-287."""
+    price = 0.0
+    for c in cands:
+        p = _offering_price(types[c.instance_type], c.capacity_type, c.zone)
+        if p is None:
+            raise ValueError(f"unable to determine offering for {c.instance_type}/{c.capacity_type}/{c.zone}")
+        price += p
+    return price
+
+
+def _has(r: Optional[RequirementOut], value: str) -> bool:
+    """Requirements.Get(key).Has(value): a missing key reads as Exists (requirements.go:114-120, requirement.go:171-176)."""
+    if r is None:
+        return True
+    inside = value in r.values
+    if (inside if r.complement else not inside):
+        return False
+    if r.greater_than is None and r.less_than is None:
+        return True
+    try:
+        v = int(value)
+    except ValueError:
+        return False
+    return not ((r.greater_than is not None and r.greater_than >= v) or (r.less_than is not None and r.less_than <= v))
+
+
+def _req_tuple(r: RequirementOut) -> tuple:
+    return (r.complement, tuple(sorted(r.values)), r.greater_than, r.less_than)
+
+
+def compute_consolidations(snapshot: Snapshot, candidate_sets: Sequence[Sequence[int]]) -> Tuple[List[Command], list, list]:
+    """computeConsolidation (consolidation.go:190-274) for every candidate set at once: one batched Solve, one batched
+    price stage.  Returns (commands, flat problems, results); the caller closes the flat problems."""
+    from . import scheduler, workloads
+    types = {it.name: it for it in snapshot.instance_types}
+    tindex = {it.name: i for i, it in enumerate(snapshot.instance_types)}
+    problems = [workloads.whatif(snapshot.instance_types, snapshot.provisioner, snapshot.nodes, snapshot.bound, list(cs))
+                for cs in candidate_sets]
+    flats = [scheduler.FlatProblem(p) for p in problems]
+    results, _, _ = scheduler.solve_batch(flats)
+    cmds = [Command() for _ in candidate_sets]
+    need, prices = [], []
+    for i, (cs, res) in enumerate(zip(candidate_sets, results)):
+        cands = [candidate(snapshot, j) for j in cs]
+        if res.unscheduled:                                     # "not all pods would schedule"
+            continue
+        if not res.new_nodes:                                   # everything fits on the remaining nodes
+            cmds[i] = Command(ACTION_DELETE, [c.name for c in cands])
+            continue
+        if len(res.new_nodes) != 1:                             # "we're not going to turn a single node into multiple nodes"
+            continue
+        need.append(i)
+        prices.append(get_node_prices(types, cands))
+    kept = scheduler.price_filter([flats[i] for i in need], [0] * len(need), prices)
+    for i, keep in zip(need, kept):
+        res = results[i]
+        node = res.new_nodes[0]
+        keep = set(keep)
+        options = [n for n in node.instance_types if tindex[n] in keep]   # filterByPrice preserves the option order
+        if not options:                                         # "can't replace with a cheaper node"
+            continue
+        cands = [candidate(snapshot, j) for j in candidate_sets[i]]
+        ct = node.requirements.get(LABEL_CAPACITY_TYPE)
+        if all(c.capacity_type == CAPACITY_TYPE_SPOT for c in cands) and _has(ct, CAPACITY_TYPE_SPOT):
+            continue                                            # "can't replace a spot node with a spot node"
+        reqs = {k: _req_tuple(r) for k, r in node.requirements.items()}
+        if _has(ct, CAPACITY_TYPE_SPOT) and _has(ct, CAPACITY_TYPE_ON_DEMAND):
+            # OD -> [OD, spot] was priced on the spot assumption: pin the launch to spot (Requirements.Add = intersection)
+            reqs[LABEL_CAPACITY_TYPE] = (False, (CAPACITY_TYPE_SPOT,), None, None)
+        cmds[i] = Command(ACTION_REPLACE, [c.name for c in cands], options, reqs)
+    return cmds, flats, results
+
+
+def _filter_out_same_type(snapshot: Snapshot, flat, result, cmd: Command, cands: Sequence[CandidateNode]) -> List[str]:
+    """filterOutSameType, multinodeconsolidation.go:132-165 (the second filterByPrice runs on the device as well)."""
+    from . import scheduler
+    types = {it.name: it for it in snapshot.instance_types}
+    tindex = {it.name: i for i, it in enumerate(snapshot.instance_types)}
+    existing, by_type = set(), {}
+    for c in cands:
+        existing.add(c.instance_type)
+        p = _offering_price(types[c.instance_type], c.capacity_type, c.zone)
+        if p is None:
+            continue
+        if p < by_type.get(c.instance_type, float("inf")) or c.instance_type not in by_type:
+            by_type[c.instance_type] = min(p, by_type.get(c.instance_type, 1.7976931348623157e308))
+    max_price = 1.7976931348623157e308
+    for n in cmd.replacement_types:
+        if n in existing and by_type.get(n, 0.0) < max_price:   # a Go map miss reads 0.0
+            max_price = by_type.get(n, 0.0)
+    # computeConsolidation may have narrowed the replacement's capacity-type to spot after pricing; the device still holds the
+    # Solve's requirements, so the second pricing is told about the narrowing
+    narrowed = cmd.replacement_requirements.get(LABEL_CAPACITY_TYPE) == (False, (CAPACITY_TYPE_SPOT,), None, None)   # idempotent if it already was
+    keep = set(scheduler.price_filter([flat], [0], [max_price], [narrowed])[0])
+    return [n for n in cmd.replacement_types if tindex[n] in keep]
+
+
+def first_n_node_consolidation_option(snapshot: Snapshot, candidates: Sequence[int], max_nodes: int = 100) -> Command:
+    """firstNNodeConsolidationOption, multinodeconsolidation.go:74-114: every prefix the binary search could probe is
+    solved in one launch, then the search is replayed over the commands."""
+    if len(candidates) < 2:
+        return Command()
+    lo, hi = 1, max_nodes
+    if len(candidates) <= hi:
+        hi = len(candidates) - 1
+    prefixes = [list(candidates[0:mid + 1]) for mid in range(lo, hi + 1)]
+    cmds, flats, results = compute_consolidations(snapshot, prefixes)
+    try:
+        last = Command()
+        while lo <= hi:
+            mid = (lo + hi) // 2
+            k = mid - 1
+            action = cmds[k]
+            if action.action == ACTION_REPLACE:
+                cands = [candidate(snapshot, j) for j in prefixes[k]]
+                opts = _filter_out_same_type(snapshot, flats[k], results[k], action, cands)
+                action = Command(ACTION_REPLACE if opts else ACTION_DO_NOTHING, action.nodes_to_remove if opts else [], opts,
+                                 action.replacement_requirements if opts else {})
+            if action.action in (ACTION_REPLACE, ACTION_DELETE):
+                last = action
+                lo = mid + 1
+            else:
+                hi = mid - 1
+        return last
+    finally:
+        for f in flats:
+            f.close()
+
+
+def single_node_consolidation_option(snapshot: Snapshot, candidates: Sequence[int]) -> Command:
+    """SingleNodeConsolidation.ComputeCommand's scan, singlenodeconsolidation.go:54-78 (validation stays in Go): every
+    singleton in one launch, first replace/delete in candidate order wins."""
+    cmds, flats, _ = compute_consolidations(snapshot, [[c] for c in candidates])
+    for f in flats:
+        f.close()
+    for cmd in cmds:
+        if cmd.action in (ACTION_REPLACE, ACTION_DELETE):
+            return cmd
+    return Command()

@@ -63,6 +63,7 @@ struct DevProb {
   u32 P, C, T, TW, M, E, K, R, G, GH, S, SC, NMAX, flags, n_topologies, ge_max;   // ge_max: largest ge_cnt[r]
   u32 wellknown_mask; const u32* key_nvalues; const i32* value_int; i32 key_zone, key_ct; u32 n_ct;
   const u32* it_present; const u32* it_complement; const u64* it_mask; const i64* it_alloc; const i64* it_cap; const u64* it_offer;
+  const double* it_price; i32 ct_spot, ct_ondemand;     // consolidation price stage (ks_price_filter)
   const u16* its_inter; const u8* its_fail; const u8* its_nidne; const u64* its_types;
   ReqSetsD tmpl; const u64* tmpl_taints; const i64* tmpl_daemon; const u32* tmpl_daemon_present; const u64* tmpl_types;
   const u32* tmpl_limit_present; const i64* tmpl_remaining;
@@ -1656,6 +1657,8 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   TRY(dev_copy(d, p->it_present, T, &h.it_present)); TRY(dev_copy(d, p->it_complement, T, &h.it_complement));
   TRY(dev_copy(d, p->it_mask, (size_t)K * T, &h.it_mask)); TRY(dev_copy(d, p->it_alloc, (size_t)R * T, &h.it_alloc));
   TRY(dev_copy(d, p->it_cap, (size_t)R * T, &h.it_cap)); TRY(dev_copy(d, p->it_offer, T, &h.it_offer));
+  h.it_price = nullptr; h.ct_spot = p->ct_spot; h.ct_ondemand = p->ct_ondemand;
+  if (p->it_price && p->key_zone >= 0 && p->key_ct >= 0) TRY(dev_copy(d, p->it_price, (size_t)T * p->key_nvalues[p->key_zone] * p->n_ct, &h.it_price));
   TRY(dev_copy(d, p->its_inter, (size_t)h.S * h.SC, &h.its_inter)); TRY(dev_copy(d, p->its_fail, (size_t)h.S * h.SC, &h.its_fail));
   TRY(dev_copy(d, p->its_nidne, h.S, &h.its_nidne)); TRY(dev_copy(d, p->its_types, (size_t)h.S * TW, &h.its_types));
   TRY(copy_reqsets(d, p->tmpl, M, K, &h.tmpl)); TRY(dev_copy(d, p->tmpl_taints, M, &h.tmpl_taints));
@@ -1895,6 +1898,80 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   if (n > 1) { rc = download_batch(ds, n, dsv, d_meta, outs); hipFree(dp); hipFree(dsv); hipFree(d_meta); }
   else rc = download(ds[0], outs[0]);
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Consolidation price stage: filterByPrice over worstLaunchPrice (deprovisioning/helpers.go:148-157,
+// :292-315) on a what-if's replacement node while its result is still on the device.  One block per problem,
+// lane w owns word w of the node's InstanceTypeOptions; float64 compares only (prices are never added here).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ks_price_filter(const DevProb* probs, const DevState* states, const u32* node, const double* max_price, const u32* spot_only, u64* const* outs, u32* counts) {
+  const DevProb& P = probs[blockIdx.x]; const DevState& S = states[blockIdx.x];
+  const u32 j = node[blockIdx.x]; const double maxp = max_price[blockIdx.x]; const int lane = threadIdx.x;
+  const u32 pres = S.o_present[j], comp = S.o_complement[j];
+  // reqs.Get(key): a missing key reads as Exists (requirements.go:114-120), which Has() every value
+  const KReq zq = ((pres >> P.key_zone) & 1u) ? load_req(pres, comp, S.o_mask + (size_t)j * P.K, S.o_gt + (size_t)j * P.K, S.o_lt + (size_t)j * P.K, P.key_zone) : kreq_exists();
+  const KReq cq = ((pres >> P.key_ct) & 1u) ? load_req(pres, comp, S.o_mask + (size_t)j * P.K, S.o_gt + (size_t)j * P.K, S.o_lt + (size_t)j * P.K, P.key_ct) : kreq_exists();
+  const u64 allowZ = kreq_has_mask(zq, P.value_int + P.key_zone * 64, P.key_nvalues[P.key_zone]);
+  u64 allowC = kreq_has_mask(cq, P.value_int + P.key_ct * 64, P.key_nvalues[P.key_ct]);
+  if (spot_only && spot_only[blockIdx.x]) allowC &= P.ct_spot >= 0 ? (1ull << P.ct_spot) : 0ull;     // Requirements.Add(capacity-type In [spot])
+  const u32 NP = P.key_nvalues[P.key_zone] * P.n_ct;
+  const bool spot = P.ct_spot >= 0 && ((allowC >> P.ct_spot) & 1ull), od = P.ct_ondemand >= 0 && ((allowC >> P.ct_ondemand) & 1ull);
+  u32 kept = 0;
+  for (u32 wbase = 0; wbase < P.TW; wbase += 64) {
+    const u32 w = wbase + lane; u64 out = 0;
+    if (w < P.TW) {
+      for (u64 bits = S.n_alive[(size_t)j * P.TW + w]; bits; bits &= bits - 1) {
+        const u32 b = (u32)__builtin_ctzll(bits), t = w * 64 + b; const u64 offer = P.it_offer[t];
+        double launch = 1.7976931348623157e308; bool got = false;      // math.MaxFloat64
+        if (spot) {          // "we prefer to launch spot offerings": the worst (highest) spot price in the allowed zones
+          double mx = 0.0;
+          for (u64 zz = allowZ; zz; zz &= zz - 1) { const u32 pair = (u32)__builtin_ctzll(zz) * P.n_ct + (u32)P.ct_spot; if (pair < 64 && ((offer >> pair) & 1ull)) { const double pr = P.it_price[(size_t)t * NP + pair]; if (!got || pr > mx) mx = pr; got = true; } }
+          if (got) launch = mx;
+        }
+        if (!got && od) {
+          double mx = 0.0;
+          for (u64 zz = allowZ; zz; zz &= zz - 1) { const u32 pair = (u32)__builtin_ctzll(zz) * P.n_ct + (u32)P.ct_ondemand; if (pair < 64 && ((offer >> pair) & 1ull)) { const double pr = P.it_price[(size_t)t * NP + pair]; if (!got || pr > mx) mx = pr; got = true; } }
+          if (got) launch = mx;
+        }
+        if (launch < maxp) out |= 1ull << b;
+      }
+      outs[blockIdx.x][w] = out;
+    }
+    u32 pc = (u32)__builtin_popcountll(out); for (int off = 32; off > 0; off >>= 1) pc += __shfl_xor(pc, off);
+    kept += pc;
+  }
+  if (lane == 0) counts[blockIdx.x] = kept;
+}
+
+extern "C" int ks_price_filter_dev(ks_dev_problem* const* ds, uint32_t n, const uint32_t* node, const double* max_price, const uint32_t* spot_only, uint64_t* const* out_types, uint32_t* out_counts) {
+  if (!n) return KS_OK;
+  if (!ds || !node || !max_price || !out_types || !out_counts) return fail(KS_ERR_INVALID, "null argument");
+  const int device = ds[0]->device; HIPCHK(hipSetDevice(device));
+  std::vector<DevProb> hp(n); std::vector<DevState> hs(n); size_t words = 0; std::vector<size_t> off(n);
+  for (u32 i = 0; i < n; ++i) {
+    if (ds[i]->device != device) return fail(KS_ERR_INVALID, "batch spans devices");
+    if (!ds[i]->h.it_price || ds[i]->h.key_zone < 0 || ds[i]->h.key_ct < 0) return fail(KS_ERR_INVALID, "problem carries no offering prices");
+    if (node[i] >= ds[i]->h.NMAX) return fail(KS_ERR_INVALID, "node index out of range");
+    hp[i] = ds[i]->h; hs[i] = ds[i]->hs; off[i] = words; words += ds[i]->h.TW;
+  }
+  DevProb* dp = nullptr; DevState* dsv = nullptr; u32* dnode = nullptr; double* dmax = nullptr; u64* dout = nullptr; u64** dptr = nullptr; u32* dcnt = nullptr; u32* dspot = nullptr;
+  if (spot_only) { HIPCHK(hipMalloc((void**)&dspot, n * sizeof(u32))); HIPCHK(hipMemcpy(dspot, spot_only, n * sizeof(u32), hipMemcpyHostToDevice)); }
+  HIPCHK(hipMalloc((void**)&dp, n * sizeof(DevProb))); HIPCHK(hipMalloc((void**)&dsv, n * sizeof(DevState)));
+  HIPCHK(hipMalloc((void**)&dnode, n * sizeof(u32))); HIPCHK(hipMalloc((void**)&dmax, n * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&dout, (words ? words : 1) * sizeof(u64))); HIPCHK(hipMalloc((void**)&dptr, n * sizeof(u64*))); HIPCHK(hipMalloc((void**)&dcnt, n * sizeof(u32)));
+  std::vector<u64*> ptrs(n); for (u32 i = 0; i < n; ++i) ptrs[i] = dout + off[i];
+  HIPCHK(hipMemcpy(dp, hp.data(), n * sizeof(DevProb), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dsv, hs.data(), n * sizeof(DevState), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dnode, node, n * sizeof(u32), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dmax, max_price, n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dptr, ptrs.data(), n * sizeof(u64*), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ks_price_filter, dim3(n), dim3(64), 0, ds[0]->stream, dp, dsv, dnode, dmax, (const u32*)dspot, dptr, dcnt);
+  std::vector<u64> host(words ? words : 1);
+  HIPCHK(hipMemcpyAsync(host.data(), dout, (words ? words : 1) * sizeof(u64), hipMemcpyDeviceToHost, ds[0]->stream));
+  HIPCHK(hipMemcpyAsync(out_counts, dcnt, n * sizeof(u32), hipMemcpyDeviceToHost, ds[0]->stream));
+  HIPCHK(hipStreamSynchronize(ds[0]->stream)); HIPCHK(hipGetLastError());
+  for (u32 i = 0; i < n; ++i) memcpy(out_types[i], host.data() + off[i], ds[i]->h.TW * sizeof(u64));
+  hipFree(dp); hipFree(dsv); hipFree(dnode); hipFree(dmax); hipFree(dout); hipFree(dptr); hipFree(dcnt); if (dspot) hipFree(dspot);
+  return KS_OK;
 }
 
 extern "C" int ks_solve_dev(ks_dev_problem* d, ks_result* out, float* kernel_ms) {

@@ -71,6 +71,21 @@ int ksh_solve_batch(void** hv, uint32_t n, char** out_texts, float* kernel_ms, d
   return KS_OK;
 }
 
+// Consolidation price stage on the results of the last ksh_solve / ksh_solve_batch, which are still on the device:
+// for handle i, of new node node[i]'s InstanceTypeOptions keep the types whose worst launch price is < max_price[i]
+// (filterByPrice, deprovisioning/helpers.go:148-157).  out_masks: n * ceil(T_max/64) words with row stride `stride_words`.
+int ksh_price_filter(void** hv, uint32_t n, const uint32_t* node, const double* max_price, const uint32_t* spot_only, uint64_t* out_masks, uint32_t stride_words, uint32_t* out_counts) {
+  std::vector<ks_dev_problem*> ds(n); std::vector<uint64_t*> outs(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    Handle* h = (Handle*)hv[i]; if (!h->dev) return set_err(KS_ERR_INVALID, "price filter before solve");
+    if ((h->enc->prob.T + 63) / 64 > stride_words) return set_err(KS_ERR_INVALID, "mask row too short");
+    ds[i] = h->dev; outs[i] = out_masks + (size_t)i * stride_words;
+  }
+  int rc = ks_price_filter_dev(ds.data(), n, node, max_price, spot_only, outs.data(), out_counts);
+  if (rc != KS_OK) return set_err(rc, ks_last_error());
+  return KS_OK;
+}
+
 // Static feasibility grid [M][C][TW]; `out` may be NULL (timing only).
 int ksh_grid(void* hv, uint64_t* out, float* kernel_ms) {
   Handle* h = (Handle*)hv; int rc = ksh_upload(hv, 0); if (rc != KS_OK) return rc;

@@ -59,6 +59,8 @@ def libs():
         kh.ksh_solve.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
         kh.ksh_solve_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
         kh.ksh_grid.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        kh.ksh_price_filter.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32),
+                                        ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
         kh.ksh_dims.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         kh.ksh_free.argtypes = [ctypes.c_void_p]
         _LIBS = (ks, kh)
@@ -146,6 +148,33 @@ def solve_batch(flats: Sequence[FlatProblem], decode: bool = True):
             res.append(parse_result(ctypes.string_at(outs[i]).decode()))
             kh.ksh_free(outs[i])
     return res, float(kms.value), float(wms.value)
+
+
+def price_filter(flats: Sequence[FlatProblem], nodes: Sequence[int], max_prices: Sequence[float], spot_only: Optional[Sequence[bool]] = None) -> List[List[int]]:
+    """filterByPrice (deprovisioning/helpers.go:148-157) on the device, over the results the last solve / solve_batch of
+    `flats` left there: for flats[i], the instance-type indices of new node nodes[i]'s InstanceTypeOptions whose worst
+    launch price is < max_prices[i] (ascending type index; the caller restores the option order).  spot_only[i]: price the
+    node as if its capacity-type requirement were already In [spot] (consolidation.go:262-265)."""
+    kh = libs()[1]
+    n = len(flats)
+    if n == 0:
+        return []
+    stride = max((f.dims["T"] + 63) // 64 for f in flats)
+    hs = (ctypes.c_void_p * n)(*[f._h for f in flats])
+    node = (ctypes.c_uint32 * n)(*[int(x) for x in nodes])
+    mp = (ctypes.c_double * n)(*[float(x) for x in max_prices])
+    masks = (ctypes.c_uint64 * (n * stride))()
+    counts = (ctypes.c_uint32 * n)()
+    so = (ctypes.c_uint32 * n)(*[1 if x else 0 for x in spot_only]) if spot_only is not None else None
+    rc = kh.ksh_price_filter(hs, n, node, mp, so, masks, stride, counts)
+    if rc != KS_OK:
+        raise KSolveError(rc, kh.ksh_last_error().decode())
+    out = []
+    for i in range(n):
+        row = [w * 64 + b for w in range(stride) for b in range(64) if (masks[i * stride + w] >> b) & 1]
+        assert len(row) == counts[i]
+        out.append(row)
+    return out
 
 
 def solve_problem(problem: Problem, stats: bool = False) -> SolveResult:

@@ -1,0 +1,193 @@
+"""Consolidation decisions on top of batched what-ifs (SURVEY 8f-2 price stage, 8f-3 speculative search).
+
+Product: every probe the reference would make is solved in ONE ks_solve_batch launch, filterByPrice / worstLaunchPrice run
+in a HIP kernel over the results still on the device (ks_price_filter_dev), and the reference's binary search / first-success
+scan is replayed.  Oracle: `oracle/consolidation_ref.py` follows the Go code literally, one CPU Solve per probe.
+Scenarios restate pkg/controllers/deprovisioning/suite_test.go (each cites its lines); validation / TTL / PDB handling needs
+the live cluster and is not part of the path."""
+import numpy as np
+import pytest
+
+from karpenter_core_amd import fake, workloads as W
+from karpenter_core_amd.consolidation import Snapshot
+from karpenter_core_amd.model import (parse_quantity_milli, Container, LABEL_ARCH, LABEL_CAPACITY_TYPE, LABEL_HOSTNAME, LABEL_INSTANCE_TYPE, LABEL_OS,
+                                      LABEL_PROVISIONER, LABEL_ZONE, Offering, Pod, StateNode)
+from oracle import consolidation_ref as CR
+
+
+def node(name, it, capacity_type, zone, cpu="32", pods="100"):
+    """test.Node with the labels the deprovisioner reads (suite_test.go:896-905)."""
+    labels = {LABEL_PROVISIONER: "default", LABEL_INSTANCE_TYPE: it.name, LABEL_CAPACITY_TYPE: capacity_type, LABEL_ZONE: zone,
+              LABEL_HOSTNAME: name}
+    alloc = {"cpu": cpu, "pods": pods}
+    return StateNode(name=name, labels=labels, available=dict(alloc), capacity=dict(alloc))
+
+
+def pod(uid, cpu="1"):
+    return Pod(uid=uid, labels={"app": "test"}, containers=[Container(requests={"cpu": cpu})])
+
+
+def _on_demand_by_price(its):     # suite_test.go:105-121: instances with an available on-demand offering, cheapest offering ascending
+    od = [i for i in its if any(o.available and o.capacity_type == "on-demand" for o in i.offerings)]
+    return sorted(od, key=lambda i: min(o.price for o in i.offerings))
+
+
+def most_expensive(its):
+    it = _on_demand_by_price(its)[-1]
+    return it, it.offerings[0]
+
+
+def least_expensive(its):
+    it = _on_demand_by_price(its)[0]
+    return it, it.offerings[0]
+
+
+def snapshot(its, nodes, bound):
+    return Snapshot(its, fake.provisioner("default", len(its)), nodes, bound)
+
+
+def scenarios():
+    out = {}
+    its = fake.instance_types_assorted()          # suite_test.go:104
+    big, big_of = most_expensive(its)
+    small, small_of = least_expensive(its)
+    # "can replace node" suite_test.go:874-928: one pod on the most expensive instance -> a cheaper node replaces it
+    out["can_replace_node"] = (snapshot(its, [node("n1", big, big_of.capacity_type, big_of.zone)], [[pod("p1")]]), [0], "replace")
+    # "won't replace node if any spot replacement is more expensive" :1155-1241
+    cur = fake.new_instance_type("current-on-demand", offerings=[Offering("on-demand", "test-zone-1a", 0.5, False)])
+    rep = fake.new_instance_type("potential-spot-replacement", offerings=[Offering("spot", "test-zone-1a", 1.0), Offering("spot", "test-zone-1b", 0.2),
+                                                                           Offering("spot", "test-zone-1c", 0.4)])
+    out["spot_replacement_more_expensive"] = (snapshot([cur, rep], [node("n1", cur, "on-demand", "test-zone-1a")], [[pod("p1")]]), [0], "do-nothing")
+    # "won't replace on-demand node if on-demand replacement is more expensive" :1243-1344
+    rep2 = fake.new_instance_type("on-demand-replacement", offerings=[Offering("on-demand", "test-zone-1a", 0.6), Offering("on-demand", "test-zone-1b", 0.6),
+                                                                       Offering("spot", "test-zone-1b", 0.2), Offering("spot", "test-zone-1c", 0.3)])
+    p = pod("p1")
+    p.node_selector = {LABEL_CAPACITY_TYPE: "on-demand"}          # :1306-1314 the pod insists on on-demand
+    out["on_demand_replacement_more_expensive"] = (snapshot([cur, rep2], [node("n1", cur, "on-demand", "test-zone-1a")], [[p]]), [0], "do-nothing")
+    # "can delete nodes" :1423-1495: two nodes, the pods of one fit on the other
+    n1, n2 = node("n1", big, big_of.capacity_type, big_of.zone), node("n2", big, big_of.capacity_type, big_of.zone)
+    out["can_delete_nodes"] = (snapshot(its, [n1, n2], [[pod("p1")], [pod("p2"), pod("p3")]]), [0], "delete")
+    return out
+
+
+def multi_scenarios():
+    out = {}
+    its = fake.instance_types_assorted()
+    big, big_of = most_expensive(its)
+    small, small_of = least_expensive(its)
+    # "can merge 3 nodes into 1" :2555-2642: three expensive nodes with one pod each -> one cheaper replacement
+    ns = [node(f"n{i}", big, big_of.capacity_type, big_of.zone) for i in range(3)]
+    out["merge_3_into_1"] = (snapshot(its, ns, [[pod("p1")], [pod("p2")], [pod("p3")]]), [0, 1, 2], "replace", 3)
+    # "won't merge 2 nodes into 1 of the same type" :2644-2719: the only candidate replacement is the type being removed
+    ns = [node(f"n{i}", small, small_of.capacity_type, small_of.zone) for i in range(2)]
+    out["wont_merge_same_type"] = (snapshot(its, ns, [[pod("p1")], [pod("p2"), pod("p3")]]), [0, 1], "do-nothing", 0)
+    return out
+
+
+def busy_cluster(existing, seed, util=(0.75, 0.98), sizes=8):
+    """A snapshot tight enough that removing nodes needs replacements, with a mix of spot / on-demand nodes."""
+    rs = np.random.RandomState(seed)
+    its, prov, nodes, bound = W.cluster_snapshot(existing=existing, sizes=sizes, seed=seed)
+    # fill the nodes up: give every node pods until it is `util` full (the generator stops at 30-70 %)
+    uid = 0
+    for i, n in enumerate(nodes):
+        target = rs.uniform(*util)
+        cap = parse_quantity_milli(n.capacity["cpu"])
+        used = cap - parse_quantity_milli(n.available["cpu"])
+        added = 0
+        while used + 500 <= target * cap and int(n.available["pods"]) - added > 1:
+            bound[i].append(Pod(uid=f"fill-{uid:06d}", labels={"my-label": "a"}, containers=[Container(requests={"cpu": "500m", "memory": "64Mi"})]))
+            uid += 1
+            used += 500
+            added += 1
+        n.available = {"cpu": f"{parse_quantity_milli(n.available['cpu']) - 500 * added}m",
+                       "memory": f"{parse_quantity_milli(n.available['memory']) // 1000 // 2**20 - 64 * added}Mi",
+                       "pods": str(int(n.available["pods"]) - added)}
+    return Snapshot(its, prov, nodes, bound)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU: the restated scenarios on the oracle (pins the restatement against the reference's expectations)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(scenarios()))
+def test_oracle_single_node_scenarios(name):
+    snap, cands, want = scenarios()[name]
+    assert CR.compute_consolidation(snap, cands)[0] == want
+
+
+@pytest.mark.parametrize("name", sorted(multi_scenarios()))
+def test_oracle_multi_node_scenarios(name):
+    snap, cands, want, n_removed = multi_scenarios()[name]
+    cmd = CR.first_n_node_consolidation_option(snap, cands)
+    assert cmd[0] == want and len(cmd[1]) == n_removed
+    if name == "merge_3_into_1":
+        removed_type = snap.nodes[0].labels[LABEL_INSTANCE_TYPE]
+        assert removed_type not in cmd[2] and cmd[2]        # cheaper types only
+
+
+def test_worst_launch_price_prefers_spot_then_on_demand():
+    """helpers.go:292-315 on the reference's own offering lists (suite_test.go:1166-1186, :1254-1280)."""
+    from karpenter_core_amd.model import RequirementOut
+    ofs = [Offering("on-demand", "a", 0.6), Offering("on-demand", "b", 0.7), Offering("spot", "b", 0.2), Offering("spot", "c", 0.3), Offering("spot", "d", 9.0, False)]
+    assert CR.worst_launch_price(ofs, {}) == 0.3                                             # spot allowed: worst available spot
+    only_od = {LABEL_CAPACITY_TYPE: RequirementOut(LABEL_CAPACITY_TYPE, False, ("on-demand",), None, None)}
+    assert CR.worst_launch_price(ofs, only_od) == 0.7
+    zone_a = {LABEL_ZONE: RequirementOut(LABEL_ZONE, False, ("a",), None, None)}
+    assert CR.worst_launch_price(ofs, zone_a) == 0.6                                         # no spot in zone a -> on-demand
+    nowhere = {LABEL_ZONE: RequirementOut(LABEL_ZONE, False, ("z",), None, None)}
+    assert CR.worst_launch_price(ofs, nowhere) == CR.MAX_FLOAT64
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU: batched what-ifs + device price stage + replayed search  ==  the literal sequential reference path
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(scenarios()))
+def test_gpu_single_node_scenarios(name):
+    from karpenter_core_amd import consolidation as C
+    snap, cands, want = scenarios()[name]
+    cmds, flats, _ = C.compute_consolidations(snap, [cands])
+    for f in flats:
+        f.close()
+    assert cmds[0].action == want
+    assert cmds[0].canonical() == CR.canonical(CR.compute_consolidation(snap, cands))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(multi_scenarios()))
+def test_gpu_multi_node_scenarios(name):
+    from karpenter_core_amd import consolidation as C
+    snap, cands, want, _ = multi_scenarios()[name]
+    got = C.first_n_node_consolidation_option(snap, cands)
+    assert got.action == want
+    assert got.canonical() == CR.first_n_node_consolidation_option(snap, cands)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 11])
+def test_gpu_searches_on_a_busy_cluster(seed):
+    from karpenter_core_amd import consolidation as C
+    snap = busy_cluster(24, seed, util=(0.93, 0.999))        # tight: singletons come out as replace / delete / do-nothing
+    rs = np.random.RandomState(seed)
+    cands = [int(x) for x in rs.choice(len(snap.nodes), size=12, replace=False)]
+    multi = C.first_n_node_consolidation_option(snap, cands, max_nodes=100)
+    assert multi.canonical() == CR.first_n_node_consolidation_option(snap, cands, 100)
+    single = C.single_node_consolidation_option(snap, cands)
+    assert single.canonical() == CR.single_node_consolidation_option(snap, cands)
+    # every singleton, action by action (replace / delete / do-nothing all occur on a busy cluster)
+    cmds, flats, _ = C.compute_consolidations(snap, [[c] for c in cands])
+    for f in flats:
+        f.close()
+    want = [CR.canonical(CR.compute_consolidation(snap, [c])) for c in cands]
+    assert [c.canonical() for c in cmds] == want
+    assert len({w[0] for w in want}) == 3
+
+
+@pytest.mark.gpu
+def test_gpu_multi_node_search_on_a_roomy_cluster():
+    from karpenter_core_amd import consolidation as C
+    snap = busy_cluster(60, 11)                               # roomier: the binary search finds a multi-node replace
+    cands = [int(x) for x in np.random.RandomState(11).choice(len(snap.nodes), size=16, replace=False)]
+    want = CR.first_n_node_consolidation_option(snap, cands, 100)
+    assert want[0] == "replace"
+    assert C.first_n_node_consolidation_option(snap, cands, max_nodes=100).canonical() == want
