@@ -411,6 +411,18 @@ class RequirementOut:
             return "NotIn" if self.values else "Exists"
         return "In" if self.values else "DoesNotExist"
 
+    def node_selector_requirement(self) -> Tuple[str, str, Tuple[str, ...]]:
+        """Requirement.NodeSelectorRequirement (requirement.go:70-113): the wire form (key, operator, values) that
+        `MachineTemplate.ToMachine` puts into `Machine.Spec.Requirements` (machinetemplate.go:77-100).  Bounds win over
+        the value set; values come out sorted (`sets.String.List()`)."""
+        if self.greater_than is not None:
+            return (self.key, "Gt", (str(self.greater_than),))
+        if self.less_than is not None:
+            return (self.key, "Lt", (str(self.less_than),))
+        if self.complement:
+            return (self.key, "NotIn", tuple(sorted(self.values))) if self.values else (self.key, "Exists", ())
+        return (self.key, "In", tuple(sorted(self.values))) if self.values else (self.key, "DoesNotExist", ())
+
 
 @dataclass
 class NewNodeOut:

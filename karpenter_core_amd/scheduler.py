@@ -203,6 +203,29 @@ class Node:
     Requirements: Dict[str, object]
     Requests: Dict[str, int]
 
+    def ToMachine(self, provisioner: Optional[Provisioner] = None) -> dict:
+        """MachineTemplate.ToMachine (machinetemplate.go:77-100) as far as Solve's result determines it: the requirements
+        gain `instance-type In [names of InstanceTypeOptions]` (Requirements.Add = intersection with what is there) and
+        are emitted through NodeSelectorRequirements() (requirements.go:80-84, one entry per key); requests are the
+        node's accumulated requests.  Labels / taints / kubelet / provider ref come from the provisioner unchanged."""
+        from .model import LABEL_INSTANCE_TYPE, RequirementOut
+        reqs = dict(self.Requirements)
+        names = [it.name for it in self.InstanceTypeOptions]
+        cur = reqs.get(LABEL_INSTANCE_TYPE)
+        if cur is None:
+            merged = RequirementOut(LABEL_INSTANCE_TYPE, False, tuple(names), None, None)
+        else:                                   # Intersection of `In names` with the existing requirement (requirement.go:117-150)
+            keep = [n for n in names if (n not in cur.values) == cur.complement]
+            merged = RequirementOut(LABEL_INSTANCE_TYPE, False, tuple(keep), None, None)
+        reqs[LABEL_INSTANCE_TYPE] = merged
+        out = {"generateName": self.ProvisionerName,
+               "requirements": sorted(r.node_selector_requirement() for r in reqs.values()),
+               "resources": {"requests": dict(sorted(self.Requests.items()))}}
+        if provisioner is not None:
+            out["labels"] = dict(provisioner.labels)
+            out["taints"] = [(t.key, t.value, t.effect) for t in provisioner.taints]
+        return out
+
 
 @dataclass
 class ExistingNode:

@@ -70,3 +70,26 @@ def test_quantity_exact(text, milli):
 def test_quantity_rejects_sub_milli():
     with pytest.raises(ValueError):
         O.parse_quantity_milli("0.0001")
+
+
+def test_node_selector_requirement_conversion():
+    """Requirement.NodeSelectorRequirement, pinned by requirement_test.go:446-463 (the wire form ToMachine emits)."""
+    from karpenter_core_amd.model import RequirementOut as R
+    want = {
+        "exists": (R("key", True, (), None, None), ("key", "Exists", ())),
+        "doesNotExist": (R("key", False, (), None, None), ("key", "DoesNotExist", ())),
+        "inA": (R("key", False, ("A",), None, None), ("key", "In", ("A",))),
+        "inB": (R("key", False, ("B",), None, None), ("key", "In", ("B",))),
+        "inAB": (R("key", False, ("B", "A"), None, None), ("key", "In", ("A", "B"))),
+        "notInA": (R("key", True, ("A",), None, None), ("key", "NotIn", ("A",))),
+        "in1": (R("key", False, ("1",), None, None), ("key", "In", ("1",))),
+        "in9": (R("key", False, ("9",), None, None), ("key", "In", ("9",))),
+        "in19": (R("key", False, ("9", "1"), None, None), ("key", "In", ("1", "9"))),
+        "notIn12": (R("key", True, ("2", "1"), None, None), ("key", "NotIn", ("1", "2"))),
+        "greaterThan1": (R("key", True, (), 1, None), ("key", "Gt", ("1",))),
+        "greaterThan9": (R("key", True, (), 9, None), ("key", "Gt", ("9",))),
+        "lessThan1": (R("key", True, (), None, 1), ("key", "Lt", ("1",))),
+        "lessThan9": (R("key", True, (), None, 9), ("key", "Lt", ("9",))),
+    }
+    for name, (req, expect) in want.items():
+        assert req.node_selector_requirement() == expect, name

@@ -72,6 +72,32 @@ def test_single_wave_kernel_on_a_multi_wave_problem(monkeypatch):
     assert_same(W.config2(pods=2000, sizes=10, seed=43))
 
 
+def test_to_machine_wire_format():
+    """MachineTemplate.ToMachine (machinetemplate.go:77-100) over a Solve result: `instance-type In [options]` is added,
+    every requirement goes out as a NodeSelectorRequirement, requests are the node's accumulated requests."""
+    from karpenter_core_amd.model import Container, LABEL_INSTANCE_TYPE, LABEL_ZONE, Pod
+    its = fake.default_instance_types()
+    prov = fake.provisioner("default", len(its), labels={"team": "a"})
+    s = S.NewScheduler([prov], its, extra_well_known=fake.EXTRA_WELL_KNOWN)
+    pods = [Pod(uid="p1", node_selector={LABEL_ZONE: "test-zone-2"}, containers=[Container(requests={"cpu": "1", "memory": "100Mi"})])]
+    nodes, _, err = s.Solve(pods)
+    assert err is None and len(nodes) == 1
+    m = nodes[0].ToMachine(prov)
+    reqs = {k: (op, vals) for k, op, vals in m["requirements"]}
+    assert reqs[LABEL_ZONE] == ("In", ("test-zone-2",))
+    assert reqs[LABEL_INSTANCE_TYPE] == ("In", tuple(sorted(it.name for it in nodes[0].InstanceTypeOptions)))
+    assert m["generateName"] == "default" and m["labels"] == {"team": "a"}
+    assert m["resources"]["requests"]["cpu"] == 1000 + 0 and m["resources"]["requests"]["pods"] == 1000
+    want = O.solve(s_problem(s, pods)).new_nodes[0]
+    assert sorted(r.node_selector_requirement() for r in want.requirements.values() if r.key != LABEL_INSTANCE_TYPE) == \
+        [r for r in m["requirements"] if r[0] != LABEL_INSTANCE_TYPE]
+
+
+def s_problem(s, pods):
+    return Problem(instance_types=s.instance_types, provisioners=s.provisioners, pods=list(pods), daemonset_pods=s.daemonset_pods,
+                   nodes=s.state_nodes, cluster_pods=s.cluster_pods, extra_well_known=s.extra_well_known, simulation_mode=s.opts.SimulationMode)
+
+
 def test_whatifs_single_and_batched():
     its, prov, nodes, bound = W.cluster_snapshot(existing=96, sizes=8, seed=45)
     probs = [W.whatif(its, prov, nodes, bound, list(range(0, i + 1))) for i in range(6)] + \
