@@ -1878,14 +1878,20 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   if (!attr_set) { for (int i = 0; i < 8; ++i) HIPCHK(hipFuncSetAttribute((const void*)variants[i], hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024)); attr_set = true; }
   // A single Solve whose problem takes the LEAN, FAST, no-bounds kernel gets 8 waves: waves 1..7 join wave 0 for the
   // speculation rounds (see ks_pack).  T <= 4096 keeps a node's surviving-type mask in one register per lane.
-  bool multi = n == 1 && lean && fast && !bounds && ds[0]->h.TW <= 64 && !getenv("KS_ONE_WAVE");
+  bool multi = n == 1 && fast && !bounds && ds[0]->h.TW <= 64 && !(ds[0]->h.flags & KS_FLAG_STATS) && !getenv("KS_ONE_WAVE");
   if (multi) {
     const u32 lds_mw = 44u * 1024u;
     if ((size_t)ds[0]->h.R * ds[0]->h.ge_max * 8 + 8192 > lds_mw) multi = false;
     else {
       static bool attr_mw = false;
-      if (!attr_mw) { HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024)); attr_mw = true; }
-      hipLaunchKernelGGL((ks_pack<true, false, true, 8>), dim3(1), dim3(512), lds_mw, st, dp, dsv, lds_mw);
+      if (!attr_mw) {
+        HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
+        attr_mw = true;
+      }
+      if (lean) hipLaunchKernelGGL((ks_pack<true, false, true, 8>), dim3(1), dim3(512), lds_mw, st, dp, dsv, lds_mw);
+      else hipLaunchKernelGGL((ks_pack<true, false, false, 4>), dim3(1), dim3(256), lds_mw, st, dp, dsv, lds_mw);     // host ports / limits / selectors on hostname or instance type: the general code
+                                                                                                                     // needs > 256 VGPRs, so 4 waves (one per SIMD): leader + 3 workers
     }
   }
   if (!multi) hipLaunchKernelGGL(variants[(lean ? 4 : 0) + (fast ? 2 : 0) + (bounds ? 1 : 0)], dim3(n), dim3(64), lds_bytes, st, dp, dsv, lds_bytes);
