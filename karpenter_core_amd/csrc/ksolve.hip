@@ -848,7 +848,7 @@ __device__ __forceinline__ void ge_row_indices(const Tabs& tb, const PubT<RM>& p
 // Lane w owns word w; there is no per-type loop: resources.Fits is one precomputed row per requested resource.
 template <int RM>
 __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, const PubT<RM>& pb, WaveShared& sh, const Rec& r, const GA u64* alive_in, GA u64* alive_out, u32 reqmask_new,
-                             u32 changed_keys, bool check_offer, bool check_it, int lane, u64& tprobe, u64& word) {   // alive_out == nullptr (TW <= 64 only): the result stays in `word`
+                             u32 changed_keys, bool check_offer, bool check_it, int lane, u64& tprobe, u64 (&word)[2]) {   // alive_out == nullptr (TW <= 128 only): the result stays in `word` (lane l: words l and 64+l)
   const GA u64* rows[RM]; u32 ridx[RM];
   ge_row_indices(tb, pb, reqmask_new, lane, ridx);
   bool none = false;
@@ -857,7 +857,7 @@ __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, c
     rows[i] = nullptr;
     if ((reqmask_new >> i) & 1u) { if (ridx[i] >= tb.ge_cnt[i]) none = true; rows[i] = tb.ge_rows + ((size_t)i * tb.T + ridx[i]) * tb.TW; }
   }
-  word = 0;
+  word[0] = 0; word[1] = 0;
   if (none) { if (alive_out) for (u32 w = lane; w < tb.TW; w += 64) alive_out[w] = 0; LSYNC(); return false; }   // nothing has that much of some resource
 #pragma unroll
   for (int i = 0; i < RM; ++i) if (lane == 0 && ((reqmask_new >> i) & 1u)) sh.low_new[i] = tb.ge_vals[(size_t)i * tb.ge_stride + ridx[i]];
@@ -876,7 +876,7 @@ __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, c
       a &= x;
       if (alive_out) alive_out[w] = a;
     }
-    if (wbase == 0) word = a;
+    if (wbase == 0) word[0] = a; else if (wbase == 64) word[1] = a;
     if (ballot64(a != 0)) any = true;
   }
   LSYNC();
@@ -1215,12 +1215,12 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           const bool zc = (tb.key_zone >= 0 && ((keys >> tb.key_zone) & 1u)) || (tb.key_ct >= 0 && ((keys >> tb.key_ct) & 1u));
           const bool itc = !fresh && pb.it_state != pb.it_before;
           if (pb.need) {     // otherwise the filter would pick the same rows as last time: InstanceTypeOptions unchanged
-            const bool inreg = !fresh && tb.TW <= 64;   // the surviving-type word stays in a register: no scratch round trip
-            u64 aw;
+            const bool inreg = !fresh && tb.TW <= 128;  // the surviving-type words stay in registers: no scratch round trip
+            u64 aw[2];
             const bool ok = filter_types(P, tb, pb, sh, r, fresh ? scratch : alive, fresh ? alive : (inreg ? (GA u64*)nullptr : scratch), rm, keys, zc, itc, lane, tprobe, aw);
             PROBE(16);
             if (!ok) { CTR(KS_STAT_FULLFAILS, 1); if (!fresh) recompute_cap<RM>(P, tb, alive, r, lane); m &= m - 1; continue; }
-            if (inreg) { if ((u32)lane < tb.TW) alive[lane] = aw; }
+            if (inreg) { if ((u32)lane < tb.TW) alive[lane] = aw[0]; if ((u32)lane + 64 < tb.TW) alive[lane + 64] = aw[1]; }
             else if (!fresh) for (u32 w = lane; w < tb.TW; w += 64) alive[w] = scratch[w];
             if ((u32)lane < tb.R && ((rm >> lane) & 1u)) r.low()[lane] = sh.low_new[lane];
           }
@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       // ---- P3: workers publish their assigned candidate and run the instance-type filter; meanwhile the leader moves the
       //      winners in the visiting order (speculatively: a failed filter -- 2 in 10 000 -- undoes the moves behind it) ----
       const u32 n_ok = UF(rc.n_ok);
-      Pub pb; u64 aw = 0; bool filtered = false;
+      Pub pb; u64 aw[2] = {0, 0}; bool filtered = false;
       if (wv != 0 && kw < n_ok) {
         const int win = (int)UF(rc.win[kw]);
         publish_eval<BOUNDS, RM>(tb, sh, wb, ev, slot, false, lane, win, cr, pb);
@@ -1495,7 +1495,8 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         const Rec r = slot_rec(S, tb, sw);
         if (filtered) {
           GA u64* const alive = tb.n_alive + (size_t)(sw - tb.E) * tb.TW;
-          if ((u32)lane < tb.TW) alive[lane] = aw;
+          if ((u32)lane < tb.TW) alive[lane] = aw[0];
+          if ((u32)lane + 64 < tb.TW) alive[lane + 64] = aw[1];
           if ((u32)lane < tb.R && ((pb.rm >> lane) & 1u)) r.low()[lane] = sh.low_new[lane];
         }
         topology_record<true>(P, S, tb, pb, sh, r, sw, lane);
@@ -1877,8 +1878,8 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
                                       ks_pack<false, false, true, 1>, ks_pack<false, true, true, 1>, ks_pack<true, false, true, 1>, ks_pack<true, true, true, 1>};
   if (!attr_set) { for (int i = 0; i < 8; ++i) HIPCHK(hipFuncSetAttribute((const void*)variants[i], hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024)); attr_set = true; }
   // A single Solve whose problem takes the LEAN, FAST, no-bounds kernel gets 8 waves: waves 1..7 join wave 0 for the
-  // speculation rounds (see ks_pack).  T <= 4096 keeps a node's surviving-type mask in one register per lane.
-  bool multi = n == 1 && fast && !bounds && ds[0]->h.TW <= 64 && !(ds[0]->h.flags & KS_FLAG_STATS) && !getenv("KS_ONE_WAVE");
+  // speculation rounds (see ks_pack).  T <= 8192 keeps a node's surviving-type mask in two registers per lane.
+  bool multi = n == 1 && fast && ds[0]->h.TW <= 128 && !(ds[0]->h.flags & KS_FLAG_STATS) && !getenv("KS_ONE_WAVE");
   if (multi) {
     const u32 lds_mw = 44u * 1024u;
     if ((size_t)ds[0]->h.R * ds[0]->h.ge_max * 8 + 8192 > lds_mw) multi = false;
@@ -1887,9 +1888,11 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
       if (!attr_mw) {
         HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, true, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
         attr_mw = true;
       }
-      if (lean) hipLaunchKernelGGL((ks_pack<true, false, true, 8>), dim3(1), dim3(512), lds_mw, st, dp, dsv, lds_mw);
+      if (lean && !bounds) hipLaunchKernelGGL((ks_pack<true, false, true, 8>), dim3(1), dim3(512), lds_mw, st, dp, dsv, lds_mw);
+      else if (bounds) hipLaunchKernelGGL((ks_pack<true, true, false, 4>), dim3(1), dim3(256), lds_mw, st, dp, dsv, lds_mw);
       else hipLaunchKernelGGL((ks_pack<true, false, false, 4>), dim3(1), dim3(256), lds_mw, st, dp, dsv, lds_mw);     // host ports / limits / selectors on hostname or instance type: the general code
                                                                                                                      // needs > 256 VGPRs, so 4 waves (one per SIMD): leader + 3 workers
     }

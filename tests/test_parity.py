@@ -98,6 +98,14 @@ def s_problem(s, pods):
                    nodes=s.state_nodes, cluster_pods=s.cluster_pods, extra_well_known=s.extra_well_known, simulation_mode=s.opts.SimulationMode)
 
 
+@pytest.mark.parametrize("maker", [lambda: W.config5(pods=1200, sizes=56, seed=3), lambda: W.config5(pods=2500, sizes=60, seed=8)])
+def test_more_than_4096_instance_types(maker):
+    """T > 4096: a node's surviving-type mask spans two words per lane in the multi-wave kernel (4 480 / 4 800 types here; more than 64 ladder sizes would exceed the 64-values-per-key limit of the encoding)."""
+    p = maker()
+    assert len(p.instance_types) > 4096
+    assert_same(p)
+
+
 def test_whatifs_single_and_batched():
     its, prov, nodes, bound = W.cluster_snapshot(existing=96, sizes=8, seed=45)
     probs = [W.whatif(its, prov, nodes, bound, list(range(0, i + 1))) for i in range(6)] + \
