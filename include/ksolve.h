@@ -6,6 +6,8 @@
  *                                     called from provisioner.go:307 and deprovisioning/helpers.go:93
  *   ks_solve_batch               <->  N independent simulateScheduling what-ifs, deprovisioning/helpers.go:42-115
  *                                     (multinodeconsolidation.go:74-114, singlenodeconsolidation.go:43-78)
+ *   ks_price_filter_dev          <->  filterByPrice / worstLaunchPrice on a what-if's replacement node,
+ *                                     deprovisioning/helpers.go:148-157,292-315 (consolidation.go:238, multinodeconsolidation.go:164)
  *   ks_feasibility_grid          <->  filterInstanceTypesByRequirements for a fresh node, node.go:137-159
  *                                     (compatible && fits && hasOffering over every instance type)
  *   ks_probe_*                   <->  Requirement.Intersection/Has/Operator, Requirements.Compatible
@@ -22,8 +24,8 @@
  *             byte-wise string order (bit i of a mask == value i).  A requirement on key k is
  *             {present, complement, mask, gt, lt} == reference Requirement{complement, values,
  *             greaterThan, lessThan} (requirement.go:36-42).
- *   instance-type key  handled through a finite intersection-closed set of "it-states" (tables
- *             its_inter / its_fail / its_types) because its universe is the whole catalogue.
+ *   instance-type key  node-side states x pod-side requirement columns (tables its_inter / its_fail / its_types)
+ *             because its universe is the whole catalogue.
  *   hostname key       implicit: new node n owns a placeholder hostname no pod can name (node.go:46);
  *             existing node e owns hostname e.  Pod classes carry {mode, list of existing-node ids}.
  *   resources R <= 8 int64 milli-units; index 0 = cpu, 1 = memory, 2 = pods.
