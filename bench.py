@@ -154,8 +154,9 @@ def main():
     if args.whatifs and world == 1:
         # BASELINE configs[3] shape, bounded: independent consolidation what-ifs over one 2048-node snapshot, ONE launch,
         # one single-wave workgroup per what-if (what fills the other 255 CUs; untimed setup, timed solve_batch).
-        probs = W.config4(args.whatifs, 2048, args.sizes)
-        flats = [S.FlatProblem(p) for p in probs]
+        c_its, c_prov, c_nodes, c_bound = W.cluster_snapshot(2048, args.sizes, 45)
+        c_snap, c_pn = W.snapshot_problem(c_its, c_prov, c_nodes, c_bound, False)
+        flats = S.open_whatifs(c_snap, c_pn, W.config4_sets(args.whatifs, 2048, 45))
         for f in flats:
             f.upload(local_rank)
         S.solve_batch(flats, decode=False)

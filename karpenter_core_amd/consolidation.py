@@ -183,9 +183,9 @@ def compute_consolidations(snapshot: Snapshot, candidate_sets: Sequence[Sequence
     from . import scheduler, workloads
     types = {it.name: it for it in snapshot.instance_types}
     tindex = {it.name: i for i, it in enumerate(snapshot.instance_types)}
-    problems = [workloads.whatif(snapshot.instance_types, snapshot.provisioner, snapshot.nodes, snapshot.bound, list(cs))
-                for cs in candidate_sets]
-    flats = [scheduler.FlatProblem(p) for p in problems]
+    # one snapshot, flattened natively per what-if on all host cores (scheduler.open_whatifs)
+    snap, pod_node = workloads.snapshot_problem(snapshot.instance_types, snapshot.provisioner, snapshot.nodes, snapshot.bound)
+    flats = scheduler.open_whatifs(snap, pod_node, [list(cs) for cs in candidate_sets])
     results, _, _ = scheduler.solve_batch(flats)
     cmds = [Command() for _ in candidate_sets]
     need, prices = [], []

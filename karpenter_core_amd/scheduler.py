@@ -62,6 +62,10 @@ def libs():
         kh.ksh_price_filter.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32),
                                         ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
         kh.ksh_dims.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        kh.ksh_open_whatifs.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
+                                        ctypes.POINTER(ctypes.c_int32), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+        kh.ksh_fingerprint.argtypes = [ctypes.c_void_p]
+        kh.ksh_fingerprint.restype = ctypes.c_uint64
         kh.ksh_free.argtypes = [ctypes.c_void_p]
         _LIBS = (ks, kh)
     return _LIBS
@@ -74,19 +78,26 @@ def device_count() -> int:
 class FlatProblem:
     """A Solve() problem flattened to the C-ABI `ks_problem` (host side only until `upload`)."""
 
-    def __init__(self, problem: Problem, stats: bool = False):
+    def __init__(self, problem: Optional[Problem], stats: bool = False, _handle=None):
         ks, kh = libs()
-        text = problem.to_ksp().encode()
-        self._h = ctypes.c_void_p()
-        flags = KS_FLAG_STATS if stats else 0
-        rc = kh.ksh_open(text, len(text), flags, ctypes.byref(self._h))
-        if rc != KS_OK:
-            raise KSolveError(rc, kh.ksh_last_error().decode())
+        if _handle is not None:
+            self._h = _handle
+        else:
+            text = problem.to_ksp().encode()
+            self._h = ctypes.c_void_p()
+            flags = KS_FLAG_STATS if stats else 0
+            rc = kh.ksh_open(text, len(text), flags, ctypes.byref(self._h))
+            if rc != KS_OK:
+                raise KSolveError(rc, kh.ksh_last_error().decode())
         d = (ctypes.c_uint32 * 10)()
         kh.ksh_dims(self._h, d)
         self.dims = dict(zip(["P", "C", "T", "M", "E", "K", "R", "G", "GH", "S"], [int(x) for x in d]))
         self.kernel_ms = None
         self.wall_ms = None
+
+    def fingerprint(self) -> int:
+        """Hash of every array of the flat problem (equal iff two construction routes flattened to the same ks_problem)."""
+        return int(libs()[1].ksh_fingerprint(self._h))
 
     def close(self):
         if self._h:
@@ -129,6 +140,29 @@ class FlatProblem:
         if rc != KS_OK:
             raise KSolveError(rc, kh.ksh_last_error().decode())
         return arr, float(ms.value)
+
+
+def open_whatifs(snapshot: Problem, pod_node: Sequence[int], candidate_sets: Sequence[Sequence[int]], threads: int = 0) -> List[FlatProblem]:
+    """Flatten N consolidation what-ifs over one cluster snapshot natively (simulateScheduling, deprovisioning/helpers.go:42-115):
+    `snapshot` lists every state node and, as its pod batch, every bound pod (full spec); pod_node[i] = node index of pod i.
+    What-if w removes candidate_sets[w] from the state nodes and makes their pods (candidate order, then pod order) the pending
+    batch.  The snapshot is serialised and parsed once; the per-what-if NewScheduler/NewTopology flattening runs on `threads`
+    host threads (0 = all cores)."""
+    kh = libs()[1]
+    n = len(candidate_sets)
+    text = snapshot.to_ksp().encode()
+    off = [0]
+    for cs in candidate_sets:
+        off.append(off[-1] + len(cs))
+    flat = [int(c) for cs in candidate_sets for c in cs]
+    c_off = (ctypes.c_uint32 * (n + 1))(*off)
+    c_cand = (ctypes.c_uint32 * max(1, len(flat)))(*flat)
+    c_pn = (ctypes.c_int32 * max(1, len(pod_node)))(*[int(x) for x in pod_node])
+    hs = (ctypes.c_void_p * max(1, n))()
+    rc = kh.ksh_open_whatifs(text, len(text), 0, n, c_off, c_cand, c_pn, threads, hs)
+    if rc != KS_OK:
+        raise KSolveError(rc, kh.ksh_last_error().decode())
+    return [FlatProblem(None, _handle=ctypes.c_void_p(hs[i])) for i in range(n)]
 
 
 def solve_batch(flats: Sequence[FlatProblem], decode: bool = True):

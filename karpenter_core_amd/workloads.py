@@ -248,15 +248,31 @@ def whatif(its, prov, nodes, bound, candidates: List[int], with_cluster_pods: bo
                    extra_well_known=fake.EXTRA_WELL_KNOWN, simulation_mode=True)
 
 
-def config4(whatifs: int = 512, existing: int = 2048, sizes: int = 50, seed: int = 45, with_cluster_pods: bool = False) -> List[Problem]:
-    """512 what-ifs: half are multi-node prefixes (multinodeconsolidation.go:86-90), half singletons
+def snapshot_problem(its, prov, nodes, bound, with_cluster_pods: bool = True):
+    """The whole cluster as ONE problem for `scheduler.open_whatifs`: every node a state node, every bound pod in the pod
+    batch (full spec); returns (problem, pod_node).  `whatif()` below builds the same what-if one problem at a time."""
+    pods, pod_node = [], []
+    for i in range(len(nodes)):
+        for p in bound[i]:
+            pods.append(p)
+            pod_node.append(i)
+    ns = [StateNode(name=n.name, labels=n.labels, taints=n.taints, available=n.available, capacity=n.capacity,
+                    daemonset_requests=n.daemonset_requests, host_ports=n.host_ports, in_state=True) for n in nodes]
+    cps = [ClusterPod(uid=p.uid, namespace=p.namespace, node_name=nodes[i].name, labels=p.labels)
+           for i in range(len(nodes)) for p in bound[i]] if with_cluster_pods else []
+    return Problem(instance_types=its, provisioners=[prov], pods=pods, nodes=ns, cluster_pods=cps,
+                   extra_well_known=fake.EXTRA_WELL_KNOWN, simulation_mode=True), pod_node
+
+
+def config4_sets(whatifs: int = 512, existing: int = 2048, seed: int = 45) -> List[List[int]]:
+    """Candidate sets of config #4: half multi-node prefixes (multinodeconsolidation.go:86-90), half singletons
     (singlenodeconsolidation.go:54)."""
-    its, prov, nodes, bound = cluster_snapshot(existing, sizes, seed)
-    out = []
     half = whatifs // 2
-    for i in range(half):
-        out.append(whatif(its, prov, nodes, bound, list(range(0, i + 1)), with_cluster_pods))          # prefix [0..i]
     rs = np.random.RandomState(seed + 1)
-    for _ in range(whatifs - half):
-        out.append(whatif(its, prov, nodes, bound, [int(rs.randint(existing))], with_cluster_pods))      # singleton
-    return out
+    return [list(range(0, i + 1)) for i in range(half)] + [[int(rs.randint(existing))] for _ in range(whatifs - half)]
+
+
+def config4(whatifs: int = 512, existing: int = 2048, sizes: int = 50, seed: int = 45, with_cluster_pods: bool = False) -> List[Problem]:
+    """512 what-ifs, one Problem each (the per-what-if construction the oracle and the fingerprint tests use)."""
+    its, prov, nodes, bound = cluster_snapshot(existing, sizes, seed)
+    return [whatif(its, prov, nodes, bound, cs, with_cluster_pods) for cs in config4_sets(whatifs, existing, seed)]
