@@ -1461,6 +1461,33 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         if (lane == 0) rc.fail[kw] = failed ? 1u : 0u;
       }
       if (wv == 0) {
+        // The usual round: every winner is a new node of ONE count bucket.  Moving them one after the other leaves the rest of
+        // the bucket compacted to the left in its old order and winner k at endc-1-k (each goes to the FRONT of the next
+        // bucket, so later winners end up before earlier ones): do that in one pass over the bucket's tail.
+        const u32 cnt0 = RL(my_cnt, 0);
+        const bool uniform = n_ok >= 2 && ballot64((u32)lane < n_ok && (my_win < tb.E || my_cnt != cnt0)) == 0;
+        if (uniform) {
+          const u32 endc = UF(BST(cnt0 + 1));
+          const u32 pos_l = my_win - tb.E;                                                   // lane k: winner k's position (no move yet this round)
+          u32 jw_l = 0; if ((u32)lane < n_ok) jw_l = ORD_RD(pos_l);
+          u32 pmin = 0xFFFFFFFFu; for (u32 k = 0; k < n_ok; ++k) pmin = min(pmin, RL(pos_l, k));
+          // sequential-semantics position of winner k at its turn: earlier winners that stood before it have left
+          { u32 before = 0; for (u32 j = 0; j < n_ok; ++j) { const u32 pj = RL(pos_l, j); if (j < (u32)lane && pj < pos_l) ++before; }
+            if ((u32)lane < n_ok) { mv_p = pos_l - before; mv_cnt = cnt0; mv_maxc = lane == 0 ? maxc : max(maxc, cnt0 + 1); mv_done = true; } }
+          if (ord_in_lds) LSYNC(); else GSYNC();
+          for (u32 b = pmin; b < endc; b += 64) {
+            const u32 ii = b + lane; u32 v = 0; if (ii < endc) v = ORD_RD(ii);
+            u32 before = 0; bool is_w = false;
+            for (u32 k = 0; k < n_ok; ++k) { const u32 pk = RL(pos_l, k); if (pk < ii) ++before; if (pk == ii) is_w = true; }
+            if (ord_in_lds) LSYNC(); else GSYNC();
+            if (ii < endc && !is_w) ORD_WR(ii - before, v);
+          }
+          if (ord_in_lds) LSYNC(); else GSYNC();
+          if ((u32)lane < n_ok) ORD_WR(endc - 1 - lane, jw_l);
+          if (lane == 0) { BST(cnt0 + 1) = endc - n_ok; if (cnt0 + 1 > maxc) BST(cnt0 + 2) = nnew; }
+          if (cnt0 + 1 > maxc) maxc = cnt0 + 1;
+          if (ord_in_lds) LSYNC(); else GSYNC();
+        } else
         for (u32 k = 0; k < n_ok; ++k) {
           const u32 u = RL(my_win, k);
           if (u < tb.E) continue;                       // existing nodes keep their place
