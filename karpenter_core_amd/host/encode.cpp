@@ -158,11 +158,6 @@ struct Builder {
     for (auto& k : pr.extra_well_known) wellKnown.insert(k);
     res_of("cpu"); res_of("memory"); res_of("pods");
     key_of(ksp::kZone, true); key_of(ksp::kCapacityType, true);
-    for (auto& it : pr.instance_types) {
-      for (auto& e : it.requirements) { if (e.op == Op::Gt || e.op == Op::Lt) throw Unsupported("instance type requirement with Gt/Lt bounds"); note_expr(e); }
-      for (auto& o : it.offerings) { key_vals[key_of(ksp::kZone, true)].insert(o.zone); key_vals[key_of(ksp::kCapacityType, true)].insert(o.capacity_type); }
-      note_res(it.capacity); note_res(it.overhead);
-    }
     for (auto& p : pr.provisioners) {
       for (auto& e : p.requirements) { if (ksp::normalize_key(e.key) == ksp::kHostname) throw Unsupported("provisioner requirement on kubernetes.io/hostname"); note_expr(e); }
       for (auto& kv : p.labels) { if (ksp::normalize_key(kv.first) == ksp::kHostname) throw Unsupported("provisioner label kubernetes.io/hostname"); note_label(kv.first, kv.second); }
@@ -173,6 +168,19 @@ struct Builder {
     for (auto& p : pr.pods) note_pod(p);
     for (auto& p : pr.daemons) note_pod(p);
     for (auto& cp : pr.cluster_pods) for (auto& t : cp.anti_required) { if (t.topology_key != ksp::kHostname) key_of(t.topology_key, true); }
+    // Instance types last: a label key that ONLY instance types carry (real catalogues have many, often with hundreds of
+    // values -- the fake provider's `integer` has one per type) can never meet a node requirement: node requirements come from
+    // provisioners, pods, topology keys and existing-node labels, and Intersects / Compatible only look at keys both sides
+    // have (requirements.go:123-133,189-206).  Such keys are left out of the encoding altogether.
+    for (auto& it : pr.instance_types) {
+      for (auto& e : it.requirements) {
+        if (e.op == Op::Gt || e.op == Op::Lt) throw Unsupported("instance type requirement with Gt/Lt bounds");
+        const std::string k = ksp::normalize_key(e.key);
+        if (special_key(k) || key_id.count(k)) note_expr(e);
+      }
+      for (auto& o : it.offerings) { key_vals[key_of(ksp::kZone, true)].insert(o.zone); key_vals[key_of(ksp::kCapacityType, true)].insert(o.capacity_type); }
+      note_res(it.capacity); note_res(it.overhead);
+    }
     // node labels: only keys something else references matter (existing-node requirements are never
     // returned); values of referenced keys join the universe (they become topology domains / In sets)
     for (auto& n : pr.nodes) {
@@ -266,7 +274,8 @@ struct Builder {
       for (auto& kv : rs.m) {
         if (kv.first == ksp::kInstanceType) continue;
         if (kv.first == ksp::kHostname) throw Unsupported("instance type requirement on hostname");
-        int k = key_id.at(kv.first);
+        auto kf = key_id.find(kv.first); if (kf == key_id.end()) continue;      // a key nothing else references (collect_universes)
+        int k = kf->second;
         E.it_present[t] |= 1u << k; if (kv.second.complement) E.it_complement[t] |= 1u << k;
         uint64_t m = 0; for (auto& v : kv.second.values) m |= 1ull << value_id(k, v);
         E.it_mask[(size_t)k * T + t] = m;

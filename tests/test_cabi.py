@@ -8,7 +8,7 @@ import re
 import pytest
 
 import __graft_entry__ as ge
-from karpenter_core_amd import scheduler as S, workloads as W
+from karpenter_core_amd import fake, scheduler as S, workloads as W
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -70,7 +70,10 @@ def test_whatif_flattening():
 
 
 def test_unsupported_is_loud():
-    pr = W.reference_benchmark(50, instance_count=100)   # `integer` label with 100 distinct values
+    pr = W.reference_benchmark(50, instance_count=100)   # `integer` label with 100 distinct values ...
+    S.FlatProblem(pr).close()                             # ... is fine while only instance types carry it (the key is left out)
+    from karpenter_core_amd.model import Expr
+    pr.pods[0].required_affinity = [[Expr(fake.LABEL_INTEGER, "Gt", ["50"])]]   # a pod references it: 100 values do not fit a 64-bit mask
     with pytest.raises(S.KSolveError) as ei:
         S.FlatProblem(pr)
     assert ei.value.code == S.KS_ERR_UNSUPPORTED

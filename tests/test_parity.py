@@ -51,6 +51,14 @@ def test_reference_benchmark_mix(pods, seed):
     assert_same(pr)
 
 
+def test_reference_benchmark_catalogue_of_400():
+    """The reference benchmark's own catalogue, fake.InstanceTypes(400) (scheduling_benchmark_test.go:113-133): its `integer`
+    label has 400 values, but only instance types carry it, so it never meets a node requirement and stays out of the encoding."""
+    p = W.reference_benchmark(1400, instance_count=400, seed=7)
+    got = S.solve_problem(p).canonical()
+    assert got == O.solve(p).canonical()
+
+
 @pytest.mark.parametrize("pods,seed", [(1000, 3), (4000, 46)])
 def test_config5_full_constraint_set(pods, seed):
     assert_same(W.config5(pods=pods, sizes=10, seed=seed))
