@@ -10,12 +10,17 @@
 //                         instance type (its requirement masks / allocatable vector live in registers,
 //                         loaded once, coalesced SoA), streams over (template,class) records that are
 //                         wave-uniform, and emits one 64-bit word per __ballot.  HBM-bound.
-//   ks_pack               one persistent single-wavefront workgroup per Solve(): the first-fit-decreasing
-//                         loop of scheduler.go:96-219 with no barriers.  Per pod the next 64 open nodes in
-//                         the reference's visiting order are screened one-per-lane (taints, host ports,
-//                         requirement intersection, topology domain choice, resource screen), __ballot +
-//                         count-trailing-zeros is the first-fit pick, the instance-type filter runs on
-//                         T-bit masks (word per lane, then type per lane), lane-parallel stores commit.
+//   ks_pack               one persistent workgroup per Solve(): the first-fit-decreasing loop of
+//                         scheduler.go:96-219.  Per pod the next 64 open nodes in the reference's visiting
+//                         order are screened one-per-lane (taints, host ports, requirement intersection,
+//                         topology domain choice, resource screen), __ballot + count-trailing-zeros is the
+//                         first-fit pick, the instance-type filter runs on T-bit masks (a word per lane),
+//                         lane-parallel stores commit.  A batch of what-ifs runs one single-wave workgroup
+//                         each; a single Solve gets 8 (or 4) waves: wave 0 carries the sequential state, the
+//                         others evaluate the next queued pods against the same snapshot (speculation rounds,
+//                         resolved exactly) and scan ahead for pods whose first fit lies deep in the order.
+//   ks_price_filter       consolidation price stage (filterByPrice / worstLaunchPrice) on device-resident results.
+//   ks_gather             batched read-back of a what-if batch's results.
 //
 // The reference functions each device function restates are cited inline (paths relative to
 // aws/karpenter-core pkg/).  There is deliberately NO CPU fallback in this library: if no gfx950
@@ -266,11 +271,11 @@ __global__ __launch_bounds__(256) void ks_grid_types(DevProb P, u32 chunks) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// pack kernel: ONE wavefront per Solve(), no barriers.
+// pack kernel: ONE workgroup per Solve().
 //
 // The Solve() loop is a serial dependency chain (pod k sees the state pods 0..k-1 left behind), so
-// the only parallelism inside one pod step is across candidate nodes and across instance types.  One
-// 64-lane wave owns the whole Solve:
+// the only parallelism inside one pod step is across candidate nodes and across instance types.  Wave 0
+// owns the Solve's sequential state (the other waves of a multi-wave workgroup only help, see ks_pack):
 //   * open nodes are kept in an array sorted in the reference's visiting order -- the stable
 //     `sort.Slice(newNodes, len(Pods))` of scheduler.go:183 -- which is maintained incrementally (a node
 //     whose pod count grows moves to the FRONT of the next count bucket; a new node is appended to the
@@ -660,7 +665,7 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
   ev.rc = fit ? 2 : 1;
 }
 
-// Synchronisation inside the single-wave workgroup.
+// Synchronisation.  The sequential path runs on wave 0 alone:
 //   LSYNC: cross-lane hand-off through LDS.  LDS instructions of one wave execute in program order, so only
 //          the compiler must be stopped from reordering -- no instruction is emitted.
 //   GSYNC: cross-lane hand-off through GLOBAL memory: the writer's stores must have completed
