@@ -138,6 +138,56 @@ def test_worst_launch_price_prefers_spot_then_on_demand():
     assert CR.worst_launch_price(ofs, nowhere) == CR.MAX_FLOAT64
 
 
+def _with_zone(its, zone, most=False):          # leastExpensiveInstanceWithZone / mostExpensiveInstanceWithZone, suite_test.go:2816-2833
+    od = _on_demand_by_price(its)
+    for it in (reversed(od) if most else od):
+        if any(o.zone == zone for o in it.offerings):
+            return it
+    return od[0] if most else od[-1]
+
+
+def _zonal_nodes(its, most_expensive_zone=None):
+    nodes = []
+    for z in ("test-zone-1", "test-zone-2", "test-zone-3"):
+        it = _with_zone(its, z, most=(z == most_expensive_zone))
+        nodes.append(node(f"n-{z}", it, it.offerings[0].capacity_type, z, cpu="1"))
+    return nodes
+
+
+def test_oracle_replace_keeps_zonal_spread():
+    """ "can replace node maintaining zonal topology spread" suite_test.go:1828-1934: three one-pod nodes, one per zone, the pods
+    spread over zones with maxSkew 1; only the zone-2 node is expensive.  Its replacement must come up in zone 2."""
+    from karpenter_core_amd.model import DO_NOT_SCHEDULE, LabelSelector, TopologySpreadConstraint
+    its = fake.instance_types_assorted()
+    nodes = _zonal_nodes(its, most_expensive_zone="test-zone-2")
+    labels = {"app": "test-zonal-spread"}
+    bound = []
+    for i in range(3):
+        p = Pod(uid=f"p{i}", labels=dict(labels), containers=[Container(requests={"cpu": "1"})],
+                spread=[TopologySpreadConstraint(1, LABEL_ZONE, DO_NOT_SCHEDULE, LabelSelector(dict(labels)))])
+        bound.append([p])
+    snap = snapshot(its, nodes, bound)
+    cmd = CR.single_node_consolidation_option(snap, [0, 1, 2])
+    assert cmd[0] == "replace" and cmd[1] == ("n-test-zone-2",)
+    reqs = dict(cmd[3])
+    assert reqs[LABEL_ZONE] == (False, ("test-zone-2",), None, None)
+    assert all("test-zone-2" in n for n in cmd[2])             # InstanceTypesAssorted names carry their zone
+
+
+def test_oracle_anti_affinity_blocks_consolidation():
+    """ "won't delete node if it would violate pod anti-affinity" suite_test.go:1936-2030: the cheapest instance in each zone,
+    one pod each with required hostname anti-affinity against its own label -- nothing can be deleted or replaced cheaper."""
+    from karpenter_core_amd.model import LabelSelector, PodAffinityTerm
+    its = fake.instance_types_assorted()
+    nodes = _zonal_nodes(its)
+    labels = {"app": "test"}
+    bound = [[Pod(uid=f"p{i}", labels=dict(labels), containers=[Container(requests={"cpu": "1"})],
+                  anti_required=[PodAffinityTerm(LABEL_HOSTNAME, LabelSelector(dict(labels)))])] for i in range(3)]
+    snap = snapshot(its, nodes, bound)
+    assert CR.single_node_consolidation_option(snap, [0, 1, 2])[0] == "do-nothing"
+    assert CR.first_n_node_consolidation_option(snap, [0, 1, 2])[0] == "do-nothing"
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # GPU: batched what-ifs + device price stage + replayed search  ==  the literal sequential reference path
 # ---------------------------------------------------------------------------------------------------------------------
