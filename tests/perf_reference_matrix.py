@@ -3,7 +3,9 @@
 makeDiversePods for {1, 50, 100, 500, 1000, 2000, 5000} pods; pods/sec = len(pods) / Solve time, scheduler construction
 excluded.  Two differences, both on the strict side: topology is LIVE here (the reference benchmark passes an inert
 `&scheduling.Topology{}`, :123) and pod UIDs are unique.  The reference asserts a floor of 100 pods/s for
-batches over 100 pods (:48,178-182); no measured numbers are published.  Prints one JSON object."""
+batches over 100 pods (:48,178-182); no measured numbers are published.  Prints one JSON object.
+Lives under tests/ (not collected by pytest) because it runs the CPU oracle next to the GPU path, which only test
+infrastructure may do.  usage: python tests/perf_reference_matrix.py"""
 import json, os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from karpenter_core_amd import scheduler as S, workloads as W

@@ -45,6 +45,12 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in src and "oracle_py" not in src and "ko_solve" not in src, f
+    for f in os.listdir(os.path.join(ROOT, "tools")):          # measurement helpers are not test infrastructure either
+        if f.endswith((".py", ".sh")):
+            src = open(os.path.join(ROOT, "tools", f), errors="ignore").read()
+            assert "oracle_py" not in src and "liboracle" not in src and "from oracle" not in src, f
+    bench = open(os.path.join(ROOT, "bench.py")).read()          # bench.py: the cpu_baseline leg only
+    assert bench.count("from oracle import") == 1 and bench.index("from oracle import") > bench.index("if not args.no_cpu_baseline")
 
 
 @pytest.mark.parametrize("name,problem,dims", [
