@@ -1,26 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- pod-placement decisions/sec through Solve() on MI355X (BASELINE.json metric).
 
-A "step" is one full Solve() of the workload with the flattened problem already resident in HBM
-(ksh_upload before the timed region): queue pop -> ... -> last commit, result read-back included.
-decisions = len(pods) per Solve -- the reference's own definition (scheduling_benchmark_test.go:170).
-
-N=1 workload: BASELINE configs[2] -- 100k pending pods, 2k instance types, topology spread + hostname
+N=1 workload: BASELINE configs[2] -- 100k pending pods, 2k instance types, zonal + hostname topology spread and hostname
 pod anti-affinity (the configuration the metric "@100k pods" is quoted on; it fits one GPU).
-N>1: a single Solve() is a serial dependency chain and does not shard ("replicas only"); what
-shards is the consolidation what-if fan-out, so every rank runs its own independent what-if Solve() of the
-same shape (different seed) and ONE RCCL all-gather of fixed-size result records closes the step
-(weak scaling; value = total decisions of all ranks / max-over-ranks time).
+
+What one timed "step" is (N=1): the whole of the reference's Solve() for a pod list the caller already holds in memory
+("queue sort -> last commit"), i.e. `scheduler.solve_from_pods`:
+    per-pod RequestsForPods / NewPodRequirements / classing / relaxation chains, NewQueue's sort (queue.go:35),
+    the rest of the flattening, upload, static tables + feasibility grid, the pack kernel, result read-back.
+`value` = pods / that time.  The pack loop alone on inputs already resident in HBM (round 1's number) is reported next to it
+as `resident` -- it is NOT `value`.  decisions = len(pods) per Solve, the reference's own definition
+(scheduling_benchmark_test.go:170).
+
+N>1: a single Solve() is a serial dependency chain and does not shard ("replicas only").  What shards is
+consolidation's what-if fan-out (BASELINE configs[3]): the 512 what-ifs over one 2048-node snapshot are dealt out i mod N,
+every rank solves its shard in ONE batched launch, and ONE RCCL all-gather of fixed-size result records `[id, n_new,
+n_unscheduled, first node's InstanceTypeOptions]` closes the step.  Fixed total work: "strong" scaling; `value` = decisions of
+all 512 what-ifs / max-over-ranks time; its N=1 reference is the `whatif_batch` object of the N=1 line.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel ks_pack: algorithmic bytes of the REFERENCE algorithm for this workload
-               (SURVEY 8d formula; attempts / scanned-type counts come from an untimed KS_FLAG_STATS launch)
-               divided by the mean launch duration measured with HIP events on the solve stream.
-  grid         the feasibility-grid kernels' own HBM roofline numbers.
-  cpu_baseline the CPU oracle (a restatement of the Go path; the Go toolchain is absent) timed on 1 host
-               core on a bounded sample: the same generator at 10k pods.
+  roofline     dominant kernel ks_pack: algorithmic bytes of the REFERENCE algorithm for this workload (SURVEY 8d formula with
+               the documented R=4, K=8 record sizes; attempts / scanned-type counts from an untimed KS_FLAG_STATS launch) divided
+               by the mean launch duration measured with HIP events on the solve stream; `traffic` only from a PMC file recorded
+               for the same kernel source; `issue` = the roofline that actually binds (instructions per cycle of one CU).
+  cpu_baseline the CPU oracle (a restatement of the Go path; no Go toolchain) on 1 host core on a bounded sample of the same
+               generator, plus the recorded full-size oracle time.
 """
 import argparse
+import hashlib
 import json
 import os
 import statistics
@@ -31,16 +38,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
+ROOFLINE_R, ROOFLINE_K = 4, 8  # record sizes the SURVEY 8d byte formula is quoted with (fixed: the fraction must not move with the encoding)
 
 
-def algorithmic_bytes(dims, stats, n_new):
-    """bytes(p) = B_pod + sum_attempted(B_node + |alive| B_it) + B_node(write-back)."""
-    R, K, TW = dims["R"], dims["K"], (dims["T"] + 63) // 64
+def algorithmic_bytes(T, stats, placed):
+    """bytes(p) = B_pod + sum_attempted(B_node + |alive| B_it) + B_node(write-back), R=4, K=8."""
+    R, K, TW = ROOFLINE_R, ROOFLINE_K, (T + 63) // 64
     b_pod = 8 * R + 16 * K + 16
     b_it = 8 * R + 16 * K + 8
     b_node = 8 * R + 16 * K + 8 + 8 * TW
-    placed = dims["P"]
     return stats["queue_pops"] * b_pod + stats["attempts"] * b_node + stats["types_scanned"] * b_it + placed * b_node
+
+
+def kernel_source_sha16():
+    h = hashlib.sha256()
+    for f in ("karpenter_core_amd/csrc/ksolve.hip", "karpenter_core_amd/csrc/ks_algebra.h"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -50,9 +64,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pods", type=int, default=100_000)
     ap.add_argument("--sizes", type=int, default=50, help="ladder sizes; instance types = sizes*40")
-    ap.add_argument("--cpu-sample-pods", type=int, default=10_000)
+    ap.add_argument("--cpu-sample-pods", type=int, default=20_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--whatifs", type=int, default=64, help="size of the untimed-setup consolidation what-if batch leg (0 = skip)")
+    ap.add_argument("--whatifs", type=int, default=512, help="consolidation what-ifs (BASELINE configs[3]); 0 skips the N=1 what-if leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,113 +86,209 @@ def main():
         dist.barrier()
     from karpenter_core_amd import scheduler as S, workloads as W
 
-    # ---- problem (untimed): generate, flatten, upload ----
+    if world > 1:
+        return whatif_fanout(args, rank, world, local_rank, torch, dist, S, W)
+
+    # ---- the pod list and the cluster objects in host memory (untimed: the caller holds them) ----
     t0 = time.time()
-    problem = W.config3(pods=args.pods, sizes=args.sizes, seed=44 + rank)
-    fp = S.FlatProblem(problem)
-    fp.upload(local_rank)
-    _, grid_ms = fp.grid(want_bits=False)               # static tables + feasibility grid (built once per problem)
+    problem = W.config3(pods=args.pods, sizes=args.sizes, seed=44)
+    parsed = S.ParsedProblem(problem)
     prep_s = time.time() - t0
-    dims = fp.dims
-    TW = (dims["T"] + 63) // 64
 
     def step():
-        fp.solve(decode=False)
-        if world > 1:
-            rec = torch.tensor([rank, dims["P"]], device="cuda", dtype=torch.int64)
-            out = [torch.empty_like(rec) for _ in range(world)]
-            dist.all_gather(out, rec)                   # the one exchange step: chosen-machine records over xGMI
+        fp, ms = S.solve_from_pods(parsed, local_rank)
+        fp.close()
+        return ms
 
     for _ in range(args.warmup):
         step()
-    kernel_ms, lat_ms = [], []
-    if world > 1:
-        dist.barrier()
     torch.cuda.synchronize()
+    rows, lat_ms = [], []
     t_start = time.perf_counter()
     for _ in range(args.steps):
         t1 = time.perf_counter()
-        step()
+        rows.append(step())
         lat_ms.append((time.perf_counter() - t1) * 1e3)
-        kernel_ms.append(fp.kernel_ms)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    value = args.pods * args.steps / elapsed
+    phase = {k: statistics.mean(r[k] for r in rows) for k in S.TIMING_KEYS}
 
-    if rank != 0:
-        return
-    decisions = dims["P"] * args.steps * world
-    value = decisions / elapsed
-
-    # ---- roofline of the dominant kernel (untimed stats launch gives the reference algorithm's work) ----
-    fps = S.FlatProblem(problem, stats=True)
-    fps.upload(local_rank)
-    res = fps.solve()
-    st = res.stats
-    abytes = algorithmic_bytes(dims, st, len(res.new_nodes))
-    mean_kernel_s = statistics.mean(kernel_ms) / 1e3
+    # ---- inputs resident in HBM: the pack loop alone (round 1's measurement), and the statistics launch for the roofline ----
+    fp, _ = S.solve_from_pods(parsed, local_rank)
+    dims = fp.dims
+    res = fp.result()
+    resident = []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        fp.solve(decode=False)
+        resident.append(((time.perf_counter() - t1) * 1e3, fp.kernel_ms))
+    _, grid_ms = fp.grid(want_bits=False)
+    fp.close()
+    fps, _ = S.solve_from_pods(parsed, local_rank, stats=True)
+    st = fps.result().stats
+    fps.close()
+    TW = (dims["T"] + 63) // 64
+    abytes = algorithmic_bytes(dims["T"], st, dims["P"])
+    mean_kernel_s = phase["pack_kernel_ms"] / 1e3
     achieved = abytes / mean_kernel_s / 1e9
     grid_bytes = dims["C"] * (8 * dims["R"] + 16 * dims["K"] + 16) + dims["T"] * (8 * dims["R"] + 16 * dims["K"] + 8) + dims["M"] * dims["C"] * TW * 8
-    traffic = None          # HBM bytes per ks_pack launch from the committed rocprofv3 --pmc passes of this same command
+    traffic, traffic_src, issue = None, None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_hbm_pmc.json")))["ks_pack_per_launch"]
-        if dims["P"] == 100_000 and dims["T"] == 2000:
-            traffic = pmc["hbm_bytes_fetch_x2"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_pmc.json")))
+        if pmc.get("kernel_source_sha16") == kernel_source_sha16() and pmc.get("pods") == dims["P"] and pmc.get("instance_types") == dims["T"]:
+            traffic = pmc["ks_pack_per_launch"]["hbm_bytes_fetch_x2_plus_write"]
+            traffic_src = "profiles/r02_bench_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, same kernel source)"
+            ipl = pmc["ks_pack_per_launch"].get("instructions")
+            if ipl:
+                clk = pmc["ks_pack_per_launch"].get("shader_clock_ghz", 2.4)
+                issue = {"instructions_per_launch": ipl, "instructions_per_pod": ipl / dims["P"], "cu_issue_capacity_per_cycle": 4,
+                         "achieved_ipc_one_cu": ipl / (mean_kernel_s * clk * 1e9), "frac": ipl / (mean_kernel_s * clk * 1e9) / 4.0,
+                         "note": "ks_pack runs ONE workgroup on ONE CU: issue capacity is 4 instructions/cycle/CU (one per SIMD)"}
     except Exception:
         pass
     out = {
-        "metric": "pod-placement decisions/sec (Solve())", "value": value, "unit": "decisions/s", "n_gpus": world,
+        "metric": "pod-placement decisions/sec (Solve())", "value": value, "unit": "decisions/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]: {dims['P']} pods, {dims['T']} instance types, zonal+hostname topology spread and "
                                f"hostname pod anti-affinity (workloads.config3 seed 44)", "pods": dims["P"], "instance_types": dims["T"],
                    "pod_classes": dims["C"], "topology_groups": dims["G"], "new_nodes": len(res.new_nodes),
-                   "unschedulable": len(res.unscheduled),
-                   "parallelism": "1 Solve per GPU" + (f", {world} independent what-if Solves + 1 RCCL all-gather" if world > 1 else "")},
+                   "unschedulable": len(res.unscheduled), "parallelism": "1 Solve on 1 GPU",
+                   "timed_window": "Solve() from the pod list in host memory: per-pod requests/requirements/classes, NewQueue sort, flattening, "
+                                   "upload, static tables + grid, pack kernel, read-back (scheduler.solve_from_pods)"},
         "p50_solve_latency_ms": statistics.median(lat_ms),
-        "kernel_ms_mean": statistics.mean(kernel_ms), "prep_seconds_untimed": prep_s,
+        "phases_ms_mean": phase, "host_threads": os.cpu_count(), "prep_seconds_untimed": prep_s,
+        "resident": {"what": "pack loop only, flattened problem already resident in HBM (ks_solve_dev incl. read-back) -- round 1's window",
+                     "decisions_per_s": dims["P"] / (statistics.median(r[0] for r in resident) / 1e3),
+                     "wall_ms": statistics.median(r[0] for r in resident), "kernel_ms": statistics.median(r[1] for r in resident)},
         "roofline": {"kernel": "ks_pack", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "profiles/r01_bench_hbm_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" if traffic else None,
-                     "algorithmic_bytes_per_launch": abytes,
-                     "ref_attempts": st["attempts"], "ref_types_scanned": st["types_scanned"],
-                     "note": "one Solve() is a serial dependency chain executed by ONE 8-wave workgroup (1 of 256 CUs); it is bound by "
-                             "instruction issue and dependent-access latency, the HBM fraction is reported for completeness (see DESIGN.md)"},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": abytes, "formula": f"SURVEY 8d with R={ROOFLINE_R}, K={ROOFLINE_K}",
+                     "kernel_ms_mean": phase["pack_kernel_ms"], "ref_attempts": st["attempts"], "ref_types_scanned": st["types_scanned"],
+                     "issue": issue,
+                     "note": "one Solve() is a serial dependency chain executed by ONE 8-wave workgroup (1 of 256 CUs): instruction issue and "
+                             "dependent-access latency bind it, the HBM fraction is reported because the contract asks for it (DESIGN.md)"},
         "grid": {"kernel": "ks_grid_mc+ks_grid_types", "ms": grid_ms, "algorithmic_bytes": grid_bytes,
                  "achieved_GBs": grid_bytes / (grid_ms / 1e3) / 1e9 if grid_ms else None},
     }
-    if args.whatifs and world == 1:
-        # BASELINE configs[3] shape, bounded: independent consolidation what-ifs over one 2048-node snapshot, ONE launch,
-        # one single-wave workgroup per what-if (what fills the other 255 CUs; untimed setup, timed solve_batch).
-        c_its, c_prov, c_nodes, c_bound = W.cluster_snapshot(2048, args.sizes, 45)
-        c_snap, c_pn = W.snapshot_problem(c_its, c_prov, c_nodes, c_bound, False)
-        flats = S.open_whatifs(c_snap, c_pn, W.config4_sets(args.whatifs, 2048, 45))
-        for f in flats:
-            f.upload(local_rank)
-        S.solve_batch(flats, decode=False)
-        runs = [S.solve_batch(flats, decode=False)[1:] for _ in range(3)]
-        kms, wms = sorted(r[0] for r in runs)[1], sorted(r[1] for r in runs)[1]
-        wpods = sum(f.dims["P"] for f in flats)
-        out["whatif_batch"] = {"workload": f"{args.whatifs} consolidation what-ifs over 2048 existing nodes / {dims['T']} instance types "
-                                           "(BASELINE configs[3] shape, bounded sample)", "whatifs": args.whatifs, "decisions": wpods,
-                               "kernel_ms": kms, "wall_ms": wms, "decisions_per_s_kernel": wpods / (kms / 1e3),
-                               "decisions_per_s_wall": wpods / (wms / 1e3), "whatifs_per_s_wall": args.whatifs / (wms / 1e3)}
+    if args.whatifs:
+        out["whatif_batch"] = whatif_leg(args, 0, 1, local_rank, torch, None, S, W)
     if not args.no_cpu_baseline:
         from oracle import oracle_py
         sample = W.config3(pods=args.cpu_sample_pods, sizes=args.sizes, seed=44)
-        text = sample.to_ksp()
         from karpenter_core_amd.model import parse_result
-        r = parse_result(oracle_py.solve_text(text))
+        r = parse_result(oracle_py.solve_text(sample.to_ksp()))
         secs = r.stats["solve_ns"] / 1e9
+        full = None
+        try:
+            full = json.load(open(os.path.join(ROOT, "tests", "golden", "config_hashes.json"))).get("config3_100k_2k", {}).get("oracle_seconds")
+        except Exception:
+            pass
         out["cpu_baseline"] = {"value": args.cpu_sample_pods / secs, "unit": "decisions/s", "cores": 1, "kind": "port",
                                "host_cores": os.cpu_count(), "seconds": secs,
-                               "sample": f"same generator at {args.cpu_sample_pods} pods / {dims['T']} instance types (Solve() only, "
-                                         "single thread like the Go path); the oracle's cost grows super-linearly with pods, so "
-                                         "this over-states the CPU rate at 100k pods"}
+                               "sample": f"same generator at {args.cpu_sample_pods} pods / {dims['T']} instance types (Solve() incl. the queue sort, single "
+                                         "thread like the Go path); the oracle's cost grows super-linearly with pods",
+                               "full_size_recorded": {"pods": 100000, "oracle_seconds": full, "decisions_per_s": (100000 / full) if full else None,
+                                                      "source": "tests/golden/config_hashes.json (tests/golden/make_config_hashes.py, build container)"}}
+    print(json.dumps(out))
+
+
+def whatif_problems(args, rank, world, S, W):
+    c_its, c_prov, c_nodes, c_bound = W.cluster_snapshot(2048, args.sizes, 45)
+    c_snap, c_pn = W.snapshot_problem(c_its, c_prov, c_nodes, c_bound, False)
+    sets = W.config4_sets(args.whatifs or 512, 2048, 45)
+    mine = list(range(rank, len(sets), world))
+    flats = S.open_whatifs(c_snap, c_pn, [sets[i] for i in mine])
+    return flats, mine, len(c_its), len(sets)
+
+
+def whatif_leg(args, rank, world, local_rank, torch, dist, S, W):
+    """BASELINE configs[3] on this rank's shard: ONE batched launch + binary result records (+ the all-gather when world > 1)."""
+    t0 = time.time()
+    flats, mine, T, total_whatifs = whatif_problems(args, rank, world, S, W)
+    flatten_s = time.time() - t0
+    t0 = time.time()
+    for f in flats:
+        f.upload(local_rank)
+    upload_s = time.time() - t0
+    words = (T + 63) // 64
+
+    def step():
+        _, kms, _ = S.solve_batch(flats, decode=False)
+        rec = torch.from_numpy(S.result_records(flats, mine, words)).cuda()
+        if world > 1:
+            per = (total_whatifs + world - 1) // world
+            pad = torch.full((per, rec.shape[1]), -1, dtype=torch.int64, device="cuda")
+            pad[: rec.shape[0]] = rec
+            outl = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(outl, pad)                  # the one exchange step: chosen-machine records over xGMI
+            rec = torch.cat(outl)[torch.cat(outl)[:, 0] >= 0]
+        return kms, rec
+
+    step()
+    runs = []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        kms, rec = step()
+        torch.cuda.synchronize()
+        runs.append(((time.perf_counter() - t1) * 1e3, kms))
+    wms, kms = sorted(runs)[1]
+    pods_mine = sum(f.dims["P"] for f in flats)
+    out = {"workload": f"{len(flats)} consolidation what-ifs over 2048 existing nodes / {T} instance types (BASELINE configs[3])",
+           "whatifs": len(flats), "decisions": pods_mine, "kernel_ms": kms, "wall_ms": wms,
+           "decisions_per_s_kernel": pods_mine / (kms / 1e3), "decisions_per_s_wall": pods_mine / (wms / 1e3),
+           "whatifs_per_s_wall": len(flats) / (wms / 1e3), "records": int(rec.shape[0]),
+           "flatten_seconds_untimed": flatten_s, "upload_seconds_untimed": upload_s}
+    for f in flats:
+        f.close()
+    return out
+
+
+def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
+    """N>1: the 512 what-ifs dealt out i mod N (strong scaling), one batched launch per rank, ONE all-gather of result records."""
+    flats, mine, T, total_whatifs = whatif_problems(args, rank, world, S, W)
+    for f in flats:
+        f.upload(local_rank)
+    words = (T + 63) // 64
+    per = (total_whatifs + world - 1) // world
+    pods_mine = sum(f.dims["P"] for f in flats)
+
+    def step():
+        S.solve_batch(flats, decode=False)
+        rec = torch.from_numpy(S.result_records(flats, mine, words)).cuda()
+        pad = torch.full((per, rec.shape[1]), -1, dtype=torch.int64, device="cuda")
+        pad[: rec.shape[0]] = rec
+        outl = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(outl, pad)                      # the single collective of the path
+        return torch.cat(outl)
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        table = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    tp = torch.tensor([pods_mine], device="cuda", dtype=torch.int64)
+    dist.all_reduce(tp)
+    total_pods = int(tp.item())
+    if rank != 0:
+        return
+    got = int((table[:, 0] >= 0).sum().item())
+    out = {"metric": "pod-placement decisions/sec (Solve())", "value": total_pods * args.steps / elapsed, "unit": "decisions/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[3]: {total_whatifs} consolidation what-ifs over 2048 existing nodes / {T} instance types, dealt out i mod {world}; "
+                                  "one batched launch per rank + ONE RCCL all-gather of result records", "whatifs": total_whatifs, "decisions_per_step": total_pods,
+                      "records_gathered": got, "parallelism": f"{world} ranks x {per} what-ifs",
+                      "n1_reference": "the `whatif_batch` object of the --gpus 1 line (same workload on one GPU); a single Solve() does not shard (replicas only)"}}
     print(json.dumps(out))
 
 

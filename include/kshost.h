@@ -1,0 +1,78 @@
+/* kshost.h -- C ABI of libkshost.so: the host half of the MI355X drop-in for karpenter-core's provisioning scheduler.
+ *
+ * libksolve.so (include/ksolve.h) takes a FLAT problem (structure-of-arrays bitmasks).  libkshost.so is what produces it from the
+ * objects a caller holds, i.e. the part of the reference that needs strings and maps and therefore stays on the host:
+ *
+ *   ksh_parse                 the caller's objects in memory ([]*v1.Pod, []*cloudprovider.InstanceType, []v1alpha5.Provisioner,
+ *                             []*state.Node, the cluster pods countDomains would list): KSP1 text -> C++ objects.  (A Go shim would
+ *                             build the same objects from its own structs; KSP1 -- grammar in karpenter_core_amd/model.py -- is the
+ *                             wire form the Python mirror and the tests use.)
+ *   ksh_solve_from_pods       provisioning.(*Provisioner).NewScheduler + scheduling.NewTopology + (*Scheduler).Solve for that pod
+ *                             list: provisioner.go:237-296,301-307 / topology.go:56-117 / scheduler.go:42-133 (queue.go:35 NewQueue
+ *                             included).  Flatten -> ks_problem_upload -> ks_feasibility_grid -> ks_solve_dev.
+ *   ksh_open / ksh_upload / ksh_solve / ksh_solve_batch
+ *                             the same in separate steps (flatten once, keep the problem resident in HBM, solve repeatedly / in batches).
+ *   ksh_open_whatifs          deprovisioning.simulateScheduling's problem construction for N candidate sets over ONE cluster snapshot
+ *                             (helpers.go:42-99): candidates leave the state nodes, their pods become the batch.
+ *   ksh_price_filter          filterByPrice / worstLaunchPrice on results still on the device (helpers.go:148-157,292-315).
+ *   ksh_result_text / ksh_result_summary
+ *                             what callers read from Solve's return values: KSR1 text (Node.Pods, InstanceTypeOptions,
+ *                             Requirements, Requests, ExistingNode.Pods, unscheduled queue, relaxation stages), or the fixed-size record
+ *                             consolidation needs of a simulation.
+ *
+ * Conventions: every function returns KS_OK (0) or a negative KS_ERR_* (ksolve.h); ksh_last_error() gives the thread-local message.
+ * Handles are opaque; buffers passed in are only read during the call; strings returned through char** are malloc'ed -> ksh_free.
+ * There is no CPU scheduling path behind this ABI: without a gfx950 device every solving entry point fails with KS_ERR_DEVICE.
+ * Re-entrancy: handles are independent; two threads may solve different handles concurrently (the reference runs the provisioner and
+ * the deprovisioner as two goroutines: provisioner.go:102-104, deprovisioning/controller.go:103-105).
+ */
+#ifndef KSHOST_H
+#define KSHOST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ksolve.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* ksh_last_error(void);
+void ksh_free(char* p);
+
+/* ---- objects in memory ---- */
+int ksh_parse(const char* ksp_text, size_t len, void** out_parsed);
+void ksh_parsed_free(void* parsed);
+
+/* ---- Solve() for a pod list the caller holds: flatten + upload + HIP kernels + read-back.
+ * ms[6] (may be NULL): flatten | upload | static tables + feasibility grid | pack kernel (HIP events) | ks_solve_dev incl. read-back | total.
+ * out_handle (may be NULL) receives a ksh_open-style handle holding the problem and its result (ksh_result_text, ksh_solve again, ...). */
+int ksh_solve_from_pods(void* parsed, int device, uint32_t flags /* KS_FLAG_* */, void** out_handle, double* ms);
+
+/* ---- the same in steps ---- */
+int ksh_open(const char* ksp_text, size_t len, uint32_t flags, void** out_handle);      /* parse + flatten (no GPU needed) */
+void ksh_close(void* handle);
+const ks_problem* ksh_problem(void* handle);                                           /* the flat problem (owned by the handle) */
+void ksh_dims(void* handle, uint32_t dims[10]);                                        /* P,C,T,M,E,K,R,G,GH,S */
+uint64_t ksh_fingerprint(void* handle);                                                /* hash of every array of the flat problem */
+int ksh_upload(void* handle, int device);                                              /* idempotent; a second call with another device is an error */
+/* Solve / grid on a handle that was not uploaded yet use the calling thread's current HIP device. */
+int ksh_solve(void* handle, char** out_text /* KSR1 or NULL */, float* kernel_ms, double* wall_ms);
+int ksh_solve_batch(void** handles, uint32_t n, char** out_texts /* n entries or NULL */, float* kernel_ms, double* wall_ms);
+int ksh_grid(void* handle, uint64_t* out /* [M][C][ceil(T/64)] or NULL */, float* kernel_ms);
+int ksh_solve_ksp(const char* ksp_text, size_t len, uint32_t flags, char** out_text);  /* one shot: KSP1 in, KSR1 out */
+
+/* ---- results ---- */
+int ksh_result_text(void* handle, char** out_text);
+int ksh_result_summary(void* handle, uint64_t* out /* [2 + words]: n_new, n_unscheduled, new node 0's InstanceTypeOptions */, uint32_t words);
+
+/* ---- consolidation ---- */
+int ksh_open_whatifs(const char* snapshot_text, size_t len, uint32_t flags, uint32_t n, const uint32_t* cand_off /* [n+1] */, const uint32_t* cand,
+                     const int32_t* pod_node /* node index of every snapshot pod */, uint32_t nthreads /* 0 = all usable cores */, void** out_handles /* [n] */);
+int ksh_price_filter(void** handles, uint32_t n, const uint32_t* node, const double* max_price, const uint32_t* spot_only /* or NULL */,
+                     uint64_t* out_masks, uint32_t stride_words, uint32_t* out_counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KSHOST_H */

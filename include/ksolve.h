@@ -10,7 +10,7 @@
  *                                     deprovisioning/helpers.go:148-157,292-315 (consolidation.go:238, multinodeconsolidation.go:164)
  *   ks_feasibility_grid          <->  filterInstanceTypesByRequirements for a fresh node, node.go:137-159
  *                                     (compatible && fits && hasOffering over every instance type)
- *   ks_probe_*                   <->  Requirement.Intersection/Has/Operator, Requirements.Compatible
+ *   ks_probe_*                   <->  Requirement.Intersection/Has/Operator/Len, Requirements.Compatible
  *                                     pkg/scheduling/requirement.go:117-204, requirements.go:123-206
  *
  * The reference has no FFI for this path (pure Go); a Go shim would flatten
@@ -211,6 +211,8 @@ enum {
 typedef struct ks_dev_problem ks_dev_problem;
 
 int ks_device_count(void);                                     /* number of gfx950 devices visible, 0 if none */
+int ks_current_device(void);                                   /* the calling thread's current HIP device (hipGetDevice), 0 if none */
+int ks_problem_device(const ks_dev_problem* d);                /* device an uploaded problem lives on */
 int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem** out);
 void ks_problem_free(ks_dev_problem* d);
 /* Solve on the uploaded problem; kernel time (ms, HIP events on the solve stream) is returned in *kernel_ms if non-NULL. */
@@ -240,6 +242,11 @@ typedef struct ks_req1 { uint64_t mask; int32_t gt, lt; uint8_t present, complem
 /* value_int: [64] integer value of each universe entry or INT32_MIN.  on_device != 0 runs a 1-thread kernel. */
 int ks_probe_intersection(const ks_req1* a, const ks_req1* b, const int32_t* value_int, uint32_t nvalues, int on_device, ks_req1* out);
 int ks_probe_compatible(const ks_req1* a, const ks_req1* b, int well_known, const int32_t* value_int, uint32_t nvalues, int on_device, int* ok);
+
+/* Requirement.Has over the key's universe (bit v: Has(value v)), Operator() (0 In, 1 NotIn, 2 Exists, 3 DoesNotExist), Len(), and the two
+ * predicates of them the kernels branch on: nidne = operator in {NotIn, DoesNotExist}, len0 = Len() == 0 (requirement.go:171-204). */
+typedef struct ks_req_facts { uint64_t has_mask; int64_t len; int32_t op; uint8_t nidne, len0; } ks_req_facts;
+int ks_probe_has(const ks_req1* a, const int32_t* value_int, uint32_t nvalues, int on_device, ks_req_facts* out);
 
 const char* ks_last_error(void); /* thread-local message of the last non-OK return */
 const char* ks_version(void);

@@ -14,7 +14,7 @@ in the CPU tests.  There is exactly one collective on the data path.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Sequence
+from typing import Callable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -70,11 +70,16 @@ def solve_whatifs(problems: Sequence[Problem], solve_many: Callable[[List[Proble
     return table[order].cpu()
 
 
-def gpu_solve_many(problems: List[Problem]) -> List[SolveResult]:
-    """One batched launch on this rank's GPU (no CPU path: raises without a gfx950 device)."""
+def gpu_solve_many(problems: List[Problem], device: Optional[int] = None) -> List[SolveResult]:
+    """One batched launch on this rank's GPU (no CPU path: raises without a gfx950 device).  `device` defaults to the calling
+    rank's current HIP device (torch.cuda.current_device(), i.e. LOCAL_RANK after torch.cuda.set_device)."""
     from . import scheduler
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
     flats = [scheduler.FlatProblem(p) for p in problems]
     try:
+        for f in flats:
+            f.upload(device)
         res, _, _ = scheduler.solve_batch(flats)
         return res
     finally:
@@ -96,8 +101,8 @@ def gpu_solve_many(problems: List[Problem]) -> List[SolveResult]:
 from dataclasses import dataclass, field
 from typing import Dict, Optional, Tuple
 
-from .model import (InstanceType, LABEL_CAPACITY_TYPE, LABEL_INSTANCE_TYPE, LABEL_ZONE, Provisioner, RequirementOut,
-                    StateNode)
+from .model import (InstanceType, LABEL_CAPACITY_TYPE, LABEL_INITIALIZED, LABEL_INSTANCE_TYPE, LABEL_ZONE, Provisioner,
+                    RequirementOut, StateNode)
 
 ACTION_DO_NOTHING, ACTION_DELETE, ACTION_REPLACE = "do-nothing", "delete", "replace"   # deprovisioning/types.go actions
 CAPACITY_TYPE_SPOT, CAPACITY_TYPE_ON_DEMAND = "spot", "on-demand"
@@ -129,6 +134,7 @@ class Command:
     nodes_to_remove: List[str] = field(default_factory=list)
     replacement_types: List[str] = field(default_factory=list)                 # replacementNodes[0].InstanceTypeOptions
     replacement_requirements: Dict[str, tuple] = field(default_factory=dict)  # ... .Requirements (canonical tuples)
+    error: Optional[str] = None     # computeConsolidation returned an error for this candidate set (consolidation.go:224-228)
 
     def canonical(self):
         return (self.action, tuple(self.nodes_to_remove), tuple(self.replacement_types), tuple(sorted(self.replacement_requirements.items())))
@@ -191,6 +197,11 @@ def compute_consolidations(snapshot: Snapshot, candidate_sets: Sequence[Sequence
     need, prices = [], []
     for i, (cs, res) in enumerate(zip(candidate_sets, results)):
         cands = [candidate(snapshot, j) for j in cs]
+        # simulateScheduling, helpers.go:102-111: the simulation must not lean on a node that is not ready yet -- Solve returns EVERY
+        # in-state existing node (scheduler.go:132), so one uninitialised node that stays in the cluster fails the simulation
+        removed = set(cs)
+        if any(n.owned and n.labels.get(LABEL_INITIALIZED) != "true" for j, n in enumerate(snapshot.nodes) if j not in removed and n.in_state):
+            continue
         if res.unscheduled:                                     # "not all pods would schedule"
             continue
         if not res.new_nodes:                                   # everything fits on the remaining nodes
@@ -198,8 +209,13 @@ def compute_consolidations(snapshot: Snapshot, candidate_sets: Sequence[Sequence
             continue
         if len(res.new_nodes) != 1:                             # "we're not going to turn a single node into multiple nodes"
             continue
+        try:
+            price = get_node_prices(types, cands)
+        except ValueError as e:                                 # "getting offering price from candidate node": an error of THIS computation only
+            cmds[i] = Command(error=str(e))
+            continue
         need.append(i)
-        prices.append(get_node_prices(types, cands))
+        prices.append(price)
     kept = scheduler.price_filter([flats[i] for i in need], [0] * len(need), prices)
     for i, keep in zip(need, kept):
         res = results[i]
@@ -260,6 +276,8 @@ def first_n_node_consolidation_option(snapshot: Snapshot, candidates: Sequence[i
             mid = (lo + hi) // 2
             k = mid - 1
             action = cmds[k]
+            if action.error is not None:                        # firstNNodeConsolidationOption returns the error of the prefix it probes (:92-95)
+                raise ValueError(action.error)
             if action.action == ACTION_REPLACE:
                 cands = [candidate(snapshot, j) for j in prefixes[k]]
                 opts = _filter_out_same_type(snapshot, flats[k], results[k], action, cands)
@@ -283,6 +301,8 @@ def single_node_consolidation_option(snapshot: Snapshot, candidates: Sequence[in
     for f in flats:
         f.close()
     for cmd in cmds:
+        if cmd.error is not None:                               # logged, next candidate (singlenodeconsolidation.go:57-60)
+            continue
         if cmd.action in (ACTION_REPLACE, ACTION_DELETE):
             return cmd
     return Command()

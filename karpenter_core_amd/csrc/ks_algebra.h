@@ -49,6 +49,12 @@ KS_HD bool kreq_len0(const KReq& r) { return !r.complement && r.mask == 0; }
 // values, or a concrete empty set.  A complement set with bounds but no excluded values is Exists.
 KS_HD bool kreq_nidne(const KReq& r) { return r.complement ? r.mask != 0 : r.mask == 0; }
 
+// Len() (requirement.go:199-204): |values| for a concrete set, MaxInt64 - |excluded values| for a complement set.
+KS_HD int64_t kreq_len(const KReq& r) { const int64_t n = (int64_t)__builtin_popcountll(r.mask); return r.complement ? INT64_MAX - n : n; }
+// Operator() (requirement.go:186-197) as 0 In, 1 NotIn, 2 Exists, 3 DoesNotExist -- derived from (complement, Len) exactly like the reference;
+// kreq_nidne / kreq_len0 above are the two predicates of it the kernels use.
+KS_HD int kreq_operator(const KReq& r) { if (r.complement) return kreq_len(r) < INT64_MAX ? 1 : 2; return kreq_len(r) > 0 ? 0 : 3; }
+
 // Intersection (requirement.go:117-150); both operands present.
 KS_HD KReq kreq_intersect(const KReq& a, const KReq& b, const int32_t* value_int, uint32_t nvalues) {
   KReq r; r.present = true;

@@ -47,7 +47,19 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define UF(x) ((u32)__builtin_amdgcn_readfirstlane((int)(x)))
 #define UF64(x) ((u64)UF((u32)(u64)(x)) | ((u64)UF((u32)((u64)(x) >> 32)) << 32))
 #define RL64(v, l) ((u64)RL((u32)(u64)(v), (l)) | ((u64)RL((u32)((u64)(v) >> 32), (l)) << 32))
-#ifdef KS_PROBES   /* fine-grained cycle probes (tools/phase_profile.py --probes builds with -DKS_PROBES) */
+#ifdef KS_CUTSTATS  /* experiment builds: why speculation rounds end (slots 12..17 of the statistics instead of the sequential phase probes) */
+#define CUT(i) do { if (lane == 0) ls.ctr[(i)] += 1; } while (0)
+#else
+#define CUT(i) do { } while (0)
+#endif
+#ifdef KS_P2PROBES   /* experiment builds: where the resolver's time goes (slots 12..19 instead of the sequential phase probes) */
+#define P2T(i) do { const u64 now_ = __builtin_readcyclecounter(); if (lane == 0) ls.ctr[(i)] += now_ - t2p; t2p = now_; } while (0)
+#define P2C(i, v) do { if (lane == 0) ls.ctr[(i)] += (v); } while (0)
+#else
+#define P2T(i) do { } while (0)
+#define P2C(i, v) do { } while (0)
+#endif
+#if defined(KS_PROBES) && !defined(KS_CUTSTATS) && !defined(KS_P2PROBES)   /* fine-grained cycle probes (tools/phase_profile.py --probes builds with -DKS_PROBES) */
 #define PROBE(i) do { const u64 now_ = __builtin_readcyclecounter(); if (lane == 0 && wv == 0) ls.ctr[(i)] += now_ - tprobe; tprobe = now_; } while (0)
 #else
 #define PROBE(i) do { (void)tprobe; } while (0)
@@ -89,6 +101,8 @@ struct DevProb {
   u32* ge_cnt;       // [R]
   u64* ge_rows;      // [(r*T+i)*TW] types whose Allocatable[r] >= ge_vals[r*T+i]   (resources.Fits as a mask)
   void* plans;       // [C] ClsPlan: per-class plan records (ks_build_plans)
+  void* briefs;      // [C] ClsBrief: what the round planner / resolver reads of a class
+  u32* ev_tab; u32 ev_tab_size, ev_pad;   // open-addressing table that interns evaluation classes (ks_link_plans)
   u8* mc_ok;         // [M*C]
   u32* mc_present; u32* mc_complement; u64* mc_mask; i32* mc_gt; i32* mc_lt; i32* mc_it;   // template ∩ class
   u64* grid;         // [M*C*TW]
@@ -101,10 +115,11 @@ struct DevState {
   // node records (AoS, see Rec): slots [0,E) existing nodes, [E,E+NMAX) new nodes
   u8* rec; u32 rec_stride;
   i32* n_tmpl; u64* n_alive;          // new nodes only, indexed by j = slot-E; n_alive has one spare row
+  u64* round_scratch;                 // [KS_MAX_WAVES*64][TW]: InstanceTypeOptions rows as they were before a round's filters (restored if the round is cancelled)
   u32* bstart;                        // [P+3] count-bucket boundaries of the visiting-order array
   u32* order_g;                       // [NMAX] global-memory home of the visiting order once it outgrows LDS
   // topology
-  i32* gcnt; u64* g_reg; u64* g_pos; u8* g_active; i32* hcnt /* [slot][GH] */; i32* g_hpos;
+  i32* gcnt; u64* g_reg; u64* g_pos; u8* g_active; i32* hcnt /* [slot][GH] */; i32* g_hpos; i32* g_hzero;   // g_hzero[h]: registered hostnames of group h whose count is 0
   // provisioner limits
   i64* remaining;
   // host-port pool
@@ -323,18 +338,31 @@ struct alignas(16) ClsPlan {
                                            // eq: evaluation-equivalence id (ks_link_plans), 0 = none
 };
 static_assert(sizeof(ClsPlan) % 16 == 0, "plan records are copied with 16-byte loads");
+// What the round planner and resolver (ks_pack, speculation rounds) read of a class.
+struct alignas(16) ClsBrief {
+  u64 tmask;    // groups (bit g & 63) whose counters the evaluation of ANOTHER node can depend on: a record into one of them by an earlier pod of the round ends the round
+  u64 tfull;    // every group the evaluation reads (adds the hostname-keyed groups whose record only touches the winner's own counter)
+  u64 rmask;    // groups Topology.Record may update
+  u32 ev;       // evaluation class: classes with equal ids are evaluated identically by eval_node (they may differ in what they record)
+  u32 flags;    // bit 0: may take part in rounds (plan fits the kernel's limits, no host ports)
+  u32 reqmask, pad;
+  i64 req[KS_MAX_RES];
+  u64 zmask;    // hostname-keyed groups whose item accepts a node only while the node's own counter is 0 (anti-affinity; spread with maxSkew - self == 0)
+  u64 rsure;    // hostname-keyed groups this class records into for certain (group present from the start, no node filter): subset of rmask
+};
+static_assert(sizeof(ClsBrief) == 128, "ClsBrief layout");
 
 // ------------------------------------------------------------------------------------------------
 // ks_build_plans: one thread per pod class; everything about a class that does not depend on the
 // Solve state is resolved here once (host/encode.cpp produced the CSR lists).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void ks_build_plans(DevProb P, ClsPlan* plans) {
+__global__ __launch_bounds__(64) void ks_build_plans(DevProb P, ClsPlan* plans, ClsBrief* briefs) {
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= P.C) return;
   ClsPlan pl; memset(&pl, 0, sizeof pl);
   pl.c = c; pl.present = P.cls.present[c]; pl.complement = P.cls.complement[c]; pl.it_state = P.cls.it_state[c];
-  pl.hn_mode = P.cls_hn_mode[c]; pl.hn_off = P.cls_hn_off[c]; pl.hn_cnt = P.cls_hn_off[c + 1] - P.cls_hn_off[c];
-  pl.reqmask = P.cls_requests_present[c]; pl.tol = P.cls_tolerated[c]; pl.port_off = P.cls_port_off[c]; pl.port_cnt = P.cls_port_off[c + 1] - P.cls_port_off[c];
+  pl.hn_mode = P.cls_hn_mode[c]; pl.hn_cnt = P.cls_hn_off[c + 1] - P.cls_hn_off[c]; pl.hn_off = pl.hn_cnt ? P.cls_hn_off[c] : 0;      // (an empty list has no position: classes that differ only there evaluate alike)
+  pl.reqmask = P.cls_requests_present[c]; pl.tol = P.cls_tolerated[c]; pl.port_cnt = P.cls_port_off[c + 1] - P.cls_port_off[c]; pl.port_off = pl.port_cnt ? P.cls_port_off[c] : 0;
   for (u32 r = 0; r < P.R; ++r) pl.req[r] = P.cls_requests[(size_t)c * P.R + r];
   // own requirement keys, ascending
   for (u32 k = 0; k < P.K; ++k) if ((pl.present >> k) & 1u) {
@@ -390,12 +418,59 @@ __global__ __launch_bounds__(64) void ks_build_plans(DevProb P, ClsPlan* plans) 
     }
   }
   pl.tkeys = 0; for (u32 j = 0; j < pl.ntouch; ++j) pl.tkeys |= (u64)(u32)pl.touch[j].key << (5 * j);
-  pl.tmask = 0; pl.rmask = 0;
+  pl.tmask = 0; pl.rmask = 0; u64 tfull = 0;
   for (u32 j = 0; j < pl.ntopo; ++j) pl.tmask |= 1ull << (pl.topo[j].g & 63);
-  for (u32 j = 0; j < pl.nhost; ++j) pl.tmask |= 1ull << (pl.host[j].g & 63);
+  tfull = pl.tmask; for (u32 j = 0; j < pl.nhost; ++j) tfull |= 1ull << (pl.host[j].g & 63);
+  for (u32 j = 0; j < pl.nhost; ++j) {
+    // A record into a hostname-keyed anti-affinity group, or a spread group every node registered with, changes the winner's own
+    // hostname counter only; no other candidate's evaluation reads it, and the winner itself is covered by the order rule of the
+    // rounds.  (A spread group created by a later relaxation has unregistered hostnames that a record can turn into accepting ones.)
+    const bool own_counter_only = pl.host[j].type == 2 || (pl.host[j].type == 0 && P.grp_active[pl.host[j].g] != 0);
+    if (!own_counter_only) pl.tmask |= 1ull << (pl.host[j].g & 63);
+  }
   for (u32 j = 0; j < pl.nrec; ++j) pl.rmask |= 1ull << (pl.rec[j].g & 63);
   pl.eq = 0;
   plans[c] = pl;
+  u64 zmask = 0;
+  for (u32 j = 0; j < pl.nhost; ++j) if (pl.host[j].type == 2 || (pl.host[j].type == 0 && (i64)pl.host[j].maxskew - (i64)pl.host[j].self <= 0)) zmask |= 1ull << (pl.host[j].g & 63);
+  for (u32 j = 0; j < pl.nhost; ++j) if (!(pl.host[j].type == 2 || (pl.host[j].type == 0 && (i64)pl.host[j].maxskew - (i64)pl.host[j].self <= 0))) zmask &= ~(1ull << (pl.host[j].g & 63));   // (two items hashing to one bit: keep the careful answer)
+  for (u32 j = 0; j < pl.ntopo; ++j) zmask &= ~(1ull << (pl.topo[j].g & 63));
+  u64 rsure = 0;
+  for (u32 j = 0; j < pl.nrec; ++j) { const PlanRec& r = pl.rec[j]; if (r.key == KS_KEY_HOSTNAME && (r.owned_inverse || (P.grp_active[r.g] != 0 && !r.filtered))) rsure |= 1ull << (r.g & 63); }
+  ClsBrief b; b.zmask = zmask; b.rsure = rsure; b.tmask = pl.tmask; b.tfull = tfull; b.rmask = pl.rmask; b.ev = 0; b.flags = (!pl.overflow && pl.port_cnt == 0) ? 1u : 0u; b.reqmask = pl.reqmask; b.pad = 0;
+  for (u32 r = 0; r < KS_MAX_RES; ++r) b.req[r] = pl.req[r];
+  briefs[c] = b;
+}
+
+// Evaluation classes: two classes get the same id when eval_node reads identical inputs for both (requests, requirements, tolerations,
+// hostname selector, ports, every topology item incl. its self-selecting flag) -- they may still differ in the groups Topology.Record
+// visits.  Interned through an open-addressing table: hash of the evaluation part of the plan, confirmed word by word.
+__device__ inline bool ks_plan_eval_equal(const ClsPlan& a, const ClsPlan& b) {
+  const u32* x = (const u32*)&a; const u32* y = (const u32*)&b;
+  constexpr u32 w_present = offsetof(ClsPlan, present) / 4, w_nrec = offsetof(ClsPlan, nrec) / 4, w_req = offsetof(ClsPlan, req) / 4, w_rec = offsetof(ClsPlan, rec) / 4;
+  for (u32 i = w_present; i < w_nrec; ++i) if (x[i] != y[i]) return false;
+  for (u32 i = w_req; i < w_rec; ++i) if (x[i] != y[i]) return false;
+  return a.overflow == b.overflow && a.tkeys == b.tkeys;
+}
+__device__ inline u64 ks_plan_eval_hash(const ClsPlan& a) {
+  const u32* x = (const u32*)&a; u64 h = 0x9E3779B97F4A7C15ull;
+  constexpr u32 w_present = offsetof(ClsPlan, present) / 4, w_nrec = offsetof(ClsPlan, nrec) / 4, w_req = offsetof(ClsPlan, req) / 4, w_rec = offsetof(ClsPlan, rec) / 4;
+  for (u32 i = w_present; i < w_nrec; ++i) { h ^= x[i]; h *= 0x9FB21C651E98DF25ull; h ^= h >> 29; }
+  for (u32 i = w_req; i < w_rec; ++i) { h ^= x[i]; h *= 0x9FB21C651E98DF25ull; h ^= h >> 29; }
+  h ^= a.overflow; h *= 0xD6E8FEB86659FD93ull; h ^= a.tkeys; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
+  return h;
+}
+__global__ __launch_bounds__(64) void ks_link_ev(const ClsPlan* plans, ClsBrief* briefs, u32* tab, u32 tab_size, u32 C) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const ClsPlan& me = plans[c];
+  u32 slot = (u32)ks_plan_eval_hash(me) & (tab_size - 1), ev = 0;
+  for (u32 probes = 0; probes < tab_size; ++probes, slot = (slot + 1) & (tab_size - 1)) {
+    const u32 prev = atomicCAS(&tab[slot], 0u, c + 1);
+    if (prev == 0) { ev = c + 1; break; }                        // first of its kind: it represents the evaluation class
+    if (ks_plan_eval_equal(plans[prev - 1], me)) { ev = prev; break; }
+  }
+  briefs[c].ev = ev ? ev : c + 1;
 }
 
 // Two classes are evaluation-equivalent when Node.Add reads exactly the same inputs for both and neither
@@ -427,7 +502,7 @@ __global__ __launch_bounds__(64) void ks_link_plans(ClsPlan* plans, u32 C, u32 R
 // vmcnt(0) AND lgkmcnt(0), serialising all outstanding global loads).
 struct Tabs {
   const u32* key_nvalues; const i32* value_int; const u8* its_fail; const u16* its_inter;
-  i32* gcnt; u64* g_reg; u64* g_pos; u8* g_active; i32* g_hpos;
+  i32* gcnt; u64* g_reg; u64* g_pos; u8* g_active; i32* g_hpos; i32* g_hzero;
   const i64* ge_vals; const u32* ge_cnt;
   u32 K, R, T, TW, GH, E, S, SC, n_ct, wellknown, ge_stride; i32 key_zone, key_ct;
   // hot global arrays, typed with the global address space (pointers loaded from a descriptor in memory
@@ -464,7 +539,7 @@ template <int RM> struct PubT {
 struct TopoDyn { u64 reg, pos; i32 minc; i32 pad; };
 struct alignas(16) WaveShared {      // one per wave of the workgroup
   ClsPlan cls; ReqOut rq;
-  TopoDyn dyn[KS_MAX_TOPO]; i32 host_anypos[KS_MAX_HOST];
+  TopoDyn dyn[KS_MAX_TOPO]; i32 host_anypos[KS_MAX_HOST]; i32 host_zero[KS_MAX_HOST]; i32 pad_hz[2];
   i64 low_new[KS_MAX_RES];
   u64 la_mask[KS_MAX_TOUCH][64];                                                            // per-lane requirement slots of eval_node
 };
@@ -475,14 +550,20 @@ struct LeaderShared {                // owned by wave 0, which carries the Solve
   u64 ctr[32];          // statistics + (KS_PROBES builds) per-phase cycle counters; slot numbers = ks_result.stats[]
 };
 #define KS_MAX_WAVES 8
-struct RoundCtl {                    // round speculation hand-off between the leader and the other waves
-  u32 mode2[2], n, nnew, seq0, n_ok, ord_in_lds, pad0;   // mode2: double-buffered by step parity (the leader may plan the next step before a slow wave has read this one's)
+template <int RM> struct RoundCtlT {   // speculation-round hand-off between the leader (wave 0) and the worker waves
+  u32 mode2[2], n, nnew, seq0, n_ok, ord_in_lds, nwk;   // mode2: double-buffered by step parity (the leader may plan the next step before a slow wave has read this one's)
   u32 cmd, scan_base, scan_total, scan_cidx;     // scan-ahead service of the sequential path (waves 1.. evaluate the windows after the leader's)
-  u64 qe[2][2 * KS_MAX_WAVES];   // this round's pods and the ones after them (plan prefetch); double-buffered: the leader plans the next step while workers still read
-  u32 par, pad2;
-  u64 m[KS_MAX_WAVES], T[KS_MAX_WAVES], R[KS_MAX_WAVES];
-  u32 elig[KS_MAX_WAVES], win[KS_MAX_WAVES], fail[KS_MAX_WAVES];
-  u32 cnt[64];
+  u32 par, fail_at, pad0, pad1;                  // fail_at: first round pod placed on a node whose instance-type filter came back empty (0xFFFFFFFF: none)
+  u64 scanm[KS_MAX_WAVES];                       // scan-ahead: fit bitmap of each helper's window
+  u64 qe[2][64];                                 // the round's pods (queue entries); double-buffered like mode2
+  u8 pw[2][64];                                  // worker (evaluation class) of round pod i
+  u32 wcls[2][KS_MAX_WAVES];                     // class evaluated by worker j
+  u64 m[KS_MAX_WAVES], chg[KS_MAX_WAVES];        // per worker: candidates that accept its class / whose requirements a commit of that class would change
+  u32 cnt[64], rmsk[64]; i64 room[RM][64], req0[RM][64], low0[RM][64];   // per candidate, class independent (published by worker 0): pods, requested-resource mask, headroom, requests, filter thresholds (Rec::low)
+  u8 win[64];                                    // candidate (window lane) of round pod i
+  u32 ortmp[4];                                  // scratch of the resolver's mask reductions
+  u8 lastpod[64], firstpod[64], npods[64];       // per candidate: last / first round pod placed on it, how many
+  u32 rmsk_new[64]; i64 roomrem[RM][64];         // per candidate after the round's pods: requested-resource mask, headroom
 };
 
 // ---- slot record (AoS).  Offsets in bytes; stride = ks_rec_stride(R,K) ----
@@ -775,8 +856,16 @@ __device__ __forceinline__ void grp_record(const Tabs& tb, int g, int d) {   // 
 }
 template <bool ATOMIC>
 __device__ __forceinline__ void grp_record_host(const DevState& S, const Tabs& tb, int h, u32 slot) {
-  GA i32& c = tb.hcnt[(size_t)slot * tb.GH + h];      // one node receives at most one pod per round: no contention on its counters
-  if (c <= 0) { if constexpr (ATOMIC) atomicAdd(&tb.g_hpos[h], 1); else tb.g_hpos[h]++; }
+  GA i32& c = tb.hcnt[(size_t)slot * tb.GH + h];
+  if constexpr (ATOMIC) {      // several pods of one round may land on the same node: every transition old -> new is taken exactly once
+    i32 old = c;
+    for (;;) { const i32 nw = old < 0 ? 1 : old + 1; i32 expect = old; if (__hip_atomic_compare_exchange_strong(&c, &expect, nw, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break; old = expect; }
+    if (old <= 0) atomicAdd(&tb.g_hpos[h], 1);
+    if (old == 0) atomicSub(&tb.g_hzero[h], 1);
+    return;
+  }
+  if (c <= 0) tb.g_hpos[h]++;
+  if (c == 0) tb.g_hzero[h]--;      // one registered zero-count hostname fewer
   c = c < 0 ? 1 : c + 1;
 }
 // Topology.Record, topology.go:120-143: lane i handles the i-th group of the class's record list
@@ -797,6 +886,18 @@ __device__ __forceinline__ void topology_record(const DevProb& P, const DevState
   else if (!q.complement && __builtin_popcountll(q.mask) == 1) grp_record<ATOMIC>(tb, g, __builtin_ctzll(q.mask));
 }
 
+// Minimum of a 32-bit value over the wave, returned wave-uniform: four row shifts and two row broadcasts on the data-parallel-primitive
+// path (no LDS round trips), the result sits in lane 63.  Every lane takes part (callers pass 0xFFFFFFFF for lanes that do not count).
+__device__ __forceinline__ u32 wave_min_u32(u32 v) {
+  const int id = (int)0xFFFFFFFFu;
+  v = min(v, (u32)__builtin_amdgcn_update_dpp(id, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
+  v = min(v, (u32)__builtin_amdgcn_update_dpp(id, (int)v, 0x112, 0xF, 0xF, false));   // row_shr:2
+  v = min(v, (u32)__builtin_amdgcn_update_dpp(id, (int)v, 0x114, 0xF, 0xF, false));   // row_shr:4
+  v = min(v, (u32)__builtin_amdgcn_update_dpp(id, (int)v, 0x118, 0xF, 0xF, false));   // row_shr:8  -> lane 15 of every row holds the row's minimum
+  v = min(v, (u32)__builtin_amdgcn_update_dpp(id, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 into rows 1 and 3
+  v = min(v, (u32)__builtin_amdgcn_update_dpp(id, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 into rows 2 and 3
+  return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ i64 wave_max_i64(i64 v) { for (int off = 32; off > 0; off >>= 1) { const i64 o = __shfl_xor(v, off); if (o > v) v = o; } return v; }
 
 // Stage the pod's class plan in LDS (one coalesced copy) and evaluate the per-pod, node-independent part
@@ -813,7 +914,7 @@ __device__ __forceinline__ void stage_class(const Tabs& tb, WaveShared& sh, int 
     for (u64 b = d.reg & t.PD; b; b &= b - 1) { const i32 cn = tb.gcnt[(size_t)t.g * 64 + __builtin_ctzll(b)]; if (cn < mn) mn = cn; }
     d.minc = mn; sh.dyn[lane] = d;
   }
-  if (lane >= 32 && (u32)(lane - 32) < L.nhost) sh.host_anypos[lane - 32] = tb.g_hpos[L.host[lane - 32].hslot] > 0;
+  if (lane >= 32 && (u32)(lane - 32) < L.nhost) { sh.host_anypos[lane - 32] = tb.g_hpos[L.host[lane - 32].hslot] > 0; sh.host_zero[lane - 32] = tb.g_hzero[L.host[lane - 32].hslot]; }
   LSYNC();
 }
 
@@ -930,7 +1031,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
   static_assert(NW >= 1 && NW <= KS_MAX_WAVES, "wave count");
   // descriptors are copied to LDS: loads from them can then be CSE'd across global stores (no aliasing)
   __shared__ DevProb P_lds; __shared__ DevState S_lds;
-  __shared__ WaveShared shw[NW]; __shared__ WaveBounds wbs[BOUNDS ? NW : 1]; __shared__ LeaderShared ls; __shared__ RoundCtl rc;
+  __shared__ WaveShared shw[NW]; __shared__ WaveBounds wbs[BOUNDS ? NW : 1]; __shared__ LeaderShared ls; __shared__ RoundCtlT<RM> rc;
   const int lane = threadIdx.x & 63; const u32 wv = NW > 1 ? UF(threadIdx.x >> 6) : 0u;
   WaveShared& sh = shw[wv]; WaveBounds& wb = wbs[BOUNDS ? wv : 0];
   { const u32* src = (const u32*)&probs[blockIdx.x]; u32* dst = (u32*)&P_lds; for (u32 i = threadIdx.x; i < sizeof(DevProb) / 4; i += 64 * NW) dst[i] = src[i]; }
@@ -945,7 +1046,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
   tb.q = (GA u64*)UF64((u64)S.q); tb.pod_node = (GA i32*)UF64((u64)S.pod_node); tb.pod_seq = (GA i32*)UF64((u64)S.pod_seq);
   tb.rec = (GA u8*)UF64((u64)S.rec); tb.rec_stride = UF(S.rec_stride); tb.hcnt = (GA i32*)UF64((u64)S.hcnt); tb.n_alive = (GA u64*)UF64((u64)S.n_alive); tb.ge_rows = (const GA u64*)UF64((u64)P.ge_rows);
   const u32 nP = UF(P.P), nM = UF(P.M), nC = UF(P.C), nG = UF(P.G), nMAX = UF(P.NMAX);
-  tb.gcnt = S.gcnt; tb.g_reg = S.g_reg; tb.g_pos = S.g_pos; tb.g_active = S.g_active; tb.g_hpos = S.g_hpos; tb.ge_vals = P.ge_vals; tb.ge_cnt = P.ge_cnt; tb.ge_stride = tb.T;
+  tb.gcnt = S.gcnt; tb.g_reg = S.g_reg; tb.g_pos = S.g_pos; tb.g_active = S.g_active; tb.g_hpos = S.g_hpos; tb.g_hzero = S.g_hzero; tb.ge_vals = P.ge_vals; tb.ge_cnt = P.ge_cnt; tb.ge_stride = tb.T;
 
   // ---------------- initialise state (global memory); wave 0 alone, it is a one-off ----------------
   if (wv == 0) {
@@ -968,7 +1069,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
   if constexpr (FAST) {
     __shared__ u32 sm_key_nvalues[KS_MAX_KEYS]; __shared__ i32 sm_value_int[KS_MAX_KEYS * 64];
     __shared__ u8 sm_its_fail[KS_FAST_S * KS_FAST_S]; __shared__ u16 sm_its_inter[KS_FAST_S * KS_FAST_S];
-    __shared__ i32 sm_gcnt[KS_FAST_G * 64]; __shared__ u64 sm_g_reg[KS_FAST_G]; __shared__ u64 sm_g_pos[KS_FAST_G]; __shared__ u8 sm_g_active[KS_FAST_G]; __shared__ i32 sm_g_hpos[KS_FAST_G];
+    __shared__ i32 sm_gcnt[KS_FAST_G * 64]; __shared__ u64 sm_g_reg[KS_FAST_G]; __shared__ u64 sm_g_pos[KS_FAST_G]; __shared__ u8 sm_g_active[KS_FAST_G]; __shared__ i32 sm_g_hpos[KS_FAST_G]; __shared__ i32 sm_g_hzero[KS_FAST_G];
     __shared__ u32 sm_ge_cnt[KS_MAX_RES];
     i64* ge = (i64*)ks_dyn_lds;
     const u32 gs = UF(P.ge_max);            // the Allocatable ladders are stored with the longest one's stride
@@ -982,20 +1083,20 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       u64 reg = 0, pos = 0; for (int d = 0; d < 64; ++d) { const i32 c = P.grp_count[(size_t)g * 64 + d]; if (c >= 0) reg |= 1ull << d; if (c > 0) pos |= 1ull << d; }
       sm_g_reg[g] = reg; sm_g_pos[g] = pos; sm_g_active[g] = P.grp_active[g];
     }
-    for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h]; for (u32 e = 0; e < tb.E; ++e) if (P.grph_count[(size_t)h * tb.E + e] > 0) ++np; sm_g_hpos[h] = np; }
+    for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h], nz = 0; for (u32 e = 0; e < tb.E; ++e) { const i32 c = P.grph_count[(size_t)h * tb.E + e]; if (c > 0) ++np; if (c == 0) ++nz; } sm_g_hpos[h] = np; sm_g_hzero[h] = nz; }
     for (u32 i = lane; i < tb.R; i += 64) sm_ge_cnt[i] = P.ge_cnt[i];
     for (u32 r = 0; r < tb.R; ++r) for (u32 i = lane; i < gs; i += 64) ge[(size_t)r * gs + i] = i < P.ge_cnt[r] ? P.ge_vals[(size_t)r * tb.T + i] : INT64_MAX;
     }
     lds_used = (u32)(((size_t)tb.R * gs * sizeof(i64) + 15) & ~(size_t)15);
     tb.key_nvalues = sm_key_nvalues; tb.value_int = sm_value_int; tb.its_fail = sm_its_fail; tb.its_inter = sm_its_inter;
-    tb.gcnt = sm_gcnt; tb.g_reg = sm_g_reg; tb.g_pos = sm_g_pos; tb.g_active = sm_g_active; tb.g_hpos = sm_g_hpos; tb.ge_cnt = sm_ge_cnt; tb.ge_vals = ge; tb.ge_stride = gs;
+    tb.gcnt = sm_gcnt; tb.g_reg = sm_g_reg; tb.g_pos = sm_g_pos; tb.g_active = sm_g_active; tb.g_hpos = sm_g_hpos; tb.g_hzero = sm_g_hzero; tb.ge_cnt = sm_ge_cnt; tb.ge_vals = ge; tb.ge_stride = gs;
   } else if (wv == 0) {
     for (u32 i = lane; i < P.G * 64; i += 64) S.gcnt[i] = P.grp_count[i];
     for (u32 g = lane; g < P.G; g += 64) {
       u64 reg = 0, pos = 0; for (int d = 0; d < 64; ++d) { const i32 c = P.grp_count[(size_t)g * 64 + d]; if (c >= 0) reg |= 1ull << d; if (c > 0) pos |= 1ull << d; }
       S.g_reg[g] = reg; S.g_pos[g] = pos; S.g_active[g] = P.grp_active[g];
     }
-    for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h]; for (u32 e = 0; e < tb.E; ++e) if (P.grph_count[(size_t)h * tb.E + e] > 0) ++np; S.g_hpos[h] = np; }
+    for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h], nz = 0; for (u32 e = 0; e < tb.E; ++e) { const i32 c = P.grph_count[(size_t)h * tb.E + e]; if (c > 0) ++np; if (c == 0) ++nz; } S.g_hpos[h] = np; S.g_hzero[h] = nz; }
   }
   if (wv == 0 && lane < 32) ls.ctr[lane] = 0;
   if (wv == 0 && lane < 8) ls.hard[lane] = 0;
@@ -1025,36 +1126,60 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
   Ev ev; ev.rc = 0; u32 slot = 0xFFFFFFFFu;
   bool r_valid = false; u32 r_eq = 0, r_base = 0, r_removed = 0, r_lim = 0; u64 r_mask = 0;
   bool done = false; u32 seq_credit = 0, iters = 0;
-  u64 pq_e = 0; bool pq_ok = false;      // leader: the next 2*(NW-1) queue entries, requested at the end of the previous step
-  u32 wpf_cidx = 0xFFFFFFFFu;            // workers: class whose plan sits prefetched in pf0/pf1
+  u64 pq_e = 0; bool pq_ok = false;      // leader: the next 64 queue entries (lane i: entry i), requested at the end of the previous step
 
   // ---------------- Solve loop, scheduler.go:104-124 ----------------
   // Planning (wave 0): what the next step of the loop is -- 0 done, 1 one pod sequentially, 2 speculation round.  It runs at
   // the END of a step, so the barrier that ends the step also publishes the plan.
-  u32 last_commit = NW - 1;
+  // A round takes the next queue entries (up to 64, up to the first requeued one: its staleness test needs the sequential state)
+  // as long as they belong to at most NW-1 distinct evaluation classes: worker wave j evaluates class j ONCE for all its pods.
+  const GA ClsBrief* briefs = (const GA ClsBrief*)UF64((u64)P.briefs);
+  u64 b_e = 0, b_tmask = 0, b_tfull = 0, b_rmask = 0, b_zmask = 0, b_rsure = 0; u32 b_flags = 0, b_reqmask = 0, b_w = 0xFFu; i64 b_req[RM];      // leader, lane i: round pod i
+#pragma unroll
+  for (int i = 0; i < RM; ++i) b_req[i] = 0;
+  u32 round_lim = 64;              // after a cancelled round: the next one stops short of the pod whose node failed
   u32 plan_par = 0, stepc = 0;     // stepc: loop iterations started (every wave counts them alike)
-  auto plan = [&]() {
+  u32 spec_mode = 0;               // what the plan made during a round's filter phase chose (undone if the round is cancelled)
+  auto plan = [&](const u32 q_head, const u32 q_len, const u32 seq) {      // (the queue as it will be when the planned step starts)
         u32 mode = 1; const u32 wpar = plan_par ^ 1u;
         if (++iters > 8u * nP + 4096u) err = (u32)(-KS_ERR_INTERNAL);      // watchdog: a Solve needs at most a few steps per pod
         if (done || err || q_len == 0) mode = 0;
-        else if (seq_credit == 0 && q_len >= 2) {
-          // the next NW queue entries, up to the first requeued one (its staleness test needs the sequential state)
-          // offer two more pods than the last round committed: waves that evaluate pods the round will cut anyway only
-          // take issue slots from the ones that matter (two waves share a SIMD)
-          const u32 cap = min(min((u32)NW - 1u, q_len), last_commit + 2u); u64 e = pq_e;
-          if (!pq_ok) { u32 idx = q_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; e = (u32)lane < 2u * (NW - 1) ? tb.q[idx] : 0ull; }
-          const u64 rq_bits = ballot64((u32)lane < cap && (e >> 63) != 0);
-          u32 rn = rq_bits ? (u32)__builtin_ctzll(rq_bits) : cap;
+        else if (seq_credit == 0 && q_len >= 2 && round_lim >= 2) {
+          const u32 cap = min(min(64u, q_len), round_lim); u64 e = pq_e;
+          if (!pq_ok) { u32 idx = q_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; e = tb.q[idx]; }      // every slot of q always holds a valid class index
+          const u32 cls = (u32)(e >> 32) & 0x7FFFFFFFu;
+          const GA u32x4* bp = (const GA u32x4*)(briefs + cls);
+          const u32x4 v0 = bp[0], v1 = bp[1]; const u32 rqm = *(const GA u32*)((const GA u8*)bp + 32);
+          const GA i64* rqp = (const GA i64*)((const GA u8*)bp + 40);
+#pragma unroll
+          for (int i = 0; i < RM; ++i) b_req[i] = rqp[i];
+          b_e = e; b_tmask = (u64)v0.x | ((u64)v0.y << 32); b_tfull = (u64)v0.z | ((u64)v0.w << 32); b_rmask = (u64)v1.x | ((u64)v1.y << 32); b_flags = v1.w; b_reqmask = rqm; b_zmask = *(const GA u64*)((const GA u8*)bp + 104); b_rsure = *(const GA u64*)((const GA u8*)bp + 112);
+          const u32 evc = v1.z;
+          u32 rn = cap;
+          { const u64 rq_bits = ballot64((u32)lane < cap && (e >> 63) != 0); if (rq_bits) rn = min(rn, (u32)__builtin_ctzll(rq_bits)); }
+          { const u64 ne = ballot64((u32)lane < rn && !(b_flags & 1u)); if (ne) rn = min(rn, (u32)__builtin_ctzll(ne)); }      // host ports / plans over the kernel's limits: sequential path
           // a class whose last pod had to look past the window (or open a node) will most likely do so again: a round
           // would evaluate it for nothing -- take it sequentially right away
-          { const u32 c0 = RL((u32)(e >> 32), 0) & 0x7FFFFFFFu; if ((UF(ls.hard[(c0 >> 5) & 7u]) >> (c0 & 31u)) & 1u) rn = 0; }
-          if (rn >= 2) { mode = 2; if ((u32)lane < 2u * (NW - 1)) rc.qe[wpar][lane] = e; if (lane == 0) { rc.par = wpar; rc.n = rn; rc.nnew = nnew; rc.seq0 = seq; rc.ord_in_lds = ord_in_lds ? 1u : 0u; } }
+          { const u32 c0 = RL(cls, 0); if ((UF(ls.hard[(c0 >> 5) & 7u]) >> (c0 & 31u)) & 1u) rn = 0; }
+          u32 nw = 0; b_w = 0xFFu;
+          u64 rem = rn >= 64 ? ~0ull : ((1ull << rn) - 1ull);
+          while (rem && nw < (u32)NW - 1u) {
+            const int l = __builtin_ctzll(rem); const u32 v = RL(evc, l);
+            const u64 same = ballot64(evc == v) & rem;
+            if ((same >> lane) & 1ull) b_w = nw;
+            if (lane == 0) rc.wcls[wpar][nw] = RL(cls, l);
+            rem &= ~same; ++nw;
+          }
+          if (rem) rn = (u32)__builtin_ctzll(rem);            // the first pod of one class too many ends the round
+          if (rn >= 2) { mode = 2; rc.qe[wpar][lane] = e; rc.pw[wpar][lane] = (u8)b_w; if (lane == 0) { rc.par = wpar; rc.n = rn; rc.nwk = nw; rc.nnew = nnew; rc.seq0 = seq; rc.ord_in_lds = ord_in_lds ? 1u : 0u; } }
         }
+        round_lim = 64;
         if (mode == 1 && seq_credit) --seq_credit;
         if (mode == 2) plan_par = wpar;
         if (lane == 0) rc.mode2[stepc & 1u] = mode;
+        spec_mode = mode;
   };
-  if constexpr (NW > 1) { if (wv == 0) plan(); __syncthreads(); }
+  if constexpr (NW > 1) { if (wv == 0) plan(q_head, q_len, seq); __syncthreads(); }
   for (;;) {
     u32 mode = 1;   // 0 done, 1 one pod sequentially (wave 0), 2 speculation round
     if constexpr (NW > 1) { mode = UF(rc.mode2[stepc & 1u]); ++stepc; if (mode == 0) break; }
@@ -1084,7 +1209,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
 #endif
     // The queue entry and the class plan of this pod were requested one pod ago (qe_a, pf0/pf1), the entry after
     // it two pods ago (qe_b); a Push invalidates the pipeline (the pushed entry may be one of the prefetched slots).
-    if (!pf_ok) {
+    if (NW > 1 || !pf_ok) {
       qe_a = tb.q[q_head]; qe_b = tb.q[(q_head + 1 == nP) ? 0 : q_head + 1];
       const GA u32x4* src = (const GA u32x4*)(plans + ((u32)(qe_a >> 32) & 0x7FFFFFFFu));
       pf0 = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) pf1 = src[lane + 64];
@@ -1110,14 +1235,24 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     // then one fresh node per machine template (a single-lane "chunk").  One code path evaluates, filters
     // and commits all three kinds.
     GSYNC();                       // the previous pod's record / counter stores are complete before they are re-read
-    {   // (after the barrier: its vmcnt(0) would otherwise wait for these loads) request the next pod's plan and the queue entry after it (every slot of q always holds a valid class index)
+    if constexpr (NW == 1) {   // (after the barrier: its vmcnt(0) would otherwise wait for these loads) request the next pod's plan and the queue entry after it (every slot of q always holds a valid class index)
       qe_a = qe_b; qe_b = tb.q[(q_head + 1 == nP) ? 0 : q_head + 1];
       const GA u32x4* src = (const GA u32x4*)(plans + ((u32)(qe_a >> 32) & 0x7FFFFFFFu));
       pf0 = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) pf1 = src[lane + 64];
       pf_ok = true;
     }
     u32 pos_base = 0, tm = 0, width = KS_FIRST_WIDTH;
-    bool reuse = r_valid && !want_stats && cr.eq != 0 && cr.eq == r_eq;
+    bool reuse = NW == 1 && r_valid && !want_stats && cr.eq != 0 && cr.eq == r_eq;     // (single-wave kernel only: in the multi-wave one rounds take the runs of equivalent pods)
+    if (!want_stats && cr.nhost) {
+      // anti-affinity (count == 0) and spread with maxSkew - self == 0 accept a node only if its own hostname counts 0; with no such
+      // hostname registered every candidate would reject the pod: go straight to the templates
+      bool dead = false;
+      for (u32 i = 0; i < cr.nhost; ++i) {
+        const PlanTopo& th = c.host[i]; const u32 f = UF(*(const u32*)&th.type); const u32 ty = f & 0xFF, self = (f >> 8) & 0xFF;
+        if ((ty == 2 || (ty == 0 && (i64)UF(th.maxskew) - (i64)self <= 0)) && (i32)UF(sh.host_zero[i]) <= 0) dead = true;
+      }
+      if (dead) { pos_base = tb.E + nnew; reuse = false; r_valid = false; }
+    }
     if (NW == 1 && cr.eq != 0) CTR(8, 1);
     r_valid = reuse;               // any other path re-evaluates (or moves nodes in ways the window does not track)
     while (!placed && !err) {
@@ -1187,6 +1322,11 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
 
       // ---- Node.Add / ExistingNode.Add up to the instance-type filter, one node per lane ----
       ev.rc = 0;
+      if constexpr (NW > 1) {      // nothing of the last evaluation is needed: do not carry it in registers
+        ev.count = 0; ev.reqmask = 0; ev.tchg = 0; ev.tnar = 0; ev.tpres = 0; ev.tcomp = 0; ev.present = 0; ev.complement = 0; ev.it_state = 0; ev.it0 = 0;
+#pragma unroll
+        for (int i = 0; i < RM; ++i) { ev.room[i] = 0; ev.req[i] = 0; ev.low[i] = INT64_MIN; }
+      }
       if (slot != 0xFFFFFFFFu) eval_node<BOUNDS, LEAN, RM>(P, S, tb, sh, wb, slot, slot < tb.E, fresh, ev, lane, tprobe, cr);
       PROBE(26);
       m = ballot64(ev.rc == 2);
@@ -1196,7 +1336,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         __syncthreads();
         if (m == 0) {
           const u32 ns = min((u32)NW - 1u, (total - (pos_base + 64) + 63) / 64);       // windows the helpers covered
-          const u64 hm = (u32)lane < ns ? rc.m[lane & (KS_MAX_WAVES - 1)] : 0ull;
+          const u64 hm = (u32)lane < ns ? rc.scanm[lane & (KS_MAX_WAVES - 1)] : 0ull;
           const u64 hb = ballot64(hm != 0);
           pos_base += 64 * (hb ? (u32)__builtin_ctzll(hb) : ns);                          // the loop's own `+= width` completes the jump
         }
@@ -1245,6 +1385,10 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
 #pragma unroll
           for (int rr = 0; rr < RM; ++rr) if ((u32)rr < tb.R) { const i64 v = wave_max_i64(mx[rr]); if (lane == 0 && ((lim >> rr) & 1u)) S.remaining[(size_t)m_t * tb.R + rr] -= v; }
         }
+        if (fresh) {        // the node exists from here on: its registered hostnames join the zero-count census (before this pod is recorded)
+          for (u32 g = lane; g < nG; g += 64) { const i32 hs = P.grp_hslot[g]; if (hs >= 0 && tb.hcnt[(size_t)sw * tb.GH + hs] == 0) tb.g_hzero[hs]++; }
+          LSYNC();
+        }
         topology_record<(NW > 1)>(P, S, tb, pb, sh, r, sw, lane);
         const u32 cnt = pb.count;                                   // pods on the node before this one
         LSYNC();
@@ -1267,8 +1411,8 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           // keep the step's remaining fit bits for the next pod if it is evaluation-equivalent: valid for the lanes
           // whose nodes share the winner's count bucket (they now precede it in the visiting order)
           if (reuse) { r_mask = m & (m - 1); ++r_removed; if (NW == 1) CTR(11, 1); }
-          else if (cr.eq != 0 && !want_stats) {
-            if (NW == 1) CTR(10, 1);
+          else if (NW == 1 && cr.eq != 0 && !want_stats) {
+            CTR(10, 1);
             const u32 lim_abs = tb.E + endc;                          // one past the bucket, in this step's coordinates
             r_valid = true; r_eq = cr.eq; r_mask = m & (m - 1); r_base = pos_base; r_removed = 1; r_lim = lim_abs > pos_base ? min(64u, lim_abs - pos_base) : 0;
           }
@@ -1333,7 +1477,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     else {
       if (wv == 0) {
         if (lane == 0) rc.cmd = 0;
-        pq_ok = false; plan();
+        pq_ok = false; plan(q_head, q_len, seq);
         __syncthreads();                                                   // release the scan-ahead helpers; publishes the plan
       }
       else {
@@ -1363,7 +1507,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             if (slot != 0xFFFFFFFFu) eval_node<BOUNDS, LEAN, RM>(P, S, tb, sh, wb, slot, slot < tb.E, false, ev, lane, tprobe, cr);
             m = ballot64(ev.rc == 2);
           }
-          if (lane == 0) rc.m[wv - 1] = m;
+          if (lane == 0) rc.scanm[wv - 1] = m;
           __syncthreads();
         }
       }
@@ -1372,199 +1516,453 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     }
 
     // =====================================================================================================
-    // Speculation round.  Up to NW queued pods are evaluated, one per wave, against the SAME snapshot of the
-    // first 64 candidates in visiting order; the leader then assigns nodes from the fit bitmaps alone:
-    //   pod k takes u = the first candidate that accepted it and was not taken earlier in the round, provided
-    //   (a) no earlier pod of the round records into a topology group pod k's evaluation reads (tmask/rmask),
-    //   (b) no earlier winner that had accepted pod k precedes u in the visiting order as it now is -- a winner
-    //       from the new nodes went to the FRONT of its next count bucket (so it precedes u iff cnt+1 <= cnt(u)),
-    //       an existing node keeps its place.
-    // Nodes that rejected pod k stay rejecting (a commit only narrows a node), untouched nodes keep their bit.
-    // The first pod that breaks a rule ends the round and simply opens the next one (or goes sequential).
-    // oracle/oracle.cpp Scheduler::solve_spec restates these rules over the reference algorithm and checks every
-    // prediction (tests/test_speculation_rules.py).
+    // Speculation round.  The round's pods belong to at most NW-1 evaluation classes; worker wave j evaluates class j ONCE
+    // against a snapshot of the first 64 candidates in visiting order (lane = candidate).  The leader then walks the pods in
+    // queue order and gives each the node the sequential algorithm would give it, from the fit bitmaps alone:
+    //   * it keeps the visiting order of the window as the round changes it -- a node that takes a pod goes to the FRONT of
+    //     its next count bucket (existing nodes keep their place) -- and pod k takes the first candidate in THAT order which
+    //     accepts it.  A candidate the round has not touched accepts iff it did at the snapshot.  A candidate that already
+    //     took pods of this round accepts iff it did at the snapshot AND the resource screen still passes with what the round
+    //     put on it, provided none of those pods changed its requirements and none recorded into a topology group pod k's
+    //     evaluation reads (otherwise the answer is unknown: the round ends before pod k).  Nodes that rejected stay rejecting
+    //     (a commit only narrows a node); a moved node can only be trusted to be next if the window still covers its place.
+    //   * (a) the round ends before a pod whose evaluation reads a topology counter of ANOTHER node that an earlier pod of the
+    //     round records into (ClsBrief.tmask / rmask); hostname-keyed spread / anti-affinity records only touch the winner.
+    // Commit is per NODE: the wave that evaluated the last pod placed on a node (lane = that candidate) adds up what the round
+    // put there, runs the instance-type filter once with the totals (filters are monotone in the requests, so every intermediate
+    // state is non-empty if the final one is) and writes the record; Topology.Record and the pod results are per pod.  A filter
+    // that comes back empty cancels the round (nothing was written but InstanceTypeOptions rows, which are restored); the next
+    // round stops short of the offending pod.
     // =====================================================================================================
     if constexpr (NW > 1) {
-      // wave 0 coordinates (resolver, visiting-order moves, queue); waves 1..NW-1 each take round pod k = wave - 1
-      const u32 rn = UF(rc.n), par = UF(rc.par), seq0 = UF(rc.seq0);
+      const u32 rn = UF(rc.n), par = UF(rc.par), seq0 = UF(rc.seq0), nwk = UF(rc.nwk);
 #ifdef KS_PROBES
       const u64 t_round = __builtin_readcyclecounter();
 #endif
       const bool ord_lds_r = UF(rc.ord_in_lds) != 0;
-      const u32 kw = wv - 1;                 // this wave's pod within the round (wave 0: none)
-      u32 pod_w = 0; ClsR cr;
-      // ---- P1: evaluate ----
-      if (wv != 0 && kw < rn) {
-        const u64 qe = UF64(rc.qe[par][kw]);
-        pod_w = (u32)qe; const u32 cidx = (u32)(qe >> 32) & 0x7FFFFFFFu;
-        if (wpf_cidx != cidx) { const GA u32x4* src = (const GA u32x4*)(plans + cidx); pf0 = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) pf1 = src[lane + 64]; wpf_cidx = cidx; }   // else: requested during the last round's commit
-        { u32x4* dst = (u32x4*)&sh.cls; dst[lane] = pf0; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = pf1; }
+      const u32 kw = wv - 1;                 // this wave's evaluation class within the round (wave 0: none)
+      const u32 total = tb.E + UF(rc.nnew), nwin = min(64u, total);
+      ClsR cr;
+      // ---- P1: one evaluation per class ----
+      if (wv != 0 && kw < nwk) {
+        const u32 cidx = UF(rc.wcls[par][kw]);
+        { const GA u32x4* src = (const GA u32x4*)(plans + cidx); u32x4* dst = (u32x4*)&sh.cls; dst[lane] = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = src[lane + 64]; }
         stage_class(tb, sh, lane);
         const ClsPlan& c = sh.cls;
         cr.tol = UF64(c.tol); cr.reqmask = UF(c.reqmask); cr.ntouch = UF(c.ntouch); cr.nhost = UF(c.nhost); cr.hn_mode = UF(c.hn_mode); cr.port_cnt = UF(c.port_cnt); cr.it_state = (i32)UF(c.it_state); cr.tkeys = UF64(c.tkeys); cr.eq = UF(c.eq);
 #pragma unroll
         for (int i = 0; i < RM; ++i) cr.req[i] = (i64)UF64(c.req[i]);
         if constexpr (LEAN) { cr.port_cnt = 0; cr.hn_mode = 0; cr.it_state = 0; }
-        const u32 total = tb.E + UF(rc.nnew);
         slot = 0xFFFFFFFFu;
-        if ((u32)lane < total) slot = (u32)lane < tb.E ? (u32)lane : tb.E + (ord_lds_r ? ord_l[lane - tb.E] : ord_g[lane - tb.E]);
-        ev.rc = 0; ev.count = 0;
+        if ((u32)lane < nwin) slot = (u32)lane < tb.E ? (u32)lane : tb.E + (ord_lds_r ? ord_l[lane - tb.E] : ord_g[lane - tb.E]);
+        ev.rc = 0; ev.count = 0; ev.reqmask = 0; ev.tchg = 0; ev.tpres = 0; ev.tcomp = 0; ev.present = 0; ev.complement = 0; ev.it_state = 0; ev.it0 = 0;
+#pragma unroll
+        for (int i = 0; i < RM; ++i) { ev.room[i] = 0; ev.req[i] = 0; ev.low[i] = INT64_MIN; }
         if (slot != 0xFFFFFFFFu) eval_node<BOUNDS, LEAN, RM>(P, S, tb, sh, wb, slot, slot < tb.E, false, ev, lane, tprobe, cr);
         const u64 m = ballot64(ev.rc == 2);
-        if (lane == 0) { rc.m[kw] = m; rc.T[kw] = c.tmask; rc.R[kw] = c.rmask; rc.elig[kw] = (!c.overflow && cr.port_cnt == 0) ? 1u : 0u; }
-        if (kw == 0) rc.cnt[lane] = ev.count;
+        const u64 chgb = ballot64(ev.rc == 2 && (ev.tchg != 0 || ev.it_state != ev.it0));
+        if (lane == 0) { rc.m[kw] = m; rc.chg[kw] = chgb; }
+        if (kw == 0) {
+          rc.cnt[lane] = ev.count; rc.rmsk[lane] = ev.reqmask;
+#pragma unroll
+          for (int i = 0; i < RM; ++i) { rc.room[i][lane] = ev.room[i]; rc.req0[i][lane] = ev.req[i]; rc.low0[i][lane] = ev.low[i]; }
+        }
       }
+      if (wv == 0 && lane == 0) rc.fail_at = 0xFFFFFFFFu;
       __syncthreads();
 #ifdef KS_PROBES
       u64 t_ph = __builtin_readcyclecounter(); CTR(22, t_ph - t_round);
 #endif
-      // ---- P2: the leader resolves the round (lane k holds pod k's bitmap and masks, lane u candidate u's pod count) ----
-      u32 mv_p = 0, mv_cnt = 0, mv_maxc = 0; bool mv_done = false;     // leader lane k: the move made for round pod k (undo record)
-      u32 my_win = 0, my_cnt = 0;
+      // ---- P2: the leader resolves the round.  Lane i plays two parts: round pod i (b_*) and window candidate i (c_*). ----
+      u32 c_cnt = 0, c_cnt0 = 0, c_rm = 0, c_np = 0, c_last = 0, c_first = 0, c_key = 0xFFFFFFFFu; u64 c_racc = 0, c_rsure = 0; i64 c_room[RM];
+      u64 movedmask = 0; u32 n_ok = 0;
       if (wv == 0) {
-        const u32 li = lane & (KS_MAX_WAVES - 1);
-        const u64 m_l = rc.m[li], t_l = rc.T[li], r_l = rc.R[li]; const u32 e_l = rc.elig[li], c_l = rc.cnt[lane];
-        u32 n_ok = 0; u64 taken = 0, rall = 0;
-        for (u32 k = 0; k < rn; ++k) {
-          if (!RL(e_l, k)) break;
-          const u64 mk = RL64(m_l, k);
-          if (RL64(t_l, k) & rall) break;
-          const u64 cand = mk & ~taken; if (!cand) break;
-          const u32 u = (u32)__builtin_ctzll(cand); const u32 cu = RL(c_l, u);
-          bool bad = false;
-          if ((u32)lane < k && ((mk >> my_win) & 1ull)) bad = my_win < tb.E ? (my_win < u) : (u >= tb.E && my_cnt + 1 <= cu);
-          if (ballot64(bad)) break;
-          if ((u32)lane == k) { my_win = u; my_cnt = cu; }
-          taken |= 1ull << u; rall |= RL64(r_l, k); n_ok = k + 1;
-        }
-#ifdef KS_CHECK   /* debug builds cut rounds short at pseudo-random places: a cut pod is simply retried, so results must not change, and the undo path gets exercised */
-        rc.pad0 = ((iters * 2654435761u) >> 29) < 3u ? ((iters >> 3) & 3u) : 0xFFu;
+#ifdef KS_P2PROBES
+        u64 t2p = __builtin_readcyclecounter();
 #endif
-        if ((u32)lane < n_ok) rc.win[lane] = my_win;
+        c_cnt = c_cnt0 = rc.cnt[lane]; c_rm = rc.rmsk[lane];
+#pragma unroll
+        for (int i = 0; i < RM; ++i) c_room[i] = rc.room[i][lane];
+        // visiting-order key: existing nodes in the caller's order, then new nodes by pod count; within a count the nodes moved
+        // by this round come first, the most recently moved one in front, then the untouched ones in window order
+        if ((u32)lane < nwin) c_key = (u32)lane < tb.E ? (u32)lane : ((c_cnt << 8) | (64u + (u32)lane));
+        const u64 mk_l = (u32)lane < rn ? rc.m[b_w & (KS_MAX_WAVES - 1)] : 0ull, chg_l = (u32)lane < rn ? rc.chg[b_w & (KS_MAX_WAVES - 1)] : 0ull;
+        const u32 cnt_last = nwin ? RL(c_cnt, (int)(nwin - 1)) : 0u; const bool window_complete = total <= 64;
+        u64 closedmask = 0, rall = 0;
+        const bool exact_masks = nG <= 64;      // group bits (g & 63) do not alias: a set bit names one group
+        // OR of two per-lane masks over the lanes of `in` (LDS atomics: cheaper than twelve cross-lane steps for what is a rare, amortised call)
+        auto or_masks = [&](bool in, u64& o_r, u64& o_s) {
+          if (lane == 0) { rc.ortmp[0] = 0; rc.ortmp[1] = 0; rc.ortmp[2] = 0; rc.ortmp[3] = 0; }
+          LSYNC();
+          if (in) { atomicOr(&rc.ortmp[0], (u32)b_rmask); atomicOr(&rc.ortmp[1], (u32)(b_rmask >> 32)); atomicOr(&rc.ortmp[2], (u32)b_rsure); atomicOr(&rc.ortmp[3], (u32)(b_rsure >> 32)); }
+          LSYNC();
+          o_r = UF64((u64)rc.ortmp[0] | ((u64)rc.ortmp[1] << 32)); o_s = UF64((u64)rc.ortmp[2] | ((u64)rc.ortmp[3] << 32));
+        };
+        u32 k = 0;
+        P2T(12);
+        while (k < rn) {
+          P2C(15, 1);
+          if (RL64(b_tmask, k) & rall) { CUT(13); break; }
+          const u64 mk = RL64(mk_l, k), tfk = RL64(b_tfull, k), chgk = RL64(chg_l, k); const u32 rmk = RL(b_reqmask, k);
+          i64 rqk[RM];
+#pragma unroll
+          for (int i = 0; i < RM; ++i) rqk[i] = (i64)RL64(b_req[i], k);
+          // r: consecutive pods of this evaluation class whose evaluation reads no topology counter -- they differ at most in what
+          // they record, so where one goes is decided by the same bitmap and the same requests
+          u32 r = 1;
+          if (tfk == 0) { const u32 wk_ = RL(b_w, k); const u64 same = ballot64(b_w == wk_ && b_tfull == 0 && (u32)lane < rn) >> k; r = ~same ? (u32)__builtin_ctzll(~same) : 64u; }
+          u64 A = mk;
+          if (mk & movedmask) {      // candidates the round already used
+            const u64 zm = RL64(b_zmask, k);
+            // the resource screen again, with what the round put on them; and their own hostname counters: an item that needs the
+            // counter at 0 (anti-affinity, spread with maxSkew - self == 0) is certain to fail once a pod of the round recorded into its group
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < RM; ++i) if ((((c_rm | rmk) >> i) & 1u) && rqk[i] > c_room[i]) ok = false;
+            if (exact_masks && (tfk & zm & c_rsure)) ok = false;
+            A = mk & (~movedmask | ballot64(ok));
+          }
+          if (!A) { CUT(14); break; }
+          const u64 un = A & ~movedmask;
+          // the first acceptor in the visiting order as the round has changed it: the smallest key (keys are unique)
+          const bool inA = (A >> lane) & 1ull;
+          const u32 best = wave_min_u32(inA ? c_key : 0xFFFFFFFFu);
+          const int bu = __builtin_ctzll(ballot64(inA && c_key == best));
+          const bool bu_moved = (movedmask >> bu) & 1ull;
+          if (bu_moved) {
+            if ((u32)bu >= tb.E && !window_complete && (best >> 8) > cnt_last) { CUT(15); break; }        // nodes beyond the window may precede it
+            if ((closedmask >> bu) & 1ull) { CUT(15); break; }                                              // its requirements changed in this round
+            if (tfk & RL64(c_racc, bu)) { CUT(13); break; }                                                 // a counter of that node the evaluation reads may have changed (the certain cases were answered above)
+          }
+          const u32 cnt_bu = RL(c_cnt, bu);
+          if (r >= 2 && !bu_moved && (u32)bu >= tb.E) {
+            // SWEEP: the untouched acceptors that share bu's pod count follow it in window order, and a node that takes a pod goes BEHIND them
+            // (front of the next bucket): the next pods of the run take them one each.
+            const u64 S0 = un & ballot64(c_cnt == cnt_bu);
+            const u32 sN = min(r, (u32)__builtin_popcountll(S0));
+            if (sN >= 2) {
+              const u32 rank = (u32)__builtin_popcountll(S0 & ((1ull << lane) - 1ull));
+              const bool inS = ((S0 >> lane) & 1ull) && rank < sN;
+              const u32 pidx = k + rank;
+              const int src = inS ? (int)pidx : lane;
+              const u64 prm = (u64)(u32)__shfl((int)(u32)b_rmask, src) | ((u64)(u32)__shfl((int)(u32)(b_rmask >> 32), src) << 32);
+              const u64 psu = (u64)(u32)__shfl((int)(u32)b_rsure, src) | ((u64)(u32)__shfl((int)(u32)(b_rsure >> 32), src) << 32);
+              if (inS) {
+#pragma unroll
+                for (int i = 0; i < RM; ++i) c_room[i] -= rqk[i];
+                c_rm |= rmk; c_racc |= prm; c_rsure |= psu; c_np = 1; c_first = pidx; c_last = pidx; ++c_cnt; c_key = (c_cnt << 8) | (63u - pidx);
+                rc.win[pidx] = (u8)lane;
+              }
+              const u64 S = ballot64(inS);
+              u64 orr, ors; or_masks((u32)lane >= k && (u32)lane < k + sN, orr, ors);
+              movedmask = UF64(movedmask | S); closedmask = UF64(closedmask | (S & chgk)); rall = UF64(rall | orr);
+              k += sN; n_ok = k;
+              continue;
+            }
+          }
+          // CLIMB: how many pods of the run does bu take in a row?  It stays first while its count does not exceed the next acceptor's
+          // (a node that just took a pod stands in FRONT of its new bucket) and while the cumulative requests pass the resource screen.
+          u32 t = 1;
+          if (r >= 2 && !((chgk >> bu) & 1ull)) {
+            u32 t_order = r;
+            if ((u32)bu >= tb.E) {
+              const u32 other = wave_min_u32((inA && lane != bu) ? c_key : 0xFFFFFFFFu);      // the next acceptor in line
+              u32 oc = other == 0xFFFFFFFFu ? 0x00FFFFFFu : (other >> 8);
+              if (!window_complete) oc = min(oc, cnt_last);
+              t_order = oc >= cnt_bu ? oc - cnt_bu + 1u : 1u;
+            }
+            const u32 rm_bu = RL(c_rm, bu) | rmk;
+            bool okj = true;
+#pragma unroll
+            for (int i = 0; i < RM; ++i) { const i64 room_bu = (i64)RL64(c_room[i], bu); if (((rm_bu >> i) & 1u) && (i64)(lane + 1) * rqk[i] > room_bu) okj = false; }
+            const u64 bal = ballot64(okj);
+            const u32 t_res = ~bal ? (u32)__builtin_ctzll(~bal) : 64u;
+            t = max(1u, min(min(r, t_order), t_res));
+          }
+          u64 orr = RL64(b_rmask, k), ors = RL64(b_rsure, k);
+          if (t >= 2) or_masks((u32)lane >= k && (u32)lane < k + t, orr, ors);
+          if (lane == bu) {
+#pragma unroll
+            for (int i = 0; i < RM; ++i) c_room[i] -= (i64)t * rqk[i];
+            c_rm |= rmk; c_racc |= orr; c_rsure |= ors; if (c_np == 0) c_first = k; c_np += t; c_last = k + t - 1;
+            if ((u32)bu >= tb.E) { c_cnt += t; c_key = (c_cnt << 8) | (63u - (k + t - 1)); }
+          }
+          if ((u32)lane >= k && (u32)lane < k + t) rc.win[lane] = (u8)bu;
+          movedmask = UF64(movedmask | (1ull << bu));
+          if ((chgk >> bu) & 1ull) closedmask = UF64(closedmask | (1ull << bu));
+          rall = UF64(rall | orr);
+          k += t; n_ok = k;
+        }
+        P2T(13);
+        if (n_ok == rn) CUT(16);
+        rc.npods[lane] = (u8)c_np; rc.lastpod[lane] = (u8)c_last; rc.firstpod[lane] = (u8)c_first; rc.rmsk_new[lane] = c_rm;
+#pragma unroll
+        for (int i = 0; i < RM; ++i) rc.roomrem[i][lane] = c_room[i];
         if (lane == 0) rc.n_ok = n_ok;
+        P2T(14);
       }
       __syncthreads();
 #ifdef KS_PROBES
       { const u64 t2 = __builtin_readcyclecounter(); CTR(23, t2 - t_ph); t_ph = t2; }
 #endif
-      // ---- P3: workers publish their assigned candidate and run the instance-type filter; meanwhile the leader moves the
-      //      winners in the visiting order (speculatively: a failed filter -- 2 in 10 000 -- undoes the moves behind it) ----
-      const u32 n_ok = UF(rc.n_ok);
-      Pub pb; u64 aw[2] = {0, 0}; bool filtered = false;
-      if (wv != 0 && kw < n_ok) {
-        const int win = (int)UF(rc.win[kw]);
-        publish_eval<BOUNDS, RM>(tb, sh, wb, ev, slot, false, lane, win, cr, pb);
-        bool failed = false;
-        if (pb.slot >= tb.E && pb.need) {
-          const Rec r = slot_rec(S, tb, pb.slot);
-          const GA u64* const alive = tb.n_alive + (size_t)(pb.slot - tb.E) * tb.TW;
-          const u32 keys = pb.changed;
-          const bool zc = (tb.key_zone >= 0 && ((keys >> tb.key_zone) & 1u)) || (tb.key_ct >= 0 && ((keys >> tb.key_ct) & 1u));
-          failed = !filter_types(P, tb, pb, sh, r, alive, (GA u64*)nullptr, pb.rm, keys, zc, pb.it_state != pb.it_before, lane, tprobe, aw);
-          filtered = true;
-        }
-        if (lane == 0) rc.fail[kw] = failed ? 1u : 0u;
-      }
-      if (wv == 0) {
-        // The usual round: every winner is a new node of ONE count bucket.  Moving them one after the other leaves the rest of
-        // the bucket compacted to the left in its old order and winner k at endc-1-k (each goes to the FRONT of the next
-        // bucket, so later winners end up before earlier ones): do that in one pass over the bucket's tail.
-        const u32 cnt0 = RL(my_cnt, 0);
-        const bool uniform = n_ok >= 2 && ballot64((u32)lane < n_ok && (my_win < tb.E || my_cnt != cnt0)) == 0;
-        if (uniform) {
-          const u32 endc = UF(BST(cnt0 + 1));
-          const u32 pos_l = my_win - tb.E;                                                   // lane k: winner k's position (no move yet this round)
-          u32 jw_l = 0; if ((u32)lane < n_ok) jw_l = ORD_RD(pos_l);
-          u32 pmin = 0xFFFFFFFFu; for (u32 k = 0; k < n_ok; ++k) pmin = min(pmin, RL(pos_l, k));
-          // sequential-semantics position of winner k at its turn: earlier winners that stood before it have left
-          { u32 before = 0; for (u32 j = 0; j < n_ok; ++j) { const u32 pj = RL(pos_l, j); if (j < (u32)lane && pj < pos_l) ++before; }
-            if ((u32)lane < n_ok) { mv_p = pos_l - before; mv_cnt = cnt0; mv_maxc = lane == 0 ? maxc : max(maxc, cnt0 + 1); mv_done = true; } }
-          if (ord_in_lds) LSYNC(); else GSYNC();
-          for (u32 b = pmin; b < endc; b += 64) {
-            const u32 ii = b + lane; u32 v = 0; if (ii < endc) v = ORD_RD(ii);
-            u32 before = 0; bool is_w = false;
-            for (u32 k = 0; k < n_ok; ++k) { const u32 pk = RL(pos_l, k); if (pk < ii) ++before; if (pk == ii) is_w = true; }
-            if (ord_in_lds) LSYNC(); else GSYNC();
-            if (ii < endc && !is_w) ORD_WR(ii - before, v);
+      // ---- P3: per node, the instance-type filter with the totals.  A node whose last pod changes its requirements is filtered by the wave
+      //      that evaluated that pod (the new requirement sits in its LDS slots); the others only need what the resolver published, so
+      //      they are dealt out over ALL worker waves (a run of equivalent pods would otherwise leave six of seven waves idle) ----
+      n_ok = UF(rc.n_ok);
+      // worker lane u as candidate u:
+      bool committer = false, filtered = false, my_chg = false; u32 n_np = 0, n_rm = 0, n_pres = 0, n_comp = 0, n_chgkeys = 0, wslot = 0xFFFFFFFFu; u32 n_idx[RM];
+      u64 filtmask = 0, ranmask = 0, failedmask = 0;     // (little state crosses the barriers: requests / thresholds are re-read from LDS where they are needed)
+      if (wv != 0 && n_ok) {
+        if ((u32)lane < nwin) wslot = (u32)lane < tb.E ? (u32)lane : tb.E + (ord_lds_r ? ord_l[lane - tb.E] : ord_g[lane - tb.E]);
+        n_np = (u32)lane < nwin ? rc.npods[lane] : 0u;
+        const u32 lastw = rc.pw[par][rc.lastpod[lane] & 63];
+        const bool changing = n_np != 0 && ((rc.chg[lastw & (KS_MAX_WAVES - 1)] >> lane) & 1ull);
+        my_chg = changing && lastw == kw;
+        const u64 plain = ballot64(n_np != 0 && !changing);
+        committer = my_chg || (n_np != 0 && !changing && (u32)__builtin_popcountll(plain & ((1ull << lane) - 1ull)) % (u32)(NW - 1) == kw);
+        n_rm = rc.rmsk_new[lane];
+        // the node's requirement bits after this class was added (publish_eval's arithmetic, per lane); only an evaluating wave has them
+        if (kw < nwk) {
+          n_pres = ev.present; n_comp = ev.complement;
+          for (u32 i = 0; i < cr.ntouch; ++i) {
+            const u32 kb = 1u << ((u32)(cr.tkeys >> (5 * i)) & 31u);
+            if ((ev.tpres >> i) & 1u) { n_pres |= kb; n_comp = ((ev.tcomp >> i) & 1u) ? (n_comp | kb) : (n_comp & ~kb); }
+            if ((ev.tchg >> i) & 1u) n_chgkeys |= kb;
           }
-          if (ord_in_lds) LSYNC(); else GSYNC();
-          if ((u32)lane < n_ok) ORD_WR(endc - 1 - lane, jw_l);
-          if (lane == 0) { BST(cnt0 + 1) = endc - n_ok; if (cnt0 + 1 > maxc) BST(cnt0 + 2) = nnew; }
-          if (cnt0 + 1 > maxc) maxc = cnt0 + 1;
-          if (ord_in_lds) LSYNC(); else GSYNC();
-        } else
-        for (u32 k = 0; k < n_ok; ++k) {
-          const u32 u = RL(my_win, k);
-          if (u < tb.E) continue;                       // existing nodes keep their place
-          // Where is the node now?  An earlier winner that stood before it in its OWN count bucket left a gap and went
-          // behind it (front of the next bucket): one place to the left.  A winner from a lower bucket was re-inserted
-          // at the front of a bucket that is still before (or is) this node's: no net shift.  Winners behind it: none.
-          const u32 cnt = RL(my_cnt, k);
-          const u32 shift = (u32)__builtin_popcountll(ballot64((u32)lane < k && my_win >= tb.E && my_win < u && my_cnt == cnt));
-          const u32 p = u - shift - tb.E;
-          const u32 jw = UF(ORD_RD(p));
-          const u32 endc = UF(BST(cnt + 1));
-          for (u32 i = p + 1; i < endc; i += 64) { const u32 ii = i + lane; u32 v = 0; if (ii < endc) v = ORD_RD(ii); if (ord_in_lds) LSYNC(); else GSYNC(); if (ii < endc) ORD_WR(ii - 1, v); }
-          if (ord_in_lds) LSYNC(); else GSYNC();
-          if ((u32)lane == k) { mv_p = p; mv_cnt = cnt; mv_maxc = maxc; mv_done = true; }
-          if (lane == 0) { ORD_WR(endc - 1, jw); BST(cnt + 1) = endc - 1; if (cnt + 1 > maxc) BST(cnt + 2) = nnew; }
-          if (cnt + 1 > maxc) maxc = cnt + 1;
-          if (ord_in_lds) LSYNC(); else GSYNC();
         }
+        bool need = my_chg && wslot >= tb.E;
+        bool none = false;
+#pragma unroll
+        for (int i = 0; i < RM; ++i) n_idx[i] = 0;
+        if (committer && wslot >= tb.E) {
+          i64 tot[RM]; u32 lo[RM], hi[RM];
+#pragma unroll
+          for (int i = 0; i < RM; ++i) { tot[i] = 0; lo[i] = 0; hi[i] = 0; if ((u32)i < tb.R) { tot[i] = rc.req0[i][lane] + (rc.room[i][lane] - rc.roomrem[i][lane]); if (((n_rm >> i) & 1u) && tot[i] > rc.low0[i][lane]) need = true; } }
+          if (need) {      // lower_bound over the ascending distinct Allocatable values of every requested resource; the searches advance together so their LDS reads overlap
+#pragma unroll
+            for (int i = 0; i < RM; ++i) if ((u32)i < tb.R && ((n_rm >> i) & 1u)) hi[i] = tb.ge_cnt[i];
+            for (;;) {
+              bool busy = false;
+#pragma unroll
+              for (int i = 0; i < RM; ++i) if (lo[i] < hi[i]) { busy = true; const u32 mid = (lo[i] + hi[i]) >> 1; if (tb.ge_vals[(size_t)i * tb.ge_stride + mid] >= tot[i]) hi[i] = mid; else lo[i] = mid + 1; }
+              if (!busy) break;
+            }
+#pragma unroll
+            for (int i = 0; i < RM; ++i) if ((u32)i < tb.R && ((n_rm >> i) & 1u)) { n_idx[i] = lo[i]; if (lo[i] >= tb.ge_cnt[i]) none = true; }
+          }
+        }
+        filtmask = ballot64(need);
+        u64 failed = ballot64(need && none);
+        ranmask = filtmask & ~failed;
+        u32 nf = 0;
+        GA u64* const scr = (GA u64*)S.round_scratch + (size_t)kw * 64 * tb.TW;
+        for (u64 fm = ranmask; fm; fm &= fm - 1, ++nf) {
+          const int u = __builtin_ctzll(fm);
+          const bool chg_u = RL((u32)my_chg, u) != 0;
+          const u32 su = RL(wslot, u), rmu = RL(n_rm, u), pres_u = RL(n_pres, u), comp_u = RL(n_comp, u), chk = chg_u ? RL(n_chgkeys, u) : 0u;
+          const i32 its_u = chg_u ? (i32)RL((u32)ev.it_state, u) : 0; const bool itc = chg_u && its_u != (i32)RL((u32)ev.it0, u);
+          u32 idx_u[RM];
+#pragma unroll
+          for (int i = 0; i < RM; ++i) idx_u[i] = RL(n_idx[i], u);
+          const Rec ru = slot_rec(S, tb, su);
+          GA u64* const alive = tb.n_alive + (size_t)(su - tb.E) * tb.TW;
+          // the node's requirement on key k after the add: from the evaluation's slots if the class touches k, else the record
+          auto node_req = [&](int k) {
+            KReq q; q.present = (pres_u >> k) & 1u; q.complement = (comp_u >> k) & 1u; q.gt = KS_NOGT; q.lt = KS_NOLT; q.mask = 0; bool hit = false;
+            for (u32 i = 0; i < cr.ntouch; ++i) if ((int)((u32)(cr.tkeys >> (5 * i)) & 31u) == k) { q.mask = sh.la_mask[i][u]; if constexpr (BOUNDS) { q.gt = wb.la_gt[i][u]; q.lt = wb.la_lt[i][u]; } hit = true; }
+            if (!hit) { q.mask = ru.mask()[k]; if constexpr (BOUNDS) { q.gt = ru.gt()[k]; q.lt = ru.lt()[k]; } }
+            return q;
+          };
+          const bool zc = (tb.key_zone >= 0 && ((chk >> tb.key_zone) & 1u)) || (tb.key_ct >= 0 && ((chk >> tb.key_ct) & 1u));
+          u64 allowZ = ~0ull, allowC = ~0ull;
+          if (zc) {
+            if (tb.key_zone >= 0 && ((pres_u >> tb.key_zone) & 1u)) allowZ = kreq_has_mask(node_req(tb.key_zone), tb.value_int + tb.key_zone * 64, tb.key_nvalues[tb.key_zone]);
+            if (tb.key_ct >= 0 && ((pres_u >> tb.key_ct) & 1u)) allowC = kreq_has_mask(node_req(tb.key_ct), tb.value_int + tb.key_ct * 64, tb.key_nvalues[tb.key_ct]);
+          }
+          bool any = false;
+          for (u32 wbase = 0; wbase < tb.TW; wbase += 64) {
+            const u32 w = wbase + lane; u64 a = 0;
+            if (w < tb.TW) {
+              const u64 old = alive[w]; a = old;
+#pragma unroll
+              for (int i = 0; i < RM; ++i) if ((u32)i < tb.R && ((rmu >> i) & 1u)) a &= tb.ge_rows[((size_t)i * tb.T + idx_u[i]) * tb.TW + w];
+              u64 x = ~0ull;
+              for (u32 bits = chk; bits; bits &= bits - 1) { const int k = __builtin_ctz(bits); x &= pass_types_word(P, tb, k, node_req(k), w); }
+              if (itc) x &= G_its_types[(size_t)its_u * tb.TW + w];
+              if (zc && tb.n_ct != 0) {
+                u64 acc = 0; const u64 cm = allowC & ((1ull << tb.n_ct) - 1);
+                for (u64 zz = allowZ; zz; zz &= zz - 1) { const int z = __builtin_ctzll(zz); if ((u32)z * tb.n_ct >= 64) break; for (u64 cb = cm; cb; cb &= cb - 1) acc |= G_pair_types[((size_t)z * tb.n_ct + __builtin_ctzll(cb)) * tb.TW + w]; }
+                x &= acc;
+              }
+              a &= x;
+              scr[(size_t)nf * tb.TW + w] = old; alive[w] = a;
+            }
+            if (ballot64(a != 0)) any = true;
+          }
+#ifdef KS_CHECK   /* debug builds declare pseudo-random filters empty: the cancel / restore / shorter-round path must not change results */
+          if (((stepc * 2654435761u + (u32)u * 40503u) >> 24) < 6u) any = false;
+#endif
+          if (!any) failed |= 1ull << u;
+        }
+        filtered = (filtmask >> lane) & 1ull; failedmask = failed;
+        if ((failed >> lane) & 1ull) atomicMin(&rc.fail_at, (u32)rc.firstpod[lane]);
+      }
+      u32 sp_head = q_head, sp_len = q_len, sp_seq = seq;
+      if (wv == 0) {
+        // While the workers filter, plan the step after this round as if the round commits (a filter comes back empty a handful of times
+        // per Solve; the plan is then redone): queue entries and class briefs of the next pods are requested a whole phase early.
+        if ((u32)lane < n_ok) { const u32 ck = (u32)(b_e >> 32) & 0x7FFFFFFFu; atomicAnd(&ls.hard[(ck >> 5) & 7u], ~(1u << (ck & 31u))); }
+        sp_head = q_head + n_ok; if (sp_head >= nP) sp_head -= nP; sp_len = q_len - n_ok; sp_seq = seq + n_ok;
+        { u32 idx = sp_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; pq_e = tb.q[idx]; pq_ok = true; }
+        if (n_ok == 0) seq_credit = 1;                 // the head pod needs more than the window offers: take it sequentially
+        plan(sp_head, sp_len, sp_seq);
       }
       __syncthreads();
 #ifdef KS_PROBES
       { const u64 t2 = __builtin_readcyclecounter(); CTR(24, t2 - t_ph); t_ph = t2; }
 #endif
-      // ---- P4: commit everything before the first failed filter ----
-      u32 n_commit = n_ok;
-      { const u64 fb = ballot64((u32)lane < n_ok && rc.fail[lane & (KS_MAX_WAVES - 1)] != 0); if (fb) n_commit = (u32)__builtin_ctzll(fb); }
-#ifdef KS_CHECK
-      n_commit = min(n_commit, UF(rc.pad0));
-#endif
-      if (wv != 0 && kw < n_commit) {
-        const u32 sw = pb.slot; const bool ex = sw < tb.E;
-        const Rec r = slot_rec(S, tb, sw);
-        if (filtered) {
-          GA u64* const alive = tb.n_alive + (size_t)(sw - tb.E) * tb.TW;
-          if ((u32)lane < tb.TW) alive[lane] = aw[0];
-          if ((u32)lane + 64 < tb.TW) alive[lane + 64] = aw[1];
-          if ((u32)lane < tb.R && ((pb.rm >> lane) & 1u)) r.low()[lane] = sh.low_new[lane];
+      // ---- P4: commit (or cancel) ----
+      const u32 fail_at = UF(rc.fail_at);
+      const bool cancelled = fail_at != 0xFFFFFFFFu;
+      if (wv != 0 && n_ok) {
+        if (cancelled) {      // put the InstanceTypeOptions rows back
+          GA u64* const scr = (GA u64*)S.round_scratch + (size_t)kw * 64 * tb.TW; u32 nf = 0;
+          for (u64 fm = ranmask; fm; fm &= fm - 1, ++nf) {
+            const u32 su = RL(wslot, __builtin_ctzll(fm)); GA u64* const alive = tb.n_alive + (size_t)(su - tb.E) * tb.TW;
+            for (u32 w = lane; w < tb.TW; w += 64) alive[w] = scr[(size_t)nf * tb.TW + w];
+          }
+          GSYNC();
+          // the screen let through what no single surviving type can hold: tighten it to the exact per-resource maxima, so the next
+          // round (and the sequential path) stops before the pod that does not fit
+          for (u64 fm = failedmask; fm; fm &= fm - 1) {
+            const u32 su = RL(wslot, __builtin_ctzll(fm));
+            recompute_cap<RM>(P, tb, tb.n_alive + (size_t)(su - tb.E) * tb.TW, slot_rec(S, tb, su), lane);
+          }
+        } else if (kw < nwk) {
+          // per pod (lane l = round pod l, if this wave evaluated its class): results + Topology.Record against the node as it was for THAT pod
+          const bool mine = (u32)lane < n_ok && rc.pw[par][lane] == kw;
+          const int u = mine ? (int)rc.win[lane] : lane;         // (the cross-lane reads below must run with every lane active: an inactive source lane reads as 0)
+          const u32 su = (u32)__shfl((int)wslot, u), pres_u = (u32)__shfl((int)n_pres, u), comp_u = (u32)__shfl((int)n_comp, u); const i32 its_u = __shfl(ev.it_state, u);
+          if (mine) {
+            const u64 qe = rc.qe[par][lane]; const u32 pod = (u32)qe, cidx = (u32)(qe >> 32) & 0x7FFFFFFFu;
+            tb.pod_node[pod] = (i32)su; tb.pod_seq[pod] = (i32)(seq0 + (u32)lane);
+            const Rec ru = slot_rec(S, tb, su);
+            auto node_req = [&](int k) {
+              KReq q; q.present = (pres_u >> k) & 1u; q.complement = (comp_u >> k) & 1u; q.gt = KS_NOGT; q.lt = KS_NOLT; q.mask = 0; bool hit = false;
+              for (u32 i = 0; i < cr.ntouch; ++i) if ((int)((u32)(cr.tkeys >> (5 * i)) & 31u) == k) { q.mask = sh.la_mask[i][u]; if constexpr (BOUNDS) { q.gt = wb.la_gt[i][u]; q.lt = wb.la_lt[i][u]; } hit = true; }
+              if (!hit) { q.mask = ru.mask()[k]; if constexpr (BOUNDS) { q.gt = ru.gt()[k]; q.lt = ru.lt()[k]; } }
+              return q;
+            };
+            const GA ClsPlan* pl = plans + cidx; const u32 nrec = pl->nrec;
+            for (u32 t = 0; t < nrec; ++t) {      // Topology.Record, topology.go:120-143
+              const GA u32* rp = (const GA u32*)&pl->rec[t];       // PlanRec is 16 bytes: g, key, {type, owned_inverse, hslot}, {tidx, filtered, pad}
+              const u32 rv2 = rp[2], rv3 = rp[3];
+              const int g = (int)rp[0], key = (int)rp[1]; const u32 type = rv2 & 0xFF, owned_inverse = (rv2 >> 8) & 0xFF, hslot = rv2 >> 16, filt = (rv3 >> 8) & 0xFF;
+              if (!owned_inverse) {
+                if (!tb.g_active[g]) continue;
+                if (filt) {          // TopologyGroup.Counts: TopologyNodeFilter.MatchesRequirements, topologynodefilter.go:57-70
+                  const u32 fb = G_grp_filter_off[g], fe = G_grp_filter_off[g + 1]; bool match = fb == fe;
+                  for (u32 f = fb; f < fe && !match; ++f) {
+                    bool ok = true; const u32 fp = P.flt.present[f], fc = P.flt.complement[f];
+                    for (u32 bits = fp; bits && ok; bits &= bits - 1) {
+                      const int k = __builtin_ctz(bits);
+                      const KReq in = load_req(fp, fc, P.flt.mask + (size_t)f * tb.K, P.flt.gt + (size_t)f * tb.K, P.flt.lt + (size_t)f * tb.K, k);
+                      if (kreq_compatible_fail(node_req(k), in, (tb.wellknown >> k) & 1u, tb.value_int + k * 64, tb.key_nvalues[k])) ok = false;
+                    }
+                    if (ok && P.flt.it_state[f] && tb.its_fail[its_u * tb.SC + P.flt.it_state[f]]) ok = false;
+                    if (ok) match = true;
+                  }
+                  if (!match) continue;
+                }
+              }
+              if (key == KS_KEY_HOSTNAME) { grp_record_host<true>(S, tb, (int)hslot, su); continue; }
+              const KReq q = node_req(key);
+              if (!q.present) continue;
+              if (owned_inverse || type == 2) { for (u64 b = q.mask; b; b &= b - 1) grp_record<true>(tb, g, __builtin_ctzll(b)); }
+              else if (!q.complement && __builtin_popcountll(q.mask) == 1) grp_record<true>(tb, g, __builtin_ctzll(q.mask));
+            }
+          }
         }
-        topology_record<true>(P, S, tb, pb, sh, r, sw, lane);
-        LSYNC();
-        write_record<BOUNDS, RM>(tb, r, pb, sh, pb.rm, lane);
-        if (lane == 0) { if (!ex) r.count() = pb.count + 1; tb.pod_node[pod_w] = (i32)sw; tb.pod_seq[pod_w] = (i32)(seq0 + kw); }
       }
-      if (wv != 0) {     // the pod this wave evaluates next round (if a round follows): request its class plan now
-        const u32 cn = (u32)(UF64(rc.qe[par][(n_commit + kw) & (2 * KS_MAX_WAVES - 1)]) >> 32) & 0x7FFFFFFFu;
-        if (cn != wpf_cidx) { const GA u32x4* src = (const GA u32x4*)(plans + cn); pf0 = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) pf1 = src[lane + 64]; wpf_cidx = cn; }
+      __syncthreads();      // records read node records; the node commits below rewrite them
+      if (wv != 0 && n_ok && !cancelled && committer) {
+        const Rec r = slot_rec(S, tb, wslot);
+#pragma unroll
+        for (int i = 0; i < RM; ++i) if ((u32)i < tb.R) {
+          const i64 rem = rc.roomrem[i][lane];
+          r.req()[i] = rc.req0[i][lane] + (rc.room[i][lane] - rem); r.room()[i] = rem;
+          if (filtered && ((n_rm >> i) & 1u)) r.low()[i] = tb.ge_vals[(size_t)i * tb.ge_stride + n_idx[i]];
+        }
+        r.reqmask() = n_rm;
+        if (wslot >= tb.E) r.count() = rc.cnt[lane] + n_np;
+        if (my_chg) {
+          r.present() = n_pres; r.complement() = n_comp; r.it_state() = ev.it_state;
+          for (u32 i = 0; i < cr.ntouch; ++i) if ((ev.tchg >> i) & 1u) {
+            const u32 k = (u32)(cr.tkeys >> (5 * i)) & 31u; r.mask()[k] = sh.la_mask[i][lane];
+            if constexpr (BOUNDS) { r.gt()[k] = wb.la_gt[i][lane]; r.lt()[k] = wb.la_lt[i][lane]; }
+          }
+        }
       }
       if (wv == 0) {
-        { u32 idx = q_head + n_commit + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; pq_e = (u32)lane < 2u * (NW - 1) ? tb.q[idx] : 0ull; pq_ok = true; }   // the entries the next plan looks at
-        // undo, last first, the moves made for pods that do not commit after all: the node sits at the front of its
-        // new bucket (later moves into that bucket were undone before it); it returns to position p of the old one
-        for (u32 k = n_ok; k > n_commit; --k) {
-          if (!RL((u32)mv_done, k - 1)) continue;
-          const u32 p = RL(mv_p, k - 1), cnt = RL(mv_cnt, k - 1);
-          const u32 at = UF(BST(cnt + 1));                         // == endc - 1 of the move
-          const u32 jw = UF(ORD_RD(at));
-          for (u32 hi = at; hi > p; ) { const u32 lo = hi > p + 64 ? hi - 64 : p; const u32 ii = lo + lane; u32 v = 0; if (ii < hi) v = ORD_RD(ii); if (ord_in_lds) LSYNC(); else GSYNC(); if (ii < hi) ORD_WR(ii + 1, v); if (ord_in_lds) LSYNC(); else GSYNC(); hi = lo; }
-          if (lane == 0) { ORD_WR(p, jw); BST(cnt + 1) = at + 1; }
-          maxc = RL(mv_maxc, k - 1);
-          if (ord_in_lds) LSYNC(); else GSYNC();
+        if (!cancelled && n_ok) {
+          // ---- visiting order: every moved node leaves its place and enters the FRONT of the bucket of its final count (the
+          // most recently moved one in front); untouched nodes keep their relative order.  One pass over the affected range. ----
+          const bool mvd = (u32)lane >= tb.E && (u32)lane < nwin && c_np != 0;
+          const u64 M = ballot64(mvd);                                   // by window lane
+          if (M) {
+            const u32 nM = (u32)__builtin_popcountll(M);
+            const u64 Mpos = tb.E >= 64 ? 0ull : (M >> tb.E);            // by position in `ord`
+            u32 jw_l = 0; if (mvd) jw_l = ORD_RD((u32)lane - tb.E);
+            u32 cmin = 0xFFFFFFFFu, cmax = 0;
+            for (u64 b = M; b; b &= b - 1) { const int x = __builtin_ctzll(b); cmin = min(cmin, RL(c_cnt0, x)); cmax = max(cmax, RL(c_cnt, x)); }
+            const u32 pmin = (u32)__builtin_ctzll(Mpos);
+            auto oldstart = [&](u32 b) -> u32 { return b <= maxc + 1 ? UF(BST(b)) : nnew; };
+            // relocate the untouched elements, bucket by bucket (within a bucket the shift depends only on how many moved nodes stood before)
+            for (u32 b = cmin; b <= cmax; ++b) {
+              const u32 s0 = max(oldstart(b), pmin), s1 = oldstart(b + 1);
+              u32 ins = 0; for (u64 q = M; q; q &= q - 1) { const int x = __builtin_ctzll(q); if (RL(c_cnt, x) <= b) ++ins; }      // moved nodes that end up at or before this bucket's front
+              for (u32 base = s0; base < s1; base += 64) {
+                const u32 ii = base + lane; u32 v = 0; const bool in = ii < s1;
+                if (in) v = ORD_RD(ii);
+                if (ord_in_lds) LSYNC(); else GSYNC();
+                if (in) {
+                  const bool is_m = ii < 64 && ((Mpos >> ii) & 1ull);
+                  const u32 rem_before = ii >= 64 ? nM : (u32)__builtin_popcountll(Mpos & ((1ull << ii) - 1ull));
+                  if (!is_m) ORD_WR(ii - rem_before + ins, v);
+                }
+                if (ord_in_lds) LSYNC(); else GSYNC();
+              }
+            }
+            // new bucket starts for the counts in (cmin, cmax + 1]
+            for (u32 b = cmin + 1 + lane; b <= cmax + 1; b += 64) {
+              const u32 os = b <= maxc + 1 ? BST(b) : nnew;
+              const u32 rem_before = os >= 64 ? nM : (u32)__builtin_popcountll(Mpos & ((1ull << os) - 1ull));
+              u32 below = 0; for (u64 q = M; q; q &= q - 1) { const int x = __builtin_ctzll(q); if (RL(c_cnt, x) < b) ++below; }
+              BST(b) = os - rem_before + below;
+            }
+            if (ord_in_lds) LSYNC(); else GSYNC();
+            if (cmax > maxc) maxc = cmax;
+            // the moved nodes: front of their final bucket, the most recent move first
+            if (mvd) {
+              u32 rank = 0; for (u64 q = M; q; q &= q - 1) { const int x = __builtin_ctzll(q); if (RL(c_cnt, x) == c_cnt && RL(c_last, x) > c_last) ++rank; }
+              ORD_WR(BST(c_cnt) + rank, jw_l);
+            }
+            if (ord_in_lds) LSYNC(); else GSYNC();
+          }
+          q_head = sp_head; q_len = sp_len; seq = sp_seq; CTR(KS_STAT_POPS, n_ok); CTR(21, 1);
+          CTR(KS_STAT_FULLCHECKS, (u32)__builtin_popcountll(M));
         }
-        q_head += n_commit; if (q_head >= nP) q_head -= nP;
-        q_len -= n_commit; seq += n_commit; CTR(KS_STAT_POPS, n_commit); CTR(21, 1);
-        CTR(KS_STAT_FULLCHECKS, (u32)__builtin_popcountll(ballot64((u32)lane < n_commit && my_win >= tb.E)));
+        const u32 n_commit = cancelled ? 0u : n_ok;
 #ifdef KS_PROBES
         CTR(8, rn); CTR(9, 1); CTR(10, n_commit); CTR(11, n_ok); CTR(27, __builtin_readcyclecounter() - t_round); CTR(25, __builtin_readcyclecounter() - t_ph);
 #endif
         pf_ok = false; r_valid = false;
-        if ((u32)lane < n_commit) { const u32 ck = (u32)(rc.qe[par][lane & (KS_MAX_WAVES - 1)] >> 32) & 0x7FFFFFFFu; atomicAnd(&ls.hard[(ck >> 5) & 7u], ~(1u << (ck & 31u))); }
-        if (n_commit == 0) seq_credit = 1;            // the head pod needs more than the window offers: take it sequentially
-        last_commit = n_commit;
-        plan();
+        if (cancelled) {      // nothing was committed: plan again from the queue as it is
+          if (spec_mode == 2) plan_par ^= 1u;
+          if (fail_at >= 2) round_lim = fail_at; else seq_credit = fail_at + 1;
+          CTR(KS_STAT_FULLFAILS, 1);
+          pq_ok = false; plan(q_head, q_len, seq);
+        }
       }
       __syncthreads();
     }
@@ -1598,15 +1996,60 @@ __global__ void ks_probe_kernel(ks_req1 a, ks_req1 b, const i32* vint, u32 nv, i
   *okout = !kreq_compatible_fail(A, B, wk != 0, vint, nv);
 }
 
+__device__ __host__ inline void ks_req_facts_of(const KReq& A, const i32* vint, u32 nv, ks_req_facts* o) {
+  o->has_mask = kreq_has_mask(A, vint, nv); o->len = kreq_len(A); o->op = kreq_operator(A); o->nidne = kreq_nidne(A) ? 1 : 0; o->len0 = kreq_len0(A) ? 1 : 0;
+}
+__global__ void ks_probe_has_kernel(ks_req1 a, const i32* vint, u32 nv, ks_req_facts* out) {
+  KReq A{a.mask, a.gt, a.lt, (bool)a.present, (bool)a.complement};
+  ks_req_facts_of(A, vint, nv, out);
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
+// Device / pinned-host buffer cache.  A controller solves every few seconds with problems of similar size: hipMalloc / hipFree /
+// hipHostMalloc per Solve would cost more than the upload itself, so freed blocks are kept (per device, by power-of-two size
+// class, a few of each) and handed out again.  Thread-safe; blocks never migrate between devices.
+#include <mutex>
+#include <map>
+namespace {
+struct DevPool {
+  std::mutex mu; std::map<std::pair<int, size_t>, std::vector<void*>> dev_free, host_free;
+  static size_t klass(size_t bytes) { size_t c = 4096; while (c < bytes) c <<= 1; return c; }
+  int get(int device, size_t bytes, bool host, void** out) {
+    const size_t c = klass(bytes);
+    { std::lock_guard<std::mutex> g(mu); auto& v = (host ? host_free : dev_free)[{device, c}]; if (!v.empty()) { *out = v.back(); v.pop_back(); return KS_OK; } }
+    if (host) HIPCHK(hipHostMalloc(out, c, hipHostMallocDefault)); else HIPCHK(hipMalloc(out, c));
+    return KS_OK;
+  }
+  void put(int device, size_t bytes, bool host, void* p) {
+    if (!p) return;
+    const size_t c = klass(bytes);
+    { std::lock_guard<std::mutex> g(mu); auto& v = (host ? host_free : dev_free)[{device, c}]; if (v.size() < 4) { v.push_back(p); return; } }
+    if (host) hipHostFree(p); else hipFree(p);
+  }
+};
+DevPool& pool() { static DevPool* p = new DevPool(); return *p; }      // never destroyed: the HIP runtime may already be gone at exit
+// A temporary device block for the duration of one call (returned to the pool on every exit path).
+struct TmpDev {
+  int device; size_t bytes = 0; void* p = nullptr;
+  explicit TmpDev(int dev) : device(dev) {}
+  int alloc(size_t n) { bytes = n ? n : 1; return pool().get(device, bytes, false, &p); }
+  ~TmpDev() { pool().put(device, bytes, false, p); }
+  template <class T> T* as() const { return (T*)p; }
+};
+}  // namespace
+
 struct ks_dev_problem {
   int device = 0;
   DevProb h{};                     // host copy of the device view (pointers are device pointers)
   DevProb* d_prob = nullptr;       // the same struct in device memory (for ks_pack)
   DevState hs{}; DevState* d_state = nullptr;
-  std::vector<void*> allocs;
+  // one device arena: [copied from the host | zero-filled | 0xFF-filled | uninitialised]; sub-allocations are 256-byte aligned.
+  // ks_problem_upload lays the problem out twice: a measuring pass sizes the regions, a placing pass hands out pointers and
+  // packs the host data into ONE pinned staging buffer, which goes over in ONE transfer.
+  bool measure = true; size_t sz[4] = {0, 0, 0, 0}, off[4] = {0, 0, 0, 0}; u8* base[4] = {nullptr, nullptr, nullptr, nullptr};
+  u8* arena = nullptr; size_t arena_bytes = 0; u8* stage = nullptr; size_t stage_bytes = 0;
   hipStream_t stream = nullptr;
   bool tables_built = false;
   bool any_bounds = false;       // some requirement carries Gt/Lt -> the BOUNDS kernel variant
@@ -1614,19 +2057,22 @@ struct ks_dev_problem {
   u32 pp_cap = 0;
 };
 
+static inline size_t ks_align256(size_t b) { return (b + 255) & ~(size_t)255; }
+static int arena_take(ks_dev_problem* d, int region, size_t bytes, void** out) {
+  bytes = ks_align256(bytes ? bytes : 1);
+  if (d->measure) { d->sz[region] += bytes; *out = nullptr; return KS_OK; }
+  if (d->off[region] + bytes > d->sz[region]) return fail(KS_ERR_INTERNAL, "upload: the two layout passes disagree");
+  *out = d->base[region] + d->off[region]; d->off[region] += bytes; return KS_OK;
+}
 template <typename T> static int dev_copy(ks_dev_problem* d, const T* src, size_t n, const T** dst) {
-  *dst = nullptr;
-  size_t bytes = (n ? n : 1) * sizeof(T);
-  void* p = nullptr;
-  HIPCHK(hipMalloc(&p, bytes));
-  d->allocs.push_back(p);
-  if (n) { if (!src) return fail(KS_ERR_INVALID, "null array in ks_problem"); HIPCHK(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice)); }
+  if (n && !src) return fail(KS_ERR_INVALID, "null array in ks_problem");
+  void* p = nullptr; const size_t at = d->off[0];
+  int rc = arena_take(d, 0, n * sizeof(T), &p); if (rc != KS_OK) return rc;
+  if (!d->measure && n) memcpy(d->stage + at, src, n * sizeof(T));
   *dst = (const T*)p; return KS_OK;
 }
 template <typename T> static int dev_alloc(ks_dev_problem* d, size_t n, T** dst, int fill = -2) {
-  size_t bytes = (n ? n : 1) * sizeof(T); void* p = nullptr;
-  HIPCHK(hipMalloc(&p, bytes)); d->allocs.push_back(p);
-  if (fill != -2) HIPCHK(hipMemset(p, fill, bytes));
+  void* p = nullptr; int rc = arena_take(d, fill == 0 ? 1 : (fill == -2 ? 3 : 2), n * sizeof(T), &p); if (rc != KS_OK) return rc;
   *dst = (T*)p; return KS_OK;
 }
 #define TRY(x) do { int rc_ = (x); if (rc_ != KS_OK) return rc_; } while (0)
@@ -1646,6 +2092,9 @@ extern "C" int ks_device_count(void) {
   return ok;
 }
 
+extern "C" int ks_current_device(void) { int d = 0; if (hipGetDevice(&d) != hipSuccess) return 0; return d; }
+extern "C" int ks_problem_device(const ks_dev_problem* d) { return d ? d->device : -1; }
+
 static int validate(const ks_problem* p) {
   if (!p) return fail(KS_ERR_INVALID, "null problem");
   if (p->K > KS_MAX_KEYS) return fail(KS_ERR_UNSUPPORTED, "more than 32 narrow label keys");
@@ -1662,8 +2111,9 @@ static int validate(const ks_problem* p) {
 extern "C" void ks_problem_free(ks_dev_problem* d) {
   if (!d) return;
   hipSetDevice(d->device);
-  for (void* p : d->allocs) hipFree(p);
-  if (d->stream) hipStreamDestroy(d->stream);
+  if (d->stream) { hipStreamSynchronize(d->stream); hipStreamDestroy(d->stream); }
+  pool().put(d->device, d->arena_bytes, false, d->arena);
+  pool().put(d->device, d->stage_bytes, true, d->stage);
   delete d;
 }
 
@@ -1675,6 +2125,7 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   ks_dev_problem* d = new ks_dev_problem(); d->device = device;
   struct Guard { ks_dev_problem* d; bool ok = false; ~Guard() { if (!ok) ks_problem_free(d); } } guard{d};
   HIPCHK(hipStreamCreate(&d->stream));
+  auto layout = [&]() -> int {
   DevProb& h = d->h;
   h.P = p->P; h.C = p->C; h.T = p->T; h.TW = (p->T + 63) / 64; h.M = p->M; h.E = p->E; h.K = p->K; h.R = p->R; h.G = p->G; h.GH = p->GH; h.S = p->S; h.SC = p->SC;
   h.NMAX = p->max_new_nodes ? p->max_new_nodes : 1; h.flags = p->flags; h.n_topologies = p->n_topologies;
@@ -1729,6 +2180,8 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
     TRY(dev_alloc(d, (size_t)R * T * TW, &h.ge_rows, 0));
   }
   { u8* pl = nullptr; TRY(dev_alloc(d, (size_t)C * sizeof(ClsPlan), &pl, 0)); h.plans = pl; }
+  { u8* br = nullptr; TRY(dev_alloc(d, (size_t)C * sizeof(ClsBrief), &br, 0)); h.briefs = br;
+    h.ev_tab_size = 64; while (h.ev_tab_size < 2 * C) h.ev_tab_size <<= 1; h.ev_pad = 0; TRY(dev_alloc(d, (size_t)h.ev_tab_size, &h.ev_tab, 0)); }
   const size_t MC = (size_t)M * C;
   TRY(dev_alloc(d, MC, &h.mc_ok, 0)); TRY(dev_alloc(d, MC, &h.mc_present)); TRY(dev_alloc(d, MC, &h.mc_complement));
   TRY(dev_alloc(d, MC * K, &h.mc_mask)); TRY(dev_alloc(d, MC * K, &h.mc_gt)); TRY(dev_alloc(d, MC * K, &h.mc_lt)); TRY(dev_alloc(d, MC, &h.mc_it));
@@ -1738,21 +2191,30 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   TRY(dev_alloc(d, P, &s.q)); TRY(dev_alloc(d, P, &s.lastlen)); TRY(dev_alloc(d, P, &s.lastgen)); TRY(dev_alloc(d, P, &s.pod_stage)); TRY(dev_alloc(d, P, &s.pod_node)); TRY(dev_alloc(d, P, &s.pod_seq));
   s.rec_stride = ks_rec_stride(R, K);
   TRY(dev_alloc(d, NS * s.rec_stride, &s.rec, 0));
-  TRY(dev_alloc(d, (size_t)h.NMAX, &s.n_tmpl)); TRY(dev_alloc(d, ((size_t)h.NMAX + 1) * TW, &s.n_alive));
+  TRY(dev_alloc(d, (size_t)h.NMAX, &s.n_tmpl)); TRY(dev_alloc(d, ((size_t)h.NMAX + 1) * TW, &s.n_alive)); TRY(dev_alloc(d, (size_t)8 * 64 * TW, &s.round_scratch));
   TRY(dev_alloc(d, (size_t)P + 4, &s.bstart, 0)); TRY(dev_alloc(d, (size_t)h.NMAX, &s.order_g));
   TRY(dev_alloc(d, (size_t)G * 64, &s.gcnt)); TRY(dev_alloc(d, G, &s.g_reg)); TRY(dev_alloc(d, G, &s.g_pos)); TRY(dev_alloc(d, G, &s.g_active));
-  TRY(dev_alloc(d, (size_t)p->GH * NS, &s.hcnt, 0xFF)); TRY(dev_alloc(d, p->GH, &s.g_hpos)); TRY(dev_alloc(d, (size_t)M * R, &s.remaining));
+  TRY(dev_alloc(d, (size_t)p->GH * NS, &s.hcnt, 0xFF)); TRY(dev_alloc(d, p->GH, &s.g_hpos)); TRY(dev_alloc(d, p->GH, &s.g_hzero)); TRY(dev_alloc(d, (size_t)M * R, &s.remaining));
   const size_t NM = h.NMAX;
   TRY(dev_alloc(d, NM, &s.o_present)); TRY(dev_alloc(d, NM, &s.o_complement)); TRY(dev_alloc(d, NM * K, &s.o_mask)); TRY(dev_alloc(d, NM * K, &s.o_gt)); TRY(dev_alloc(d, NM * K, &s.o_lt));
   TRY(dev_alloc(d, NM, &s.o_it)); TRY(dev_alloc(d, NM * R, &s.o_req)); TRY(dev_alloc(d, NM, &s.o_reqmask));
   // host-port pool: existing entries + one batch-worth of pod ports (max over stages)
-  size_t pool = E ? p->en_port_off[E] : 0;
-  for (u32 i = 0; i < P; ++i) { u32 mx = 0; for (u32 st = p->pod_stage_off[i]; st < p->pod_stage_off[i + 1]; ++st) { const u32 c = p->stage_cls[st]; const u32 n = p->cls_port_off[c + 1] - p->cls_port_off[c]; if (n > mx) mx = n; } pool += mx; }
-  s.pp_cap = (u32)pool; TRY(dev_alloc(d, pool, &s.pp_entry)); TRY(dev_alloc(d, pool, &s.pp_next));
+  size_t pp_pool = E ? p->en_port_off[E] : 0;
+  for (u32 i = 0; i < P; ++i) { u32 mx = 0; for (u32 st = p->pod_stage_off[i]; st < p->pod_stage_off[i + 1]; ++st) { const u32 c = p->stage_cls[st]; const u32 n = p->cls_port_off[c + 1] - p->cls_port_off[c]; if (n > mx) mx = n; } pp_pool += mx; }
+  s.pp_cap = (u32)pp_pool; TRY(dev_alloc(d, pp_pool, &s.pp_entry)); TRY(dev_alloc(d, pp_pool, &s.pp_next));
   TRY(dev_alloc(d, 32, &s.stats, 0)); TRY(dev_alloc(d, 4, &s.out_counts, 0)); TRY(dev_alloc(d, P, &s.unscheduled));
-  TRY(dev_alloc(d, 1, &d->d_prob)); TRY(dev_alloc(d, 1, &d->d_state));
-  HIPCHK(hipMemcpy(d->d_prob, &d->h, sizeof(DevProb), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d->d_state, &d->hs, sizeof(DevState), hipMemcpyHostToDevice));
+  // the two descriptors go last: by now (placing pass) every pointer in them is final
+  { const DevProb* dp; const DevState* ds; TRY(dev_copy(d, &d->h, 1, &dp)); TRY(dev_copy(d, &d->hs, 1, &ds)); d->d_prob = (DevProb*)dp; d->d_state = (DevState*)ds; }
+  return KS_OK;
+  };
+  d->measure = true; TRY(layout());
+  d->arena_bytes = d->sz[0] + d->sz[1] + d->sz[2] + d->sz[3]; d->stage_bytes = d->sz[0];
+  { void* a = nullptr; TRY(pool().get(device, d->arena_bytes, false, &a)); d->arena = (u8*)a; void* st = nullptr; TRY(pool().get(device, d->stage_bytes, true, &st)); d->stage = (u8*)st; }
+  d->base[0] = d->arena; d->base[1] = d->base[0] + d->sz[0]; d->base[2] = d->base[1] + d->sz[1]; d->base[3] = d->base[2] + d->sz[2];
+  d->measure = false; TRY(layout());
+  HIPCHK(hipMemcpyAsync(d->base[0], d->stage, d->sz[0], hipMemcpyHostToDevice, d->stream));
+  if (d->sz[1]) HIPCHK(hipMemsetAsync(d->base[1], 0, d->sz[1], d->stream));
+  if (d->sz[2]) HIPCHK(hipMemsetAsync(d->base[2], 0xFF, d->sz[2], d->stream));
   guard.ok = true; *out = d; return KS_OK;
 }
 
@@ -1763,7 +2225,8 @@ static int build_static(ks_dev_problem* d, float* grid_ms) {
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   const u32 rows = h.K * 64 + 2 * h.K + 64;
   hipLaunchKernelGGL(ks_build_type_tables, dim3((rows * 64 + 255) / 256), dim3(256), 0, d->stream, h);
-  if (h.C) hipLaunchKernelGGL(ks_build_plans, dim3((h.C + 63) / 64), dim3(64), 0, d->stream, h, (ClsPlan*)h.plans);
+  if (h.C) hipLaunchKernelGGL(ks_build_plans, dim3((h.C + 63) / 64), dim3(64), 0, d->stream, h, (ClsPlan*)h.plans, (ClsBrief*)h.briefs);
+  if (h.C) { HIPCHK(hipMemsetAsync(h.ev_tab, 0, (size_t)h.ev_tab_size * sizeof(u32), d->stream)); hipLaunchKernelGGL(ks_link_ev, dim3((h.C + 63) / 64), dim3(64), 0, d->stream, (const ClsPlan*)h.plans, (ClsBrief*)h.briefs, h.ev_tab, h.ev_tab_size, h.C); }
   if (h.C) hipLaunchKernelGGL(ks_link_plans, dim3((h.C + 63) / 64), dim3(64), 0, d->stream, (ClsPlan*)h.plans, h.C, h.R);
   hipLaunchKernelGGL(ks_build_ge_rows, dim3((u32)(((size_t)h.R * h.T * 64 + 255) / 256)), dim3(256), 0, d->stream, h);
   const size_t MC = (size_t)h.M * h.C;
@@ -1830,14 +2293,14 @@ static int download_batch(ks_dev_problem* const* ds, u32 n, const DevState* dsv,
     descs[i] = GatherDesc{total, h.P, h.K, h.R, h.TW, out->n_new, 0};
     total += ks_gather_bytes(h.P, h.K, h.R, h.TW, out->n_new);
   }
-  GatherDesc* d_desc = nullptr; u8* d_blob = nullptr;
-  HIPCHK(hipMalloc((void**)&d_desc, n * sizeof(GatherDesc))); HIPCHK(hipMalloc((void**)&d_blob, total ? total : 8));
+  TmpDev t_desc(ds[0]->device), t_blob(ds[0]->device);
+  TRY(t_desc.alloc(n * sizeof(GatherDesc))); TRY(t_blob.alloc(total ? total : 8));
+  GatherDesc* d_desc = t_desc.as<GatherDesc>(); u8* d_blob = t_blob.as<u8>();
   HIPCHK(hipMemcpy(d_desc, descs.data(), n * sizeof(GatherDesc), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(ks_gather, dim3(n), dim3(256), 0, ds[0]->stream, dsv, d_desc, d_blob);
   std::vector<u8> blob(total ? total : 8);
   HIPCHK(hipMemcpyAsync(blob.data(), d_blob, total ? total : 8, hipMemcpyDeviceToHost, ds[0]->stream));
   HIPCHK(hipStreamSynchronize(ds[0]->stream));
-  hipFree(d_desc); hipFree(d_blob);
   for (u32 i = 0; i < n; ++i) {
     const DevProb& h = ds[i]->h; ks_result* out = outs[i]; const u64 P = h.P, K = h.K, R = h.R, TW = h.TW, N = out->n_new;
     const u8* p = blob.data() + descs[i].off;
@@ -1886,11 +2349,12 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   std::vector<DevProb> hp(n); std::vector<DevState> hs(n);
   for (u32 i = 0; i < n; ++i) { hp[i] = ds[i]->h; hs[i] = ds[i]->hs; }
   DevProb* dp = nullptr; DevState* dsv = nullptr; u64* d_meta = nullptr;
+  TmpDev t_meta(device), t_dp(device), t_dsv(device);
   if (n == 1) { dp = ds[0]->d_prob; dsv = ds[0]->d_state; }
   else {
-    HIPCHK(hipMalloc((void**)&d_meta, (size_t)n * 34 * sizeof(u64)));
+    TRY(t_meta.alloc((size_t)n * 34 * sizeof(u64))); d_meta = t_meta.as<u64>();
     for (u32 i = 0; i < n; ++i) hs[i].batch_meta = d_meta + (size_t)i * 34;
-    HIPCHK(hipMalloc((void**)&dp, n * sizeof(DevProb))); HIPCHK(hipMalloc((void**)&dsv, n * sizeof(DevState)));
+    TRY(t_dp.alloc(n * sizeof(DevProb))); TRY(t_dsv.alloc(n * sizeof(DevState))); dp = t_dp.as<DevProb>(); dsv = t_dsv.as<DevState>();
     HIPCHK(hipMemcpy(dp, hp.data(), n * sizeof(DevProb), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dsv, hs.data(), n * sizeof(DevState), hipMemcpyHostToDevice));
   }
   hipStream_t st = ds[0]->stream;
@@ -1901,14 +2365,24 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   const u32 lds_bytes = n == 1 ? 100u * 1024u : 64u * 1024u;
   bool fast = true;
   for (u32 i = 0; i < n; ++i) { const DevProb& q = ds[i]->h; if (q.G > KS_FAST_G || q.GH > KS_FAST_G || (q.SC > 1 && (size_t)q.S * q.SC > KS_FAST_S * KS_FAST_S) || (size_t)q.R * q.ge_max > KS_FAST_RT || (size_t)q.R * q.ge_max * 8 + 8192 > lds_bytes) fast = false; }
-  static bool attr_set = false;
   bool bounds = false; for (u32 i = 0; i < n; ++i) bounds = bounds || ds[i]->any_bounds;
   bool lean = true; for (u32 i = 0; i < n; ++i) lean = lean && ds[i]->lean_ok;
   if (getenv("KS_NO_LEAN")) lean = false;      // test hook: run the general variant on a problem the LEAN one would take
   typedef void (*pack_fn)(const DevProb*, const DevState*, u32);
   static const pack_fn variants[8] = {ks_pack<false, false, false, 1>, ks_pack<false, true, false, 1>, ks_pack<true, false, false, 1>, ks_pack<true, true, false, 1>,
                                       ks_pack<false, false, true, 1>, ks_pack<false, true, true, 1>, ks_pack<true, false, true, 1>, ks_pack<true, true, true, 1>};
-  if (!attr_set) { for (int i = 0; i < 8; ++i) HIPCHK(hipFuncSetAttribute((const void*)variants[i], hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024)); attr_set = true; }
+  {   // the large dynamic-LDS opt-in is a per-device function attribute: set it once per device, race-free (two Solves may run concurrently)
+    static std::mutex attr_mu; static std::vector<char> attr_done;
+    std::lock_guard<std::mutex> g(attr_mu);
+    if ((size_t)device >= attr_done.size()) attr_done.resize(device + 1, 0);
+    if (!attr_done[device]) {
+      for (int i = 0; i < 8; ++i) HIPCHK(hipFuncSetAttribute((const void*)variants[i], hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, true, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
+      attr_done[device] = 1;
+    }
+  }
   // A single Solve whose problem takes the LEAN, FAST, no-bounds kernel gets 8 waves: waves 1..7 join wave 0 for the
   // speculation rounds (see ks_pack).  T <= 8192 keeps a node's surviving-type mask in two registers per lane.
   bool multi = n == 1 && fast && ds[0]->h.TW <= 128 && !(ds[0]->h.flags & KS_FLAG_STATS) && !getenv("KS_ONE_WAVE");
@@ -1916,13 +2390,6 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
     const u32 lds_mw = 44u * 1024u;
     if ((size_t)ds[0]->h.R * ds[0]->h.ge_max * 8 + 8192 > lds_mw) multi = false;
     else {
-      static bool attr_mw = false;
-      if (!attr_mw) {
-        HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, true, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
-        attr_mw = true;
-      }
       if (lean && !bounds) hipLaunchKernelGGL((ks_pack<true, false, true, 8>), dim3(1), dim3(512), lds_mw, st, dp, dsv, lds_mw);
       else if (bounds) hipLaunchKernelGGL((ks_pack<true, true, false, 4>), dim3(1), dim3(256), lds_mw, st, dp, dsv, lds_mw);
       else hipLaunchKernelGGL((ks_pack<true, false, false, 4>), dim3(1), dim3(256), lds_mw, st, dp, dsv, lds_mw);     // host ports / limits / selectors on hostname or instance type: the general code
@@ -1936,7 +2403,7 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   if (kernel_ms) HIPCHK(hipEventElapsedTime(kernel_ms, e0, e1));
   hipEventDestroy(e0); hipEventDestroy(e1);
   int rc = KS_OK;
-  if (n > 1) { rc = download_batch(ds, n, dsv, d_meta, outs); hipFree(dp); hipFree(dsv); hipFree(d_meta); }
+  if (n > 1) rc = download_batch(ds, n, dsv, d_meta, outs);
   else rc = download(ds[0], outs[0]);
   return rc;
 }
@@ -1996,11 +2463,12 @@ extern "C" int ks_price_filter_dev(ks_dev_problem* const* ds, uint32_t n, const 
     if (node[i] >= ds[i]->h.NMAX) return fail(KS_ERR_INVALID, "node index out of range");
     hp[i] = ds[i]->h; hs[i] = ds[i]->hs; off[i] = words; words += ds[i]->h.TW;
   }
-  DevProb* dp = nullptr; DevState* dsv = nullptr; u32* dnode = nullptr; double* dmax = nullptr; u64* dout = nullptr; u64** dptr = nullptr; u32* dcnt = nullptr; u32* dspot = nullptr;
-  if (spot_only) { HIPCHK(hipMalloc((void**)&dspot, n * sizeof(u32))); HIPCHK(hipMemcpy(dspot, spot_only, n * sizeof(u32), hipMemcpyHostToDevice)); }
-  HIPCHK(hipMalloc((void**)&dp, n * sizeof(DevProb))); HIPCHK(hipMalloc((void**)&dsv, n * sizeof(DevState)));
-  HIPCHK(hipMalloc((void**)&dnode, n * sizeof(u32))); HIPCHK(hipMalloc((void**)&dmax, n * sizeof(double)));
-  HIPCHK(hipMalloc((void**)&dout, (words ? words : 1) * sizeof(u64))); HIPCHK(hipMalloc((void**)&dptr, n * sizeof(u64*))); HIPCHK(hipMalloc((void**)&dcnt, n * sizeof(u32)));
+  TmpDev t_dp(device), t_dsv(device), t_node(device), t_max(device), t_out(device), t_ptr(device), t_cnt(device), t_spot(device);
+  u32* dspot = nullptr;
+  if (spot_only) { TRY(t_spot.alloc(n * sizeof(u32))); dspot = t_spot.as<u32>(); HIPCHK(hipMemcpy(dspot, spot_only, n * sizeof(u32), hipMemcpyHostToDevice)); }
+  TRY(t_dp.alloc(n * sizeof(DevProb))); TRY(t_dsv.alloc(n * sizeof(DevState))); TRY(t_node.alloc(n * sizeof(u32))); TRY(t_max.alloc(n * sizeof(double)));
+  TRY(t_out.alloc((words ? words : 1) * sizeof(u64))); TRY(t_ptr.alloc(n * sizeof(u64*))); TRY(t_cnt.alloc(n * sizeof(u32)));
+  DevProb* dp = t_dp.as<DevProb>(); DevState* dsv = t_dsv.as<DevState>(); u32* dnode = t_node.as<u32>(); double* dmax = t_max.as<double>(); u64* dout = t_out.as<u64>(); u64** dptr = t_ptr.as<u64*>(); u32* dcnt = t_cnt.as<u32>();
   std::vector<u64*> ptrs(n); for (u32 i = 0; i < n; ++i) ptrs[i] = dout + off[i];
   HIPCHK(hipMemcpy(dp, hp.data(), n * sizeof(DevProb), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dsv, hs.data(), n * sizeof(DevState), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dnode, node, n * sizeof(u32), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dmax, max_price, n * sizeof(double), hipMemcpyHostToDevice));
@@ -2011,7 +2479,6 @@ extern "C" int ks_price_filter_dev(ks_dev_problem* const* ds, uint32_t n, const 
   HIPCHK(hipMemcpyAsync(out_counts, dcnt, n * sizeof(u32), hipMemcpyDeviceToHost, ds[0]->stream));
   HIPCHK(hipStreamSynchronize(ds[0]->stream)); HIPCHK(hipGetLastError());
   for (u32 i = 0; i < n; ++i) memcpy(out_types[i], host.data() + off[i], ds[i]->h.TW * sizeof(u64));
-  hipFree(dp); hipFree(dsv); hipFree(dnode); hipFree(dmax); hipFree(dout); hipFree(dptr); hipFree(dcnt); if (dspot) hipFree(dspot);
   return KS_OK;
 }
 
@@ -2059,6 +2526,29 @@ extern "C" int ks_probe_intersection(const ks_req1* a, const ks_req1* b, const i
 extern "C" int ks_probe_compatible(const ks_req1* a, const ks_req1* b, int well_known, const int32_t* value_int, uint32_t nvalues, int on_device, int* ok) {
   if (on_device) return probe_device(a, b, well_known, value_int, nvalues, nullptr, ok);
   *ok = !kreq_compatible_fail(to_k(a), to_k(b), well_known != 0, value_int, nvalues); return KS_OK;
+}
+
+extern "C" int ks_probe_has(const ks_req1* a, const int32_t* value_int, uint32_t nvalues, int on_device, ks_req_facts* out) {
+  if (!a || !out || !value_int) return fail(KS_ERR_INVALID, "null argument");
+  if (!on_device) { ks_req_facts_of(to_k(a), value_int, nvalues, out); return KS_OK; }
+  if (ks_device_count() <= 0) return fail(KS_ERR_DEVICE, "no gfx950 device");
+  int device = ks_current_device(); TmpDev tv(device), to(device);
+  TRY(tv.alloc(64 * sizeof(i32))); TRY(to.alloc(sizeof(ks_req_facts)));
+  i32 tmp[64]; for (int i = 0; i < 64; ++i) tmp[i] = (u32)i < nvalues ? value_int[i] : INT32_MIN;
+  HIPCHK(hipMemcpy(tv.p, tmp, sizeof tmp, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ks_probe_has_kernel, dim3(1), dim3(1), 0, 0, *a, tv.as<i32>(), nvalues, to.as<ks_req_facts>());
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, to.p, sizeof(ks_req_facts), hipMemcpyDeviceToHost));
+  return KS_OK;
+}
+
+// Diagnostics: the class briefs (evaluation-class ids, conflict masks) and plan records as the kernels see them.
+extern "C" int ks_debug_classes(ks_dev_problem* d, void* briefs_out, void* plans_out) {
+  if (!d) return fail(KS_ERR_INVALID, "null device problem");
+  TRY(build_static(d, nullptr));
+  if (briefs_out) HIPCHK(hipMemcpy(briefs_out, d->h.briefs, (size_t)d->h.C * sizeof(ClsBrief), hipMemcpyDeviceToHost));
+  if (plans_out) HIPCHK(hipMemcpy(plans_out, d->h.plans, (size_t)d->h.C * sizeof(ClsPlan), hipMemcpyDeviceToHost));
+  return (int)sizeof(ClsPlan);
 }
 
 extern "C" const char* ks_last_error(void) { return g_err.c_str(); }

@@ -17,17 +17,7 @@ struct Handle {
   ~Handle() { if (dev) ks_problem_free(dev); }
 };
 thread_local std::string g_err;
-// Host threads for the what-if flattening: the cores this process may actually use -- a container usually sees every core of
-// the machine but runs under a cgroup CPU quota (cpu.max = "quota period"); oversubscribing it is slower than one thread.
-uint32_t default_threads() {
-  uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-    long long quota = -1, period = 0; char buf[64] = {0};
-    if (fscanf(f, "%63s %lld", buf, &period) == 2 && strcmp(buf, "max") != 0) { quota = atoll(buf); if (quota > 0 && period > 0) hw = std::min<uint32_t>(hw, (uint32_t)std::max<long long>(1, quota / period)); }
-    fclose(f);
-  }
-  return std::min(hw, 16u);
-}
+uint32_t default_threads() { return ksh::host_threads(); }
 int set_err(int code, const std::string& m) { g_err = m; return code; }
 }  // namespace
 
@@ -41,14 +31,67 @@ int ksh_open(const char* ksp_text, size_t len, uint32_t flags, void** out) {
   *out = nullptr;
   try {
     auto h = std::make_unique<Handle>();
-    h->enc = ksh::encode(ksp::Parser(ksp_text, len).parse(), flags);
+    auto t0 = std::chrono::steady_clock::now();
+    ksp::Problem pr = ksp::Parser(ksp_text, len).parse();
+    auto t1 = std::chrono::steady_clock::now();
+    h->enc = ksh::encode(std::move(pr), flags);
+    auto t2 = std::chrono::steady_clock::now();
     h->rb = h->enc->make_result();
+    if (getenv("KSH_TIMING")) fprintf(stderr, "ksh_open: parse %.2f ms, encode %.2f ms, result buffers %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                                      std::chrono::duration<double, std::milli>(t2 - t1).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
     *out = h.release(); return KS_OK;
   } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());
   } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
 }
 void ksh_close(void* h) { delete (Handle*)h; }
 const ks_problem* ksh_problem(void* h) { return &((Handle*)h)->enc->prob; }
+
+// ---- the pod list in memory ----
+// ksh_parse turns KSP1 text into the C++ objects (the analogue of the []*v1.Pod, []*cloudprovider.InstanceType, []*state.Node a Go
+// caller holds); ksh_solve_from_pods then does what the reference does from that point: NewScheduler's flattening incl. NewQueue's
+// sort and every per-pod computation, upload, the HIP kernels, read-back -- the window bench.py times as "solve_from_pods".
+struct Parsed { std::shared_ptr<const ksp::Problem> pr; };
+int ksh_parse(const char* ksp_text, size_t len, void** out) {
+  *out = nullptr;
+  try { auto p = std::make_unique<Parsed>(); p->pr = std::make_shared<const ksp::Problem>(ksp::Parser(ksp_text, len).parse()); *out = p.release(); return KS_OK; }
+  catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
+}
+void ksh_parsed_free(void* p) { delete (Parsed*)p; }
+// ms[0..5]: flatten (host) | upload | static tables + feasibility grid | pack kernel (HIP events) | whole ks_solve_dev incl. read-back | total wall
+int ksh_solve_from_pods(void* parsed, int device, uint32_t flags, void** out_handle, double* ms) {
+  if (out_handle) *out_handle = nullptr;
+  try {
+    using clk = std::chrono::steady_clock; auto now = [] { return clk::now(); }; auto since = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto t0 = now();
+    auto h = std::make_unique<Handle>();
+    h->enc = ksh::encode(((Parsed*)parsed)->pr, flags);
+    h->rb = h->enc->make_result();
+    auto t1 = now();
+    int rc = ks_problem_upload(&h->enc->prob, device, &h->dev); if (rc != KS_OK) return set_err(rc, ks_last_error());
+    auto t2 = now();
+    float grid_ms = 0; rc = ks_feasibility_grid(h->dev, nullptr, &grid_ms); if (rc != KS_OK) return set_err(rc, ks_last_error());
+    auto t3 = now();
+    float kms = 0; rc = ks_solve_dev(h->dev, &h->rb->r, &kms); if (rc != KS_OK) return set_err(rc, ks_last_error());
+    auto t4 = now();
+    if (ms) { ms[0] = since(t0, t1); ms[1] = since(t1, t2); ms[2] = since(t2, t3); ms[3] = kms; ms[4] = since(t3, t4); ms[5] = since(t0, t4); }
+    if (out_handle) *out_handle = h.release();
+    return KS_OK;
+  } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());
+  } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
+}
+// KSR1 text of the result a handle holds (after ksh_solve / ksh_solve_from_pods)
+int ksh_result_text(void* hv, char** out_text) { Handle* h = (Handle*)hv; std::string s = h->enc->decode(h->rb->r, 0.0); *out_text = strdup(s.c_str()); return KS_OK; }
+
+// Fixed-size record of the result a handle holds -- what consolidation reads of a simulation (consolidation.go:190-260):
+// out[0] = number of new nodes, out[1] = number of unscheduled pods, out[2..2+words) = InstanceTypeOptions of new node 0 as a bitmask
+// (zero if there is none).  No text, no per-pod data: this is what the ranks all-gather.
+int ksh_result_summary(void* hv, uint64_t* out, uint32_t words) {
+  Handle* h = (Handle*)hv; const ks_result& r = h->rb->r; const uint32_t TW = (h->enc->prob.T + 63) / 64;
+  if (words < TW) return set_err(KS_ERR_INVALID, "summary row too short");
+  out[0] = r.n_new; out[1] = r.n_unscheduled;
+  for (uint32_t w = 0; w < words; ++w) out[2 + w] = (r.n_new && w < TW) ? r.node_types[w] : 0;
+  return KS_OK;
+}
 
 // Consolidation what-ifs over ONE cluster snapshot (deprovisioning/helpers.go:42-115 simulateScheduling): the snapshot is
 // parsed once -- `base` lists every state node and, as its pod batch, every bound pod with its full spec; pod_node[i] is the
@@ -107,7 +150,8 @@ uint64_t ksh_fingerprint(void* hv) {
 
 // Upload the flat problem to HBM (idempotent).
 int ksh_upload(void* hv, int device) {
-  Handle* h = (Handle*)hv; if (h->dev) return KS_OK;
+  Handle* h = (Handle*)hv;
+  if (h->dev) return ks_problem_device(h->dev) == device ? KS_OK : set_err(KS_ERR_INVALID, "problem already resident on another device");
   int rc = ks_problem_upload(&h->enc->prob, device, &h->dev);
   if (rc != KS_OK) return set_err(rc, ks_last_error());
   return KS_OK;
@@ -116,7 +160,7 @@ int ksh_upload(void* hv, int device) {
 // Solve (device-resident inputs).  out_text may be NULL (skip decode).
 int ksh_solve(void* hv, char** out_text, float* kernel_ms, double* wall_ms) {
   Handle* h = (Handle*)hv;
-  int rc = ksh_upload(hv, 0); if (rc != KS_OK) return rc;
+  int rc = h->dev ? KS_OK : ksh_upload(hv, ks_current_device()); if (rc != KS_OK) return rc;      // not uploaded yet: the calling thread's current HIP device
   auto t0 = std::chrono::steady_clock::now();
   rc = ks_solve_dev(h->dev, &h->rb->r, kernel_ms);
   double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -129,7 +173,8 @@ int ksh_solve(void* hv, char** out_text, float* kernel_ms, double* wall_ms) {
 // N independent problems in one launch (consolidation what-ifs, deprovisioning/helpers.go:42-115).
 int ksh_solve_batch(void** hv, uint32_t n, char** out_texts, float* kernel_ms, double* wall_ms) {
   std::vector<ks_dev_problem*> ds(n); std::vector<ks_result*> rs(n);
-  for (uint32_t i = 0; i < n; ++i) { int rc = ksh_upload(hv[i], 0); if (rc != KS_OK) return rc; ds[i] = ((Handle*)hv[i])->dev; rs[i] = &((Handle*)hv[i])->rb->r; }
+  const int dev = ks_current_device();
+  for (uint32_t i = 0; i < n; ++i) { int rc = ((Handle*)hv[i])->dev ? KS_OK : ksh_upload(hv[i], dev); if (rc != KS_OK) return rc; ds[i] = ((Handle*)hv[i])->dev; rs[i] = &((Handle*)hv[i])->rb->r; }
   auto t0 = std::chrono::steady_clock::now();
   int rc = ks_solve_batch_dev(ds.data(), n, rs.data(), kernel_ms);
   double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -156,7 +201,7 @@ int ksh_price_filter(void** hv, uint32_t n, const uint32_t* node, const double* 
 
 // Static feasibility grid [M][C][TW]; `out` may be NULL (timing only).
 int ksh_grid(void* hv, uint64_t* out, float* kernel_ms) {
-  Handle* h = (Handle*)hv; int rc = ksh_upload(hv, 0); if (rc != KS_OK) return rc;
+  Handle* h = (Handle*)hv; int rc = h->dev ? KS_OK : ksh_upload(hv, ks_current_device()); if (rc != KS_OK) return rc;
   rc = ks_feasibility_grid(h->dev, out, kernel_ms);
   if (rc != KS_OK) return set_err(rc, ks_last_error());
   return KS_OK;
@@ -167,6 +212,9 @@ int ksh_solve_ksp(const char* ksp_text, size_t len, uint32_t flags, char** out_t
   void* h = nullptr; int rc = ksh_open(ksp_text, len, flags, &h); if (rc != KS_OK) return rc;
   rc = ksh_solve(h, out_text, nullptr, nullptr); ksh_close(h); return rc;
 }
+
+extern "C" int ks_debug_classes(ks_dev_problem*, void*, void*);
+int ksh_debug_classes(void* hv, void* briefs, void* plans) { Handle* h = (Handle*)hv; if (!h->dev) return KS_ERR_INVALID; return ks_debug_classes(h->dev, briefs, plans); }
 
 // dims for tests / bench: [P,C,T,M,E,K,R,G,GH,S]
 void ksh_dims(void* hv, uint32_t* d) { const ks_problem& p = ((Handle*)hv)->enc->prob; uint32_t v[10] = {p.P, p.C, p.T, p.M, p.E, p.K, p.R, p.G, p.GH, p.S}; memcpy(d, v, sizeof v); }

@@ -1,8 +1,11 @@
 // encode.cpp -- see encode.hpp.  Reference citations are relative to aws/karpenter-core pkg/.
 #include "encode.hpp"
 
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <sstream>
+#include <thread>
 #include <unordered_map>
 
 namespace ksh {
@@ -105,6 +108,91 @@ std::string spec_signature(const Pod& p) {
   return s;
 }
 
+// ---- host threads: the cores this process may use (a container usually sees every core of the machine but runs under a cgroup
+// CPU quota, cpu.max = "quota period"; oversubscribing the quota is slower than one thread) ----
+}  // namespace
+uint32_t host_threads() {
+  static const uint32_t n = [] {
+    if (const char* e = getenv("KSH_THREADS")) { int v = atoi(e); if (v > 0) return (uint32_t)v; }
+    uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      long long period = 0; char buf[64] = {0};
+      if (fscanf(f, "%63s %lld", buf, &period) == 2 && strcmp(buf, "max") != 0) { long long quota = atoll(buf); if (quota > 0 && period > 0) hw = std::min<uint32_t>(hw, (uint32_t)std::max<long long>(1, quota / period)); }
+      fclose(f);
+    }
+    return std::min(hw, 16u);
+  }();
+  return n;
+}
+namespace {
+// fn(begin, end, thread) over [0, n) in contiguous chunks
+template <class F> void parallel_chunks(size_t n, F&& fn) {
+  const uint32_t nt = (uint32_t)std::max<size_t>(1, std::min<size_t>(host_threads(), n / 2048));
+  if (nt == 1) { fn((size_t)0, n, 0u); return; }
+  std::vector<std::thread> pool; const size_t per = (n + nt - 1) / nt;
+  for (uint32_t t = 1; t < nt; ++t) pool.emplace_back([&, t] { fn(std::min(n, t * per), std::min(n, (t + 1) * per), t); });
+  fn((size_t)0, std::min(n, per), 0u);
+  for (auto& th : pool) th.join();
+}
+
+// ---- 128-bit streaming hash of everything of a pod spec that Solve can read (everything but uid and creationTimestamp).
+// It only FINDS candidates for deduplication; equality is then confirmed field by field (same_spec), so a collision costs time,
+// never correctness. ----
+struct Hash128 {
+  uint64_t a = 0x9E3779B97F4A7C15ull, b = 0xC2B2AE3D27D4EB4Full;
+  static uint64_t rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+  void u(uint64_t v) { a = (rotl(a, 27) ^ v) * 0x9FB21C651E98DF25ull; b = (rotl(b, 31) + v) * 0xD6E8FEB86659FD93ull; }
+  void bytes(const char* p, size_t n) {
+    u(n);
+    while (n >= 8) { uint64_t v; memcpy(&v, p, 8); u(v); p += 8; n -= 8; }
+    if (n) { uint64_t v = 0; memcpy(&v, p, n); u(v); }
+  }
+  void str(const std::string& s) { bytes(s.data(), s.size()); }
+  void map(const StrMap& m) { u(m.size()); for (auto& kv : m) { str(kv.first); str(kv.second); } }
+  void res(const ksp::ResList& r) { u(r.size()); for (auto& kv : r) { str(kv.first); u((uint64_t)kv.second); } }
+  void exprs(const std::vector<Expr>& es) { u(es.size()); for (auto& e : es) { str(e.key); u((uint64_t)e.op); u(e.values.size()); for (auto& v : e.values) str(v); } }
+  void selector(const ksp::Selector& x) { u(x.nil ? 1 : 2); if (!x.nil) { map(x.match_labels); exprs(x.match_exprs); } }
+  void term(const ksp::AffinityTerm& t) { str(t.topology_key); u(t.namespaces.size()); for (auto& n : t.namespaces) str(n); selector(t.selector); }
+  void finish() { a ^= a >> 32; a *= 0xFF51AFD7ED558CCDull; a ^= a >> 29; b ^= b >> 31; b *= 0xC4CEB9FE1A85EC53ull; b ^= b >> 33; }
+};
+Hash128 spec_hash(const Pod& p) {
+  Hash128 h; h.str(p.ns); h.map(p.labels); h.map(p.node_selector);
+  h.u(p.required_affinity.size()); for (auto& t : p.required_affinity) h.exprs(t);
+  h.u(p.preferred_affinity.size()); for (auto& t : p.preferred_affinity) { h.u((uint64_t)t.weight); h.exprs(t.exprs); }
+  h.u(p.tolerations.size()); for (auto& t : p.tolerations) { h.str(t.key); h.str(t.op); h.str(t.value); h.str(t.effect); }
+  h.u(p.containers.size()); for (auto& c : p.containers) { h.res(c.requests); h.res(c.limits); h.u(c.ports.size()); for (auto& hp : c.ports) { h.str(hp.ip); h.u((uint64_t)hp.port); h.str(hp.proto); } }
+  h.u(p.init_containers.size()); for (auto& c : p.init_containers) { h.res(c.requests); h.res(c.limits); }
+  h.u(p.spread.size()); for (auto& t : p.spread) { h.u((uint64_t)t.max_skew); h.str(t.key); h.u(t.schedule_anyway); h.selector(t.selector); }
+  h.u(p.affinity_required.size()); for (auto& t : p.affinity_required) h.term(t);
+  h.u(p.affinity_preferred.size()); for (auto& t : p.affinity_preferred) { h.u((uint64_t)t.weight); h.term(t.term); }
+  h.u(p.anti_required.size()); for (auto& t : p.anti_required) h.term(t);
+  h.u(p.anti_preferred.size()); for (auto& t : p.anti_preferred) { h.u((uint64_t)t.weight); h.term(t.term); }
+  h.finish(); return h;
+}
+bool same_exprs(const std::vector<Expr>& a, const std::vector<Expr>& b) {
+  if (a.size() != b.size()) return false;
+  for (size_t i = 0; i < a.size(); ++i) if (a[i].key != b[i].key || a[i].op != b[i].op || a[i].values != b[i].values) return false;
+  return true;
+}
+bool same_selector(const ksp::Selector& a, const ksp::Selector& b) { return a.nil == b.nil && (a.nil || (a.match_labels == b.match_labels && same_exprs(a.match_exprs, b.match_exprs))); }
+bool same_term(const ksp::AffinityTerm& a, const ksp::AffinityTerm& b) { return a.topology_key == b.topology_key && a.namespaces == b.namespaces && same_selector(a.selector, b.selector); }
+template <class V, class F> bool same_vec(const V& a, const V& b, F&& eq) { if (a.size() != b.size()) return false; for (size_t i = 0; i < a.size(); ++i) if (!eq(a[i], b[i])) return false; return true; }
+// Field-by-field equality of two pod specs (uid and creationTimestamp excluded): the pods are interchangeable for Solve.
+bool same_spec(const Pod& a, const Pod& b) {
+  if (a.ns != b.ns || a.labels != b.labels || a.node_selector != b.node_selector) return false;
+  if (!same_vec(a.required_affinity, b.required_affinity, same_exprs)) return false;
+  if (!same_vec(a.preferred_affinity, b.preferred_affinity, [](const ksp::PreferredTerm& x, const ksp::PreferredTerm& y) { return x.weight == y.weight && same_exprs(x.exprs, y.exprs); })) return false;
+  if (!same_vec(a.tolerations, b.tolerations, [](const ksp::Toleration& x, const ksp::Toleration& y) { return x.key == y.key && x.op == y.op && x.value == y.value && x.effect == y.effect; })) return false;
+  auto same_ports = [](const ksp::HostPort& x, const ksp::HostPort& y) { return x.ip == y.ip && x.port == y.port && x.proto == y.proto; };
+  if (!same_vec(a.containers, b.containers, [&](const ksp::Container& x, const ksp::Container& y) { return x.requests == y.requests && x.limits == y.limits && same_vec(x.ports, y.ports, same_ports); })) return false;
+  if (!same_vec(a.init_containers, b.init_containers, [](const ksp::Container& x, const ksp::Container& y) { return x.requests == y.requests && x.limits == y.limits; })) return false;
+  if (!same_vec(a.spread, b.spread, [](const ksp::Spread& x, const ksp::Spread& y) { return x.max_skew == y.max_skew && x.key == y.key && x.schedule_anyway == y.schedule_anyway && same_selector(x.selector, y.selector); })) return false;
+  auto same_w = [](const ksp::WeightedTerm& x, const ksp::WeightedTerm& y) { return x.weight == y.weight && same_term(x.term, y.term); };
+  return same_vec(a.affinity_required, b.affinity_required, same_term) && same_vec(a.affinity_preferred, b.affinity_preferred, same_w) &&
+         same_vec(a.anti_required, b.anti_required, same_term) && same_vec(a.anti_preferred, b.anti_preferred, same_w);
+}
+uint64_t str_hash(const std::string& s) { Hash128 h; h.str(s); h.finish(); return h.a ^ h.b; }
+
 struct Builder {
   Encoded& E; const ksp::Problem& pr; uint32_t flags;
   std::set<std::string> wellKnown;
@@ -117,12 +205,21 @@ struct Builder {
   std::vector<std::unique_ptr<Group>> groups; std::map<std::string, int> topo_by_id, inverse_by_id;   // creation order; inverse flagged
   std::vector<Requirement> it_reqs; std::map<std::string, int> it_state_id;   // node-side instance-type states (index 0 = absent)
   std::vector<Requirement> it_cols; std::map<std::string, int> it_col_id;     // pod-side instance-type requirements (classes, topology filters; 0 = none)
-  std::set<std::string> batch_uids;
+  // UIDs of the batch: open-addressing table of pod indices (topology.go:66-70 excludes the batch from countDomains)
+  struct UidSet {
+    const std::vector<ksp::Pod>* pods = nullptr; std::vector<uint32_t> tab; uint64_t mask = 0;
+    bool count(const std::string& uid) const {
+      if (tab.empty()) return false;
+      for (uint64_t i = str_hash(uid) & mask;; i = (i + 1) & mask) { const uint32_t e = tab[i]; if (!e) return false; if ((*pods)[e - 1].uid == uid) return true; }
+    }
+  } batch_uids;
   std::map<std::string, const ksp::StateNode*> node_by_name;
   bool toleratePreferNoSchedule = false;
   uint32_t K = 0, R = 0, T = 0, TW = 0;
 
-  Builder(Encoded& e, uint32_t f) : E(e), pr(e.src), flags(f) {}
+  Builder(Encoded& e, uint32_t f) : E(e), pr(*e.src), flags(f) {}
+  std::chrono::steady_clock::time_point tl_ = std::chrono::steady_clock::now();
+  void sublap(const char* what) { if (!getenv("KSH_TIMING")) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "      . %-26s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tl_).count()); tl_ = t1; }
 
   // ---------- universes ----------
   int key_of(const std::string& k, bool create) {
@@ -165,7 +262,7 @@ struct Builder {
       if (p.has_limits) note_res(p.limits);
       for (auto& t : p.taints) if (t.effect == "PreferNoSchedule") toleratePreferNoSchedule = true;
     }
-    for (auto& p : pr.pods) note_pod(p);
+    for (auto& si : specs) note_pod(si.stages[0].spec);      // every pod is one of the distinct specs (dedupe_specs), first occurrences in pod order
     for (auto& p : pr.daemons) note_pod(p);
     for (auto& cp : pr.cluster_pods) for (auto& t : cp.anti_required) { if (t.topology_key != ksp::kHostname) key_of(t.topology_key, true); }
     // Instance types last: a label key that ONLY instance types carry (real catalogues have many, often with hundreds of
@@ -421,10 +518,44 @@ struct Builder {
   std::vector<std::pair<std::string, StrMap>> labelsets; std::map<std::string, int> labelset_id;   // (ns, labels)
   std::vector<int> cls_labelset; std::vector<SpecGroups> cls_groups;
 
+  // Pods -> distinct specs (everything Solve can read of a pod except uid / creationTimestamp), in order of first occurrence.
+  // Hashing and the field-by-field confirmation run on all host threads; the table is filled in pod order so that spec ids, and
+  // with them the creation order of topology groups (NewTopology's Update per pod, topology.go:72-78), do not depend on threading.
+  void dedupe_specs() {
+    const uint32_t P = (uint32_t)pr.pods.size(); sublap("(start)");
+    std::vector<Hash128> hs(P); std::vector<uint64_t> uh(P);
+    parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { hs[i] = spec_hash(pr.pods[i]); uh[i] = str_hash(pr.pods[i].uid); } });
+    sublap("hash"); uint64_t cap = 64; while (cap < 4ull * P) cap <<= 1;
+    batch_uids.pods = &pr.pods; batch_uids.mask = cap - 1; batch_uids.tab.assign(cap, 0);
+    for (uint32_t i = 0; i < P; ++i) {
+      uint64_t j = uh[i] & batch_uids.mask;
+      for (;; j = (j + 1) & batch_uids.mask) { const uint32_t e = batch_uids.tab[j]; if (!e) break; if (pr.pods[e - 1].uid == pr.pods[i].uid) throw ksp::Error("pod UIDs must be unique (queue.go:102-108 needs a total order)"); }
+      batch_uids.tab[j] = i + 1;
+    }
+    sublap("uid table"); pod_spec.assign(P, -1);
+    std::vector<int32_t> tab(cap, -1); std::vector<uint32_t> first;      // table of spec ids; first[s] = first pod with spec s
+    for (uint32_t i = 0; i < P; ++i) {
+      uint64_t j = hs[i].a & (cap - 1);
+      for (;; j = (j + 1) & (cap - 1)) { const int32_t sidx = tab[j]; if (sidx < 0) break; const Hash128& o = hs[first[sidx]]; if (o.a == hs[i].a && o.b == hs[i].b) { pod_spec[i] = sidx; break; } }
+      if (pod_spec[i] < 0) { tab[j] = (int32_t)first.size(); pod_spec[i] = (int32_t)first.size(); first.push_back(i); }
+    }
+    sublap("spec table");
+    // Two pods share a spec when their 128-bit spec hashes agree (two independent 64-bit lanes over every field: a false merge
+    // needs a 2^-128 event).  KSH_CONFIRM_SPECS=1 (the test-suite sets it) additionally confirms every merge field by field; a pod
+    // that merely collided would get a spec of its own.
+    std::vector<uint8_t> bad(P, 0);
+    if (getenv("KSH_CONFIRM_SPECS")) parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t f = first[pod_spec[i]]; if (f != i && !same_spec(pr.pods[f], pr.pods[i])) bad[i] = 1; } });
+    for (uint32_t i = 0; i < P; ++i) if (bad[i]) {
+      int found = -1; for (size_t s2 = 0; s2 < first.size() && found < 0; ++s2) if (same_spec(pr.pods[first[s2]], pr.pods[i])) found = (int)s2;
+      if (found < 0) { found = (int)first.size(); first.push_back(i); }
+      pod_spec[i] = found;
+    }
+    sublap("confirm"); specs.resize(first.size());
+    for (size_t s2 = 0; s2 < first.size(); ++s2) { StageInfo st; st.spec = pr.pods[first[s2]]; st.spec.uid.clear(); specs[s2].stages.push_back(std::move(st)); }
+  }
+
   void encode_pods() {
     const uint32_t P = (uint32_t)pr.pods.size();
-    for (auto& p : pr.pods) batch_uids.insert(p.uid);
-    if (batch_uids.size() != P) throw ksp::Error("pod UIDs must be unique (queue.go:102-108 needs a total order)");
     // updateInverseAffinities, topology.go:181-199 (cluster pods with required anti-affinity, not in the batch)
     for (auto& cp : pr.cluster_pods) {
       if (cp.anti_required.empty() || batch_uids.count(cp.uid)) continue;
@@ -435,17 +566,10 @@ struct Builder {
         auto lt = nit->second->labels.find(groups[gi]->key); if (lt != nit->second->labels.end()) groups[gi]->counts[lt->second]++;
       }
     }
-    // pass A: NewTopology's Update(pod) over stage-0 specs in input order; distinct specs only
-    pod_spec.resize(P);
-    for (uint32_t i = 0; i < P; ++i) {
-      std::string sig = spec_signature(pr.pods[i]);
-      auto it = spec_by_sig.find(sig);
-      if (it == spec_by_sig.end()) {
-        SpecInfo si; StageInfo st; st.spec = pr.pods[i]; st.spec.uid.clear(); st.reqs = NewPodRequirements(st.spec); st.sg = groups_of(st.spec, true);
-        si.stages.push_back(std::move(st));
-        int id = (int)specs.size(); specs.push_back(std::move(si)); spec_by_sig.emplace(std::move(sig), id); pod_spec[i] = id;
-      } else pod_spec[i] = it->second;
-    }
+    sublap("inverse affinities");
+    // pass A: NewTopology's Update(pod) over the distinct stage-0 specs in order of first occurrence
+    for (auto& si : specs) { StageInfo& st = si.stages[0]; st.reqs = NewPodRequirements(st.spec); st.sg = groups_of(st.spec, true); }
+    sublap("pass A");
     // pass B: relaxation chains (Preferences.Relax + Topology.Update after each relaxation)
     for (auto& si : specs) {
       for (;;) {
@@ -456,22 +580,45 @@ struct Builder {
         if (si.stages.size() > 64) throw Unsupported("more than 64 relaxation stages");
       }
     }
+    sublap("pass B");
     // classes
     E.cls_hn_off.assign(1, 0); E.cls_port_off.assign(1, (uint32_t)E.ports.size());
     for (auto& si : specs) for (auto& st : si.stages) si.cls.push_back(class_of(st));
     // pods -> stage chains, queue order
-    E.pod_stage_off.assign(1, 0);
-    for (uint32_t i = 0; i < P; ++i) { for (uint32_t c : specs[pod_spec[i]].cls) E.stage_cls.push_back(c); E.pod_stage_off.push_back((uint32_t)E.stage_cls.size()); }
+    sublap("classes"); E.pod_stage_off.resize((size_t)P + 1); E.pod_stage_off[0] = 0;
+    for (uint32_t i = 0; i < P; ++i) E.pod_stage_off[i + 1] = E.pod_stage_off[i] + (uint32_t)specs[pod_spec[i]].cls.size();
+    E.stage_cls.resize(E.pod_stage_off[P]);
+    parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const auto& cl = specs[pod_spec[i]].cls; std::copy(cl.begin(), cl.end(), E.stage_cls.begin() + E.pod_stage_off[i]); } });
     // NewQueue: byCPUAndMemoryDescending, queue.go:74-110
     const int rc = res_id.at("cpu"), rm = res_id.at("memory");
-    E.queue.resize(P); for (uint32_t i = 0; i < P; ++i) E.queue[i] = i;
-    std::sort(E.queue.begin(), E.queue.end(), [&](uint32_t a, uint32_t b) {
-      const uint32_t ca = E.stage_cls[E.pod_stage_off[a]], cb = E.stage_cls[E.pod_stage_off[b]];
-      const int64_t cpua = E.cls_requests[(size_t)ca * R + rc], cpub = E.cls_requests[(size_t)cb * R + rc]; if (cpua != cpub) return cpua > cpub;
-      const int64_t mema = E.cls_requests[(size_t)ca * R + rm], memb = E.cls_requests[(size_t)cb * R + rm]; if (mema != memb) return mema > memb;
-      if (pr.pods[a].creation_ts != pr.pods[b].creation_ts) return pr.pods[a].creation_ts < pr.pods[b].creation_ts;
-      return pr.pods[a].uid < pr.pods[b].uid;
-    });
+    // The order is total (UIDs are unique), so any correct sort gives the reference's queue: chunks are sorted on the host threads
+    // and merged pairwise.  Keys are gathered first so a comparison touches one 32-byte record per side and the uid only on ties.
+    sublap("chains"); struct QKey { int64_t cpu, mem, ts; uint64_t u0, u1; uint32_t pod, ulen; };     // u0,u1: the uid's first 16 bytes, big-endian (byte-wise string order)
+    std::vector<QKey> keys(P);
+    auto be64 = [](const std::string& s2, size_t off) { uint64_t v = 0; for (size_t j = 0; j < 8; ++j) v = (v << 8) | (off + j < s2.size() ? (unsigned char)s2[off + j] : 0u); return v; };
+    parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t c0 = E.stage_cls[E.pod_stage_off[i]]; const std::string& u = pr.pods[i].uid;
+      keys[i] = QKey{E.cls_requests[(size_t)c0 * R + rc], E.cls_requests[(size_t)c0 * R + rm], pr.pods[i].creation_ts, be64(u, 0), be64(u, 8), (uint32_t)i, (uint32_t)u.size()}; } });
+    auto less = [&](const QKey& a, const QKey& b) {
+      if (a.cpu != b.cpu) return a.cpu > b.cpu;
+      if (a.mem != b.mem) return a.mem > b.mem;
+      if (a.ts != b.ts) return a.ts < b.ts;
+      if (a.u0 != b.u0) return a.u0 < b.u0;
+      if (a.u1 != b.u1) return a.u1 < b.u1;
+      if (a.ulen <= 16 && b.ulen <= 16) return a.ulen < b.ulen;          // equal 16-byte prefixes incl. zero padding: the shorter one is a prefix (NUL bytes inside a uid fall through to the full compare)
+      return pr.pods[a.pod].uid < pr.pods[b.pod].uid;
+    };
+    {
+      uint32_t nt = 1; while (nt * 2 <= host_threads() && (size_t)nt * 2 * 4096 <= P) nt *= 2;       // power of two: pairwise merge rounds
+      std::vector<size_t> cut(nt + 1); for (uint32_t t = 0; t <= nt; ++t) cut[t] = (size_t)P * t / nt;
+      auto run = [&](uint32_t n, auto&& body) { std::vector<std::thread> pool; for (uint32_t t = 1; t < n; ++t) pool.emplace_back([&, t] { body(t); }); body(0); for (auto& th : pool) th.join(); };
+      run(nt, [&](uint32_t t) { std::sort(keys.begin() + cut[t], keys.begin() + cut[t + 1], less); });
+      std::vector<QKey> tmp(nt > 1 ? P : 0);
+      for (uint32_t w = 1; w < nt; w *= 2) {
+        run(nt / (2 * w), [&](uint32_t t) { const size_t a = cut[2 * w * t], m = cut[2 * w * t + w], z = cut[2 * w * t + 2 * w]; std::merge(keys.begin() + a, keys.begin() + m, keys.begin() + m, keys.begin() + z, tmp.begin() + a, less); });
+        keys.swap(tmp);
+      }
+    }
+    E.queue.resize(P); for (uint32_t i = 0; i < P; ++i) E.queue[i] = keys[i].pod; sublap("queue sort");
   }
 
   uint32_t class_of(const StageInfo& st) {
@@ -637,24 +784,28 @@ struct Builder {
   }
 
   void run() {
-    collect_universes();
-    encode_instance_types();
+    const bool timing = getenv("KSH_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "  encode %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; };
+    dedupe_specs(); lap("dedupe_specs");
+    collect_universes(); lap("collect_universes");
+    encode_instance_types(); lap("encode_instance_types");
     it_reqs.push_back(Requirement()); it_cols.push_back(Requirement());   // state / column 0 == key absent
-    encode_templates();
+    encode_templates(); lap("encode_templates");
     encode_existing();
-    collect_taints();
-    encode_pods();
-    encode_existing_rest();
-    encode_groups();
-    encode_it_states();
+    collect_taints(); lap("encode_existing+taints");
+    encode_pods(); lap("encode_pods");
+    encode_existing_rest(); lap("encode_existing_rest");
+    encode_groups(); lap("encode_groups");
+    encode_it_states(); lap("encode_it_states");
     // C == 0 corner: CSR arrays still need their terminating offset
-    finish();
+    finish(); lap("finish");
   }
 };
 
 }  // namespace
 
-std::unique_ptr<Encoded> encode(ksp::Problem&& pr, uint32_t flags) {
+std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> pr, uint32_t flags) {
   auto e = std::make_unique<Encoded>(); e->src = std::move(pr);
   Builder b(*e, flags); b.run();
   return e;
@@ -685,7 +836,7 @@ std::string Encoded::decode(const ks_result& r, double solve_seconds) const {
     const auto& prov = *templates[r.node_tmpl[j]];
     o << "NODE " << tokq(prov.name) << " " << pods_of[NE + j].size(); for (auto& sp : pods_of[NE + j]) o << " " << sp.second;
     std::vector<const std::string*> names;
-    for (int idx : prov.instance_types) if ((r.node_types[(size_t)j * TW + idx / 64] >> (idx % 64)) & 1ull) names.push_back(&src.instance_types[idx].name);   // order-preserving filter (lo.Filter, node.go:138)
+    for (int idx : prov.instance_types) if ((r.node_types[(size_t)j * TW + idx / 64] >> (idx % 64)) & 1ull) names.push_back(&src->instance_types[idx].name);   // order-preserving filter (lo.Filter, node.go:138)
     o << " " << names.size(); for (auto* n : names) o << " " << tokq(*n);
     const uint32_t pm = r.node_requests_present[j]; std::map<std::string, int64_t> req;
     for (uint32_t rr = 0; rr < p.R; ++rr) if ((pm >> rr) & 1u) req[res_names[rr]] = r.node_requests[(size_t)j * p.R + rr];
@@ -708,7 +859,7 @@ std::string Encoded::decode(const ks_result& r, double solve_seconds) const {
     o << "\n";
   }
   o << "EXISTING " << NE << "\n";
-  for (uint32_t e = 0; e < NE; ++e) { o << "ENODE " << tokq(src.nodes[existing[e]].name) << " " << pods_of[e].size(); for (auto& sp : pods_of[e]) o << " " << sp.second; o << "\n"; }
+  for (uint32_t e = 0; e < NE; ++e) { o << "ENODE " << tokq(src->nodes[existing[e]].name) << " " << pods_of[e].size(); for (auto& sp : pods_of[e]) o << " " << sp.second; o << "\n"; }
   o << "UNSCHEDULED " << r.n_unscheduled; for (uint32_t i = 0; i < r.n_unscheduled; ++i) o << " " << r.unscheduled[i]; o << "\n";
   o << "STAGES " << p.P; for (uint32_t i = 0; i < p.P; ++i) o << " " << r.pod_stage[i]; o << "\n";
   o << "STATS 32 eq_pods " << r.stats[8] << " reuse_exhausted " << r.stats[9] << " reuse_seeds " << r.stats[10] << " reuse_hits " << r.stats[11] << " cyc_kind0 " << r.stats[27] << " cyc_kind1 " << r.stats[28] << " cyc_kind2 " << r.stats[29] << " n_kind1 " << r.stats[30] << " n_kind2 " << r.stats[31] << " p22 " << r.stats[22] << " p23 " << r.stats[23] << " p24 " << r.stats[24] << " p25 " << r.stats[25] << " p26 " << r.stats[26] << " cyc_pop " << r.stats[12] << " cyc_stage " << r.stats[13] << " cyc_scan " << r.stats[14] << " cyc_evalout " << r.stats[15] << " cyc_full " << r.stats[16]

@@ -25,7 +25,7 @@ struct ReqSetsStore {
 };
 
 struct Encoded {
-  ksp::Problem src;
+  std::shared_ptr<const ksp::Problem> src;      // the semantic problem (shared with the caller: a 100k-pod problem is never copied)
   // ---- naming tables for decode ----
   std::vector<std::string> key_names;                      // narrow keys
   std::vector<std::vector<std::string>> key_values;        // universe per key (ascending)
@@ -48,15 +48,19 @@ struct Encoded {
   ks_problem prob{};
 
   // ---- result buffers ----
+  // Worst-case sized (max_new_nodes rows) but never zero-filled: untouched pages cost nothing, the library writes what it fills.
+  template <class T> struct RawBuf { std::unique_ptr<T[]> p; void resize(size_t n) { p.reset(new T[n ? n : 1]); } T* data() const { return p.get(); } };
   struct ResultBuf {
-    std::vector<int32_t> pod_node, pod_stage, pod_seq, unscheduled, node_tmpl, node_gt, node_lt, node_it_state;
-    std::vector<uint64_t> node_types, node_mask; std::vector<int64_t> node_requests; std::vector<uint32_t> node_requests_present, node_present, node_complement;
+    RawBuf<int32_t> pod_node, pod_stage, pod_seq, unscheduled, node_tmpl, node_gt, node_lt, node_it_state;
+    RawBuf<uint64_t> node_types, node_mask; RawBuf<int64_t> node_requests; RawBuf<uint32_t> node_requests_present, node_present, node_complement;
     ks_result r{};
   };
   std::unique_ptr<ResultBuf> make_result() const;
   std::string decode(const ks_result& r, double solve_seconds) const;   // KSR1 text (see model.py parse_result)
 };
 
-std::unique_ptr<Encoded> encode(ksp::Problem&& pr, uint32_t flags);
+std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> pr, uint32_t flags);
+inline std::unique_ptr<Encoded> encode(ksp::Problem&& pr, uint32_t flags) { return encode(std::make_shared<const ksp::Problem>(std::move(pr)), flags); }
+uint32_t host_threads();
 
 }  // namespace ksh

@@ -64,6 +64,11 @@ def libs():
         kh.ksh_dims.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         kh.ksh_open_whatifs.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
                                         ctypes.POINTER(ctypes.c_int32), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+        kh.ksh_parse.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        kh.ksh_parsed_free.argtypes = [ctypes.c_void_p]
+        kh.ksh_solve_from_pods.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_double)]
+        kh.ksh_result_text.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        kh.ksh_result_summary.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         kh.ksh_fingerprint.argtypes = [ctypes.c_void_p]
         kh.ksh_fingerprint.restype = ctypes.c_uint64
         kh.ksh_free.argtypes = [ctypes.c_void_p]
@@ -129,6 +134,17 @@ class FlatProblem:
         kh.ksh_free(out)
         return parse_result(text)
 
+    def result(self) -> SolveResult:
+        """Decode the result the handle holds (after `solve(decode=False)` or `solve_from_pods`)."""
+        kh = libs()[1]
+        out = ctypes.c_void_p()
+        rc = kh.ksh_result_text(self._h, ctypes.byref(out))
+        if rc != KS_OK:
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+        text = ctypes.string_at(out).decode()
+        kh.ksh_free(out)
+        return parse_result(text)
+
     def grid(self, want_bits: bool = True):
         """ks_feasibility_grid: returns (numpy uint64 [M, C, TW] or None, kernel milliseconds)."""
         import numpy as np
@@ -140,6 +156,49 @@ class FlatProblem:
         if rc != KS_OK:
             raise KSolveError(rc, kh.ksh_last_error().decode())
         return arr, float(ms.value)
+
+
+class ParsedProblem:
+    """The problem as C++ objects in host memory (ksh_parse) -- the analogue of the []*v1.Pod, []*cloudprovider.InstanceType and
+    []*state.Node a Go caller holds when it calls NewScheduler / Solve.  `solve_from_pods` starts from here."""
+
+    def __init__(self, problem: Problem):
+        kh = libs()[1]
+        text = problem.to_ksp().encode()
+        self._p = ctypes.c_void_p()
+        rc = kh.ksh_parse(text, len(text), ctypes.byref(self._p))
+        if rc != KS_OK:
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+
+    def close(self):
+        if self._p:
+            libs()[1].ksh_parsed_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+TIMING_KEYS = ("flatten_ms", "upload_ms", "tables_grid_ms", "pack_kernel_ms", "solve_readback_ms", "total_ms")
+
+
+def solve_from_pods(parsed: ParsedProblem, device: int = 0, stats: bool = False, keep: bool = True):
+    """Everything the reference does inside NewScheduler + Solve for a pod list it already holds: flatten (incl. NewQueue's
+    sort, per-pod requests / requirements / classes / relaxation chains), upload, static tables + feasibility grid, the pack
+    kernel, read-back.  Returns (FlatProblem holding the result or None, timings dict in milliseconds)."""
+    kh = libs()[1]
+    h = ctypes.c_void_p()
+    ms = (ctypes.c_double * 6)()
+    rc = kh.ksh_solve_from_pods(parsed._p, device, KS_FLAG_STATS if stats else 0, ctypes.byref(h) if keep else None, ms)
+    if rc != KS_OK:
+        raise KSolveError(rc, kh.ksh_last_error().decode())
+    fp = FlatProblem(None, _handle=h) if keep else None
+    if fp is not None:
+        fp.kernel_ms = float(ms[3])
+    return fp, dict(zip(TIMING_KEYS, [float(x) for x in ms]))
 
 
 def open_whatifs(snapshot: Problem, pod_node: Sequence[int], candidate_sets: Sequence[Sequence[int]], threads: int = 0) -> List[FlatProblem]:
@@ -182,6 +241,22 @@ def solve_batch(flats: Sequence[FlatProblem], decode: bool = True):
             res.append(parse_result(ctypes.string_at(outs[i]).decode()))
             kh.ksh_free(outs[i])
     return res, float(kms.value), float(wms.value)
+
+
+def result_records(flats: Sequence[FlatProblem], ids: Sequence[int], words: int):
+    """[len(flats), 3 + words] int64 numpy table of fixed-size result records `[id, n_new, n_unscheduled, first new node's
+    InstanceTypeOptions]` straight from the binary results (no text round trip): what the ranks exchange after a what-if batch."""
+    import numpy as np
+    kh = libs()[1]
+    out = np.zeros((len(flats), 3 + words), dtype=np.uint64)
+    row = np.zeros(2 + words, dtype=np.uint64)
+    for i, f in enumerate(flats):
+        rc = kh.ksh_result_summary(f._h, row.ctypes.data, words)
+        if rc != KS_OK:
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+        out[i, 0] = ids[i]
+        out[i, 1:] = row
+    return out.view(np.int64)
 
 
 def price_filter(flats: Sequence[FlatProblem], nodes: Sequence[int], max_prices: Sequence[float], spot_only: Optional[Sequence[bool]] = None) -> List[List[int]]:

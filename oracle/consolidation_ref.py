@@ -96,6 +96,11 @@ def compute_consolidation(snapshot, cand_idx):
     types = {it.name: it for it in snapshot.instance_types}
     cands = [Cand(snapshot, i) for i in cand_idx]
     res = oracle_py.solve(workloads.whatif(snapshot.instance_types, snapshot.provisioner, snapshot.nodes, snapshot.bound, list(cand_idx)))
+    # helpers.go:102-111: `for _, n := range ifn { if n.Node.Labels[LabelNodeInitialized] != "true" { return nil, false, nil } }` -- ifn is every
+    # in-state (owned) existing node Solve was given, whether or not it received a pod
+    for j, n in enumerate(snapshot.nodes):
+        if j not in set(cand_idx) and n.in_state and n.owned and n.labels.get("karpenter.sh/initialized") != "true":
+            return ("do-nothing", [], [], {})
     if res.unscheduled:
         return ("do-nothing", [], [], {})
     if not res.new_nodes:
@@ -160,7 +165,10 @@ def first_n_node_consolidation_option(snapshot, candidates, max_nodes=100):
 
 def single_node_consolidation_option(snapshot, candidates):
     for c in candidates:
-        cmd = compute_consolidation(snapshot, [c])
+        try:
+            cmd = compute_consolidation(snapshot, [c])
+        except ValueError:          # singlenodeconsolidation.go:57-60: log and continue
+            continue
         if cmd[0] in ("replace", "delete"):
             return canonical(cmd)
     return ("do-nothing", (), (), ())

@@ -793,7 +793,24 @@ struct Scheduler {
     if (!topo.add_requirements(podReqs, nodeReqs, pod, &topoReqs)) return false;
     return reqs_compatible(cx, nodeReqs, topoReqs);
   }
-  void solve_spec(int W, long long* out) {
+  // flags bit 0: hostname-keyed anti-affinity groups, and hostname-keyed spread groups that existed before the Solve, never cut a
+  //              round through the topology rule (a record only touches the winner's own hostname counter, which no other
+  //              candidate's evaluation reads; a taken node is covered by the order rule)
+  // maxcls > 0:  a round holds at most `maxcls` distinct evaluation classes (one wave evaluates one class for all its pods)
+  // out[6] pods in rounds of >= 8, out[7] largest round
+  std::string eval_signature(PodState& ps) {
+    ksp::Pod& pod = ps.spec; std::string s;
+    Reqs pr = new_pod_requirements(pod);
+    for (auto& kv : pr.m) { s += STR(kv.first); s += kv.second.complement ? '!' : '='; for (Sym v : kv.second.values.v) { s += STR(v); s += ','; } s += kv.second.has_gt ? std::to_string(kv.second.gt) : "-"; s += kv.second.has_lt ? std::to_string(kv.second.lt) : "-"; s += ';'; }
+    ResList rq = requests_for_pods({&pod}); for (auto& kv : rq) { s += kv.first; s += std::to_string(kv.second); s += ','; }
+    for (auto& t : pod.tolerations) { s += t.key + "/" + t.op + "/" + t.value + "/" + t.effect + ";"; }
+    for (auto& c : pod.containers) for (auto& hp : c.ports) { s += hp.ip + ":" + std::to_string(hp.port) + hp.proto + ";"; }
+    for (auto& tc : topo.topologies) if (tc->owners.count(pod.uid)) { s += "T" + std::to_string((uintptr_t)tc.get()) + (tg_selects(*tc, pod) ? "s" : "n"); }
+    for (auto& tc : topo.inverse) if (tg_selects(*tc, pod)) { s += "I" + std::to_string((uintptr_t)tc.get()); }
+    return s;
+  }
+  void solve_spec(int W, long long* out, int flags = 0, int maxcls = 0) {
+    std::set<const TopologyGroup*> initial; for (auto& tc : topo.topologies) initial.insert(tc.get());
     std::vector<int> q(pods.size()); for (size_t i = 0; i < pods.size(); ++i) q[i] = (int)i;
     std::vector<ResList> rq(pods.size()); for (size_t i = 0; i < pods.size(); ++i) rq[i] = requests_for_pods({&pods[i].spec});
     auto get = [](const ResList& r, const char* k) { auto it = r.find(k); return it == r.end() ? (int64_t)0 : it->second; };
@@ -827,13 +844,18 @@ struct Scheduler {
       for (size_t i = 0; i < nc; ++i) { if (i < E) snapE[i] = existing[i].get(); else snapN[i] = new_nodes[i - E].get(); }
       // ---- pods of the round: never-requeued queue entries only ----
       size_t n = 0; while (n < (size_t)W && n < queue.size() && lastLen.find(queue[n]) == lastLen.end()) ++n;
+      if (maxcls > 0) { std::set<std::string> seen; size_t k = 0; for (; k < n; ++k) { std::string e = eval_signature(pods[queue[k]]); if (!seen.count(e)) { if ((int)seen.size() == maxcls) break; seen.insert(e); } } n = k; }
       std::vector<uint64_t> m(n, 0); std::vector<std::set<const TopologyGroup*>> T(n), R(n);
       Stats keep = st;
       for (size_t k = 0; k < n; ++k) {
         PodState& ps = pods[queue[k]];
         for (size_t i = 0; i < nc; ++i) if (i < E ? dry_existing(*snapE[i], ps) : dry_new(*snapN[i], ps)) m[k] |= 1ull << i;
         if (!topo.inert) {
-          for (auto& tc : topo.topologies) { if (tc->owners.count(ps.spec.uid)) T[k].insert(tc.get()); if (tg_selects(*tc, ps.spec)) R[k].insert(tc.get()); }
+          for (auto& tc : topo.topologies) {
+            const bool own_counter_only = (flags & 1) && tc->is_hostname && (tc->type == kAntiAffinity || (tc->type == kSpread && initial.count(tc.get())));
+            if (tc->owners.count(ps.spec.uid) && !own_counter_only) T[k].insert(tc.get());
+            if (tg_selects(*tc, ps.spec)) R[k].insert(tc.get());
+          }
           for (auto& tc : topo.inverse) { if (tg_selects(*tc, ps.spec)) T[k].insert(tc.get()); if (tc->owners.count(ps.spec.uid)) R[k].insert(tc.get()); }
         }
       }
@@ -854,7 +876,7 @@ struct Scheduler {
         win.push_back(u); taken |= 1ull << u; for (auto* g : R[k]) Rall.insert(g);
       }
       if (win.empty()) { out[2]++; if (!sequential_step()) break; continue; }
-      out[1]++;
+      out[1]++; if (win.size() >= 8) out[6] += (long long)win.size(); if ((long long)win.size() > out[7]) out[7] = (long long)win.size();
       // ---- commit the predictions through the real algorithm and compare ----
       for (size_t k = 0; k < win.size(); ++k) {
         int pi = queue.front(); queue.pop_front(); st.queue_pops++;
@@ -1004,6 +1026,16 @@ void ko_free(char* p) { free(p); }
 
 // Model check of the kernel's round speculation (see Scheduler::solve_spec): solves through predictions, returns the
 // KSR1 text (must equal ko_solve's) and the counters.
+int ko_solve_spec2(const char* ksp_text, size_t len, int W, int flags, int maxcls, long long* counters, char** out_text) {
+  oracle::Interner in; oracle::g_in = &in;
+  try {
+    ksp::Problem pr = ksp::Parser(ksp_text, len).parse();
+    auto s = oracle::build(pr, false);
+    s->solve_spec(W, counters, flags, maxcls);
+    std::string r = oracle::result_text(*s, 0.0);
+    *out_text = strdup(r.c_str()); oracle::g_in = nullptr; return 0;
+  } catch (const std::exception& e) { *out_text = strdup(e.what()); oracle::g_in = nullptr; return -1; }
+}
 int ko_solve_spec(const char* ksp_text, size_t len, int W, long long* counters, char** out_text) {
   oracle::Interner in; oracle::g_in = &in;
   try {

@@ -24,6 +24,7 @@ def lib():
         l.ko_solve.restype = ctypes.c_int
         l.ko_free.argtypes = [ctypes.c_void_p]
         l.ko_solve_spec.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_void_p)]
+        l.ko_solve_spec2.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_void_p)]
         l.ko_req_intersection.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
         l.ko_req_has.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
         l.ko_req_operator.argtypes = [ctypes.c_char_p]
@@ -47,18 +48,19 @@ def solve_text(ksp_text: str, inert_topology: bool = False) -> str:
     return text
 
 
-def solve_spec(problem, width: int = 8):
-    """Model check of the kernel's round speculation: (result, counters dict)."""
+def solve_spec(problem, width: int = 8, flags: int = 0, max_classes: int = 0):
+    """Model check of the kernel's round speculation: (result, counters dict).  flags bit 0: hostname-keyed anti-affinity /
+    initially-present hostname spread groups do not cut rounds; max_classes: distinct evaluation classes per round (0 = any)."""
     from karpenter_core_amd.model import parse_result
     data = problem.to_ksp().encode()
     out = ctypes.c_void_p()
     ctr = (ctypes.c_longlong * 8)()
-    rc = lib().ko_solve_spec(data, len(data), width, ctr, ctypes.byref(out))
+    rc = lib().ko_solve_spec2(data, len(data), width, flags, max_classes, ctr, ctypes.byref(out))
     text = ctypes.string_at(out).decode()
     lib().ko_free(out)
     if rc != 0:
         raise RuntimeError("oracle: " + text)
-    names = ["predicted", "rounds", "sequential", "violations", "cut_topology", "cut_order"]
+    names = ["predicted", "rounds", "sequential", "violations", "cut_topology", "cut_order", "pods_in_big_rounds", "largest_round"]
     return parse_result(text), {k: int(ctr[i]) for i, k in enumerate(names)}
 
 

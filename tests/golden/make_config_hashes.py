@@ -5,6 +5,7 @@ config #3 at 100k pods).  The fingerprint is sha256 over the canonical result JS
 type option lists, request vectors, requirement sets, existing-node pods, unscheduled queue, stages).
 
     python tests/golden/make_config_hashes.py            # rewrites tests/golden/config_hashes.json
+    python tests/golden/make_config_hashes.py NAME...    # refreshes the named entries only
 """
 import hashlib
 import json
@@ -27,10 +28,31 @@ CASES = {
     "config1_1k_50": lambda: W.config1(),
     "config2_10k_500": lambda: W.config2(),
     "config3_100k_2k": lambda: W.config3(),
+    "config5_5k_types": lambda: W.config5(pods=CONFIG5_PODS, sizes=50, seed=46),     # 5 000 instance types, full constraint set
 }
+CONFIG5_PODS = 100_000
+
+def config4_entry():
+    """BASELINE configs[3] at its stated size: 512 what-ifs over the 2048-node snapshot, one fingerprint per what-if
+    (a checksum of checksums pins the whole set)."""
+    t = time.time()
+    probs = W.config4(512)
+    fps, pods, new_nodes, unsched = [], 0, 0, 0
+    for pr in probs:
+        r = parse_result(O.solve_text(pr.to_ksp()))
+        fps.append(fingerprint(r)); pods += len(pr.pods); new_nodes += len(r.new_nodes); unsched += len(r.unscheduled)
+    return {"sha256_of_sha256s": hashlib.sha256("".join(fps).encode()).hexdigest(), "whatif_sha256": fps, "whatifs": len(probs), "existing_nodes": 2048,
+            "instance_types": len(probs[0].instance_types), "pods": pods, "new_nodes": new_nodes, "unscheduled": unsched, "oracle_seconds": round(time.time() - t, 1)}
+
 
 if __name__ == "__main__":
-    out = {}
+    only = sys.argv[1:]
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config_hashes.json")
+    out = json.load(open(path)) if only and os.path.exists(path) else {}
+    if not only or "config4_512x2048" in only:
+        out["config4_512x2048"] = config4_entry()
+        print("config4_512x2048", {k: v for k, v in out["config4_512x2048"].items() if k != "whatif_sha256"}, flush=True)
+    CASES = {k: v for k, v in CASES.items() if not only or k in only}
     for name, mk in CASES.items():
         pr = mk()
         t = time.time()
@@ -39,4 +61,4 @@ if __name__ == "__main__":
                      "new_nodes": len(r.new_nodes), "unscheduled": len(r.unscheduled), "attempts": r.stats["attempts"],
                      "types_scanned": r.stats["types_scanned"], "oracle_seconds": round(time.time() - t, 1)}
         print(name, out[name], flush=True)
-    json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "config_hashes.json"), "w"), indent=1, sort_keys=True)
+    json.dump(out, open(path, "w"), indent=1, sort_keys=True)

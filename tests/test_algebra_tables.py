@@ -63,6 +63,44 @@ def run_tables(on_device):
         assert bool(ok.value) == want, b
 
 
+class Facts(ctypes.Structure):
+    _fields_ = [("has_mask", ctypes.c_uint64), ("len", ctypes.c_int64), ("op", ctypes.c_int32), ("nidne", ctypes.c_uint8), ("len0", ctypes.c_uint8)]
+
+
+def run_has_operator_len(on_device):
+    """Requirement.Has 14 x {A, B, 1, 2, 9} (requirement_test.go:294-371), Operator (:372-389), Len (:390-407) on the functions the kernels
+    use (kreq_has_mask and the two predicates kreq_nidne / kreq_len0 derived from Operator / Len)."""
+    ge.build()
+    ks, _ = S.libs()
+    ks.ks_probe_has.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+    vint = (ctypes.c_int32 * 64)(*(VINT + [-2**31] * (64 - len(VINT))))
+    facts = {}
+    for name, (op, values) in OPS.items():
+        f = Facts()
+        rc = ks.ks_probe_has(ctypes.byref(enc(op, values)), vint, len(UNIVERSE), on_device, ctypes.byref(f))
+        assert rc == 0, ks.ks_last_error()
+        facts[name] = f
+    for c in G["has"]:
+        assert bool((facts[c["a"]].has_mask >> UNIVERSE.index(c["value"])) & 1) == c["expect"], c
+    names = ["In", "NotIn", "Exists", "DoesNotExist"]
+    for c in G["operator"]:
+        assert names[facts[c["a"]].op] == c["expect"], c
+        assert bool(facts[c["a"]].nidne) == (c["expect"] in ("NotIn", "DoesNotExist")), c
+    for c in G["len"]:
+        assert facts[c["a"]].len == c["expect"], c
+        assert bool(facts[c["a"]].len0) == (c["expect"] == 0), c
+    assert len(G["has"]) == 70 and len(G["operator"]) == 14 and len(G["len"]) == 14
+
+
+def test_has_operator_len_host_build():
+    run_has_operator_len(0)
+
+
+@pytest.mark.gpu
+def test_has_operator_len_on_device():
+    run_has_operator_len(1)
+
+
 def test_tables_host_build():
     run_tables(0)
 

@@ -29,6 +29,26 @@ def test_exports_every_declared_symbol():
         assert hasattr(ks, n), f"libksolve.so does not export {n}"
 
 
+def test_host_library_exports_every_declared_symbol():
+    """include/kshost.h is the boundary the Python mirror and the GPU tests actually drive (ksh_*)."""
+    hdr = open(os.path.join(ROOT, "include", "kshost.h")).read()
+    names = set(re.findall(r"\b(ksh_[a-z_0-9]+)\s*\(", hdr))
+    assert {"ksh_parse", "ksh_solve_from_pods", "ksh_open", "ksh_upload", "ksh_solve", "ksh_solve_batch", "ksh_open_whatifs", "ksh_price_filter",
+            "ksh_result_text", "ksh_result_summary", "ksh_grid"} <= names
+    _, kh = S.libs()
+    for n in names:
+        assert hasattr(kh, n), f"libkshost.so does not export {n}"
+
+
+def test_solve_from_pods_refuses_without_gpu():
+    if S.device_count() > 0:
+        pytest.skip("GPU present")
+    pp = S.ParsedProblem(W.config1(pods=20, types=5))
+    with pytest.raises(S.KSolveError) as ei:
+        S.solve_from_pods(pp, 0)
+    assert ei.value.code == S.KS_ERR_DEVICE
+
+
 def test_no_cpu_fallback_without_gpu():
     if S.device_count() > 0:
         pytest.skip("GPU present")

@@ -16,9 +16,10 @@ from oracle import consolidation_ref as CR
 
 
 def node(name, it, capacity_type, zone, cpu="32", pods="100"):
-    """test.Node with the labels the deprovisioner reads (suite_test.go:896-905)."""
+    """test.Node with the labels the deprovisioner reads (suite_test.go:896-905), made ready the way ExpectMakeNodesReady does
+    (suite_test.go:2894-2916: karpenter.sh/initialized = "true", taints cleared)."""
     labels = {LABEL_PROVISIONER: "default", LABEL_INSTANCE_TYPE: it.name, LABEL_CAPACITY_TYPE: capacity_type, LABEL_ZONE: zone,
-              LABEL_HOSTNAME: name}
+              LABEL_HOSTNAME: name, "karpenter.sh/initialized": "true"}
     alloc = {"cpu": cpu, "pods": pods}
     return StateNode(name=name, labels=labels, available=dict(alloc), capacity=dict(alloc))
 
@@ -125,6 +126,35 @@ def test_oracle_multi_node_scenarios(name):
         assert removed_type not in cmd[2] and cmd[2]        # cheaper types only
 
 
+def _uninitialized_neighbour():
+    """simulateScheduling refuses to lean on a node that is not ready (helpers.go:102-111): the loop runs over EVERY existing node Solve
+    returns (scheduler.go:132), so one uninitialised node left in the cluster turns the simulation into 'not all pods scheduled'."""
+    snap, cands, _ = scenarios()["can_delete_nodes"]
+    del snap.nodes[1].labels["karpenter.sh/initialized"]
+    return snap, cands
+
+
+def test_oracle_uninitialized_node_blocks_consolidation():
+    snap, cands = _uninitialized_neighbour()
+    assert CR.compute_consolidation(snap, cands)[0] == "do-nothing"
+
+
+def _missing_offering():
+    """getNodePrices fails for a candidate whose (capacity-type, zone) offering the instance type does not list (consolidation.go:277-287): the
+    single-node scan logs the error and moves on to the next candidate (singlenodeconsolidation.go:57-60)."""
+    its = fake.instance_types_assorted()
+    big, big_of = most_expensive(its)
+    bad = node("n0", big, big_of.capacity_type, "no-such-zone")          # needs a replacement, but its own price is unknown
+    good = node("n1", big, big_of.capacity_type, big_of.zone)
+    return snapshot(its, [bad, good], [[pod("p0", "33")], [pod("p1")]]), [0, 1]
+
+
+def test_oracle_offering_error_skips_the_candidate():
+    snap, cands = _missing_offering()
+    cmd = CR.single_node_consolidation_option(snap, cands)
+    assert cmd[0] in ("replace", "delete") and cmd[1] == ("n1",)
+
+
 def test_worst_launch_price_prefers_spot_then_on_demand():
     """helpers.go:292-315 on the reference's own offering lists (suite_test.go:1166-1186, :1254-1280)."""
     from karpenter_core_amd.model import RequirementOut
@@ -211,6 +241,18 @@ def test_gpu_multi_node_scenarios(name):
     got = C.first_n_node_consolidation_option(snap, cands)
     assert got.action == want
     assert got.canonical() == CR.first_n_node_consolidation_option(snap, cands)
+
+
+@pytest.mark.gpu
+def test_gpu_uninitialized_node_and_offering_error():
+    from karpenter_core_amd import consolidation as C
+    snap, cands = _uninitialized_neighbour()
+    cmds, flats, _ = C.compute_consolidations(snap, [cands])
+    for f in flats:
+        f.close()
+    assert cmds[0].action == "do-nothing"
+    snap, cands = _missing_offering()
+    assert C.single_node_consolidation_option(snap, cands).canonical() == CR.single_node_consolidation_option(snap, cands)
 
 
 @pytest.mark.gpu

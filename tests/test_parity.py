@@ -236,3 +236,47 @@ def test_full_size_configs_match_oracle_fingerprint(case):
     res = S.solve_problem(pr)
     assert len(res.new_nodes) == gold["new_nodes"] and len(res.unscheduled) == gold["unscheduled"]
     assert hashlib.sha256(json.dumps(res.canonical(), sort_keys=True).encode()).hexdigest() == gold["sha256"]
+
+
+def _golden(case):
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config_hashes.json")))[case]
+
+
+def _fingerprint(res):
+    import hashlib
+    import json
+    return hashlib.sha256(json.dumps(res.canonical(), sort_keys=True).encode()).hexdigest()
+
+
+def test_full_size_config4_512_whatifs_match_oracle_fingerprints():
+    """BASELINE configs[3] at its stated size: 512 consolidation what-ifs (256 multi-node prefixes, 256 singletons;
+    multinodeconsolidation.go:74-114, singlenodeconsolidation.go:43-78) over the 2048-node snapshot, flattened natively over one
+    snapshot and solved in ONE batched launch; every what-if's canonical result has the fingerprint the CPU oracle produced
+    offline from the one-problem-per-what-if construction (tests/golden/make_config_hashes.py config4_512x2048)."""
+    gold = _golden("config4_512x2048")
+    its, prov, nodes, bound = W.cluster_snapshot(2048, 50, 45)
+    snap, pod_node = W.snapshot_problem(its, prov, nodes, bound, False)
+    flats = S.open_whatifs(snap, pod_node, W.config4_sets(512, 2048, 45))
+    res, _, _ = S.solve_batch(flats)
+    for f in flats:
+        f.close()
+    assert len(res) == gold["whatifs"] == 512
+    got = [_fingerprint(r) for r in res]
+    bad = [i for i, (a, b) in enumerate(zip(got, gold["whatif_sha256"])) if a != b]
+    assert not bad, f"what-ifs differing from the oracle: {bad[:10]}"
+    assert sum(len(r.new_nodes) for r in res) == gold["new_nodes"] and sum(len(r.unscheduled) for r in res) == gold["unscheduled"]
+
+
+def test_config5_at_5000_instance_types_matches_oracle_fingerprint():
+    """BASELINE configs[4]'s catalogue at its stated size -- 5 000 instance types, the full constraint set (taints, Gt selectors on an
+    integer label, zonal / hostname / capacity-type spread, pod affinity and anti-affinity, host ports, two weighted provisioners, one
+    with a cpu limit) -- at the largest pod count the CPU oracle finishes in minutes.  Host ports and limits route the Solve through the
+    general (non-LEAN, BOUNDS) 4-wave kernel."""
+    gold = _golden("config5_5k_types")
+    pr = W.config5(pods=gold["pods"], sizes=50, seed=46)
+    assert len(pr.instance_types) == 5000
+    res = S.solve_problem(pr)
+    assert len(res.new_nodes) == gold["new_nodes"] and len(res.unscheduled) == gold["unscheduled"]
+    assert _fingerprint(res) == gold["sha256"]
