@@ -437,7 +437,9 @@ __global__ __launch_bounds__(64) void ks_build_plans(DevProb P, ClsPlan* plans, 
   for (u32 j = 0; j < pl.ntopo; ++j) zmask &= ~(1ull << (pl.topo[j].g & 63));
   u64 rsure = 0;
   for (u32 j = 0; j < pl.nrec; ++j) { const PlanRec& r = pl.rec[j]; if (r.key == KS_KEY_HOSTNAME && (r.owned_inverse || (P.grp_active[r.g] != 0 && !r.filtered))) rsure |= 1ull << (r.g & 63); }
-  ClsBrief b; b.zmask = zmask; b.rsure = rsure; b.tmask = pl.tmask; b.tfull = tfull; b.rmask = pl.rmask; b.ev = 0; b.flags = (!pl.overflow && pl.port_cnt == 0) ? 1u : 0u; b.reqmask = pl.reqmask; b.pad = 0;
+  ClsBrief b; b.zmask = zmask; b.rsure = rsure; b.tmask = pl.tmask; b.tfull = tfull; b.rmask = pl.rmask; bool late_host = false;       // a record into a hostname-keyed group a relaxation creates later: such hostnames may be unregistered
+  for (u32 j = 0; j < pl.nrec; ++j) if (pl.rec[j].key == KS_KEY_HOSTNAME && !pl.rec[j].owned_inverse && P.grp_active[pl.rec[j].g] == 0) late_host = true;
+  b.ev = 0; b.flags = (!pl.overflow && pl.port_cnt == 0 && !late_host) ? 1u : 0u; b.reqmask = pl.reqmask; b.pad = 0;
   for (u32 r = 0; r < KS_MAX_RES; ++r) b.req[r] = pl.req[r];
   briefs[c] = b;
 }
@@ -858,10 +860,10 @@ template <bool ATOMIC>
 __device__ __forceinline__ void grp_record_host(const DevState& S, const Tabs& tb, int h, u32 slot) {
   GA i32& c = tb.hcnt[(size_t)slot * tb.GH + h];
   if constexpr (ATOMIC) {      // several pods of one round may land on the same node: every transition old -> new is taken exactly once
-    i32 old = c;
-    for (;;) { const i32 nw = old < 0 ? 1 : old + 1; i32 expect = old; if (__hip_atomic_compare_exchange_strong(&c, &expect, nw, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break; old = expect; }
-    if (old <= 0) atomicAdd(&tb.g_hpos[h], 1);
-    if (old == 0) atomicSub(&tb.g_hzero[h], 1);
+    // Rounds only admit classes whose hostname-keyed records go to groups that exist from the start (ClsBrief.flags), and every node registers
+    // its hostname with those (NewNode / NewExistingNode): the counter is never the "unregistered" -1 here, one atomic add does it.
+    const i32 old = __hip_atomic_fetch_add(&c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (old == 0) { atomicAdd(&tb.g_hpos[h], 1); atomicSub(&tb.g_hzero[h], 1); }
     return;
   }
   if (c <= 0) tb.g_hpos[h]++;
@@ -1389,7 +1391,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           for (u32 g = lane; g < nG; g += 64) { const i32 hs = P.grp_hslot[g]; if (hs >= 0 && tb.hcnt[(size_t)sw * tb.GH + hs] == 0) tb.g_hzero[hs]++; }
           LSYNC();
         }
-        topology_record<(NW > 1)>(P, S, tb, pb, sh, r, sw, lane);
+        topology_record<false>(P, S, tb, pb, sh, r, sw, lane);      // (the sequential path commits alone: nothing else records meanwhile)
         const u32 cnt = pb.count;                                   // pods on the node before this one
         LSYNC();
         write_record<BOUNDS, RM>(tb, r, pb, sh, rm, lane);
@@ -1575,7 +1577,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
 #endif
       // ---- P2: the leader resolves the round.  Lane i plays two parts: round pod i (b_*) and window candidate i (c_*). ----
       u32 c_cnt = 0, c_cnt0 = 0, c_rm = 0, c_np = 0, c_last = 0, c_first = 0, c_key = 0xFFFFFFFFu; u64 c_racc = 0, c_rsure = 0; i64 c_room[RM];
-      u64 movedmask = 0; u32 n_ok = 0;
+      u64 movedmask = 0; u32 n_ok = 0, nocand_cls = 0xFFFFFFFFu;
       if (wv == 0) {
 #ifdef KS_P2PROBES
         u64 t2p = __builtin_readcyclecounter();
@@ -1622,7 +1624,12 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             if (exact_masks && (tfk & zm & c_rsure)) ok = false;
             A = mk & (~movedmask | ballot64(ok));
           }
-          if (!A) { CUT(14); break; }
+          if (!A) {
+            // nothing in the window takes this pod (and a window only loses acceptors as the round goes on): it needs a deeper scan or a new
+            // node -- remember its class so that the next plan hands it to the sequential path instead of opening a round that ends at once
+            nocand_cls = RL((u32)(b_e >> 32), k) & 0x7FFFFFFFu;
+            CUT(14); break;
+          }
           const u64 un = A & ~movedmask;
           // the first acceptor in the visiting order as the round has changed it: the smallest key (keys are unique)
           const bool inA = (A >> lane) & 1ull;
@@ -1712,6 +1719,14 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       // worker lane u as candidate u:
       bool committer = false, filtered = false, my_chg = false; u32 n_np = 0, n_rm = 0, n_pres = 0, n_comp = 0, n_chgkeys = 0, wslot = 0xFFFFFFFFu; u32 n_idx[RM];
       u64 filtmask = 0, ranmask = 0, failedmask = 0;     // (little state crosses the barriers: requests / thresholds are re-read from LDS where they are needed)
+      // lane l as round pod l (if this wave evaluated its class): what Topology.Record will visit -- requested now, a whole phase before the commit uses it
+      u32 pr_nrec = 0, pr_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (wv != 0 && kw < nwk && (u32)lane < n_ok && rc.pw[par][lane] == kw) {
+        const GA ClsPlan* pl = plans + ((u32)(rc.qe[par][lane] >> 32) & 0x7FFFFFFFu);
+        pr_nrec = pl->nrec; const GA u32* rp = (const GA u32*)&pl->rec[0];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pr_w[i] = rp[i];
+      }
       if (wv != 0 && n_ok) {
         if ((u32)lane < nwin) wslot = (u32)lane < tb.E ? (u32)lane : tb.E + (ord_lds_r ? ord_l[lane - tb.E] : ord_g[lane - tb.E]);
         n_np = (u32)lane < nwin ? rc.npods[lane] : 0u;
@@ -1812,6 +1827,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         // While the workers filter, plan the step after this round as if the round commits (a filter comes back empty a handful of times
         // per Solve; the plan is then redone): queue entries and class briefs of the next pods are requested a whole phase early.
         if ((u32)lane < n_ok) { const u32 ck = (u32)(b_e >> 32) & 0x7FFFFFFFu; atomicAnd(&ls.hard[(ck >> 5) & 7u], ~(1u << (ck & 31u))); }
+        if (nocand_cls != 0xFFFFFFFFu && lane == 0) { LSYNC(); ls.hard[(nocand_cls >> 5) & 7u] |= 1u << (nocand_cls & 31u); }
         sp_head = q_head + n_ok; if (sp_head >= nP) sp_head -= nP; sp_len = q_len - n_ok; sp_seq = seq + n_ok;
         { u32 idx = sp_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; pq_e = tb.q[idx]; pq_ok = true; }
         if (n_ok == 0) seq_credit = 1;                 // the head pod needs more than the window offers: take it sequentially
@@ -1853,11 +1869,13 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
               if (!hit) { q.mask = ru.mask()[k]; if constexpr (BOUNDS) { q.gt = ru.gt()[k]; q.lt = ru.lt()[k]; } }
               return q;
             };
-            const GA ClsPlan* pl = plans + cidx; const u32 nrec = pl->nrec;
+            const GA ClsPlan* pl = plans + cidx; const u32 nrec = pr_nrec;
             for (u32 t = 0; t < nrec; ++t) {      // Topology.Record, topology.go:120-143
-              const GA u32* rp = (const GA u32*)&pl->rec[t];       // PlanRec is 16 bytes: g, key, {type, owned_inverse, hslot}, {tidx, filtered, pad}
-              const u32 rv2 = rp[2], rv3 = rp[3];
-              const int g = (int)rp[0], key = (int)rp[1]; const u32 type = rv2 & 0xFF, owned_inverse = (rv2 >> 8) & 0xFF, hslot = rv2 >> 16, filt = (rv3 >> 8) & 0xFF;
+              u32 rv0, rv1, rv2, rv3;              // PlanRec is 16 bytes: g, key, {type, owned_inverse, hslot}, {tidx, filtered, pad}; the first two came in early
+              if (t == 0) { rv0 = pr_w[0]; rv1 = pr_w[1]; rv2 = pr_w[2]; rv3 = pr_w[3]; }
+              else if (t == 1) { rv0 = pr_w[4]; rv1 = pr_w[5]; rv2 = pr_w[6]; rv3 = pr_w[7]; }
+              else { const GA u32* rp = (const GA u32*)&pl->rec[t]; rv0 = rp[0]; rv1 = rp[1]; rv2 = rp[2]; rv3 = rp[3]; }
+              const int g = (int)rv0, key = (int)rv1; const u32 type = rv2 & 0xFF, owned_inverse = (rv2 >> 8) & 0xFF, hslot = rv2 >> 16, filt = (rv3 >> 8) & 0xFF;
               if (!owned_inverse) {
                 if (!tb.g_active[g]) continue;
                 if (filt) {          // TopologyGroup.Counts: TopologyNodeFilter.MatchesRequirements, topologynodefilter.go:57-70

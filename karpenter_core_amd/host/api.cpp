@@ -102,20 +102,19 @@ int ksh_open_whatifs(const char* base_text, size_t len, uint32_t flags, uint32_t
                      const int32_t* pod_node, uint32_t nthreads, void** out_handles) {
   for (uint32_t w = 0; w < n; ++w) out_handles[w] = nullptr;
   try {
-    const ksp::Problem base = ksp::Parser(base_text, len).parse();
-    std::vector<std::vector<uint32_t>> by_node(base.nodes.size());
-    for (size_t i = 0; i < base.pods.size(); ++i) { if (pod_node[i] < 0 || (size_t)pod_node[i] >= base.nodes.size()) return set_err(KS_ERR_INVALID, "pod_node out of range"); by_node[pod_node[i]].push_back((uint32_t)i); }
-    for (uint32_t i = 0; i < cand_off[n]; ++i) if (cand[i] >= base.nodes.size()) return set_err(KS_ERR_INVALID, "candidate node out of range");
+    auto snapshot = std::make_shared<ksp::Problem>(ksp::Parser(base_text, len).parse());
+    for (auto& nd : snapshot->nodes) nd.in_state = true;
+    snapshot->simulation_mode = true;
+    for (uint32_t i = 0; i < cand_off[n]; ++i) if (cand[i] >= snapshot->nodes.size()) return set_err(KS_ERR_INVALID, "candidate node out of range");
+    // the snapshot is flattened ONCE (catalogue, universes, templates, every state node's row); a what-if adds only what its candidate set decides
+    auto sb = ksh::make_snapshot_base(std::shared_ptr<const ksp::Problem>(snapshot), pod_node, flags);
     std::atomic<uint32_t> next{0}; std::atomic<int> rc{KS_OK}; std::vector<std::string> errs(n);
     auto work = [&]() {
       for (;;) {
         const uint32_t w = next.fetch_add(1); if (w >= n) return;
         try {
-          ksp::Problem pr; pr.extra_well_known = base.extra_well_known; pr.instance_types = base.instance_types; pr.provisioners = base.provisioners;
-          pr.nodes = base.nodes; pr.cluster_pods = base.cluster_pods; pr.daemons = base.daemons; pr.simulation_mode = true;
-          for (uint32_t i = cand_off[w]; i < cand_off[w + 1]; ++i) { pr.nodes[cand[i]].in_state = false; for (uint32_t p : by_node[cand[i]]) pr.pods.push_back(base.pods[p]); }
           auto h = std::make_unique<Handle>();
-          h->enc = ksh::encode(std::move(pr), flags);
+          h->enc = ksh::encode_whatif(*sb, cand + cand_off[w], cand_off[w + 1] - cand_off[w], flags);
           h->rb = h->enc->make_result();
           out_handles[w] = h.release();
         } catch (const ksh::Unsupported& e) { errs[w] = e.what(); rc = KS_ERR_UNSUPPORTED;
@@ -127,6 +126,7 @@ int ksh_open_whatifs(const char* base_text, size_t len, uint32_t flags, uint32_t
     work(); for (auto& t : pool) t.join();
     if (rc != KS_OK) { std::string m; for (auto& e : errs) if (!e.empty()) { m = e; break; } for (uint32_t w = 0; w < n; ++w) { delete (Handle*)out_handles[w]; out_handles[w] = nullptr; } return set_err(rc, m); }
     return KS_OK;
+  } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());
   } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
 }
 

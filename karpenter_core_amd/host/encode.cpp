@@ -207,15 +207,23 @@ struct Builder {
   std::vector<Requirement> it_cols; std::map<std::string, int> it_col_id;     // pod-side instance-type requirements (classes, topology filters; 0 = none)
   // UIDs of the batch: open-addressing table of pod indices (topology.go:66-70 excludes the batch from countDomains)
   struct UidSet {
-    const std::vector<ksp::Pod>* pods = nullptr; std::vector<uint32_t> tab; uint64_t mask = 0;
+    const std::vector<const ksp::Pod*>* pods = nullptr; std::vector<uint32_t> tab; uint64_t mask = 0;
     bool count(const std::string& uid) const {
       if (tab.empty()) return false;
-      for (uint64_t i = str_hash(uid) & mask;; i = (i + 1) & mask) { const uint32_t e = tab[i]; if (!e) return false; if ((*pods)[e - 1].uid == uid) return true; }
+      for (uint64_t i = str_hash(uid) & mask;; i = (i + 1) & mask) { const uint32_t e = tab[i]; if (!e) return false; if ((*pods)[e - 1]->uid == uid) return true; }
     }
   } batch_uids;
   std::map<std::string, const ksp::StateNode*> node_by_name;
   bool toleratePreferNoSchedule = false;
   uint32_t K = 0, R = 0, T = 0, TW = 0;
+
+  // The pending batch: every pod of the problem, or -- for a what-if flattened over a shared snapshot -- the pods of its candidate nodes.
+  std::vector<const Pod*> podp;
+  const Builder* base = nullptr;                      // what-if mode: the finished flattening of the whole snapshot
+  const std::vector<uint8_t>* removed = nullptr;      // what-if mode: nodes that leave the state-node list (helpers.go:48-61)
+  bool node_in_state(size_t i) const { return removed ? !(*removed)[i] : pr.nodes[i].in_state; }
+  std::vector<int> base_existing_of;                  // base only: node index -> row of the base's existing-node tables (-1: not owned)
+  std::vector<ksp::ResList> base_remaining;           // base only: remainingResources with every node in state
 
   Builder(Encoded& e, uint32_t f) : E(e), pr(*e.src), flags(f) {}
   std::chrono::steady_clock::time_point tl_ = std::chrono::steady_clock::now();
@@ -413,7 +421,7 @@ struct Builder {
 
   // ---------- existing nodes ----------
   void encode_existing() {
-    for (size_t i = 0; i < pr.nodes.size(); ++i) { node_by_name[pr.nodes[i].name] = &pr.nodes[i]; if (pr.nodes[i].in_state && pr.nodes[i].owned()) E.existing.push_back((int)i); }
+    for (size_t i = 0; i < pr.nodes.size(); ++i) { node_by_name[pr.nodes[i].name] = &pr.nodes[i]; if (node_in_state(i) && pr.nodes[i].owned()) E.existing.push_back((int)i); }
     const uint32_t NE = (uint32_t)E.existing.size();
     E.en_port_off.assign(1, 0);
     for (uint32_t e = 0; e < NE; ++e) {
@@ -425,9 +433,42 @@ struct Builder {
       E.en_port_off.push_back((uint32_t)E.ports.size());
     }
   }
+  // What-if over a shared snapshot: a state node's row does not depend on which OTHER nodes leave, so the rows come from the flattening of
+  // the whole snapshot; only remainingResources (limits minus the capacity of the nodes that stay, scheduler.go:244-246) is redone.
+  void encode_existing_rest_from_base() {
+    const Encoded& B = base->E; const uint32_t NE = (uint32_t)E.existing.size(), M = (uint32_t)E.templates.size();
+    E.en.n = NE; E.en.present.resize(NE); E.en.complement.resize(NE); E.en.it_state.resize(NE);
+    E.en.mask.resize((size_t)NE * K); E.en.gt.resize((size_t)NE * K); E.en.lt.resize((size_t)NE * K);
+    E.en_taints.resize(NE); E.en_avail.resize((size_t)NE * R); E.en_requests.resize((size_t)NE * R); E.en_requests_present.resize(NE);
+    for (uint32_t e = 0; e < NE; ++e) {
+      const int b = base->base_existing_of[E.existing[e]];
+      E.en.present[e] = B.en.present[b]; E.en.complement[e] = B.en.complement[b]; E.en.it_state[e] = B.en.it_state[b];
+      std::copy_n(&B.en.mask[(size_t)b * K], K, &E.en.mask[(size_t)e * K]); std::copy_n(&B.en.gt[(size_t)b * K], K, &E.en.gt[(size_t)e * K]); std::copy_n(&B.en.lt[(size_t)b * K], K, &E.en.lt[(size_t)e * K]);
+      E.en_taints[e] = B.en_taints[b]; E.en_requests_present[e] = B.en_requests_present[b];
+      std::copy_n(&B.en_avail[(size_t)b * R], R, &E.en_avail[(size_t)e * R]); std::copy_n(&B.en_requests[(size_t)b * R], R, &E.en_requests[(size_t)e * R]);
+    }
+    std::vector<ksp::ResList> remaining = base->base_remaining;
+    for (size_t i = 0; i < pr.nodes.size(); ++i) if ((*removed)[i] && pr.nodes[i].owned()) {
+      auto pl = pr.nodes[i].labels.find(ksp::kProvisionerName);
+      for (uint32_t m = 0; m < M; ++m) if (E.templates[m]->has_limits && E.templates[m]->name == pl->second) for (auto& kv : remaining[m]) { auto c = pr.nodes[i].capacity.find(kv.first); if (c != pr.nodes[i].capacity.end()) kv.second += c->second; }
+    }
+    for (uint32_t m = 0; m < M; ++m) res_vec(remaining[m], E.tmpl_remaining, nullptr);
+  }
+  void adopt_base() {
+    const Builder& b = *base; const Encoded& B = b.E;
+    wellKnown = b.wellKnown; key_id = b.key_id; res_id = b.res_id; taint_id = b.taint_id; taints = b.taints; ip_id = b.ip_id; proto_id = b.proto_id; domains = b.domains;
+    toleratePreferNoSchedule = b.toleratePreferNoSchedule; K = b.K; R = b.R; T = b.T; TW = b.TW;
+    it_reqs = b.it_reqs; it_state_id = b.it_state_id; it_cols = b.it_cols; it_col_id = b.it_col_id;
+    E.key_names = B.key_names; E.key_values = B.key_values; E.res_names = B.res_names; E.key_nvalues = B.key_nvalues; E.value_int = B.value_int;
+    E.it_present = B.it_present; E.it_complement = B.it_complement; E.it_mask = B.it_mask; E.it_offer = B.it_offer; E.it_price = B.it_price; E.it_alloc = B.it_alloc; E.it_cap = B.it_cap;
+    E.templates = B.templates; E.tmpl = B.tmpl; E.tmpl_taints = B.tmpl_taints; E.tmpl_types = B.tmpl_types; E.tmpl_daemon = B.tmpl_daemon; E.tmpl_daemon_present = B.tmpl_daemon_present;
+    E.tmpl_limit_present = B.tmpl_limit_present;
+  }
+
   void encode_existing_rest() {
     const uint32_t NE = (uint32_t)E.existing.size();
     const uint32_t M = (uint32_t)E.templates.size();
+    base_existing_of.assign(pr.nodes.size(), -1); for (uint32_t e = 0; e < NE; ++e) base_existing_of[E.existing[e]] = (int)e;
     // remainingResources, scheduler.go:71-75,244-246
     std::vector<ksp::ResList> remaining(M);
     for (uint32_t m = 0; m < M; ++m) if (E.templates[m]->has_limits) remaining[m] = E.templates[m]->limits;
@@ -447,6 +488,7 @@ struct Builder {
       auto pl = n.labels.find(ksp::kProvisionerName);
       for (uint32_t m = 0; m < M; ++m) if (E.templates[m]->has_limits && E.templates[m]->name == pl->second) remaining[m] = Subtract(remaining[m], n.capacity);
     }
+    base_remaining = remaining;
     for (uint32_t m = 0; m < M; ++m) {
       const auto& p = *E.templates[m];
       // getDaemonOverhead, scheduler.go:250-267
@@ -522,14 +564,15 @@ struct Builder {
   // Hashing and the field-by-field confirmation run on all host threads; the table is filled in pod order so that spec ids, and
   // with them the creation order of topology groups (NewTopology's Update per pod, topology.go:72-78), do not depend on threading.
   void dedupe_specs() {
-    const uint32_t P = (uint32_t)pr.pods.size(); sublap("(start)");
+    if (podp.empty() && !base) { podp.reserve(pr.pods.size()); for (auto& p : pr.pods) podp.push_back(&p); }
+    const uint32_t P = (uint32_t)podp.size(); sublap("(start)");
     std::vector<Hash128> hs(P); std::vector<uint64_t> uh(P);
-    parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { hs[i] = spec_hash(pr.pods[i]); uh[i] = str_hash(pr.pods[i].uid); } });
+    parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { hs[i] = spec_hash(*podp[i]); uh[i] = str_hash(podp[i]->uid); } });
     sublap("hash"); uint64_t cap = 64; while (cap < 4ull * P) cap <<= 1;
-    batch_uids.pods = &pr.pods; batch_uids.mask = cap - 1; batch_uids.tab.assign(cap, 0);
+    batch_uids.pods = &podp; batch_uids.mask = cap - 1; batch_uids.tab.assign(cap, 0);
     for (uint32_t i = 0; i < P; ++i) {
       uint64_t j = uh[i] & batch_uids.mask;
-      for (;; j = (j + 1) & batch_uids.mask) { const uint32_t e = batch_uids.tab[j]; if (!e) break; if (pr.pods[e - 1].uid == pr.pods[i].uid) throw ksp::Error("pod UIDs must be unique (queue.go:102-108 needs a total order)"); }
+      for (;; j = (j + 1) & batch_uids.mask) { const uint32_t e = batch_uids.tab[j]; if (!e) break; if (podp[e - 1]->uid == podp[i]->uid) throw ksp::Error("pod UIDs must be unique (queue.go:102-108 needs a total order)"); }
       batch_uids.tab[j] = i + 1;
     }
     sublap("uid table"); pod_spec.assign(P, -1);
@@ -544,18 +587,18 @@ struct Builder {
     // needs a 2^-128 event).  KSH_CONFIRM_SPECS=1 (the test-suite sets it) additionally confirms every merge field by field; a pod
     // that merely collided would get a spec of its own.
     std::vector<uint8_t> bad(P, 0);
-    if (getenv("KSH_CONFIRM_SPECS")) parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t f = first[pod_spec[i]]; if (f != i && !same_spec(pr.pods[f], pr.pods[i])) bad[i] = 1; } });
+    if (getenv("KSH_CONFIRM_SPECS")) parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t f = first[pod_spec[i]]; if (f != i && !same_spec(*podp[f], *podp[i])) bad[i] = 1; } });
     for (uint32_t i = 0; i < P; ++i) if (bad[i]) {
-      int found = -1; for (size_t s2 = 0; s2 < first.size() && found < 0; ++s2) if (same_spec(pr.pods[first[s2]], pr.pods[i])) found = (int)s2;
+      int found = -1; for (size_t s2 = 0; s2 < first.size() && found < 0; ++s2) if (same_spec(*podp[first[s2]], *podp[i])) found = (int)s2;
       if (found < 0) { found = (int)first.size(); first.push_back(i); }
       pod_spec[i] = found;
     }
     sublap("confirm"); specs.resize(first.size());
-    for (size_t s2 = 0; s2 < first.size(); ++s2) { StageInfo st; st.spec = pr.pods[first[s2]]; st.spec.uid.clear(); specs[s2].stages.push_back(std::move(st)); }
+    for (size_t s2 = 0; s2 < first.size(); ++s2) { StageInfo st; st.spec = *podp[first[s2]]; st.spec.uid.clear(); specs[s2].stages.push_back(std::move(st)); }
   }
 
   void encode_pods() {
-    const uint32_t P = (uint32_t)pr.pods.size();
+    const uint32_t P = (uint32_t)podp.size();
     // updateInverseAffinities, topology.go:181-199 (cluster pods with required anti-affinity, not in the batch)
     for (auto& cp : pr.cluster_pods) {
       if (cp.anti_required.empty() || batch_uids.count(cp.uid)) continue;
@@ -596,8 +639,8 @@ struct Builder {
     sublap("chains"); struct QKey { int64_t cpu, mem, ts; uint64_t u0, u1; uint32_t pod, ulen; };     // u0,u1: the uid's first 16 bytes, big-endian (byte-wise string order)
     std::vector<QKey> keys(P);
     auto be64 = [](const std::string& s2, size_t off) { uint64_t v = 0; for (size_t j = 0; j < 8; ++j) v = (v << 8) | (off + j < s2.size() ? (unsigned char)s2[off + j] : 0u); return v; };
-    parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t c0 = E.stage_cls[E.pod_stage_off[i]]; const std::string& u = pr.pods[i].uid;
-      keys[i] = QKey{E.cls_requests[(size_t)c0 * R + rc], E.cls_requests[(size_t)c0 * R + rm], pr.pods[i].creation_ts, be64(u, 0), be64(u, 8), (uint32_t)i, (uint32_t)u.size()}; } });
+    parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t c0 = E.stage_cls[E.pod_stage_off[i]]; const std::string& u = podp[i]->uid;
+      keys[i] = QKey{E.cls_requests[(size_t)c0 * R + rc], E.cls_requests[(size_t)c0 * R + rm], podp[i]->creation_ts, be64(u, 0), be64(u, 8), (uint32_t)i, (uint32_t)u.size()}; } });
     auto less = [&](const QKey& a, const QKey& b) {
       if (a.cpu != b.cpu) return a.cpu > b.cpu;
       if (a.mem != b.mem) return a.mem > b.mem;
@@ -605,7 +648,7 @@ struct Builder {
       if (a.u0 != b.u0) return a.u0 < b.u0;
       if (a.u1 != b.u1) return a.u1 < b.u1;
       if (a.ulen <= 16 && b.ulen <= 16) return a.ulen < b.ulen;          // equal 16-byte prefixes incl. zero padding: the shorter one is a prefix (NUL bytes inside a uid fall through to the full compare)
-      return pr.pods[a.pod].uid < pr.pods[b.pod].uid;
+      return podp[a.pod]->uid < podp[b.pod]->uid;
     };
     {
       uint32_t nt = 1; while (nt * 2 <= host_threads() && (size_t)nt * 2 * 4096 <= P) nt *= 2;       // power of two: pairwise merge rounds
@@ -657,7 +700,7 @@ struct Builder {
   }
 
   // the taint universe must be complete before classes compute `tolerated`
-  void collect_taints() { for (auto& p : pr.provisioners) taint_mask(p.taints); for (auto& n : pr.nodes) if (n.in_state && n.owned()) taint_mask(n.taints); }
+  void collect_taints() { for (auto& p : pr.provisioners) taint_mask(p.taints); for (size_t i = 0; i < pr.nodes.size(); ++i) if (node_in_state(i) && pr.nodes[i].owned()) taint_mask(pr.nodes[i].taints); }
 
   // ---------- group tables + per-class membership lists ----------
   void encode_groups() {
@@ -719,6 +762,12 @@ struct Builder {
 
   // ---------- instance-type-key lattice ----------
   void encode_it_states() {
+    if (base && it_cols.size() == base->it_cols.size() && it_reqs.size() == base->it_reqs.size()) {      // every class / filter / node state of the what-if is one the snapshot already has
+      const Encoded& B = base->E;
+      E.its_inter = B.its_inter; E.its_fail = B.its_fail; E.its_nidne = B.its_nidne; E.its_types = B.its_types; E.it_states = B.it_states; E.prob.S = B.prob.S; E.prob.SC = B.prob.SC;
+      return;
+    }
+    const std::vector<Requirements>& it_requirements = base ? base->it_requirements : this->it_requirements;
     // Node states are closed under intersection with every pod-side requirement (a node only ever narrows its
     // instance-type requirement by a class's, node.go:79 / existingnode.go:102); it_state_of appends while we iterate.
     if (it_reqs.empty()) it_reqs.push_back(Requirement());   // state 0 placeholder ("absent")
@@ -765,8 +814,8 @@ struct Builder {
 
   void finish() {
     ks_problem& p = E.prob;
-    p.P = (uint32_t)pr.pods.size(); p.C = E.cls.n; p.T = T; p.M = (uint32_t)E.templates.size(); p.E = (uint32_t)E.existing.size(); p.K = K; p.R = R;
-    p.max_new_nodes = p.P ? p.P : 1; p.flags = flags | (pr.simulation_mode ? KS_FLAG_SIMULATION : 0);
+    p.P = (uint32_t)podp.size(); p.C = E.cls.n; p.T = T; p.M = (uint32_t)E.templates.size(); p.E = (uint32_t)E.existing.size(); p.K = K; p.R = R;
+    p.max_new_nodes = p.P ? p.P : 1; p.flags = flags | ((pr.simulation_mode || base) ? KS_FLAG_SIMULATION : 0);
     p.wellknown_mask = 0; for (uint32_t k = 0; k < K; ++k) if (wellKnown.count(E.key_names[k])) p.wellknown_mask |= 1u << k;
     p.key_nvalues = E.key_nvalues.data(); p.value_int = E.value_int.data(); p.key_zone = key_id.at(ksp::kZone); p.key_ct = key_id.at(ksp::kCapacityType); p.n_ct = E.key_nvalues[p.key_ct];
     p.it_present = E.it_present.data(); p.it_complement = E.it_complement.data(); p.it_mask = E.it_mask.data(); p.it_alloc = E.it_alloc.data(); p.it_cap = E.it_cap.data(); p.it_offer = E.it_offer.data(); p.it_price = E.it_price.data(); p.ct_spot = value_id(p.key_ct, "spot"); p.ct_ondemand = value_id(p.key_ct, "on-demand");
@@ -787,6 +836,10 @@ struct Builder {
     const bool timing = getenv("KSH_TIMING") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "  encode %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; };
+    if (base) {      // a what-if over a shared snapshot: catalogue, universes, templates and state-node rows come from the snapshot's flattening
+      adopt_base(); dedupe_specs(); encode_existing(); encode_pods(); encode_existing_rest_from_base(); encode_groups(); encode_it_states(); finish(); lap("what-if over shared snapshot");
+      return;
+    }
     dedupe_specs(); lap("dedupe_specs");
     collect_universes(); lap("collect_universes");
     encode_instance_types(); lap("encode_instance_types");
@@ -808,6 +861,27 @@ struct Builder {
 std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> pr, uint32_t flags) {
   auto e = std::make_unique<Encoded>(); e->src = std::move(pr);
   Builder b(*e, flags); b.run();
+  return e;
+}
+
+struct SnapshotBase {
+  std::shared_ptr<const ksp::Problem> snapshot; std::unique_ptr<Encoded> enc; std::unique_ptr<Builder> builder;
+  std::vector<std::vector<uint32_t>> by_node;      // pods bound to each node, in pod order
+};
+std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp::Problem> snapshot, const int32_t* pod_node, uint32_t flags) {
+  auto sb = std::make_shared<SnapshotBase>(); sb->snapshot = snapshot;
+  sb->by_node.resize(snapshot->nodes.size());
+  for (size_t i = 0; i < snapshot->pods.size(); ++i) { if (pod_node[i] < 0 || (size_t)pod_node[i] >= snapshot->nodes.size()) throw ksp::Error("pod_node out of range"); sb->by_node[pod_node[i]].push_back((uint32_t)i); }
+  sb->enc = std::make_unique<Encoded>(); sb->enc->src = snapshot;
+  sb->builder = std::make_unique<Builder>(*sb->enc, flags); sb->builder->run();
+  return sb;
+}
+std::unique_ptr<Encoded> encode_whatif(const SnapshotBase& sb, const uint32_t* cand, uint32_t ncand, uint32_t flags) {
+  auto e = std::make_unique<Encoded>(); e->src = sb.snapshot;
+  std::vector<uint8_t> removed(sb.snapshot->nodes.size(), 0);
+  Builder b(*e, flags); b.base = sb.builder.get(); b.removed = &removed;
+  for (uint32_t i = 0; i < ncand; ++i) { if (cand[i] >= removed.size()) throw ksp::Error("candidate node out of range"); removed[cand[i]] = 1; for (uint32_t p : sb.by_node[cand[i]]) b.podp.push_back(&sb.snapshot->pods[p]); }
+  b.run();
   return e;
 }
 

@@ -63,4 +63,11 @@ std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> pr, uint32_t
 inline std::unique_ptr<Encoded> encode(ksp::Problem&& pr, uint32_t flags) { return encode(std::make_shared<const ksp::Problem>(std::move(pr)), flags); }
 uint32_t host_threads();
 
+// Consolidation what-ifs over ONE cluster snapshot (deprovisioning/helpers.go:42-99): the snapshot -- every node a state node, every bound pod
+// in the batch -- is flattened once; a what-if (its candidate nodes leave the state nodes, their pods become the pending batch) then only redoes
+// what depends on the candidate set: the pod classes / queue / topology groups of ITS pods and remainingResources.  Thread-safe after construction.
+struct SnapshotBase;
+std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp::Problem> snapshot, const int32_t* pod_node, uint32_t flags);
+std::unique_ptr<Encoded> encode_whatif(const SnapshotBase& sb, const uint32_t* cand, uint32_t ncand, uint32_t flags);
+
 }  // namespace ksh
