@@ -194,52 +194,57 @@ def main():
     print(json.dumps(out))
 
 
-def whatif_problems(args, rank, world, S, W):
+def whatif_snapshot(args, S, W):
+    """BASELINE configs[3]'s cluster: 2048 existing nodes with their bound pods, held as objects in host memory (untimed, like the pod list)."""
     c_its, c_prov, c_nodes, c_bound = W.cluster_snapshot(2048, args.sizes, 45)
     c_snap, c_pn = W.snapshot_problem(c_its, c_prov, c_nodes, c_bound, False)
-    sets = W.config4_sets(args.whatifs or 512, 2048, 45)
-    mine = list(range(rank, len(sets), world))
-    flats = S.open_whatifs(c_snap, c_pn, [sets[i] for i in mine])
-    return flats, mine, len(c_its), len(sets)
+    return S.ParsedProblem(c_snap), c_pn, len(c_its), W.config4_sets(args.whatifs or 512, 2048, 45)
 
 
 def whatif_leg(args, rank, world, local_rank, torch, dist, S, W):
-    """BASELINE configs[3] on this rank's shard: ONE batched launch + binary result records (+ the all-gather when world > 1)."""
-    t0 = time.time()
-    flats, mine, T, total_whatifs = whatif_problems(args, rank, world, S, W)
-    flatten_s = time.time() - t0
-    t0 = time.time()
-    for f in flats:
-        f.upload(local_rank)
-    upload_s = time.time() - t0
+    """BASELINE configs[3] on one GPU, end to end: flatten the what-ifs over the shared snapshot, upload, ONE batched launch, binary result records."""
+    parsed, pod_node, T, sets = whatif_snapshot(args, S, W)
+    mine = list(range(rank, len(sets), world))
     words = (T + 63) // 64
 
-    def step():
+    def end_to_end():
+        t0 = time.perf_counter()
+        flats = S.open_whatifs(parsed, pod_node, [sets[i] for i in mine])
+        t1 = time.perf_counter()
+        for f in flats:
+            f.upload(local_rank)
+        t2 = time.perf_counter()
         _, kms, _ = S.solve_batch(flats, decode=False)
-        rec = torch.from_numpy(S.result_records(flats, mine, words)).cuda()
-        if world > 1:
-            per = (total_whatifs + world - 1) // world
-            pad = torch.full((per, rec.shape[1]), -1, dtype=torch.int64, device="cuda")
-            pad[: rec.shape[0]] = rec
-            outl = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(outl, pad)                  # the one exchange step: chosen-machine records over xGMI
-            rec = torch.cat(outl)[torch.cat(outl)[:, 0] >= 0]
-        return kms, rec
+        rec = S.result_records(flats, mine, words)
+        t3 = time.perf_counter()
+        return flats, rec, {"flatten_ms": (t1 - t0) * 1e3, "upload_ms": (t2 - t1) * 1e3, "solve_records_ms": (t3 - t2) * 1e3, "kernel_ms": kms, "total_ms": (t3 - t0) * 1e3}
 
-    step()
+    flats, rec, _ = end_to_end()           # warm-up (device buffer pool, code objects)
+    for f in flats:
+        f.close()
     runs = []
     for _ in range(3):
+        flats, rec, ms = end_to_end()
+        runs.append(ms)
+        if len(runs) < 3:
+            for f in flats:
+                f.close()
+    ms = sorted(runs, key=lambda r: r["total_ms"])[1]
+    # resident: the batch already in HBM, launch + read-back only (round 1's what-if window)
+    res = []
+    for _ in range(3):
         t1 = time.perf_counter()
-        kms, rec = step()
-        torch.cuda.synchronize()
-        runs.append(((time.perf_counter() - t1) * 1e3, kms))
-    wms, kms = sorted(runs)[1]
+        _, kms, _ = S.solve_batch(flats, decode=False)
+        S.result_records(flats, mine, words)
+        res.append(((time.perf_counter() - t1) * 1e3, kms))
+    wms, kms = sorted(res)[1]
     pods_mine = sum(f.dims["P"] for f in flats)
     out = {"workload": f"{len(flats)} consolidation what-ifs over 2048 existing nodes / {T} instance types (BASELINE configs[3])",
-           "whatifs": len(flats), "decisions": pods_mine, "kernel_ms": kms, "wall_ms": wms,
-           "decisions_per_s_kernel": pods_mine / (kms / 1e3), "decisions_per_s_wall": pods_mine / (wms / 1e3),
-           "whatifs_per_s_wall": len(flats) / (wms / 1e3), "records": int(rec.shape[0]),
-           "flatten_seconds_untimed": flatten_s, "upload_seconds_untimed": upload_s}
+           "whatifs": len(flats), "decisions": pods_mine, "records": int(rec.shape[0]),
+           "end_to_end": dict(ms, what="from the snapshot held as objects: flatten over the shared snapshot base + upload + one batched launch + result records",
+                              decisions_per_s=pods_mine / (ms["total_ms"] / 1e3), whatifs_per_s=len(flats) / (ms["total_ms"] / 1e3)),
+           "resident": {"kernel_ms": kms, "wall_ms": wms, "decisions_per_s_kernel": pods_mine / (kms / 1e3), "decisions_per_s_wall": pods_mine / (wms / 1e3),
+                        "whatifs_per_s_wall": len(flats) / (wms / 1e3)}}
     for f in flats:
         f.close()
     return out
@@ -247,7 +252,10 @@ def whatif_leg(args, rank, world, local_rank, torch, dist, S, W):
 
 def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
     """N>1: the 512 what-ifs dealt out i mod N (strong scaling), one batched launch per rank, ONE all-gather of result records."""
-    flats, mine, T, total_whatifs = whatif_problems(args, rank, world, S, W)
+    parsed, pod_node, T, sets = whatif_snapshot(args, S, W)
+    total_whatifs = len(sets)
+    mine = list(range(rank, total_whatifs, world))
+    flats = S.open_whatifs(parsed, pod_node, [sets[i] for i in mine])
     for f in flats:
         f.upload(local_rank)
     words = (T + 63) // 64

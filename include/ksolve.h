@@ -177,6 +177,9 @@ typedef struct ks_result {
   int32_t* pod_node;   /* [P] -1 unscheduled, [0,E) existing node, E+j new node j */
   int32_t* pod_stage;  /* [P] relaxation stage the pod ended at */
   int32_t* pod_seq;    /* [P] commit sequence number (orders Node.Pods), -1 if unscheduled */
+  uint32_t* pod_reason; /* [P] 0 if scheduled; else why the LAST scheduler.add failed (scheduler.go:193-217 keeps one error per provisioner):
+                           4 bits per machine template m (weight order, m < 8) at bit 4m -- KS_WHY_* -- so a shim can synthesise the
+                           reference's "incompatible with provisioner ..., <reason>" messages for recordSchedulingResults (scheduler.go:135-172) */
   /* unscheduled pods in final queue order (q.List(), queue.go:70-72) */
   uint32_t n_unscheduled;
   int32_t* unscheduled; /* [P] */
@@ -195,6 +198,17 @@ typedef struct ks_result {
   /* counters */
   uint64_t stats[32];      /* KS_STAT_*; [8..31] are per-phase cycle counters of the pack kernel (tools/phase_profile.py) */
 } ks_result;
+
+enum {      /* per-template failure reasons in ks_result.pod_reason */
+  KS_WHY_NONE = 0,
+  KS_WHY_LIMITS = 1,           /* "all available instance types exceed provisioner limits" (scheduler.go:198-201)              */
+  KS_WHY_TAINTS = 2,           /* Taints.Tolerates (node.go:64)                                                                 */
+  KS_WHY_HOST_PORTS = 3,       /* HostPortUsage.Validate (node.go:69); cannot happen on a fresh node, kept for completeness     */
+  KS_WHY_REQUIREMENTS = 4,     /* nodeRequirements.Compatible(podRequirements) (node.go:77)                                     */
+  KS_WHY_TOPOLOGY = 5,         /* Topology.AddRequirements: unsatisfiable topology constraint (node.go:83)                      */
+  KS_WHY_TOPOLOGY_REQS = 6,    /* nodeRequirements.Compatible(topologyRequirements) (node.go:87)                                */
+  KS_WHY_NO_INSTANCE_TYPE = 7  /* filterInstanceTypesByRequirements left nothing (node.go:94-98)                                 */
+};
 
 enum {
   KS_STAT_POPS = 0,        /* queue pops                                             */

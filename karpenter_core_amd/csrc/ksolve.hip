@@ -104,6 +104,7 @@ struct DevProb {
   void* briefs;      // [C] ClsBrief: what the round planner / resolver reads of a class
   u32* ev_tab; u32 ev_tab_size, ev_pad;   // open-addressing table that interns evaluation classes (ks_link_plans)
   u8* mc_ok;         // [M*C]
+  u8* mc_why;        // [M*C]  KS_WHY_* of a fresh node of template m refusing class c before the topology step (0 if mc_ok)
   u32* mc_present; u32* mc_complement; u64* mc_mask; i32* mc_gt; i32* mc_lt; i32* mc_it;   // template ∩ class
   u64* grid;         // [M*C*TW]
 };
@@ -111,7 +112,7 @@ struct DevProb {
 // Mutable state of one Solve (device memory).
 struct DevState {
   // queue (queue.go:29-72)
-  u64* q; u32* lastlen; u32* lastgen; i32* pod_stage; i32* pod_node; i32* pod_seq;   // q entry: pod | class<<32 | requeued-unrelaxed<<63
+  u64* q; u32* lastlen; u32* lastgen; i32* pod_stage; i32* pod_node; i32* pod_seq; u32* pod_reason;   // q entry: pod | class<<32 | requeued-unrelaxed<<63
   // node records (AoS, see Rec): slots [0,E) existing nodes, [E,E+NMAX) new nodes
   u8* rec; u32 rec_stride;
   i32* n_tmpl; u64* n_alive;          // new nodes only, indexed by j = slot-E; n_alive has one spare row
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256) void ks_grid_mc(DevProb P) {
   if (idx >= (size_t)P.M * P.C) return;
   const u32 m = idx / P.C, c = idx % P.C;
   bool ok = (P.tmpl_taints[m] & ~P.cls_tolerated[c]) == 0;
+  const bool taints_ok = ok;
   if (P.cls_hn_mode[c] == 1) ok = false;
   const u32 tp = P.tmpl.present[m], tc = P.tmpl.complement[m], cp = P.cls.present[c], cc = P.cls.complement[c];
   u32 present = tp | cp, complement = 0;
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(256) void ks_grid_mc(DevProb P) {
   if (P.its_fail[sa * P.SC + sb]) ok = false;
   P.mc_it[idx] = P.its_inter[sa * P.SC + sb];
   P.mc_present[idx] = present; P.mc_complement[idx] = complement; P.mc_ok[idx] = ok ? 1 : 0;
+  P.mc_why[idx] = ok ? KS_WHY_NONE : (!taints_ok ? KS_WHY_TAINTS : KS_WHY_REQUIREMENTS);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -680,7 +683,13 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
     if (t.type == 0) ok = cnt >= 0 && (i64)cnt + t.self <= (i64)t.maxskew;                        // nextDomainTopologySpread, min==0 for hostname (topologygroup.go:184-188)
     else if (t.type == 2) ok = cnt == 0;                                                           // nextDomainAntiAffinity :235-243
     else ok = UF(sh.host_anypos[i]) ? (cnt > 0) : (t.self && cnt >= 0);                                // nextDomainAffinity :202-233
-    if (!ok) return;
+    if (!ok) {
+      // which error the reference would raise (only read for fresh nodes): a spread picks among the NODE's domains, so nothing viable is an
+      // empty domain set ("unsatisfiable topology constraint", topology.go:160-163); affinity / anti-affinity pick among ALL domains
+      // (topologygroup.go:202-243), so a non-empty choice that excludes this node fails one step later, at Compatible (node.go:87)
+      const bool elsewhere = t.type == 1 ? UF(sh.host_anypos[i]) != 0 : (t.type == 2 && (i32)UF(sh.host_zero[i]) > 0);
+      ev.rc = elsewhere ? -KS_WHY_TOPOLOGY_REQS : -KS_WHY_TOPOLOGY; return;
+    }
   }
   // ---- per touched key: Compatible + Add of the pod's own requirement (requirements.go:123-133, :87-94; one
   //      Intersection serves both), then Topology.AddRequirements (topology.go:149-167) and the Compatible + Add
@@ -730,14 +739,14 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
             if (y) options |= y & (~y + 1);
           }
         } else options = d.reg & tt.PD & ~d.pos;                  // anti-affinity :235-243
-        if (!options) return;                                     // "unsatisfiable topology constraint"
+        if (!options) { ev.rc = -KS_WHY_TOPOLOGY; return; }        // "unsatisfiable topology constraint"
         dom &= options;
       }
       // nodeRequirements.Compatible(topologyRequirements) on this key: the topology requirement is
       // node ∩ In[dom]; see DESIGN.md "topology compatibility" for the reduction used here.
       const KReq in = kreq_in(dom);
-      if (!before.present) { if (!((tb.wellknown >> k) & 1u)) return; a = in; }
-      else { const KReq mg = kreq_intersect(in, before, vi, nv); if (kreq_len0(mg) && !kreq_nidne(before)) return; a = mg; }
+      if (!before.present) { if (!((tb.wellknown >> k) & 1u)) { ev.rc = -KS_WHY_TOPOLOGY_REQS; return; } a = in; }
+      else { const KReq mg = kreq_intersect(in, before, vi, nv); if (kreq_len0(mg) && !kreq_nidne(before)) { ev.rc = -KS_WHY_TOPOLOGY_REQS; return; } a = mg; }
       if (kreq_differs(a, before)) ev.tnar |= 1u << i;
     }
     if (a.present) ev.tpres |= 1u << i;
@@ -1052,7 +1061,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
 
   // ---------------- initialise state (global memory); wave 0 alone, it is a one-off ----------------
   if (wv == 0) {
-  for (u32 i = lane; i < P.P; i += 64) { const u32 pd = P.queue[i]; tb.q[i] = (u64)pd | ((u64)P.stage_cls[P.pod_stage_off[pd]] << 32); G_lastgen[i] = 0xFFFFFFFFu; G_lastlen[i] = 0; G_pod_stage[i] = 0; tb.pod_node[i] = -1; tb.pod_seq[i] = -1; }
+  for (u32 i = lane; i < P.P; i += 64) { const u32 pd = P.queue[i]; tb.q[i] = (u64)pd | ((u64)P.stage_cls[P.pod_stage_off[pd]] << 32); G_lastgen[i] = 0xFFFFFFFFu; G_lastlen[i] = 0; G_pod_stage[i] = 0; tb.pod_node[i] = -1; tb.pod_seq[i] = -1; S.pod_reason[i] = 0; }
   for (u32 e = lane; e < tb.E; e += 64) {
     const Rec r = slot_rec(S, tb, e);
     r.taints() = P.en_taints[e]; r.present() = P.en.present[e]; r.complement() = P.en.complement[e]; r.it_state() = P.en.it_state[e];
@@ -1243,7 +1252,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       pf0 = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) pf1 = src[lane + 64];
       pf_ok = true;
     }
-    u32 pos_base = 0, tm = 0, width = KS_FIRST_WIDTH;
+    u32 pos_base = 0, tm = 0, width = KS_FIRST_WIDTH, why = 0;       // why: one KS_WHY_* per template this pod could not use (scheduler.go:193-217)
     bool reuse = NW == 1 && r_valid && !want_stats && cr.eq != 0 && cr.eq == r_eq;     // (single-wave kernel only: in the multi-wave one rounds take the runs of equivalent pods)
     if (!want_stats && cr.nhost) {
       // anti-affinity (count == 0) and spread with maxSkew - self == 0 accept a node only if its own hostname counts 0; with no such
@@ -1303,9 +1312,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             if (want_stats) { u32 pc = __builtin_popcountll(a); for (int off = 32; off > 0; off >>= 1) pc += __shfl_xor(pc, off); ltypes += pc; }
             if (w < tb.TW) scratch[w] = a & G_grid[mc * tb.TW + w];
           }
-          if (!lany) continue;                  // "all available instance types exceed provisioner limits" (before NewNode)
+          if (!lany) { if (m_t < 8) why |= (u32)KS_WHY_LIMITS << (4 * m_t); continue; }                  // "all available instance types exceed provisioner limits" (before NewNode)
           if (want_stats) CTR(KS_STAT_REF_ATTEMPTS, 1);    // NewNode + node.Add is attempted for this template
-          if (!UF(P.mc_ok[mc])) continue;           // taints / Compatible fail inside Add
+          if (!UF(P.mc_ok[mc])) { if (m_t < 8) why |= (u32)UF(P.mc_why[mc]) << (4 * m_t); continue; }           // taints / Compatible fail inside Add
           have = true;
         }
         if (err) break;
@@ -1333,6 +1342,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       PROBE(26);
       m = ballot64(ev.rc == 2);
       reach = ballot64(ev.rc >= 1);
+      if (fresh && m == 0 && m_t < 8) { const i32 rc0 = (i32)RL((u32)ev.rc, 0); why |= (u32)(rc0 < 0 ? -rc0 : (rc0 == 1 ? KS_WHY_NO_INSTANCE_TYPE : KS_WHY_REQUIREMENTS)) << (4 * m_t); }
       }
       if constexpr (NW > 1) if (scanning) {
         __syncthreads();
@@ -1366,7 +1376,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             u64 aw[2];
             const bool ok = filter_types(P, tb, pb, sh, r, fresh ? scratch : alive, fresh ? alive : (inreg ? (GA u64*)nullptr : scratch), rm, keys, zc, itc, lane, tprobe, aw);
             PROBE(16);
-            if (!ok) { CTR(KS_STAT_FULLFAILS, 1); if (!fresh) recompute_cap<RM>(P, tb, alive, r, lane); m &= m - 1; continue; }
+            if (!ok) { CTR(KS_STAT_FULLFAILS, 1); if (!fresh) recompute_cap<RM>(P, tb, alive, r, lane); else if (m_t < 8) why |= (u32)KS_WHY_NO_INSTANCE_TYPE << (4 * m_t); m &= m - 1; continue; }
             if (inreg) { if ((u32)lane < tb.TW) alive[lane] = aw[0]; if ((u32)lane + 64 < tb.TW) alive[lane + 64] = aw[1]; }
             else if (!fresh) for (u32 w = lane; w < tb.TW; w += 64) alive[w] = scratch[w];
             if ((u32)lane < tb.R && ((rm >> lane) & 1u)) r.low()[lane] = sh.low_new[lane];
@@ -1399,7 +1409,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           if (!ex) r.count() = cnt + 1;
           if (fresh) S.n_tmpl[jw] = (i32)m_t;
           for (u32 i = 0; i < cr.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
-          tb.pod_node[pod] = (i32)sw; tb.pod_seq[pod] = (i32)seq;
+          tb.pod_node[pod] = (i32)sw; tb.pod_seq[pod] = (i32)seq; S.pod_reason[pod] = 0;
         }
         PROBE(17);
         if (!ex && !fresh) {
@@ -1462,6 +1472,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       u32 tail = q_head + q_len; if (tail >= nP) tail -= nP;
       q_len++; pf_ok = false;
       if (lane == 0) {
+        S.pod_reason[pod] = why;
         const u32 ncls = relaxed ? G_stage_cls[G_pod_stage_off[pod] + stg + 1] : cidx;
         tb.q[tail] = (u64)pod | ((u64)ncls << 32) | (relaxed ? 0ull : (1ull << 63));
         if (relaxed) {
@@ -1861,7 +1872,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           const u32 su = (u32)__shfl((int)wslot, u), pres_u = (u32)__shfl((int)n_pres, u), comp_u = (u32)__shfl((int)n_comp, u); const i32 its_u = __shfl(ev.it_state, u);
           if (mine) {
             const u64 qe = rc.qe[par][lane]; const u32 pod = (u32)qe, cidx = (u32)(qe >> 32) & 0x7FFFFFFFu;
-            tb.pod_node[pod] = (i32)su; tb.pod_seq[pod] = (i32)(seq0 + (u32)lane);
+            tb.pod_node[pod] = (i32)su; tb.pod_seq[pod] = (i32)(seq0 + (u32)lane); S.pod_reason[pod] = 0;
             const Rec ru = slot_rec(S, tb, su);
             auto node_req = [&](int k) {
               KReq q; q.present = (pres_u >> k) & 1u; q.complement = (comp_u >> k) & 1u; q.gt = KS_NOGT; q.lt = KS_NOLT; q.mask = 0; bool hit = false;
@@ -2032,18 +2043,25 @@ __global__ void ks_probe_has_kernel(ks_req1 a, const i32* vint, u32 nv, ks_req_f
 #include <map>
 namespace {
 struct DevPool {
-  std::mutex mu; std::map<std::pair<int, size_t>, std::vector<void*>> dev_free, host_free;
+  std::mutex mu; std::map<std::pair<int, size_t>, std::vector<void*>> dev_free, host_free; std::map<int, std::vector<hipStream_t>> streams;
+  size_t dev_cached = 0, host_cached = 0;       // bytes held: a consolidation pass keeps hundreds of what-if problems alive at once, so the cache is bounded by bytes, not entries
+  static constexpr size_t kDevCap = (size_t)16 << 30, kHostCap = (size_t)2 << 30;
+  int get_stream(int device, hipStream_t* out) {
+    { std::lock_guard<std::mutex> g(mu); auto& v = streams[device]; if (!v.empty()) { *out = v.back(); v.pop_back(); return KS_OK; } }
+    HIPCHK(hipStreamCreate(out)); return KS_OK;
+  }
+  void put_stream(int device, hipStream_t st) { if (!st) return; std::lock_guard<std::mutex> g(mu); streams[device].push_back(st); }
   static size_t klass(size_t bytes) { size_t c = 4096; while (c < bytes) c <<= 1; return c; }
   int get(int device, size_t bytes, bool host, void** out) {
     const size_t c = klass(bytes);
-    { std::lock_guard<std::mutex> g(mu); auto& v = (host ? host_free : dev_free)[{device, c}]; if (!v.empty()) { *out = v.back(); v.pop_back(); return KS_OK; } }
+    { std::lock_guard<std::mutex> g(mu); auto& v = (host ? host_free : dev_free)[{device, c}]; if (!v.empty()) { *out = v.back(); v.pop_back(); (host ? host_cached : dev_cached) -= c; return KS_OK; } }
     if (host) HIPCHK(hipHostMalloc(out, c, hipHostMallocDefault)); else HIPCHK(hipMalloc(out, c));
     return KS_OK;
   }
   void put(int device, size_t bytes, bool host, void* p) {
     if (!p) return;
     const size_t c = klass(bytes);
-    { std::lock_guard<std::mutex> g(mu); auto& v = (host ? host_free : dev_free)[{device, c}]; if (v.size() < 4) { v.push_back(p); return; } }
+    { std::lock_guard<std::mutex> g(mu); size_t& held = host ? host_cached : dev_cached; if (held + c <= (host ? kHostCap : kDevCap)) { (host ? host_free : dev_free)[{device, c}].push_back(p); held += c; return; } }
     if (host) hipHostFree(p); else hipFree(p);
   }
 };
@@ -2129,7 +2147,7 @@ static int validate(const ks_problem* p) {
 extern "C" void ks_problem_free(ks_dev_problem* d) {
   if (!d) return;
   hipSetDevice(d->device);
-  if (d->stream) { hipStreamSynchronize(d->stream); hipStreamDestroy(d->stream); }
+  if (d->stream) { hipStreamSynchronize(d->stream); pool().put_stream(d->device, d->stream); }
   pool().put(d->device, d->arena_bytes, false, d->arena);
   pool().put(d->device, d->stage_bytes, true, d->stage);
   delete d;
@@ -2142,7 +2160,7 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   HIPCHK(hipSetDevice(device));
   ks_dev_problem* d = new ks_dev_problem(); d->device = device;
   struct Guard { ks_dev_problem* d; bool ok = false; ~Guard() { if (!ok) ks_problem_free(d); } } guard{d};
-  HIPCHK(hipStreamCreate(&d->stream));
+  TRY(pool().get_stream(device, &d->stream));
   auto layout = [&]() -> int {
   DevProb& h = d->h;
   h.P = p->P; h.C = p->C; h.T = p->T; h.TW = (p->T + 63) / 64; h.M = p->M; h.E = p->E; h.K = p->K; h.R = p->R; h.G = p->G; h.GH = p->GH; h.S = p->S; h.SC = p->SC;
@@ -2201,12 +2219,12 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   { u8* br = nullptr; TRY(dev_alloc(d, (size_t)C * sizeof(ClsBrief), &br, 0)); h.briefs = br;
     h.ev_tab_size = 64; while (h.ev_tab_size < 2 * C) h.ev_tab_size <<= 1; h.ev_pad = 0; TRY(dev_alloc(d, (size_t)h.ev_tab_size, &h.ev_tab, 0)); }
   const size_t MC = (size_t)M * C;
-  TRY(dev_alloc(d, MC, &h.mc_ok, 0)); TRY(dev_alloc(d, MC, &h.mc_present)); TRY(dev_alloc(d, MC, &h.mc_complement));
+  TRY(dev_alloc(d, MC, &h.mc_ok, 0)); TRY(dev_alloc(d, MC, &h.mc_why, 0)); TRY(dev_alloc(d, MC, &h.mc_present)); TRY(dev_alloc(d, MC, &h.mc_complement));
   TRY(dev_alloc(d, MC * K, &h.mc_mask)); TRY(dev_alloc(d, MC * K, &h.mc_gt)); TRY(dev_alloc(d, MC * K, &h.mc_lt)); TRY(dev_alloc(d, MC, &h.mc_it));
   TRY(dev_alloc(d, MC * TW, &h.grid, 0));
   // state
   DevState& s = d->hs; const size_t NS = (size_t)E + h.NMAX;
-  TRY(dev_alloc(d, P, &s.q)); TRY(dev_alloc(d, P, &s.lastlen)); TRY(dev_alloc(d, P, &s.lastgen)); TRY(dev_alloc(d, P, &s.pod_stage)); TRY(dev_alloc(d, P, &s.pod_node)); TRY(dev_alloc(d, P, &s.pod_seq));
+  TRY(dev_alloc(d, P, &s.q)); TRY(dev_alloc(d, P, &s.lastlen)); TRY(dev_alloc(d, P, &s.lastgen)); TRY(dev_alloc(d, P, &s.pod_stage)); TRY(dev_alloc(d, P, &s.pod_node)); TRY(dev_alloc(d, P, &s.pod_seq)); TRY(dev_alloc(d, P, &s.pod_reason));
   s.rec_stride = ks_rec_stride(R, K);
   TRY(dev_alloc(d, NS * s.rec_stride, &s.rec, 0));
   TRY(dev_alloc(d, (size_t)h.NMAX, &s.n_tmpl)); TRY(dev_alloc(d, ((size_t)h.NMAX + 1) * TW, &s.n_alive)); TRY(dev_alloc(d, (size_t)8 * 64 * TW, &s.round_scratch));
@@ -2237,10 +2255,10 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
 }
 
 // Build the derived tables + the feasibility grid (idempotent).  Returns the grid kernels' time.
-static int build_static(ks_dev_problem* d, float* grid_ms) {
+static int build_static(ks_dev_problem* d, float* grid_ms, bool async = false) {
   HIPCHK(hipSetDevice(d->device));
   const DevProb& h = d->h;
-  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  hipEvent_t e0 = nullptr, e1 = nullptr; if (!async) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); }
   const u32 rows = h.K * 64 + 2 * h.K + 64;
   hipLaunchKernelGGL(ks_build_type_tables, dim3((rows * 64 + 255) / 256), dim3(256), 0, d->stream, h);
   if (h.C) hipLaunchKernelGGL(ks_build_plans, dim3((h.C + 63) / 64), dim3(64), 0, d->stream, h, (ClsPlan*)h.plans, (ClsBrief*)h.briefs);
@@ -2248,7 +2266,7 @@ static int build_static(ks_dev_problem* d, float* grid_ms) {
   if (h.C) hipLaunchKernelGGL(ks_link_plans, dim3((h.C + 63) / 64), dim3(64), 0, d->stream, (ClsPlan*)h.plans, h.C, h.R);
   hipLaunchKernelGGL(ks_build_ge_rows, dim3((u32)(((size_t)h.R * h.T * 64 + 255) / 256)), dim3(256), 0, d->stream, h);
   const size_t MC = (size_t)h.M * h.C;
-  HIPCHK(hipEventRecord(e0, d->stream));
+  if (!async) HIPCHK(hipEventRecord(e0, d->stream));
   if (MC) {
     hipLaunchKernelGGL(ks_grid_mc, dim3((u32)((MC + 255) / 256)), dim3(256), 0, d->stream, h);
     // waves = TW * chunks; aim at >= 8 waves per SIMD on 256 CUs (8192 waves) without exceeding the work
@@ -2256,12 +2274,14 @@ static int build_static(ks_dev_problem* d, float* grid_ms) {
     const size_t waves = (size_t)h.TW * chunks;
     hipLaunchKernelGGL(ks_grid_types, dim3((u32)((waves * 64 + 255) / 256)), dim3(256), 0, d->stream, h, chunks);
   }
+  d->tables_built = true;
+  if (async) return KS_OK;            // the caller waits for the device once, after queueing every problem of a batch
   HIPCHK(hipEventRecord(e1, d->stream));
   HIPCHK(hipStreamSynchronize(d->stream));
   HIPCHK(hipGetLastError());
   if (grid_ms) HIPCHK(hipEventElapsedTime(grid_ms, e0, e1));
   hipEventDestroy(e0); hipEventDestroy(e1);
-  d->tables_built = true; return KS_OK;
+  return KS_OK;
 }
 
 extern "C" int ks_feasibility_grid(ks_dev_problem* d, uint64_t* out_grid, float* kernel_ms) {
@@ -2279,18 +2299,18 @@ __device__ __host__ inline u64 ks_pad8(u64 b) { return (b + 7) & ~7ull; }
 __global__ __launch_bounds__(256) void ks_gather(const DevState* states, const GatherDesc* descs, u8* blob) {
   const DevState& s = states[blockIdx.x]; const GatherDesc g = descs[blockIdx.x];
   const u64 P = g.P, N = g.N, K = g.K, R = g.R, TW = g.TW;
-  const GatherSeg segs[14] = {{s.pod_node, P * 4}, {s.pod_stage, P * 4}, {s.pod_seq, P * 4}, {s.unscheduled, P * 4}, {s.n_tmpl, N * 4}, {s.n_alive, N * TW * 8},
+  const GatherSeg segs[15] = {{s.pod_node, P * 4}, {s.pod_stage, P * 4}, {s.pod_seq, P * 4}, {s.pod_reason, P * 4}, {s.unscheduled, P * 4}, {s.n_tmpl, N * 4}, {s.n_alive, N * TW * 8},
                               {s.o_req, N * R * 8}, {s.o_reqmask, N * 4}, {s.o_present, N * 4}, {s.o_complement, N * 4}, {s.o_mask, N * K * 8}, {s.o_gt, N * K * 4},
                               {s.o_lt, N * K * 4}, {s.o_it, N * 4}};
   u64 off = g.off;
-  for (int i = 0; i < 14; ++i) {
+  for (int i = 0; i < 15; ++i) {
     const u32* src = (const u32*)segs[i].src; u32* dst = (u32*)(blob + off);
     for (u64 j = threadIdx.x; j < segs[i].bytes / 4; j += blockDim.x) dst[j] = src[j];
     off += ks_pad8(segs[i].bytes);
   }
 }
 static u64 ks_gather_bytes(u64 P, u64 K, u64 R, u64 TW, u64 N) {
-  return 4 * ks_pad8(P * 4) + ks_pad8(N * 4) + ks_pad8(N * TW * 8) + ks_pad8(N * R * 8) + 3 * ks_pad8(N * 4) + ks_pad8(N * K * 8) + 2 * ks_pad8(N * K * 4) + ks_pad8(N * 4);
+  return 5 * ks_pad8(P * 4) + ks_pad8(N * 4) + ks_pad8(N * TW * 8) + ks_pad8(N * R * 8) + 3 * ks_pad8(N * 4) + ks_pad8(N * K * 8) + 2 * ks_pad8(N * K * 4) + ks_pad8(N * 4);
 }
 static int ks_stats_error(const u64* stats) {
   if (!stats[KS_STAT_ERR]) return KS_OK;
@@ -2323,7 +2343,7 @@ static int download_batch(ks_dev_problem* const* ds, u32 n, const DevState* dsv,
     const DevProb& h = ds[i]->h; ks_result* out = outs[i]; const u64 P = h.P, K = h.K, R = h.R, TW = h.TW, N = out->n_new;
     const u8* p = blob.data() + descs[i].off;
     auto take = [&](void* dst, u64 bytes) { if (bytes) memcpy(dst, p, bytes); p += ks_pad8(bytes); };
-    take(out->pod_node, P * 4); take(out->pod_stage, P * 4); take(out->pod_seq, P * 4); take(out->unscheduled, P * 4);
+    take(out->pod_node, P * 4); take(out->pod_stage, P * 4); take(out->pod_seq, P * 4); take(out->pod_reason, P * 4); take(out->unscheduled, P * 4);
     take(out->node_tmpl, N * 4); take(out->node_types, N * TW * 8); take(out->node_requests, N * R * 8); take(out->node_requests_present, N * 4);
     take(out->node_present, N * 4); take(out->node_complement, N * 4); take(out->node_mask, N * K * 8); take(out->node_gt, N * K * 4); take(out->node_lt, N * K * 4);
     take(out->node_it_state, N * 4);
@@ -2344,6 +2364,7 @@ static int download(ks_dev_problem* d, ks_result* out) {
   if (P) {
     HIPCHK(hipMemcpy(out->pod_node, s.pod_node, P * sizeof(i32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out->pod_stage, s.pod_stage, P * sizeof(i32), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out->pod_seq, s.pod_seq, P * sizeof(i32), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out->unscheduled, s.unscheduled, P * sizeof(i32), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out->pod_reason, s.pod_reason, P * sizeof(u32), hipMemcpyDeviceToHost));
   }
   if (N) {
     HIPCHK(hipMemcpy(out->node_tmpl, s.n_tmpl, N * sizeof(i32), hipMemcpyDeviceToHost));
@@ -2363,7 +2384,9 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   if (!ds || !outs) return fail(KS_ERR_INVALID, "null batch");
   const int device = ds[0]->device;
   HIPCHK(hipSetDevice(device));
-  for (u32 i = 0; i < n; ++i) { if (ds[i]->device != device) return fail(KS_ERR_INVALID, "batch spans devices"); if (!ds[i]->tables_built) TRY(build_static(ds[i], nullptr)); }
+  bool queued = false;
+  for (u32 i = 0; i < n; ++i) { if (ds[i]->device != device) return fail(KS_ERR_INVALID, "batch spans devices"); if (!ds[i]->tables_built) { TRY(build_static(ds[i], nullptr, n > 1)); queued = n > 1; } }
+  if (queued) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipGetLastError()); }      // every what-if built its tables on its own stream: one wait for all of them
   std::vector<DevProb> hp(n); std::vector<DevState> hs(n);
   for (u32 i = 0; i < n; ++i) { hp[i] = ds[i]->h; hs[i] = ds[i]->hs; }
   DevProb* dp = nullptr; DevState* dsv = nullptr; u64* d_meta = nullptr;

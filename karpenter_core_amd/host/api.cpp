@@ -98,16 +98,13 @@ int ksh_result_summary(void* hv, uint64_t* out, uint32_t words) {
 // node (index into base nodes) pod i runs on -- and what-if w is derived natively: its candidate nodes cand[cand_off[w] ..
 // cand_off[w+1]) leave the state-node list (helpers.go:48-61), their pods, in candidate order, become the pending batch, the
 // flattening (NewScheduler / NewTopology host half) runs on `nthreads` host threads.  out_handles[w] is a ksh_open handle.
-int ksh_open_whatifs(const char* base_text, size_t len, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand,
-                     const int32_t* pod_node, uint32_t nthreads, void** out_handles) {
+static int open_whatifs_over(std::shared_ptr<const ksp::Problem> snapshot, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand,
+                             const int32_t* pod_node, uint32_t nthreads, void** out_handles) {
   for (uint32_t w = 0; w < n; ++w) out_handles[w] = nullptr;
   try {
-    auto snapshot = std::make_shared<ksp::Problem>(ksp::Parser(base_text, len).parse());
-    for (auto& nd : snapshot->nodes) nd.in_state = true;
-    snapshot->simulation_mode = true;
     for (uint32_t i = 0; i < cand_off[n]; ++i) if (cand[i] >= snapshot->nodes.size()) return set_err(KS_ERR_INVALID, "candidate node out of range");
     // the snapshot is flattened ONCE (catalogue, universes, templates, every state node's row); a what-if adds only what its candidate set decides
-    auto sb = ksh::make_snapshot_base(std::shared_ptr<const ksp::Problem>(snapshot), pod_node, flags);
+    auto sb = ksh::make_snapshot_base(snapshot, pod_node, flags);
     std::atomic<uint32_t> next{0}; std::atomic<int> rc{KS_OK}; std::vector<std::string> errs(n);
     auto work = [&]() {
       for (;;) {
@@ -128,6 +125,19 @@ int ksh_open_whatifs(const char* base_text, size_t len, uint32_t flags, uint32_t
     return KS_OK;
   } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());
   } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
+}
+int ksh_open_whatifs(const char* base_text, size_t len, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand,
+                     const int32_t* pod_node, uint32_t nthreads, void** out_handles) {
+  try {
+    auto snapshot = std::make_shared<ksp::Problem>(ksp::Parser(base_text, len).parse());
+    for (auto& nd : snapshot->nodes) nd.in_state = true;
+    snapshot->simulation_mode = true;
+    return open_whatifs_over(std::shared_ptr<const ksp::Problem>(snapshot), flags, n, cand_off, cand, pod_node, nthreads, out_handles);
+  } catch (const std::exception& e) { for (uint32_t w = 0; w < n; ++w) out_handles[w] = nullptr; return set_err(KS_ERR_INVALID, e.what()); }
+}
+// The same over a snapshot the caller already holds as objects (ksh_parse): every node of it is a state node, every pod a bound pod.
+int ksh_open_whatifs_parsed(void* parsed, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand, const int32_t* pod_node, uint32_t nthreads, void** out_handles) {
+  return open_whatifs_over(((Parsed*)parsed)->pr, flags, n, cand_off, cand, pod_node, nthreads, out_handles);
 }
 
 // FNV-1a over every array behind the handle's ks_problem: two construction routes produced the same flat problem iff equal.

@@ -887,11 +887,11 @@ std::unique_ptr<Encoded> encode_whatif(const SnapshotBase& sb, const uint32_t* c
 
 std::unique_ptr<Encoded::ResultBuf> Encoded::make_result() const {
   auto rb = std::make_unique<ResultBuf>(); const ks_problem& p = prob; const size_t N = p.max_new_nodes, TW = (p.T + 63) / 64;
-  rb->pod_node.resize(p.P + 1); rb->pod_stage.resize(p.P + 1); rb->pod_seq.resize(p.P + 1); rb->unscheduled.resize(p.P + 1);
+  rb->pod_node.resize(p.P + 1); rb->pod_stage.resize(p.P + 1); rb->pod_seq.resize(p.P + 1); rb->unscheduled.resize(p.P + 1); rb->pod_reason.resize(p.P + 1);
   rb->node_tmpl.resize(N); rb->node_types.resize(N * TW); rb->node_requests.resize(N * p.R); rb->node_requests_present.resize(N);
   rb->node_present.resize(N); rb->node_complement.resize(N); rb->node_mask.resize(N * p.K + 1); rb->node_gt.resize(N * p.K + 1); rb->node_lt.resize(N * p.K + 1); rb->node_it_state.resize(N);
   ks_result& r = rb->r;
-  r.pod_node = rb->pod_node.data(); r.pod_stage = rb->pod_stage.data(); r.pod_seq = rb->pod_seq.data(); r.unscheduled = rb->unscheduled.data();
+  r.pod_node = rb->pod_node.data(); r.pod_stage = rb->pod_stage.data(); r.pod_seq = rb->pod_seq.data(); r.unscheduled = rb->unscheduled.data(); r.pod_reason = rb->pod_reason.data();
   r.node_tmpl = rb->node_tmpl.data(); r.node_types = rb->node_types.data(); r.node_requests = rb->node_requests.data(); r.node_requests_present = rb->node_requests_present.data();
   r.node_present = rb->node_present.data(); r.node_complement = rb->node_complement.data(); r.node_mask = rb->node_mask.data(); r.node_gt = rb->node_gt.data(); r.node_lt = rb->node_lt.data(); r.node_it_state = rb->node_it_state.data();
   return rb;
@@ -936,6 +936,7 @@ std::string Encoded::decode(const ks_result& r, double solve_seconds) const {
   for (uint32_t e = 0; e < NE; ++e) { o << "ENODE " << tokq(src->nodes[existing[e]].name) << " " << pods_of[e].size(); for (auto& sp : pods_of[e]) o << " " << sp.second; o << "\n"; }
   o << "UNSCHEDULED " << r.n_unscheduled; for (uint32_t i = 0; i < r.n_unscheduled; ++i) o << " " << r.unscheduled[i]; o << "\n";
   o << "STAGES " << p.P; for (uint32_t i = 0; i < p.P; ++i) o << " " << r.pod_stage[i]; o << "\n";
+  o << "REASONS " << r.n_unscheduled; for (uint32_t i = 0; i < r.n_unscheduled; ++i) o << " " << r.unscheduled[i] << " " << r.pod_reason[r.unscheduled[i]]; o << "\n";
   o << "STATS 32 eq_pods " << r.stats[8] << " reuse_exhausted " << r.stats[9] << " reuse_seeds " << r.stats[10] << " reuse_hits " << r.stats[11] << " cyc_kind0 " << r.stats[27] << " cyc_kind1 " << r.stats[28] << " cyc_kind2 " << r.stats[29] << " n_kind1 " << r.stats[30] << " n_kind2 " << r.stats[31] << " p22 " << r.stats[22] << " p23 " << r.stats[23] << " p24 " << r.stats[24] << " p25 " << r.stats[25] << " p26 " << r.stats[26] << " cyc_pop " << r.stats[12] << " cyc_stage " << r.stats[13] << " cyc_scan " << r.stats[14] << " cyc_evalout " << r.stats[15] << " cyc_full " << r.stats[16]
     << " cyc_commit " << r.stats[17] << " cyc_order " << r.stats[18] << " cyc_new " << r.stats[19] << " scan_chunks " << r.stats[21]
     << " queue_pops " << r.stats[KS_STAT_POPS] << " relaxations " << r.stats[KS_STAT_RELAX] << " full_checks " << r.stats[KS_STAT_FULLCHECKS] << " full_fails " << r.stats[KS_STAT_FULLFAILS]

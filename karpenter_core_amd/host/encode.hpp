@@ -52,7 +52,7 @@ struct Encoded {
   template <class T> struct RawBuf { std::unique_ptr<T[]> p; void resize(size_t n) { p.reset(new T[n ? n : 1]); } T* data() const { return p.get(); } };
   struct ResultBuf {
     RawBuf<int32_t> pod_node, pod_stage, pod_seq, unscheduled, node_tmpl, node_gt, node_lt, node_it_state;
-    RawBuf<uint64_t> node_types, node_mask; RawBuf<int64_t> node_requests; RawBuf<uint32_t> node_requests_present, node_present, node_complement;
+    RawBuf<uint64_t> node_types, node_mask; RawBuf<int64_t> node_requests; RawBuf<uint32_t> node_requests_present, node_present, node_complement, pod_reason;
     ks_result r{};
   };
   std::unique_ptr<ResultBuf> make_result() const;

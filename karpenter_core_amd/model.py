@@ -440,6 +440,8 @@ class SolveResult:
     unscheduled: List[int]                # q.List() at exit (queue order)
     final_stage: List[int]                # relaxation stage each pod ended at
     stats: Dict[str, int] = field(default_factory=dict)
+    reasons: Dict[int, int] = field(default_factory=dict)   # unscheduled pod -> why its last add() failed: 4 bits per provisioner in weight order
+                                                            # (REASON_*; scheduler.go:193-217 collects one error per provisioner)
 
     def canonical(self) -> dict:
         """Comparable structure (bit-identical parity means these compare equal)."""
@@ -463,6 +465,18 @@ class SolveResult:
         }
 
 
+# Why a provisioner could not take the pod (one 4-bit code per provisioner, weight order): the step of scheduler.add / Node.Add that refused it.
+REASON_NONE, REASON_LIMITS, REASON_TAINTS, REASON_HOST_PORTS, REASON_REQUIREMENTS, REASON_TOPOLOGY, REASON_TOPOLOGY_REQUIREMENTS, REASON_NO_INSTANCE_TYPE = range(8)
+REASON_TEXT = {REASON_LIMITS: "all available instance types exceed provisioner limits", REASON_TAINTS: "did not tolerate a taint",
+               REASON_HOST_PORTS: "host port conflict", REASON_REQUIREMENTS: "incompatible requirements",
+               REASON_TOPOLOGY: "unsatisfiable topology constraint", REASON_TOPOLOGY_REQUIREMENTS: "incompatible requirements (topology)",
+               REASON_NO_INSTANCE_TYPE: "no instance type satisfied resources and requirements"}
+
+
+def reason_codes(packed: int, n_provisioners: int) -> List[int]:
+    return [(packed >> (4 * m)) & 15 for m in range(min(n_provisioners, 8))]
+
+
 def parse_result(text: str) -> SolveResult:
     """Parse the KSR1 result text emitted by both the oracle and the host library.
 
@@ -473,6 +487,7 @@ def parse_result(text: str) -> SolveResult:
       ENODE name npods idx*
       UNSCHEDULED n idx*
       STAGES n stage*
+      REASONS n {pod code}*                 (optional)
       STATS n {name value}*
       END
     """
@@ -522,13 +537,19 @@ def parse_result(text: str) -> SolveResult:
     unscheduled = [int(nxt()) for _ in range(int(nxt()))]
     expect("STAGES")
     stages = [int(nxt()) for _ in range(int(nxt()))]
+    reasons = {}
+    if toks[pos] == "REASONS":
+        nxt()
+        for _ in range(int(nxt())):
+            k = int(nxt())
+            reasons[k] = int(nxt())
     expect("STATS")
     stats = {}
     for _ in range(int(nxt())):
         k = nxt()
         stats[k] = int(nxt())
     expect("END")
-    return SolveResult(new_nodes, existing, unscheduled, stages, stats)
+    return SolveResult(new_nodes, existing, unscheduled, stages, stats, reasons)
 
 
 # ---------------------------------------------------------------------------------------------

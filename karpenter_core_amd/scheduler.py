@@ -69,6 +69,8 @@ def libs():
         kh.ksh_solve_from_pods.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_double)]
         kh.ksh_result_text.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
         kh.ksh_result_summary.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+        kh.ksh_open_whatifs_parsed.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
+                                               ctypes.POINTER(ctypes.c_int32), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
         kh.ksh_fingerprint.argtypes = [ctypes.c_void_p]
         kh.ksh_fingerprint.restype = ctypes.c_uint64
         kh.ksh_free.argtypes = [ctypes.c_void_p]
@@ -201,15 +203,14 @@ def solve_from_pods(parsed: ParsedProblem, device: int = 0, stats: bool = False,
     return fp, dict(zip(TIMING_KEYS, [float(x) for x in ms]))
 
 
-def open_whatifs(snapshot: Problem, pod_node: Sequence[int], candidate_sets: Sequence[Sequence[int]], threads: int = 0) -> List[FlatProblem]:
+def open_whatifs(snapshot, pod_node: Sequence[int], candidate_sets: Sequence[Sequence[int]], threads: int = 0) -> List[FlatProblem]:
     """Flatten N consolidation what-ifs over one cluster snapshot natively (simulateScheduling, deprovisioning/helpers.go:42-115):
-    `snapshot` lists every state node and, as its pod batch, every bound pod (full spec); pod_node[i] = node index of pod i.
-    What-if w removes candidate_sets[w] from the state nodes and makes their pods (candidate order, then pod order) the pending
-    batch.  The snapshot is serialised and parsed once; the per-what-if NewScheduler/NewTopology flattening runs on `threads`
-    host threads (0 = all cores)."""
+    `snapshot` (a `Problem`, or a `ParsedProblem` already held as objects) lists every state node and, as its pod batch, every bound pod
+    (full spec); pod_node[i] = node index of pod i.  What-if w removes candidate_sets[w] from the state nodes and makes their pods
+    (candidate order, then pod order) the pending batch.  The snapshot is flattened ONCE; the per-what-if part (its pods' classes, queue and
+    topology groups, remainingResources) runs on `threads` host threads (0 = all usable cores)."""
     kh = libs()[1]
     n = len(candidate_sets)
-    text = snapshot.to_ksp().encode()
     off = [0]
     for cs in candidate_sets:
         off.append(off[-1] + len(cs))
@@ -218,7 +219,11 @@ def open_whatifs(snapshot: Problem, pod_node: Sequence[int], candidate_sets: Seq
     c_cand = (ctypes.c_uint32 * max(1, len(flat)))(*flat)
     c_pn = (ctypes.c_int32 * max(1, len(pod_node)))(*[int(x) for x in pod_node])
     hs = (ctypes.c_void_p * max(1, n))()
-    rc = kh.ksh_open_whatifs(text, len(text), 0, n, c_off, c_cand, c_pn, threads, hs)
+    if isinstance(snapshot, ParsedProblem):
+        rc = kh.ksh_open_whatifs_parsed(snapshot._p, 0, n, c_off, c_cand, c_pn, threads, hs)
+    else:
+        text = snapshot.to_ksp().encode()
+        rc = kh.ksh_open_whatifs(text, len(text), 0, n, c_off, c_cand, c_pn, threads, hs)
     if rc != KS_OK:
         raise KSolveError(rc, kh.ksh_last_error().decode())
     return [FlatProblem(None, _handle=ctypes.c_void_p(hs[i])) for i in range(n)]

@@ -586,7 +586,7 @@ static bool it_has_offering(const IType& it, const Reqs& reqs, Sym zoneKey, Sym 
   return false;
 }
 
-struct PodState { ksp::Pod spec; int index; int stage = 0; };
+struct PodState { ksp::Pod spec; int index; int stage = 0; uint32_t reasons = 0; };   // reasons: why the last add() failed, 4 bits per template (scheduler.go:193-217)
 
 struct Node {   // scheduling.Node, node.go:34-107
   const MachineTemplate* tmpl; Reqs requirements; std::vector<const IType*> options; ResList requests;
@@ -636,22 +636,25 @@ struct Scheduler {
   }
 
   // ---- Node.Add, node.go:62-107 ----
+  // which step of Node.Add refused the pod (node.go:62-107), for the per-pod failure reasons the boundary reports:
+  // 2 taints, 3 host ports, 4 incompatible requirements, 5 unsatisfiable topology, 6 topology requirements incompatible, 7 no instance type
+  int fail_step = 0;
   bool node_add(Node& m, PodState& ps) {
     st.attempts++;
     ksp::Pod& pod = ps.spec;
-    if (!taints_tolerates(m.tmpl->taints, pod)) return false;
-    if (!m.ports.validate(pod, nullptr)) return false;
+    if (!taints_tolerates(m.tmpl->taints, pod)) { fail_step = 2; return false; }
+    if (!m.ports.validate(pod, nullptr)) { fail_step = 3; return false; }
     Reqs nodeReqs = m.requirements;
     Reqs podReqs = new_pod_requirements(pod);
-    if (!reqs_compatible(cx, nodeReqs, podReqs)) return false;
+    if (!reqs_compatible(cx, nodeReqs, podReqs)) { fail_step = 4; return false; }
     nodeReqs.add_all(podReqs);
     Reqs topoReqs;
-    if (!topo.add_requirements(podReqs, nodeReqs, pod, &topoReqs)) return false;
-    if (!reqs_compatible(cx, nodeReqs, topoReqs)) return false;
+    if (!topo.add_requirements(podReqs, nodeReqs, pod, &topoReqs)) { fail_step = 5; return false; }
+    if (!reqs_compatible(cx, nodeReqs, topoReqs)) { fail_step = 6; return false; }
     nodeReqs.add_all(topoReqs);
     ResList requests = res_merge(m.requests, requests_for_pods({&pod}));
     auto its = filter_types(m.options, nodeReqs, requests);
-    if (its.empty()) return false;
+    if (its.empty()) { fail_step = 7; return false; }
     m.pods.push_back(ps.index); m.options = its; m.requests = requests; m.requirements = nodeReqs;
     topo.record(pod, nodeReqs); m.ports.add(pod);
     return true;
@@ -709,16 +712,19 @@ struct Scheduler {
 
   // ---- Scheduler.add, scheduler.go:174-219 ----
   bool add(PodState& ps) {
-    for (auto& n : existing) if (existing_add(*n, ps)) return true;
+    for (auto& n : existing) if (existing_add(*n, ps)) { ps.reasons = 0; return true; }
     // sort.Slice(newNodes, len(Pods) asc) -- canonical: stable
     std::stable_sort(new_nodes.begin(), new_nodes.end(), [](const std::unique_ptr<Node>& a, const std::unique_ptr<Node>& b) { return a->pods.size() < b->pods.size(); });
-    for (auto& n : new_nodes) if (node_add(*n, ps)) return true;
+    for (auto& n : new_nodes) if (node_add(*n, ps)) { ps.reasons = 0; return true; }
+    ps.reasons = 0; uint32_t ti = 0;
     for (auto& t : templates) {
+      const uint32_t shift = 4 * ti++;
       std::vector<const IType*> its = instance_types[t.prov->name];
       auto rem = remaining.find(t.prov->name);
-      if (rem != remaining.end()) { its = filter_by_remaining(instance_types[t.prov->name], rem->second); if (its.empty()) continue; }
+      if (rem != remaining.end()) { its = filter_by_remaining(instance_types[t.prov->name], rem->second); if (its.empty()) { if (shift < 32) ps.reasons |= 1u << shift; continue; } }   // "all available instance types exceed provisioner limits"
       auto node = new_node(t, daemon_overhead[&t], its);
-      if (!node_add(*node, ps)) continue;
+      if (!node_add(*node, ps)) { if (shift < 32) ps.reasons |= (uint32_t)fail_step << shift; continue; }                                        // "incompatible with provisioner ..., <step>"
+      ps.reasons = 0;
       node->seq = new_nodes.size();
       new_nodes.push_back(std::move(node));
       // NB scheduler.go:215 assigns remainingResources[name] even when the provisioner has no limits
@@ -995,6 +1001,7 @@ static std::string result_text(Scheduler& s, double solve_seconds) {
   for (auto& e : s.existing) { o << "ENODE " << tokq(e->sn->name) << " " << e->pods.size(); for (int p : e->pods) o << " " << p; o << "\n"; }
   o << "UNSCHEDULED " << s.unscheduled.size(); for (int p : s.unscheduled) o << " " << p; o << "\n";
   o << "STAGES " << s.pods.size(); for (auto& p : s.pods) o << " " << p.stage; o << "\n";
+  o << "REASONS " << s.unscheduled.size(); for (int p : s.unscheduled) o << " " << p << " " << s.pods[p].reasons; o << "\n";
   o << "STATS 6 attempts " << s.st.attempts << " types_scanned " << s.st.types_scanned << " domains_scanned " << s.st.domains_scanned
     << " relaxations " << s.st.relaxations << " queue_pops " << s.st.queue_pops << " solve_ns " << (int64_t)(solve_seconds * 1e9) << "\n";
   o << "END\n";

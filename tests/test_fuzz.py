@@ -83,6 +83,8 @@ def test_speculation_rules_hold(seed):
 
 def test_fuzz_cases_are_varied():
     res = [O.solve(fuzz_problem(s)) for s in SEEDS]
+    codes = {(r.reasons[p] >> (4 * m)) & 15 for r in res for p in r.reasons for m in range(4)}
+    assert {2, 4, 7} <= codes, codes            # taints, incompatible requirements, no instance type all occur as failure reasons
     assert any(r.unscheduled for r in res) and any(r.existing for r in res) and any(len(r.new_nodes) > 3 for r in res)
     assert any(max(r.final_stage, default=0) > 0 for r in res)          # some pod had to relax a preference
 
@@ -92,7 +94,11 @@ def test_fuzz_cases_are_varied():
 def test_gpu_matches_oracle(seed, monkeypatch):
     from karpenter_core_amd import scheduler as S
     p = fuzz_problem(seed)
-    want = O.solve(p).canonical()
-    assert S.solve_problem(p).canonical() == want
+    ref = O.solve(p)
+    want = ref.canonical()
+    got = S.solve_problem(p)
+    assert got.canonical() == want
+    assert got.reasons == ref.reasons           # per-pod failure reasons (ks_result.pod_reason): one KS_WHY_* per provisioner, like scheduler.go:193-217
     monkeypatch.setenv("KS_ONE_WAVE", "1")
-    assert S.solve_problem(p).canonical() == want
+    got = S.solve_problem(p)
+    assert got.canonical() == want and got.reasons == ref.reasons

@@ -581,3 +581,43 @@ def test_taints(backend):
             mkpod(tolerations=[Toleration(operator="Exists")])]                      # T:2243 tolerate everything
     sim.provision(pods)
     assert [sim.scheduled(p) is not None for p in pods] == [False, True, True, False, True]
+
+
+# ---------------- per-pod failure reasons (scheduler.go:135-172 recordSchedulingResults, one error per provisioner: :193-217) ----------------
+def test_failure_reasons(backend):
+    """What the reference reports through `errors[pod]` -- for each provisioner, the step of scheduler.add / Node.Add that refused the pod --
+    comes back as KS_WHY_* codes (ks_result.pod_reason; 4 bits per provisioner in weight order)."""
+    from karpenter_core_amd.model import (REASON_LIMITS, REASON_NO_INSTANCE_TYPE, REASON_REQUIREMENTS, REASON_TAINTS, REASON_TOPOLOGY, reason_codes)
+
+    def why(sim, pod, nprov=1):
+        res = sim.last
+        idx = [i for i, q in enumerate(sim.last_pods) if q.uid == pod.uid][0]
+        assert idx in res.unscheduled
+        return reason_codes(res.reasons[idx], nprov)
+
+    # "all available instance types exceed provisioner limits" (scheduler.go:198-201; provisioning/suite_test.go:238-356)
+    sim = ClusterSim(backend, provisioners=[default_prov(limits={"cpu": "0"})])
+    p = mkpod()
+    sim.last_pods = [p]; sim.provision([p])
+    assert why(sim, p) == [REASON_LIMITS]
+    # taints (node.go:64; topology_test.go:2209-2257) on the first provisioner, a clean second one that is too small (node.go:94-98)
+    tainted = fake.provisioner("tainted", 0, weight=10, taints=[Taint("dedicated", "x", "NoSchedule")], discovery_label=True)
+    sim = ClusterSim(backend, provisioners=[tainted, default_prov()])
+    p = mkpod(requests={"cpu": "10000"})
+    sim.last_pods = [p]; sim.provision([p])
+    assert why(sim, p, 2) == [REASON_TAINTS, REASON_NO_INSTANCE_TYPE]
+    # incompatible requirements (node.go:77; suite_test.go:113-553): the provisioner is pinned to another zone; a zone nobody offers gets
+    # past Compatible (the key is well known and the provisioner does not constrain it) and fails at the instance types (node.go:94-98)
+    sim = ClusterSim(backend, provisioners=[default_prov(requirements=[Expr(LABEL_ZONE, "In", ["test-zone-1"])])])
+    p = mkpod(node_selector={LABEL_ZONE: "test-zone-2"})
+    sim.last_pods = [p]; sim.provision([p])
+    assert why(sim, p) == [REASON_REQUIREMENTS]
+    sim = ClusterSim(backend)
+    p = mkpod(node_selector={LABEL_ZONE: "unknown-zone"})
+    sim.last_pods = [p]; sim.provision([p])
+    assert why(sim, p) == [REASON_NO_INSTANCE_TYPE]
+    # unsatisfiable topology constraint (node.go:83; topology_test.go:35-50)
+    sim = ClusterSim(backend)
+    p = mkpod(labels=LABELS, spread=spread("unknown"))
+    sim.last_pods = [p]; sim.provision([p])
+    assert why(sim, p) == [REASON_TOPOLOGY]
