@@ -72,6 +72,12 @@ int ksh_open_whatifs(const char* snapshot_text, size_t len, uint32_t flags, uint
 int ksh_price_filter(void** handles, uint32_t n, const uint32_t* node, const double* max_price, const uint32_t* spot_only /* or NULL */,
                      uint64_t* out_masks, uint32_t stride_words, uint32_t* out_counts);
 
+/* launch-time pick of the in-memory provider (fake/cloudprovider.go:79-84) / instanceTypesAreSubset (helpers.go:118-122), on device-resident results */
+int ksh_launch_pick(void** handles, uint32_t n, const uint32_t* node, int32_t* out_type, int32_t* out_zone, int32_t* out_ct, double* out_price);
+const char* ksh_key_value(void* handle, int which /* 0 zone, 1 capacity-type */, int32_t value_id);
+int ksh_types_subset(void** handles, uint32_t n, const uint32_t* node, const uint64_t* lhs, uint32_t stride_words, uint32_t* out);
+int ksh_open_whatifs_parsed(void* parsed_snapshot, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand, const int32_t* pod_node, uint32_t nthreads, void** out_handles);
+
 #ifdef __cplusplus
 }
 #endif

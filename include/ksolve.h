@@ -105,6 +105,7 @@ typedef struct ks_problem {
   const uint64_t* it_offer;      /* [T]    available (zone,capacity-type) pairs, types.go:106-128 */
   const double* it_price;        /* [T*NP] Offering.Price of available pair p (NP = key_nvalues[key_zone] * n_ct; the highest one if a pair is offered
                                     twice): read by the consolidation price stage only (ks_price_filter_dev); may be NULL */
+  const double* it_price_lo;     /* [T*NP] the LOWEST Offering.Price of available pair p (Offerings.Cheapest, types.go:141): read by ks_launch_pick_dev; NULL -> it_price */
   int32_t ct_spot, ct_ondemand;  /* value ids of "spot" / "on-demand" in the capacity-type key's universe, or -1 */
   /* instance-type key lattice */
   const uint16_t* its_inter; /* [S*SC] node state after intersecting node state a with pod-side req b  */
@@ -250,6 +251,19 @@ int ks_feasibility_grid(ks_dev_problem* d, uint64_t* out_grid, float* kernel_ms)
  * spot_only may be NULL.  One launch for the whole batch. */
 int ks_price_filter_dev(ks_dev_problem* const* ds, uint32_t n, const uint32_t* node, const double* max_price,
                         const uint32_t* spot_only, uint64_t* const* out_types, uint32_t* out_counts);
+
+/* Launch-time instance-type pick of the reference's in-memory provider (cloudprovider/fake/cloudprovider.go:79-84: order the machine's
+ * InstanceTypeOptions by `Offerings.Available().Requirements(reqs).Cheapest().Price`, types.go:126-145, and take the first): for problem i,
+ * of new node node[i]'s InstanceTypeOptions (as left by the last ks_solve*_dev) the type whose cheapest available offering under the node's zone /
+ * capacity-type requirements is cheapest -- a wave-wide arg-min over the surviving-type mask.  Ties go to the lowest instance-type index (the
+ * reference's sort.Slice leaves them to pdqsort).  out_type[i] = -1 when no option has a compatible available offering; out_pair[i] is the
+ * (zone, capacity-type) pair of that cheapest offering (zone_value * n_ct + ct_value), out_price[i] its price.  One launch for the batch. */
+int ks_launch_pick_dev(ks_dev_problem* const* ds, uint32_t n, const uint32_t* node, int32_t* out_type, int32_t* out_pair, double* out_price);
+
+/* instanceTypesAreSubset (deprovisioning/helpers.go:118-122; consolidation.go:177, validation.go:164): is lhs[i] (a host-held type mask of
+ * ceil(T/64) words, row stride `stride_words`, e.g. a command's price-filtered replacement options) a subset of new node node[i]'s
+ * InstanceTypeOptions on the device?  out[i] = 1 / 0. */
+int ks_types_subset_dev(ks_dev_problem* const* ds, uint32_t n, const uint32_t* node, const uint64_t* lhs, uint32_t stride_words, uint32_t* out);
 
 /* ---- requirement-algebra probes (one key); the same device functions the kernels use ---- */
 typedef struct ks_req1 { uint64_t mask; int32_t gt, lt; uint8_t present, complement; } ks_req1;

@@ -80,7 +80,7 @@ struct DevProb {
   u32 P, C, T, TW, M, E, K, R, G, GH, S, SC, NMAX, flags, n_topologies, ge_max;   // ge_max: largest ge_cnt[r]
   u32 wellknown_mask; const u32* key_nvalues; const i32* value_int; i32 key_zone, key_ct; u32 n_ct;
   const u32* it_present; const u32* it_complement; const u64* it_mask; const i64* it_alloc; const i64* it_cap; const u64* it_offer;
-  const double* it_price; i32 ct_spot, ct_ondemand;     // consolidation price stage (ks_price_filter)
+  const double* it_price; const double* it_price_lo; i32 ct_spot, ct_ondemand;     // consolidation price stage (ks_price_filter), launch pick (ks_launch_pick)
   const u16* its_inter; const u8* its_fail; const u8* its_nidne; const u64* its_types;
   ReqSetsD tmpl; const u64* tmpl_taints; const i64* tmpl_daemon; const u32* tmpl_daemon_present; const u64* tmpl_types;
   const u32* tmpl_limit_present; const i64* tmpl_remaining;
@@ -2179,6 +2179,8 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   TRY(dev_copy(d, p->it_cap, (size_t)R * T, &h.it_cap)); TRY(dev_copy(d, p->it_offer, T, &h.it_offer));
   h.it_price = nullptr; h.ct_spot = p->ct_spot; h.ct_ondemand = p->ct_ondemand;
   if (p->it_price && p->key_zone >= 0 && p->key_ct >= 0) TRY(dev_copy(d, p->it_price, (size_t)T * p->key_nvalues[p->key_zone] * p->n_ct, &h.it_price));
+  h.it_price_lo = h.it_price;
+  if (p->it_price_lo && p->key_zone >= 0 && p->key_ct >= 0) TRY(dev_copy(d, p->it_price_lo, (size_t)T * p->key_nvalues[p->key_zone] * p->n_ct, &h.it_price_lo));
   TRY(dev_copy(d, p->its_inter, (size_t)h.S * h.SC, &h.its_inter)); TRY(dev_copy(d, p->its_fail, (size_t)h.S * h.SC, &h.its_fail));
   TRY(dev_copy(d, p->its_nidne, h.S, &h.its_nidne)); TRY(dev_copy(d, p->its_types, (size_t)h.S * TW, &h.its_types));
   TRY(copy_reqsets(d, p->tmpl, M, K, &h.tmpl)); TRY(dev_copy(d, p->tmpl_taints, M, &h.tmpl_taints));
@@ -2520,6 +2522,88 @@ extern "C" int ks_price_filter_dev(ks_dev_problem* const* ds, uint32_t n, const 
   HIPCHK(hipMemcpyAsync(out_counts, dcnt, n * sizeof(u32), hipMemcpyDeviceToHost, ds[0]->stream));
   HIPCHK(hipStreamSynchronize(ds[0]->stream)); HIPCHK(hipGetLastError());
   for (u32 i = 0; i < n; ++i) memcpy(out_types[i], host.data() + off[i], ds[i]->h.TW * sizeof(u64));
+  return KS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launch-time pick (fake/cloudprovider.go:79-84) and instanceTypesAreSubset (helpers.go:118-122) on device-resident results.
+// ks_launch_pick: one wave per problem; lane w walks word w (+64, ...) of the node's InstanceTypeOptions, keeps the type whose cheapest
+// allowed available offering is cheapest, then the wave reduces (price, type index) lexicographically: the first cheapest in index order wins.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ks_launch_pick(const DevProb* probs, const DevState* states, const u32* node, i32* out_type, i32* out_pair, double* out_price) {
+  const DevProb& P = probs[blockIdx.x]; const DevState& S = states[blockIdx.x];
+  const u32 j = node[blockIdx.x]; const int lane = threadIdx.x;
+  const u32 pres = S.o_present[j], comp = S.o_complement[j];
+  const KReq zq = ((pres >> P.key_zone) & 1u) ? load_req(pres, comp, S.o_mask + (size_t)j * P.K, S.o_gt + (size_t)j * P.K, S.o_lt + (size_t)j * P.K, P.key_zone) : kreq_exists();
+  const KReq cq = ((pres >> P.key_ct) & 1u) ? load_req(pres, comp, S.o_mask + (size_t)j * P.K, S.o_gt + (size_t)j * P.K, S.o_lt + (size_t)j * P.K, P.key_ct) : kreq_exists();
+  const u64 allowZ = kreq_has_mask(zq, P.value_int + P.key_zone * 64, P.key_nvalues[P.key_zone]);
+  const u64 allowC = kreq_has_mask(cq, P.value_int + P.key_ct * 64, P.key_nvalues[P.key_ct]) & (P.n_ct >= 64 ? ~0ull : ((1ull << P.n_ct) - 1ull));
+  const u32 NP = P.key_nvalues[P.key_zone] * P.n_ct;
+  u64 pairs = 0;
+  for (u64 zz = allowZ; zz; zz &= zz - 1) { const u32 z = (u32)__builtin_ctzll(zz); if (z * P.n_ct >= 64) break; pairs |= allowC << (z * P.n_ct); }
+  double best = 1.7976931348623157e308; u32 bt = 0xFFFFFFFFu, bp = 0;
+  for (u32 w = lane; w < P.TW; w += 64) {
+    for (u64 bits = S.n_alive[(size_t)j * P.TW + w]; bits; bits &= bits - 1) {
+      const u32 t = w * 64 + (u32)__builtin_ctzll(bits);
+      for (u64 of = P.it_offer[t] & pairs; of; of &= of - 1) {          // Offerings.Available().Requirements(reqs)
+        const u32 pr = (u32)__builtin_ctzll(of); const double c = P.it_price_lo[(size_t)t * NP + pr];
+        if (c < best || (c == best && t < bt)) { best = c; bt = t; bp = pr; }
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {                               // lexicographic (price, type) minimum over the wave
+    const double ob = __shfl_xor(best, off); const u32 ot = (u32)__shfl_xor((int)bt, off), op = (u32)__shfl_xor((int)bp, off);
+    if (ob < best || (ob == best && ot < bt)) { best = ob; bt = ot; bp = op; }
+  }
+  if (lane == 0) { out_type[blockIdx.x] = bt == 0xFFFFFFFFu ? -1 : (i32)bt; out_pair[blockIdx.x] = bt == 0xFFFFFFFFu ? -1 : (i32)bp; out_price[blockIdx.x] = best; }
+}
+__global__ __launch_bounds__(64) void ks_types_subset(const DevProb* probs, const DevState* states, const u32* node, const u64* lhs, u32 stride, u32* out) {
+  const DevProb& P = probs[blockIdx.x]; const DevState& S = states[blockIdx.x]; const u32 j = node[blockIdx.x]; const int lane = threadIdx.x;
+  bool bad = false;
+  for (u32 w = lane; w < P.TW; w += 64) if (lhs[(size_t)blockIdx.x * stride + w] & ~S.n_alive[(size_t)j * P.TW + w]) bad = true;
+  const u64 b = ballot64(bad);
+  if (lane == 0) out[blockIdx.x] = b ? 0u : 1u;
+}
+static int batch_descriptors(ks_dev_problem* const* ds, u32 n, const u32* node, bool need_prices, TmpDev& t_dp, TmpDev& t_dsv, TmpDev& t_node) {
+  if (!ds || !node) return fail(KS_ERR_INVALID, "null argument");
+  const int device = ds[0]->device;
+  std::vector<DevProb> hp(n); std::vector<DevState> hs(n);
+  for (u32 i = 0; i < n; ++i) {
+    if (ds[i]->device != device) return fail(KS_ERR_INVALID, "batch spans devices");
+    if (need_prices && (!ds[i]->h.it_price || ds[i]->h.key_zone < 0 || ds[i]->h.key_ct < 0)) return fail(KS_ERR_INVALID, "problem carries no offering prices");
+    if (node[i] >= ds[i]->h.NMAX) return fail(KS_ERR_INVALID, "node index out of range");
+    hp[i] = ds[i]->h; hs[i] = ds[i]->hs;
+  }
+  TRY(t_dp.alloc(n * sizeof(DevProb))); TRY(t_dsv.alloc(n * sizeof(DevState))); TRY(t_node.alloc(n * sizeof(u32)));
+  HIPCHK(hipMemcpy(t_dp.p, hp.data(), n * sizeof(DevProb), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(t_dsv.p, hs.data(), n * sizeof(DevState), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(t_node.p, node, n * sizeof(u32), hipMemcpyHostToDevice));
+  return KS_OK;
+}
+extern "C" int ks_launch_pick_dev(ks_dev_problem* const* ds, uint32_t n, const uint32_t* node, int32_t* out_type, int32_t* out_pair, double* out_price) {
+  if (!n) return KS_OK;
+  if (!ds || !out_type || !out_pair || !out_price) return fail(KS_ERR_INVALID, "null argument");
+  const int device = ds[0]->device; HIPCHK(hipSetDevice(device));
+  TmpDev t_dp(device), t_dsv(device), t_node(device), t_type(device), t_pair(device), t_price(device);
+  TRY(batch_descriptors(ds, n, node, true, t_dp, t_dsv, t_node));
+  TRY(t_type.alloc(n * sizeof(i32))); TRY(t_pair.alloc(n * sizeof(i32))); TRY(t_price.alloc(n * sizeof(double)));
+  hipLaunchKernelGGL(ks_launch_pick, dim3(n), dim3(64), 0, ds[0]->stream, t_dp.as<DevProb>(), t_dsv.as<DevState>(), t_node.as<u32>(), t_type.as<i32>(), t_pair.as<i32>(), t_price.as<double>());
+  HIPCHK(hipMemcpyAsync(out_type, t_type.p, n * sizeof(i32), hipMemcpyDeviceToHost, ds[0]->stream)); HIPCHK(hipMemcpyAsync(out_pair, t_pair.p, n * sizeof(i32), hipMemcpyDeviceToHost, ds[0]->stream));
+  HIPCHK(hipMemcpyAsync(out_price, t_price.p, n * sizeof(double), hipMemcpyDeviceToHost, ds[0]->stream));
+  HIPCHK(hipStreamSynchronize(ds[0]->stream)); HIPCHK(hipGetLastError());
+  return KS_OK;
+}
+extern "C" int ks_types_subset_dev(ks_dev_problem* const* ds, uint32_t n, const uint32_t* node, const uint64_t* lhs, uint32_t stride_words, uint32_t* out) {
+  if (!n) return KS_OK;
+  if (!ds || !lhs || !out) return fail(KS_ERR_INVALID, "null argument");
+  const int device = ds[0]->device; HIPCHK(hipSetDevice(device));
+  for (u32 i = 0; i < n; ++i) if (ds[i]->h.TW > stride_words) return fail(KS_ERR_INVALID, "mask row too short");
+  TmpDev t_dp(device), t_dsv(device), t_node(device), t_lhs(device), t_out(device);
+  TRY(batch_descriptors(ds, n, node, false, t_dp, t_dsv, t_node));
+  TRY(t_lhs.alloc((size_t)n * stride_words * sizeof(u64))); TRY(t_out.alloc(n * sizeof(u32)));
+  HIPCHK(hipMemcpy(t_lhs.p, lhs, (size_t)n * stride_words * sizeof(u64), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ks_types_subset, dim3(n), dim3(64), 0, ds[0]->stream, t_dp.as<DevProb>(), t_dsv.as<DevState>(), t_node.as<u32>(), t_lhs.as<u64>(), stride_words, t_out.as<u32>());
+  HIPCHK(hipMemcpyAsync(out, t_out.p, n * sizeof(u32), hipMemcpyDeviceToHost, ds[0]->stream));
+  HIPCHK(hipStreamSynchronize(ds[0]->stream)); HIPCHK(hipGetLastError());
   return KS_OK;
 }
 

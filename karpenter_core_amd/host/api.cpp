@@ -209,6 +209,31 @@ int ksh_price_filter(void** hv, uint32_t n, const uint32_t* node, const double* 
   return KS_OK;
 }
 
+// Launch-time pick of the in-memory provider (fake/cloudprovider.go:79-84) and instanceTypesAreSubset (helpers.go:118-122) on results that are
+// still on the device.  launch pick: out_type = instance-type index (into the problem's catalogue) or -1, out_zone / out_ct = value ids in the zone /
+// capacity-type universes (ksh_key_value resolves them), out_price.
+int ksh_launch_pick(void** hv, uint32_t n, const uint32_t* node, int32_t* out_type, int32_t* out_zone, int32_t* out_ct, double* out_price) {
+  std::vector<ks_dev_problem*> ds(n); std::vector<int32_t> pair(n);
+  for (uint32_t i = 0; i < n; ++i) { Handle* h = (Handle*)hv[i]; if (!h->dev) return set_err(KS_ERR_INVALID, "launch pick before solve"); ds[i] = h->dev; }
+  int rc = ks_launch_pick_dev(ds.data(), n, node, out_type, pair.data(), out_price);
+  if (rc != KS_OK) return set_err(rc, ks_last_error());
+  for (uint32_t i = 0; i < n; ++i) { const uint32_t nct = ((Handle*)hv[i])->enc->prob.n_ct; out_zone[i] = pair[i] < 0 ? -1 : pair[i] / (int32_t)nct; out_ct[i] = pair[i] < 0 ? -1 : pair[i] % (int32_t)nct; }
+  return KS_OK;
+}
+// value `v` of the zone (which = 0) or capacity-type (which = 1) universe of the handle's problem; NULL when out of range (owned by the handle)
+const char* ksh_key_value(void* hv, int which, int32_t v) {
+  const ksh::Encoded& E = *((Handle*)hv)->enc; const int32_t k = which == 0 ? E.prob.key_zone : E.prob.key_ct;
+  if (k < 0 || v < 0 || (size_t)v >= E.key_values[k].size()) return nullptr;
+  return E.key_values[k][v].c_str();
+}
+int ksh_types_subset(void** hv, uint32_t n, const uint32_t* node, const uint64_t* lhs, uint32_t stride_words, uint32_t* out) {
+  std::vector<ks_dev_problem*> ds(n);
+  for (uint32_t i = 0; i < n; ++i) { Handle* h = (Handle*)hv[i]; if (!h->dev) return set_err(KS_ERR_INVALID, "subset test before solve"); ds[i] = h->dev; }
+  int rc = ks_types_subset_dev(ds.data(), n, node, lhs, stride_words, out);
+  if (rc != KS_OK) return set_err(rc, ks_last_error());
+  return KS_OK;
+}
+
 // Static feasibility grid [M][C][TW]; `out` may be NULL (timing only).
 int ksh_grid(void* hv, uint64_t* out, float* kernel_ms) {
   Handle* h = (Handle*)hv; int rc = h->dev ? KS_OK : ksh_upload(hv, ks_current_device()); if (rc != KS_OK) return rc;

@@ -371,7 +371,7 @@ struct Builder {
     const int kz = key_id.at(ksp::kZone), kc = key_id.at(ksp::kCapacityType);
     const uint32_t nct = E.key_nvalues[kc];
     if ((uint64_t)E.key_nvalues[kz] * nct > 64 || nct > 32) throw Unsupported("more than 64 zone x capacity-type pairs");
-    const uint32_t NP = (uint32_t)E.key_nvalues[kz] * nct; E.it_price.assign((size_t)T * NP, -1.0);
+    const uint32_t NP = (uint32_t)E.key_nvalues[kz] * nct; E.it_price.assign((size_t)T * NP, -1.0); E.it_price_lo.assign((size_t)T * NP, 1.7976931348623157e308);
     it_requirements.resize(T);
     for (uint32_t t = 0; t < T; ++t) {
       const auto& it = pr.instance_types[t];
@@ -389,6 +389,7 @@ struct Builder {
         const uint32_t pair = value_id(kz, o.zone) * nct + value_id(kc, o.capacity_type);
         E.it_offer[t] |= 1ull << pair;
         double& pp = E.it_price[(size_t)t * NP + pair]; if (o.price > pp) pp = o.price;     // worstLaunchPrice takes the maximum (helpers.go:303,312)
+        double& pl = E.it_price_lo[(size_t)t * NP + pair]; if (o.price < pl) pl = o.price;  // Offerings.Cheapest the minimum (types.go:141)
       }
       ksp::ResList alloc = Subtract(it.capacity, it.overhead);   // Allocatable(), types.go:87-89
       for (auto& kv : alloc) E.it_alloc[(size_t)res_id.at(kv.first) * T + t] = kv.second;
@@ -460,7 +461,7 @@ struct Builder {
     toleratePreferNoSchedule = b.toleratePreferNoSchedule; K = b.K; R = b.R; T = b.T; TW = b.TW;
     it_reqs = b.it_reqs; it_state_id = b.it_state_id; it_cols = b.it_cols; it_col_id = b.it_col_id;
     E.key_names = B.key_names; E.key_values = B.key_values; E.res_names = B.res_names; E.key_nvalues = B.key_nvalues; E.value_int = B.value_int;
-    E.it_present = B.it_present; E.it_complement = B.it_complement; E.it_mask = B.it_mask; E.it_offer = B.it_offer; E.it_price = B.it_price; E.it_alloc = B.it_alloc; E.it_cap = B.it_cap;
+    E.it_present = B.it_present; E.it_complement = B.it_complement; E.it_mask = B.it_mask; E.it_offer = B.it_offer; E.it_price = B.it_price; E.it_price_lo = B.it_price_lo; E.it_alloc = B.it_alloc; E.it_cap = B.it_cap;
     E.templates = B.templates; E.tmpl = B.tmpl; E.tmpl_taints = B.tmpl_taints; E.tmpl_types = B.tmpl_types; E.tmpl_daemon = B.tmpl_daemon; E.tmpl_daemon_present = B.tmpl_daemon_present;
     E.tmpl_limit_present = B.tmpl_limit_present;
   }
@@ -818,7 +819,7 @@ struct Builder {
     p.max_new_nodes = p.P ? p.P : 1; p.flags = flags | ((pr.simulation_mode || base) ? KS_FLAG_SIMULATION : 0);
     p.wellknown_mask = 0; for (uint32_t k = 0; k < K; ++k) if (wellKnown.count(E.key_names[k])) p.wellknown_mask |= 1u << k;
     p.key_nvalues = E.key_nvalues.data(); p.value_int = E.value_int.data(); p.key_zone = key_id.at(ksp::kZone); p.key_ct = key_id.at(ksp::kCapacityType); p.n_ct = E.key_nvalues[p.key_ct];
-    p.it_present = E.it_present.data(); p.it_complement = E.it_complement.data(); p.it_mask = E.it_mask.data(); p.it_alloc = E.it_alloc.data(); p.it_cap = E.it_cap.data(); p.it_offer = E.it_offer.data(); p.it_price = E.it_price.data(); p.ct_spot = value_id(p.key_ct, "spot"); p.ct_ondemand = value_id(p.key_ct, "on-demand");
+    p.it_present = E.it_present.data(); p.it_complement = E.it_complement.data(); p.it_mask = E.it_mask.data(); p.it_alloc = E.it_alloc.data(); p.it_cap = E.it_cap.data(); p.it_offer = E.it_offer.data(); p.it_price = E.it_price.data(); p.it_price_lo = E.it_price_lo.data(); p.ct_spot = value_id(p.key_ct, "spot"); p.ct_ondemand = value_id(p.key_ct, "on-demand");
     p.its_inter = E.its_inter.data(); p.its_fail = E.its_fail.data(); p.its_nidne = E.its_nidne.data(); p.its_types = E.its_types.data();
     p.tmpl = E.tmpl.view(); p.tmpl_taints = E.tmpl_taints.data(); p.tmpl_daemon = E.tmpl_daemon.data(); p.tmpl_daemon_present = E.tmpl_daemon_present.data(); p.tmpl_types = E.tmpl_types.data();
     p.tmpl_limit_present = E.tmpl_limit_present.data(); p.tmpl_remaining = E.tmpl_remaining.data();

@@ -35,7 +35,7 @@ struct Encoded {
   std::vector<Requirement> it_states;                      // instance-type-key requirement per state (index 0 unused)
   // ---- flat storage behind ks_problem ----
   std::vector<uint32_t> key_nvalues; std::vector<int32_t> value_int;
-  std::vector<uint32_t> it_present, it_complement; std::vector<uint64_t> it_mask, it_offer; std::vector<double> it_price; std::vector<int64_t> it_alloc, it_cap;
+  std::vector<uint32_t> it_present, it_complement; std::vector<uint64_t> it_mask, it_offer; std::vector<double> it_price, it_price_lo; std::vector<int64_t> it_alloc, it_cap;
   std::vector<uint16_t> its_inter; std::vector<uint8_t> its_fail, its_nidne; std::vector<uint64_t> its_types;
   ReqSetsStore tmpl, en, cls, flt;
   std::vector<uint64_t> tmpl_taints, tmpl_types; std::vector<int64_t> tmpl_daemon, tmpl_remaining; std::vector<uint32_t> tmpl_daemon_present, tmpl_limit_present;

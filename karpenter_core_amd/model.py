@@ -295,6 +295,20 @@ class StateNode:
         return self.labels.get(LABEL_PROVISIONER, "") != ""
 
 
+TAINT_NODE_NOT_READY = "node.kubernetes.io/not-ready"
+TAINT_NODE_UNREACHABLE = "node.kubernetes.io/unreachable"
+
+
+def state_node_taints(node_taints: Sequence["Taint"], startup_taints: Sequence["Taint"] = (), initialized: bool = False, owned: bool = True) -> List["Taint"]:
+    """state.Node.Taints() (reference pkg/controllers/state/node.go:61-78) -- what a caller must put into `StateNode.taints`: the node's taints
+    minus the ephemeral not-ready / unreachable NoSchedule taints and, until the node is initialized (and only for nodes we own), minus the
+    provisioner's startup taints (a match needs key, value AND effect to agree)."""
+    ephemeral = [Taint(TAINT_NODE_NOT_READY, "", NO_SCHEDULE), Taint(TAINT_NODE_UNREACHABLE, "", NO_SCHEDULE)]
+    if not initialized and owned:
+        ephemeral += list(startup_taints)
+    return [t for t in node_taints if not any(e.key == t.key and e.value == t.value and e.effect == t.effect for e in ephemeral)]
+
+
 @dataclass
 class ClusterPod:
     """A pod already bound in the cluster, as seen by countDomains (topology.go:231-276) and

@@ -71,6 +71,12 @@ def libs():
         kh.ksh_result_summary.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         kh.ksh_open_whatifs_parsed.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
                                                ctypes.POINTER(ctypes.c_int32), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+        kh.ksh_launch_pick.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int32),
+                                       ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)]
+        kh.ksh_key_value.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int32]
+        kh.ksh_key_value.restype = ctypes.c_char_p
+        kh.ksh_types_subset.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32,
+                                        ctypes.POINTER(ctypes.c_uint32)]
         kh.ksh_fingerprint.argtypes = [ctypes.c_void_p]
         kh.ksh_fingerprint.restype = ctypes.c_uint64
         kh.ksh_free.argtypes = [ctypes.c_void_p]
@@ -289,6 +295,50 @@ def price_filter(flats: Sequence[FlatProblem], nodes: Sequence[int], max_prices:
         assert len(row) == counts[i]
         out.append(row)
     return out
+
+
+def launch_pick(flats: Sequence[FlatProblem], nodes: Sequence[int]):
+    """The launch-time instance-type pick of the reference's in-memory provider (cloudprovider/fake/cloudprovider.go:79-84) on the device, over
+    the results the last solve of `flats` left there: for flats[i]'s new node nodes[i], (instance-type index, zone, capacity type, price) of the
+    option whose cheapest available offering under the node's zone / capacity-type requirements is cheapest (ties: lowest type index), or None."""
+    kh = libs()[1]
+    n = len(flats)
+    if n == 0:
+        return []
+    hs = (ctypes.c_void_p * n)(*[f._h for f in flats])
+    node = (ctypes.c_uint32 * n)(*[int(x) for x in nodes])
+    ty, zo, ct, pr = (ctypes.c_int32 * n)(), (ctypes.c_int32 * n)(), (ctypes.c_int32 * n)(), (ctypes.c_double * n)()
+    rc = kh.ksh_launch_pick(hs, n, node, ty, zo, ct, pr)
+    if rc != KS_OK:
+        raise KSolveError(rc, kh.ksh_last_error().decode())
+    out = []
+    for i in range(n):
+        if ty[i] < 0:
+            out.append(None)
+        else:
+            out.append((int(ty[i]), kh.ksh_key_value(flats[i]._h, 0, zo[i]).decode(), kh.ksh_key_value(flats[i]._h, 1, ct[i]).decode(), float(pr[i])))
+    return out
+
+
+def types_subset(flats: Sequence[FlatProblem], nodes: Sequence[int], type_sets: Sequence[Sequence[int]]) -> List[bool]:
+    """instanceTypesAreSubset (deprovisioning/helpers.go:118-122) on the device: is type_sets[i] (instance-type indices) a subset of the
+    InstanceTypeOptions of flats[i]'s new node nodes[i]?"""
+    kh = libs()[1]
+    n = len(flats)
+    if n == 0:
+        return []
+    stride = max((f.dims["T"] + 63) // 64 for f in flats)
+    hs = (ctypes.c_void_p * n)(*[f._h for f in flats])
+    node = (ctypes.c_uint32 * n)(*[int(x) for x in nodes])
+    lhs = (ctypes.c_uint64 * (n * stride))()
+    for i, ts in enumerate(type_sets):
+        for t in ts:
+            lhs[i * stride + t // 64] |= 1 << (t % 64)
+    out = (ctypes.c_uint32 * n)()
+    rc = kh.ksh_types_subset(hs, n, node, lhs, stride, out)
+    if rc != KS_OK:
+        raise KSolveError(rc, kh.ksh_last_error().decode())
+    return [bool(x) for x in out]
 
 
 def solve_problem(problem: Problem, stats: bool = False) -> SolveResult:

@@ -174,6 +174,26 @@ def single_node_consolidation_option(snapshot, candidates):
     return ("do-nothing", (), (), ())
 
 
+def launch_pick(instance_types, node):
+    """fake.CloudProvider.Create's instance-type choice (cloudprovider/fake/cloudprovider.go:72-84), literally: keep the options the machine's
+    instance-type requirement names (all of them: ToMachine lists exactly the options), order them by the cheapest AVAILABLE offering that the
+    zone / capacity-type requirements admit (Offerings.Available().Requirements(reqs).Cheapest(), types.go:126-145) and take the first; ties go to
+    the earlier option (sort.Slice leaves them open).  -> (name, cheapest price) or None."""
+    by_name = {it.name: it for it in instance_types}
+    zr, cr = node.requirements.get(LABEL_ZONE), node.requirements.get(LABEL_CAPACITY_TYPE)
+    best = None
+    for name in node.instance_types:
+        prices = [o.price for o in by_name[name].offerings if o.available and req_has(zr, o.zone) and req_has(cr, o.capacity_type)]
+        if prices and (best is None or min(prices) < best[1]):
+            best = (name, min(prices))
+    return best
+
+
+def instance_types_are_subset(lhs_names, rhs_names):
+    """helpers.go:118-122"""
+    return len(set(rhs_names) & set(lhs_names)) == len(set(lhs_names))
+
+
 def canonical(cmd):
     action, remove, options, reqs = cmd
     return (action, tuple(remove), tuple(options), tuple(sorted(canon_reqs(reqs).items())))

@@ -586,6 +586,75 @@ static bool it_has_offering(const IType& it, const Reqs& reqs, Sym zoneKey, Sym 
   return false;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Go's sort.Slice (go 1.19+: pdqsort_func, $GOROOT/src/sort/zsortfunc.go + sort.go), restated from SURVEY App. C.1.
+// UNVERIFIED against a Go toolchain (none in this image): it exists to QUANTIFY how far the reference's unstable sort of the open nodes
+// (scheduler.go:183) can move results away from the canonical stable order, not to define parity.  `less(i, j)` / `swap(i, j)` act on positions.
+// ------------------------------------------------------------------------------------------------
+template <class Less, class Swap> struct GoSort {
+  Less less; Swap swp;
+  static int bits_len(unsigned long long x) { int n = 0; while (x) { ++n; x >>= 1; } return n; }
+  void insertion(int a, int b) { for (int i = a + 1; i < b; ++i) for (int j = i; j > a && less(j, j - 1); --j) swp(j, j - 1); }
+  void sift_down(int lo, int hi, int first) { int root = lo; for (;;) { int child = 2 * root + 1; if (child >= hi) return; if (child + 1 < hi && less(first + child, first + child + 1)) ++child; if (!less(first + root, first + child)) return; swp(first + root, first + child); root = child; } }
+  void heap(int a, int b) { int first = a, lo = 0, hi = b - a; for (int i = (hi - 1) / 2; i >= 0; --i) sift_down(i, hi, first); for (int i = hi - 1; i >= 0; --i) { swp(first, first + i); sift_down(lo, i, first); } }
+  void order2(int& a, int& b, int& swaps) { if (less(b, a)) { ++swaps; std::swap(a, b); } }
+  int median(int a, int b, int c, int& swaps) { order2(a, b, swaps); order2(b, c, swaps); order2(a, b, swaps); return b; }
+  void choose_pivot(int a, int b, int& pivot, int& hint) {      // hint: 0 unknown, 1 increasing, 2 decreasing
+    const int l = b - a; int swaps = 0, i = a + l / 4 * 1, j = a + l / 4 * 2, k = a + l / 4 * 3;
+    if (l >= 8) { if (l >= 50) { i = median(i - 1, i, i + 1, swaps); j = median(j - 1, j, j + 1, swaps); k = median(k - 1, k, k + 1, swaps); } j = median(i, j, k, swaps); }
+    pivot = j; hint = swaps == 0 ? 1 : (swaps == 12 ? 2 : 0);
+  }
+  void reverse_range(int a, int b) { int i = a, j = b - 1; while (i < j) { swp(i, j); ++i; --j; } }
+  bool partial_insertion(int a, int b) {
+    int i = a + 1;
+    for (int step = 0; step < 5; ++step) {
+      while (i < b && !less(i, i - 1)) ++i;
+      if (i == b) return true;
+      if (b - a < 50) return false;
+      swp(i, i - 1);
+      if (i - a >= 2) for (int j = i - 1; j >= 1; --j) { if (!less(j, j - 1)) break; swp(j, j - 1); }
+      if (b - i >= 2) for (int j = i + 1; j < b; ++j) { if (!less(j, j - 1)) break; swp(j, j - 1); }
+    }
+    return false;
+  }
+  void break_patterns(int a, int b) {
+    const int l = b - a;
+    if (l >= 8) {
+      unsigned long long r = (unsigned long long)l; const unsigned long long mod = 1ull << bits_len((unsigned long long)l); const int idx = a + (l / 4) * 2 - 1;
+      for (int t = 0; t < 3; ++t) { r ^= r << 13; r ^= r >> 17; r ^= r << 5; int other = (int)(r & (mod - 1)); if (other >= l) other -= l; swp(idx - 1 + t, a + other); }
+    }
+  }
+  int partition_equal(int a, int b, int pivot) { swp(a, pivot); int i = a + 1, j = b - 1; for (;;) { while (i <= j && !less(a, i)) ++i; while (i <= j && less(a, j)) --j; if (i > j) break; swp(i, j); ++i; --j; } return i; }
+  int partition(int a, int b, int pivot, bool& already) {
+    swp(a, pivot); int i = a + 1, j = b - 1;
+    while (i <= j && less(i, a)) ++i;
+    while (i <= j && !less(j, a)) --j;
+    if (i > j) { swp(j, a); already = true; return j; }
+    swp(i, j); ++i; --j;
+    for (;;) { while (i <= j && less(i, a)) ++i; while (i <= j && !less(j, a)) --j; if (i > j) break; swp(i, j); ++i; --j; }
+    swp(j, a); already = false; return j;
+  }
+  void pdq(int a, int b, int limit) {
+    bool was_balanced = true, was_partitioned = true;
+    for (;;) {
+      const int len = b - a;
+      if (len <= 12) { insertion(a, b); return; }
+      if (limit == 0) { heap(a, b); return; }
+      if (!was_balanced) { break_patterns(a, b); --limit; }
+      int pivot, hint; choose_pivot(a, b, pivot, hint);
+      if (hint == 2) { reverse_range(a, b); pivot = (b - 1) - (pivot - a); hint = 1; }
+      if (was_balanced && was_partitioned && hint == 1) if (partial_insertion(a, b)) return;
+      if (a > 0 && !less(a - 1, pivot)) { a = partition_equal(a, b, pivot); continue; }
+      bool already; const int mid = partition(a, b, pivot, already); was_partitioned = already;
+      const int left = mid - a, right = b - mid, thr = len / 8;
+      if (left < right) { was_balanced = left >= thr; pdq(a, mid, limit); a = mid + 1; }
+      else { was_balanced = right >= thr; pdq(mid + 1, b, limit); b = mid; }
+    }
+  }
+  void sort(int n) { pdq(0, n, bits_len((unsigned long long)n)); }
+};
+template <class Less, class Swap> static void go_sort_slice(int n, Less less, Swap swp) { GoSort<Less, Swap> g{less, swp}; g.sort(n); }
+
 struct PodState { ksp::Pod spec; int index; int stage = 0; uint32_t reasons = 0; };   // reasons: why the last add() failed, 4 bits per template (scheduler.go:193-217)
 
 struct Node {   // scheduling.Node, node.go:34-107
@@ -607,6 +676,7 @@ struct Scheduler {
   std::vector<PodState> pods; bool tolerate_prefer_no_schedule = false;
   int64_t node_id = 0; Sym zoneKey, ctKey, hostnameKey;
   std::vector<int> unscheduled;
+  bool gosort = false;      // order the open nodes with the restated Go sort.Slice instead of the canonical stable sort (quantifies the unpinned region)
 
   // ---- Preferences.Relax, preferences.go:36-145 ----
   bool relax(ksp::Pod& pod) {
@@ -714,7 +784,8 @@ struct Scheduler {
   bool add(PodState& ps) {
     for (auto& n : existing) if (existing_add(*n, ps)) { ps.reasons = 0; return true; }
     // sort.Slice(newNodes, len(Pods) asc) -- canonical: stable
-    std::stable_sort(new_nodes.begin(), new_nodes.end(), [](const std::unique_ptr<Node>& a, const std::unique_ptr<Node>& b) { return a->pods.size() < b->pods.size(); });
+    if (gosort) go_sort_slice((int)new_nodes.size(), [&](int i, int j) { return new_nodes[i]->pods.size() < new_nodes[j]->pods.size(); }, [&](int i, int j) { std::swap(new_nodes[i], new_nodes[j]); });
+    else std::stable_sort(new_nodes.begin(), new_nodes.end(), [](const std::unique_ptr<Node>& a, const std::unique_ptr<Node>& b) { return a->pods.size() < b->pods.size(); });
     for (auto& n : new_nodes) if (node_add(*n, ps)) { ps.reasons = 0; return true; }
     ps.reasons = 0; uint32_t ti = 0;
     for (auto& t : templates) {
@@ -1017,11 +1088,13 @@ extern "C" {
 
 // Solve one KSP1 problem; returns 0 and a malloc'd KSR1 text, or <0 and a malloc'd error message.
 // flags bit0: inert topology (the reference benchmark's &scheduling.Topology{}, scheduling_benchmark_test.go:123)
+//       bit1: order the open nodes with the restated Go sort.Slice (pdqsort) instead of the canonical stable sort
 int ko_solve(const char* ksp_text, size_t len, int flags, char** out_text) {
   oracle::Interner in; oracle::g_in = &in;
   try {
     ksp::Problem pr = ksp::Parser(ksp_text, len).parse();
     auto s = oracle::build(pr, (flags & 1) != 0);
+    s->gosort = (flags & 2) != 0;
     auto t0 = std::chrono::steady_clock::now();
     s->solve();
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1030,6 +1103,12 @@ int ko_solve(const char* ksp_text, size_t len, int flags, char** out_text) {
   } catch (const std::exception& e) { *out_text = strdup(e.what()); oracle::g_in = nullptr; return -1; }
 }
 void ko_free(char* p) { free(p); }
+// The restated sort.Slice on plain keys: perm_out[i] = index (into keys) of the element at sorted position i.
+void ko_gosort_order(const int* keys, int n, int* perm_out) {
+  std::vector<int> perm(n); for (int i = 0; i < n; ++i) perm[i] = i;
+  oracle::go_sort_slice(n, [&](int i, int j) { return keys[perm[i]] < keys[perm[j]]; }, [&](int i, int j) { std::swap(perm[i], perm[j]); });
+  for (int i = 0; i < n; ++i) perm_out[i] = perm[i];
+}
 
 // Model check of the kernel's round speculation (see Scheduler::solve_spec): solves through predictions, returns the
 // KSR1 text (must equal ko_solve's) and the counters.

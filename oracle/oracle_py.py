@@ -37,10 +37,11 @@ def lib():
     return _LIB
 
 
-def solve_text(ksp_text: str, inert_topology: bool = False) -> str:
+def solve_text(ksp_text: str, inert_topology: bool = False, gosort: bool = False) -> str:
+    """gosort: order the open nodes with the restated Go sort.Slice (pdqsort_func) instead of the canonical stable sort."""
     data = ksp_text.encode()
     out = ctypes.c_void_p()
-    rc = lib().ko_solve(data, len(data), 1 if inert_topology else 0, ctypes.byref(out))
+    rc = lib().ko_solve(data, len(data), (1 if inert_topology else 0) | (2 if gosort else 0), ctypes.byref(out))
     text = ctypes.string_at(out).decode()
     lib().ko_free(out)
     if rc != 0:
@@ -64,9 +65,18 @@ def solve_spec(problem, width: int = 8, flags: int = 0, max_classes: int = 0):
     return parse_result(text), {k: int(ctr[i]) for i, k in enumerate(names)}
 
 
-def solve(problem, inert_topology: bool = False):
+def solve(problem, inert_topology: bool = False, gosort: bool = False):
     from karpenter_core_amd.model import parse_result
-    return parse_result(solve_text(problem.to_ksp(), inert_topology))
+    return parse_result(solve_text(problem.to_ksp(), inert_topology, gosort))
+
+
+def gosort_order(keys):
+    """The restated Go sort.Slice (pdqsort_func) on integer keys: the permutation it produces."""
+    n = len(keys)
+    arr = (ctypes.c_int * max(1, n))(*keys)
+    out = (ctypes.c_int * max(1, n))()
+    lib().ko_gosort_order(arr, n, out)
+    return [int(out[i]) for i in range(n)]
 
 
 def _spec(op, values):

@@ -283,3 +283,38 @@ def test_gpu_multi_node_search_on_a_roomy_cluster():
     want = CR.first_n_node_consolidation_option(snap, cands, 100)
     assert want[0] == "replace"
     assert C.first_n_node_consolidation_option(snap, cands, max_nodes=100).canonical() == want
+
+
+@pytest.mark.gpu
+def test_gpu_launch_pick_and_subset():
+    """The launch-time arg-min of the in-memory provider (fake/cloudprovider.go:79-84 over Offerings.Cheapest, types.go:141) and
+    instanceTypesAreSubset (helpers.go:118-122) on device-resident results, against their literal restatements, for every new node of
+    Solves whose nodes carry different zone / capacity-type requirements."""
+    from karpenter_core_amd import scheduler as S
+    for pr in (W.config2(pods=600, sizes=6, seed=5), W.config3(pods=500, sizes=6, seed=6), W.config5(pods=500, sizes=6, seed=7)):
+        tindex = {it.name: i for i, it in enumerate(pr.instance_types)}
+        fp = S.FlatProblem(pr)
+        res = fp.solve()
+        assert res.new_nodes
+        picks = S.launch_pick([fp] * len(res.new_nodes), list(range(len(res.new_nodes))))
+        for j, (node, got) in enumerate(zip(res.new_nodes, picks)):
+            want = CR.launch_pick(pr.instance_types, node)
+            if want is None:
+                assert got is None
+                continue
+            t, zone, ct, price = got
+            assert (pr.instance_types[t].name, price) == want, (j, got, want)
+            it = pr.instance_types[t]
+            assert any(o.available and o.zone == zone and o.capacity_type == ct and o.price == price for o in it.offerings)
+        sets, wants = [], []
+        for node in res.new_nodes:
+            opts = [tindex[n] for n in node.instance_types]
+            outsider = next(i for i in range(len(pr.instance_types)) if i not in set(opts)) if len(opts) < len(pr.instance_types) else None
+            sets += [opts[: max(1, len(opts) // 2)], opts + ([outsider] if outsider is not None else [])]
+            wants += [True, outsider is None]
+        nodes = [j for j in range(len(res.new_nodes)) for _ in range(2)]
+        assert S.types_subset([fp] * len(nodes), nodes, sets) == wants
+        names = [it.name for it in pr.instance_types]
+        for j, s_, w in zip(nodes, sets, wants):        # the literal restatement agrees with the expectation
+            assert CR.instance_types_are_subset([names[i] for i in s_], res.new_nodes[j].instance_types) == w
+        fp.close()

@@ -621,3 +621,105 @@ def test_failure_reasons(backend):
     p = mkpod(labels=LABELS, spread=spread("unknown"))
     sim.last_pods = [p]; sim.provision([p])
     assert why(sim, p) == [REASON_TOPOLOGY]
+
+
+# ---------------- E11: in-flight taints (suite_test.go:1533-1658; state/node.go:61-78) ----------------
+def _reuse_after(backend, mutate):
+    """Provision one pod, delete it (the node stays, empty), let `mutate(node)` change the node, provision a second pod: same node?"""
+    sim = ClusterSim(backend)
+    first = mkpod(limits={"cpu": "8"})
+    sim.provision([first])
+    node1 = sim.scheduled(first)
+    sim.delete_pod(first)
+    mutate(node1)
+    second = mkpod()
+    sim.provision([second])
+    return node1.name, sim.scheduled(second).name
+
+
+def test_inflight_taints(backend):
+    from karpenter_core_amd.model import state_node_taints, TAINT_NODE_NOT_READY, TAINT_NODE_UNREACHABLE
+    foreign = Taint("foo.com/taint", "tainted", "NoSchedule")
+    not_ready = [Taint(TAINT_NODE_NOT_READY, "", "NoSchedule"), Taint(TAINT_NODE_UNREACHABLE, "", "NoSchedule")]
+
+    def set_taints(raw, startup=(), initialized=False):
+        def f(node):
+            node.taints = state_node_taints(raw, startup, initialized)
+            if not initialized:
+                node.labels.pop("karpenter.sh/initialized", None)
+        return f
+
+    a, b = _reuse_after(backend, set_taints([]))                                     # S:1534-1553: no taints -> the empty node is reused
+    assert a == b
+    a, b = _reuse_after(backend, set_taints([foreign], initialized=True))            # S:1554-1579: a foreign taint -> a new node
+    assert a != b
+    a, b = _reuse_after(backend, set_taints([foreign] + not_ready, startup=[foreign]))   # S:1580-1608: startup + not-ready taints are ignored until initialized
+    assert a == b
+    a, b = _reuse_after(backend, set_taints([foreign], startup=[foreign], initialized=True))   # S:1609-1633: the startup taint re-appears after initialization -> it counts
+    assert a != b
+    a, b = _reuse_after(backend, set_taints(not_ready, initialized=True))            # S:1634-1657: NotReady / unreachable never count
+    assert a == b
+
+
+# ---------------- E24: topology counted across provisioners (topology_test.go:2174-2207) ----------------
+def test_zonal_spread_across_provisioners(backend):
+    its = fake.default_instance_types()
+    provs = [fake.provisioner("a", len(its), requirements=[Expr(LABEL_ZONE, "In", ["test-zone-1"])], discovery_label=True),
+             fake.provisioner("b", len(its), requirements=[Expr(LABEL_ZONE, "In", ["test-zone-2", "test-zone-3"])], discovery_label=True)]
+    sim = ClusterSim(backend, instance_types=its, provisioners=provs)
+    topo = spread(LABEL_ZONE, labels={"foo": "bar"})
+    pods = [mkpod(labels={"foo": "bar"}, spread=topo) for _ in range(10)]
+    sim.provision(pods)
+    assert sorted(sim.skew(LABEL_ZONE, topo[0].label_selector)) == [3, 3, 4]
+
+
+# ---------------- pins of host-side logic that the oracle and the product both restate (derived from the reference lines, not from either) ----------------
+def test_spread_group_identity_ignores_node_selector_values(backend):
+    """TopologyGroup.Hash (topologygroup.go:137-153) hashes with hashstructure v2, which walks EXPORTED fields only: of the spread group's
+    TopologyNodeFilter ([]map[string]*Requirement, topologynodefilter.go:28) that is the label KEYS and Requirement.Key -- not the values.  Two
+    pods whose hostname spread differs only in the VALUE of their zone node selector therefore share ONE group, and the group keeps the filter
+    of the pod that created it (Topology.Update reuses the existing group, topology.go:99-108).  Consequence: the nodes of the second pod's
+    zone do not match the group's filter (TopologyGroup.Counts, topologygroup.go:109-111), are never counted, and its replicas may pile onto one
+    node although maxSkew is 1 -- with value-sensitive identities each selector would get its own group and the pods would be spread."""
+    sim = ClusterSim(backend)
+    topo = spread(LABEL_HOSTNAME)
+    a = [mkpod(labels=LABELS, spread=topo, node_selector={LABEL_ZONE: "test-zone-1"}, requests={"cpu": "0.1"}) for _ in range(2)]
+    b = [mkpod(labels=LABELS, spread=topo, node_selector={LABEL_ZONE: "test-zone-2"}, requests={"cpu": "0.1"}) for _ in range(2)]
+    sim.provision(a + b)
+    assert len({sim.scheduled(p).name for p in a}) == 2            # counted by the group's (their own) filter: spread over two nodes
+    assert len({sim.scheduled(p).name for p in b}) == 1            # not counted by the group they share: both on one node
+
+
+def test_relaxation_order(backend):
+    """Preferences.Relax (preferences.go:36-56) tries, in this order and one per failed attempt: extra required node-affinity terms, preferred pod
+    affinity, preferred pod ANTI-affinity, preferred NODE affinity, ScheduleAnyway spreads, the PreferNoSchedule toleration.  The number of
+    relaxations a pod needs (`final_stage`) exposes the order: a harmless preference that comes EARLIER in the list is dropped before the one that
+    actually blocks."""
+    from karpenter_core_amd.model import PodAffinityTerm
+    sim = ClusterSim(backend)
+    harmless_anti = [WeightedPodAffinityTerm(1, PodAffinityTerm(LABEL_HOSTNAME, LabelSelector({"nobody": "has-this"})))]
+    blocking_pref = [PreferredTerm(1, [Expr(LABEL_ZONE, "In", ["no-such-zone"])])]
+    p = mkpod(anti_preferred=harmless_anti, preferred_affinity=blocking_pref)
+    res = sim.provision([p])
+    assert sim.scheduled(p) is not None and res.final_stage[0] == 2          # anti-affinity preference first (:45-47), node-affinity preference second (:48-50)
+    sim = ClusterSim(backend)
+    harmless_pref = [PreferredTerm(1, [Expr(LABEL_ZONE, "In", ["test-zone-1"])])]
+    blocking_spread = spread("no-such-topology-key", when=SCHEDULE_ANYWAY)
+    q = mkpod(labels=LABELS, preferred_affinity=harmless_pref, spread=blocking_spread)
+    res = sim.provision([q])
+    assert sim.scheduled(q) is not None and res.final_stage[0] == 2          # node-affinity preference (:48-50) before the ScheduleAnyway spread (:51-53)
+    zone = res.new_nodes[0].requirements.get(LABEL_ZONE)
+    assert zone is None or len(zone.values) != 1 or zone.complement         # ... so the zone preference is gone from the node
+
+
+def test_host_port_ip_forms(backend):
+    """entry.matches (hostportusage.go:45-57): same protocol and port conflict iff the IPs are equal or EITHER is unspecified -- 0.0.0.0, the empty
+    host IP (defaulted to 0.0.0.0, :133-136) and the IPv6 unspecified address in any spelling (net.IP.IsUnspecified)."""
+    def hp(ip):
+        return [HostPort(port=8080, protocol="TCP", host_ip=ip)]
+    for ip1, ip2, together in (("10.0.0.1", "10.0.0.2", True), ("10.0.0.1", "10.0.0.1", False), ("10.0.0.1", "::", False),
+                               ("10.0.0.1", "0:0:0:0:0:0:0:0", False), ("", "10.0.0.9", False), ("fe80::1", "FE80::1", False)):
+        sim = ClusterSim(backend)
+        a, b = mkpod(ports=hp(ip1)), mkpod(ports=hp(ip2))
+        sim.provision([a, b])
+        assert (sim.scheduled(a).name == sim.scheduled(b).name) == together, (ip1, ip2)
