@@ -129,6 +129,12 @@ typedef struct ks_problem {
   const int64_t* en_requests;  /* [E*R] remaining daemon requests, clamped at 0 (existingnode.go:44-53) */
   const uint32_t* en_requests_present; /* [E] */
   const uint32_t* en_port_off; /* [E+1] into ports[] */
+  /* volume limits (existingnode.go:87-94, volumeusage.go:102-143; new nodes do not track volumes).  ND == 0: no class mounts a limited volume */
+  uint32_t ND;                 /* CSI drivers some existing node limits (<= 64) */
+  uint32_t SW;                 /* 64-bit words of the shared-claim sets: claims that can be on a node before the pod arrives */
+  const int32_t* en_vol_limit; /* [E*ND] VolumeLimits()[driver], INT32_MAX == no limit */
+  const int32_t* en_vol_count; /* [E*ND] distinct claims of the driver mounted on the node */
+  const uint64_t* en_vol_set;  /* [E*SW] which shared claims those include */
 
   /* ---- pod classes ---- */
   ks_reqsets cls;                 /* n = C : NewPodRequirements, requirements.go:61-78 */
@@ -140,6 +146,10 @@ typedef struct ks_problem {
   const uint64_t* cls_tolerated;  /* [C] bit i: some toleration ToleratesTaint(taint i) (taints.go:28-40) */
   const uint32_t* cls_port_off;   /* [C+1] into ports[] */
   const uint64_t* ports;          /* proto<<56 | port<<32 | ip_id (ip_id 0 == unspecified 0.0.0.0/::), hostportusage.go:39-57 */
+  const uint32_t* cls_vol_off;    /* [C+1] into vol_list[] */
+  const uint32_t* vol_list;       /* the class's volumes, ordered by driver: driver<<24 | shared-claim bit        (bit 31 clear)
+                                     1<<31 | driver<<24 | n : n claims no other pod or node mounts
+                                     0xFFFFFFFF            : VolumeUsage.validate failed -> no existing node accepts the pod */
   /* topology membership of a class (CSR lists of group ids) */
   const uint32_t* cls_own_off;  /* [C+1] groups in Topology.topologies owned by the pod; entry = g | selfSelecting<<31 */
   const uint32_t* own_list;

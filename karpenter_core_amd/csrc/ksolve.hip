@@ -87,6 +87,7 @@ struct DevProb {
   ReqSetsD en; const u64* en_taints; const i64* en_avail; const i64* en_requests; const u32* en_requests_present; const u32* en_port_off;
   ReqSetsD cls; const u8* cls_hn_mode; const u32* cls_hn_off; const u32* hn_list; const i64* cls_requests; const u32* cls_requests_present;
   const u64* cls_tolerated; const u32* cls_port_off; const u64* ports;
+  u32 ND, SW; const i32* en_vol_limit; const i32* en_vol_count; const u64* en_vol_set; const u32* cls_vol_off; const u32* vol_list;   // volume limits of existing nodes
   const u32* cls_own_off; const u32* own_list; const u32* cls_sel_off; const u32* sel_list;
   const u32* cls_isel_off; const u32* isel_list; const u32* cls_iown_off; const u32* iown_list;
   const u32* pod_stage_off; const u32* stage_cls; const u32* queue;
@@ -125,6 +126,8 @@ struct DevState {
   i64* remaining;
   // host-port pool
   u64* pp_entry; i32* pp_next; u32 pp_cap;
+  // volumes mounted on the existing nodes (VolumeUsage.volumes as counts + the shared-claim set)
+  u32 vol_pad; i32* vol_cnt; u64* vol_set;
   // outputs
   u64* stats; u32* out_counts;   // out_counts: [0]=n_new [1]=n_unscheduled
   u64* batch_meta;               // batched launches: [0]=n_new [1]=n_unscheduled [2..33]=stats of this problem in one batch-wide array (one read-back)
@@ -330,6 +333,7 @@ struct alignas(16) ClsPlan {
   u32 c, present, complement; i32 it_state;
   u32 hn_mode, hn_off, hn_cnt, reqmask;
   u64 tol; u32 port_off, port_cnt;
+  u32 vol_off, vol_cnt, vol_pad0, vol_pad1;
   u32 ntouch, ntopo, nhost, nrec;
   i64 req[KS_MAX_RES];
   PlanTouch touch[KS_MAX_TOUCH];
@@ -347,7 +351,7 @@ struct alignas(16) ClsBrief {
   u64 tfull;    // every group the evaluation reads (adds the hostname-keyed groups whose record only touches the winner's own counter)
   u64 rmask;    // groups Topology.Record may update
   u32 ev;       // evaluation class: classes with equal ids are evaluated identically by eval_node (they may differ in what they record)
-  u32 flags;    // bit 0: may take part in rounds (plan fits the kernel's limits, no host ports)
+  u32 flags;    // bit 0: may take part in rounds (plan fits the kernel's limits, no host ports, no volumes)
   u32 reqmask, pad;
   i64 req[KS_MAX_RES];
   u64 zmask;    // hostname-keyed groups whose item accepts a node only while the node's own counter is 0 (anti-affinity; spread with maxSkew - self == 0)
@@ -366,6 +370,7 @@ __global__ __launch_bounds__(64) void ks_build_plans(DevProb P, ClsPlan* plans, 
   pl.c = c; pl.present = P.cls.present[c]; pl.complement = P.cls.complement[c]; pl.it_state = P.cls.it_state[c];
   pl.hn_mode = P.cls_hn_mode[c]; pl.hn_cnt = P.cls_hn_off[c + 1] - P.cls_hn_off[c]; pl.hn_off = pl.hn_cnt ? P.cls_hn_off[c] : 0;      // (an empty list has no position: classes that differ only there evaluate alike)
   pl.reqmask = P.cls_requests_present[c]; pl.tol = P.cls_tolerated[c]; pl.port_cnt = P.cls_port_off[c + 1] - P.cls_port_off[c]; pl.port_off = pl.port_cnt ? P.cls_port_off[c] : 0;
+  pl.vol_cnt = P.cls_vol_off[c + 1] - P.cls_vol_off[c]; pl.vol_off = pl.vol_cnt ? P.cls_vol_off[c] : 0;
   for (u32 r = 0; r < P.R; ++r) pl.req[r] = P.cls_requests[(size_t)c * P.R + r];
   // own requirement keys, ascending
   for (u32 k = 0; k < P.K; ++k) if ((pl.present >> k) & 1u) {
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(64) void ks_build_plans(DevProb P, ClsPlan* plans, 
   for (u32 j = 0; j < pl.nrec; ++j) { const PlanRec& r = pl.rec[j]; if (r.key == KS_KEY_HOSTNAME && (r.owned_inverse || (P.grp_active[r.g] != 0 && !r.filtered))) rsure |= 1ull << (r.g & 63); }
   ClsBrief b; b.zmask = zmask; b.rsure = rsure; b.tmask = pl.tmask; b.tfull = tfull; b.rmask = pl.rmask; bool late_host = false;       // a record into a hostname-keyed group a relaxation creates later: such hostnames may be unregistered
   for (u32 j = 0; j < pl.nrec; ++j) if (pl.rec[j].key == KS_KEY_HOSTNAME && !pl.rec[j].owned_inverse && P.grp_active[pl.rec[j].g] == 0) late_host = true;
-  b.ev = 0; b.flags = (!pl.overflow && pl.port_cnt == 0 && !late_host) ? 1u : 0u; b.reqmask = pl.reqmask; b.pad = 0;
+  b.ev = 0; b.flags = (!pl.overflow && pl.port_cnt == 0 && pl.vol_cnt == 0 && !late_host) ? 1u : 0u; b.reqmask = pl.reqmask; b.pad = 0;
   for (u32 r = 0; r < KS_MAX_RES; ++r) b.req[r] = pl.req[r];
   briefs[c] = b;
 }
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(64) void ks_link_ev(const ClsPlan* plans, ClsBrief*
 // consults the topology (they may still differ in the groups Topology.Record updates, e.g. replicas that
 // differ only in labels).  For a run of equivalent pods the fit bitmap of one candidate step stays valid:
 // only the node that just received a pod changed, and it moved behind the rest of its count bucket.
-__device__ inline bool ks_plan_eval_eligible(const ClsPlan& p) { return !p.overflow && p.ntopo == 0 && p.nhost == 0 && p.port_cnt == 0 && p.hn_mode == 0; }
+__device__ inline bool ks_plan_eval_eligible(const ClsPlan& p) { return !p.overflow && p.ntopo == 0 && p.nhost == 0 && p.port_cnt == 0 && p.vol_cnt == 0 && p.hn_mode == 0; }
 __global__ __launch_bounds__(64) void ks_link_plans(ClsPlan* plans, u32 C, u32 R) {
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -619,11 +624,38 @@ __device__ __forceinline__ bool ports_conflict(const DevProb& P, const DevState&
   return false;
 }
 
+// volumeUsage.Validate + VolumeCount.Exceeds for existing node e (existingnode.go:87-94, volumeusage.go:102-143): the class's volumes are
+// ordered by driver; per driver, the claims the node does not mount yet are added to its count and compared with its limit.
+// COMMIT: volumeUsage.Add (volumeusage.go:94-100) instead of the comparison.
+template <bool COMMIT>
+__device__ __forceinline__ bool volumes_walk(const DevProb& P, const DevState& S, const ClsPlan& c, u32 e) {
+  const u32 ND = P.ND, SW = P.SW; u32 cur = 0xFFFFFFFFu; i32 run = 0;
+  for (u32 i = 0; i <= c.vol_cnt; ++i) {
+    const u32 ent = i < c.vol_cnt ? P.vol_list[c.vol_off + i] : 0u;
+    if (i < c.vol_cnt && ent == 0xFFFFFFFFu) return true;                     // VolumeUsage.validate returned an error
+    const u32 d = i < c.vol_cnt ? (ent >> 24) & 63u : 0xFFFFFFFEu;
+    if (d != cur) {
+      if (cur != 0xFFFFFFFFu) {
+        if (COMMIT) S.vol_cnt[(size_t)e * ND + cur] += run;
+        else if ((i64)S.vol_cnt[(size_t)e * ND + cur] + run > (i64)P.en_vol_limit[(size_t)e * ND + cur]) return true;   // "would exceed node volume limits"
+      }
+      cur = d; run = 0;
+    }
+    if (i == c.vol_cnt) break;
+    if (ent >> 31) run += (i32)(ent & 0xFFFFFFu);
+    else {
+      const u32 id = ent & 0xFFFFFFu; u64& w = S.vol_set[(size_t)e * SW + (id >> 6)];
+      if (!((w >> (id & 63u)) & 1ull)) { ++run; if (COMMIT) w |= 1ull << (id & 63u); }
+    }
+  }
+  return false;
+}
+
 __device__ __forceinline__ bool kreq_differs(const KReq& x, const KReq& y) { return x.present != y.present || x.mask != y.mask || x.complement != y.complement || x.gt != y.gt || x.lt != y.lt; }
 
 // The popped pod's class scalars, hoisted into wave-uniform registers once per pod (a class field read from
 // LDS costs a ~60-cycle dependent round trip at every use inside eval_node).
-template <int RM> struct ClsRT { u64 tol, tkeys; u32 reqmask, ntouch, nhost, hn_mode, port_cnt, eq; i32 it_state; i64 req[RM]; };
+template <int RM> struct ClsRT { u64 tol, tkeys; u32 reqmask, ntouch, nhost, hn_mode, port_cnt, vol_cnt, eq; i32 it_state; i64 req[RM]; };
 
 // Result of evaluating one node for the current pod: scalars in registers, the per-key requirements in
 // per-lane LDS slots (sh.la_*[touch index][lane]) so the algebra below is ONE dynamic loop body instead
@@ -670,6 +702,8 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
   }
   // ---- HostPortUsage.Validate ----
   if (!LEAN && cr.port_cnt && porthead >= 0 && ports_conflict(P, S, c, porthead)) return;
+  // ---- volumeUsage.Validate / VolumeCount.Exceeds (existing nodes only) ----
+  if (!LEAN && existing && cr.vol_cnt && volumes_walk<false>(P, S, c, slot)) return;
   // ---- resources: exact for existing nodes (existingnode.go:99-103), a necessary screen for new ones ----
   bool fit = true;
 #pragma unroll
@@ -1072,6 +1106,8 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     r.porthead() = head;
     for (u32 h = 0; h < tb.GH; ++h) tb.hcnt[(size_t)e * tb.GH + h] = P.grph_count[(size_t)h * tb.E + e];
   }
+  for (u32 i = lane; i < tb.E * P.ND; i += 64) S.vol_cnt[i] = P.en_vol_count[i];
+  for (u32 i = lane; i < tb.E * P.SW; i += 64) S.vol_set[i] = P.en_vol_set[i];
   for (u32 i = lane; i < P.M * tb.R; i += 64) S.remaining[i] = P.tmpl_remaining[i];
   }
 
@@ -1234,10 +1270,10 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     stage_class(tb, sh, lane);
     const ClsPlan& c = sh.cls;
     if (UF(c.overflow)) { err = (u32)(-KS_ERR_UNSUPPORTED); break; }
-    ClsR cr; cr.tol = UF64(c.tol); cr.reqmask = UF(c.reqmask); cr.ntouch = UF(c.ntouch); cr.nhost = UF(c.nhost); cr.hn_mode = UF(c.hn_mode); cr.port_cnt = UF(c.port_cnt); cr.it_state = (i32)UF(c.it_state); cr.tkeys = UF64(c.tkeys); cr.eq = UF(c.eq);
+    ClsR cr; cr.tol = UF64(c.tol); cr.reqmask = UF(c.reqmask); cr.ntouch = UF(c.ntouch); cr.nhost = UF(c.nhost); cr.hn_mode = UF(c.hn_mode); cr.port_cnt = UF(c.port_cnt); cr.vol_cnt = UF(c.vol_cnt); cr.it_state = (i32)UF(c.it_state); cr.tkeys = UF64(c.tkeys); cr.eq = UF(c.eq);
 #pragma unroll
     for (int i = 0; i < RM; ++i) cr.req[i] = (i64)UF64(c.req[i]);
-    if constexpr (LEAN) { cr.port_cnt = 0; cr.hn_mode = 0; cr.it_state = 0; }
+    if constexpr (LEAN) { cr.port_cnt = 0; cr.vol_cnt = 0; cr.hn_mode = 0; cr.it_state = 0; }
     bool placed = false;
     PROBE(13);
 
@@ -1409,6 +1445,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           if (!ex) r.count() = cnt + 1;
           if (fresh) S.n_tmpl[jw] = (i32)m_t;
           for (u32 i = 0; i < cr.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
+          if (!LEAN && ex && cr.vol_cnt) volumes_walk<true>(P, S, c, sw);
           tb.pod_node[pod] = (i32)sw; tb.pod_seq[pod] = (i32)seq; S.pod_reason[pod] = 0;
         }
         PROBE(17);
@@ -1506,10 +1543,10 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
               { const GA u32x4* src = (const GA u32x4*)(plans + cidx); u32x4* dst = (u32x4*)&sh.cls; dst[lane] = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = src[lane + 64]; }
               stage_class(tb, sh, lane);
               const ClsPlan& c = sh.cls;
-              cr.tol = UF64(c.tol); cr.reqmask = UF(c.reqmask); cr.ntouch = UF(c.ntouch); cr.nhost = UF(c.nhost); cr.hn_mode = UF(c.hn_mode); cr.port_cnt = UF(c.port_cnt); cr.it_state = (i32)UF(c.it_state); cr.tkeys = UF64(c.tkeys); cr.eq = UF(c.eq);
+              cr.tol = UF64(c.tol); cr.reqmask = UF(c.reqmask); cr.ntouch = UF(c.ntouch); cr.nhost = UF(c.nhost); cr.hn_mode = UF(c.hn_mode); cr.port_cnt = UF(c.port_cnt); cr.vol_cnt = UF(c.vol_cnt); cr.it_state = (i32)UF(c.it_state); cr.tkeys = UF64(c.tkeys); cr.eq = UF(c.eq);
 #pragma unroll
               for (int i = 0; i < RM; ++i) cr.req[i] = (i64)UF64(c.req[i]);
-              if constexpr (LEAN) { cr.port_cnt = 0; cr.hn_mode = 0; cr.it_state = 0; }
+              if constexpr (LEAN) { cr.port_cnt = 0; cr.vol_cnt = 0; cr.hn_mode = 0; cr.it_state = 0; }
               staged = true;
             }
             const bool ol = UF(rc.ord_in_lds) != 0;
@@ -1562,10 +1599,10 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         { const GA u32x4* src = (const GA u32x4*)(plans + cidx); u32x4* dst = (u32x4*)&sh.cls; dst[lane] = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = src[lane + 64]; }
         stage_class(tb, sh, lane);
         const ClsPlan& c = sh.cls;
-        cr.tol = UF64(c.tol); cr.reqmask = UF(c.reqmask); cr.ntouch = UF(c.ntouch); cr.nhost = UF(c.nhost); cr.hn_mode = UF(c.hn_mode); cr.port_cnt = UF(c.port_cnt); cr.it_state = (i32)UF(c.it_state); cr.tkeys = UF64(c.tkeys); cr.eq = UF(c.eq);
+        cr.tol = UF64(c.tol); cr.reqmask = UF(c.reqmask); cr.ntouch = UF(c.ntouch); cr.nhost = UF(c.nhost); cr.hn_mode = UF(c.hn_mode); cr.port_cnt = UF(c.port_cnt); cr.vol_cnt = UF(c.vol_cnt); cr.it_state = (i32)UF(c.it_state); cr.tkeys = UF64(c.tkeys); cr.eq = UF(c.eq);
 #pragma unroll
         for (int i = 0; i < RM; ++i) cr.req[i] = (i64)UF64(c.req[i]);
-        if constexpr (LEAN) { cr.port_cnt = 0; cr.hn_mode = 0; cr.it_state = 0; }
+        if constexpr (LEAN) { cr.port_cnt = 0; cr.vol_cnt = 0; cr.hn_mode = 0; cr.it_state = 0; }
         slot = 0xFFFFFFFFu;
         if ((u32)lane < nwin) slot = (u32)lane < tb.E ? (u32)lane : tb.E + (ord_lds_r ? ord_l[lane - tb.E] : ord_g[lane - tb.E]);
         ev.rc = 0; ev.count = 0; ev.reqmask = 0; ev.tchg = 0; ev.tpres = 0; ev.tcomp = 0; ev.present = 0; ev.complement = 0; ev.it_state = 0; ev.it0 = 0;
@@ -2141,6 +2178,9 @@ static int validate(const ks_problem* p) {
   if (p->max_new_nodes == 0 && p->P) return fail(KS_ERR_INVALID, "max_new_nodes == 0");
   for (u32 k = 0; k < p->K; ++k) if (p->key_nvalues[k] > 64) return fail(KS_ERR_UNSUPPORTED, "label key with more than 64 distinct values");
   if (p->key_zone >= 0 && p->key_ct >= 0 && (u64)p->key_nvalues[p->key_zone] * p->n_ct > 64) return fail(KS_ERR_UNSUPPORTED, "more than 64 zone x capacity-type pairs");
+  if (p->C && !p->cls_vol_off) return fail(KS_ERR_INVALID, "cls_vol_off is required (all zeros when no class mounts volumes)");
+  if (p->ND > 64) return fail(KS_ERR_UNSUPPORTED, "more than 64 CSI drivers with volume limits");
+  if (p->C && p->cls_vol_off[p->C] && p->ND == 0) for (u32 i = 0; i < p->cls_vol_off[p->C]; ++i) if (p->vol_list[i] != 0xFFFFFFFFu) return fail(KS_ERR_INVALID, "volume entries without volume drivers");
   return KS_OK;
 }
 
@@ -2170,7 +2210,7 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   {   // LEAN kernel variant eligibility (see ks_pack)
     bool lean = R <= 4 && h.SC == 1 && !(p->flags & KS_FLAG_STATS);
     for (u32 m = 0; m < M && lean; ++m) lean = p->tmpl_limit_present[m] == 0xFFFFFFFFu || p->tmpl_limit_present[m] == 0;
-    for (u32 c = 0; c < C && lean; ++c) lean = p->cls_hn_mode[c] == 0 && p->cls_port_off[c + 1] == p->cls_port_off[c];
+    for (u32 c = 0; c < C && lean; ++c) lean = p->cls_hn_mode[c] == 0 && p->cls_port_off[c + 1] == p->cls_port_off[c] && p->cls_vol_off[c + 1] == p->cls_vol_off[c];
     d->lean_ok = lean;
   }
   TRY(dev_copy(d, p->key_nvalues, K, &h.key_nvalues)); TRY(dev_copy(d, p->value_int, (size_t)K * 64, &h.value_int));
@@ -2196,6 +2236,9 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   TRY(dev_copy(d, p->cls_tolerated, C, &h.cls_tolerated)); TRY(dev_copy(d, p->cls_port_off, (size_t)C + 1, &h.cls_port_off));
   const u32 nports_static = C ? p->cls_port_off[C] : (E ? p->en_port_off[E] : 0);
   TRY(dev_copy(d, p->ports, nports_static, &h.ports));
+  h.ND = p->ND; h.SW = p->SW;
+  TRY(dev_copy(d, p->en_vol_limit, (size_t)E * p->ND, &h.en_vol_limit)); TRY(dev_copy(d, p->en_vol_count, (size_t)E * p->ND, &h.en_vol_count)); TRY(dev_copy(d, p->en_vol_set, (size_t)E * p->SW, &h.en_vol_set));
+  TRY(dev_copy(d, p->cls_vol_off, (size_t)C + 1, &h.cls_vol_off)); TRY(dev_copy(d, p->vol_list, C ? p->cls_vol_off[C] : 0, &h.vol_list));
   TRY(dev_copy(d, p->cls_own_off, (size_t)C + 1, &h.cls_own_off)); TRY(dev_copy(d, p->own_list, C ? p->cls_own_off[C] : 0, &h.own_list));
   TRY(dev_copy(d, p->cls_sel_off, (size_t)C + 1, &h.cls_sel_off)); TRY(dev_copy(d, p->sel_list, C ? p->cls_sel_off[C] : 0, &h.sel_list));
   TRY(dev_copy(d, p->cls_isel_off, (size_t)C + 1, &h.cls_isel_off)); TRY(dev_copy(d, p->isel_list, C ? p->cls_isel_off[C] : 0, &h.isel_list));
@@ -2240,6 +2283,7 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   size_t pp_pool = E ? p->en_port_off[E] : 0;
   for (u32 i = 0; i < P; ++i) { u32 mx = 0; for (u32 st = p->pod_stage_off[i]; st < p->pod_stage_off[i + 1]; ++st) { const u32 c = p->stage_cls[st]; const u32 n = p->cls_port_off[c + 1] - p->cls_port_off[c]; if (n > mx) mx = n; } pp_pool += mx; }
   s.pp_cap = (u32)pp_pool; TRY(dev_alloc(d, pp_pool, &s.pp_entry)); TRY(dev_alloc(d, pp_pool, &s.pp_next));
+  s.vol_pad = 0; TRY(dev_alloc(d, (size_t)E * p->ND, &s.vol_cnt)); TRY(dev_alloc(d, (size_t)E * p->SW, &s.vol_set));
   TRY(dev_alloc(d, 32, &s.stats, 0)); TRY(dev_alloc(d, 4, &s.out_counts, 0)); TRY(dev_alloc(d, P, &s.unscheduled));
   // the two descriptors go last: by now (placing pass) every pointer in them is final
   { const DevProb* dp; const DevState* ds; TRY(dev_copy(d, &d->h, 1, &dp)); TRY(dev_copy(d, &d->hs, 1, &ds)); d->d_prob = (DevProb*)dp; d->d_state = (DevState*)ds; }

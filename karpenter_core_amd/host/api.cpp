@@ -152,6 +152,7 @@ uint64_t ksh_fingerprint(void* hv) {
   vec(E.tmpl_taints); vec(E.tmpl_types); vec(E.tmpl_daemon); vec(E.tmpl_remaining); vec(E.tmpl_daemon_present); vec(E.tmpl_limit_present);
   vec(E.en_taints); vec(E.en_avail); vec(E.en_requests); vec(E.en_requests_present); vec(E.en_port_off);
   vec(E.cls_hn_mode); vec(E.cls_hn_off); vec(E.hn_list); vec(E.cls_requests); vec(E.cls_requests_present); vec(E.cls_tolerated); vec(E.cls_port_off); vec(E.ports);
+  vec(E.en_vol_limit); vec(E.en_vol_count); vec(E.en_vol_set); vec(E.cls_vol_off); vec(E.vol_list);
   vec(E.cls_own_off); vec(E.own_list); vec(E.cls_sel_off); vec(E.sel_list); vec(E.cls_isel_off); vec(E.isel_list); vec(E.cls_iown_off); vec(E.iown_list);
   vec(E.pod_stage_off); vec(E.stage_cls); vec(E.queue); vec(E.grp_type); vec(E.grp_active); vec(E.grp_key); vec(E.grp_max_skew); vec(E.grp_count); vec(E.grp_hslot);
   vec(E.grph_count); vec(E.grph_extra_pos); vec(E.grp_filter_off);

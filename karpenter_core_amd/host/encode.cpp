@@ -7,6 +7,7 @@
 #include <sstream>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 
 namespace ksh {
 
@@ -155,8 +156,9 @@ struct Hash128 {
   void term(const ksp::AffinityTerm& t) { str(t.topology_key); u(t.namespaces.size()); for (auto& n : t.namespaces) str(n); selector(t.selector); }
   void finish() { a ^= a >> 32; a *= 0xFF51AFD7ED558CCDull; a ^= a >> 29; b ^= b >> 31; b *= 0xC4CEB9FE1A85EC53ull; b ^= b >> 33; }
 };
-Hash128 spec_hash(const Pod& p) {
-  Hash128 h; h.str(p.ns); h.map(p.labels); h.map(p.node_selector);
+Hash128 spec_hash(const Pod& p, const std::vector<uint32_t>* vol = nullptr) {
+  Hash128 h; if (vol) { h.u(vol->size()); for (uint32_t e : *vol) h.u(e); }
+  h.str(p.ns); h.map(p.labels); h.map(p.node_selector);
   h.u(p.required_affinity.size()); for (auto& t : p.required_affinity) h.exprs(t);
   h.u(p.preferred_affinity.size()); for (auto& t : p.preferred_affinity) { h.u((uint64_t)t.weight); h.exprs(t.exprs); }
   h.u(p.tolerations.size()); for (auto& t : p.tolerations) { h.str(t.key); h.str(t.op); h.str(t.value); h.str(t.effect); }
@@ -420,6 +422,82 @@ struct Builder {
     }
   }
 
+  // ---------- volumes: ExistingNode.Add's volumeUsage.Validate + VolumeCount.Exceeds (existingnode.go:87-94, volumeusage.go:102-143) ----------
+  // Only existing nodes track volumes.  A claim id counts once per node however many pods mount it, so the flat form distinguishes
+  //   shared claims   -- mounted by two or more batch pods, or already on a state node: one bit each in a per-node set;
+  //   unique claims   -- mounted by exactly one batch pod and on no node (every generic ephemeral volume, a StatefulSet's claims): a count.
+  // Pods that differ only in the NAMES of their unique claims then still share a class.  Drivers no in-state node limits are dropped.
+  std::map<std::string, int> vol_driver_id;
+  std::unordered_map<std::string, uint32_t> vol_ref, vol_shared;
+  bool pods_have_volumes = false; int blocked_taint = -1;
+  static std::string vol_pair(const ksp::Volume& v) { return v.driver + '\1' + v.pvc; }
+  void collect_volumes() {
+    for (size_t i = 0; i < pr.nodes.size(); ++i) if (node_in_state(i) && pr.nodes[i].owned()) for (auto& kv : pr.nodes[i].volume_limits) if (!vol_driver_id.count(kv.first)) { const int id = (int)vol_driver_id.size(); vol_driver_id[kv.first] = id; }
+    if (vol_driver_id.size() > 64) throw Unsupported("more than 64 CSI drivers with volume limits");
+    for (auto* p : podp) if (p->volume_error || !p->volumes.empty()) { pods_have_volumes = true; break; }
+    if (!pods_have_volumes || vol_driver_id.empty()) return;
+    std::unordered_set<std::string> on_node;
+    for (size_t i = 0; i < pr.nodes.size(); ++i) if (node_in_state(i) && pr.nodes[i].owned()) for (auto& v : pr.nodes[i].volumes) if (vol_driver_id.count(v.driver)) on_node.insert(vol_pair(v));
+    std::vector<std::string> mine;
+    for (auto* p : podp) {
+      mine.clear(); for (auto& v : p->volumes) if (vol_driver_id.count(v.driver)) mine.push_back(vol_pair(v));
+      std::sort(mine.begin(), mine.end()); mine.erase(std::unique(mine.begin(), mine.end()), mine.end());
+      for (auto& s2 : mine) ++vol_ref[s2];
+    }
+    for (auto* p : podp) for (auto& v : p->volumes) if (vol_driver_id.count(v.driver)) {
+      std::string s2 = vol_pair(v);
+      if ((vol_ref[s2] >= 2 || on_node.count(s2)) && !vol_shared.count(s2)) { const uint32_t id = (uint32_t)vol_shared.size(); vol_shared.emplace(std::move(s2), id); }
+    }
+    if (vol_shared.size() >= (1u << 24)) throw Unsupported("more than 16M shared volume claims");
+  }
+  // What ExistingNode.Add needs of a pod's volumes: tagged words ordered by driver (ks_problem.vol_list).
+  std::vector<uint32_t> vol_entries(const Pod& p) const {
+    std::vector<uint32_t> out;
+    if (p.volume_error) { out.push_back(0xFFFFFFFFu); return out; }
+    if (p.volumes.empty() || vol_driver_id.empty()) return out;
+    std::set<std::string> seen; std::map<int, uint32_t> uniq;
+    for (auto& v : p.volumes) {
+      auto d = vol_driver_id.find(v.driver); if (d == vol_driver_id.end()) continue;
+      std::string s2 = vol_pair(v); if (!seen.insert(s2).second) continue;
+      auto sh = vol_shared.find(s2);
+      if (sh != vol_shared.end()) out.push_back(((uint32_t)d->second << 24) | sh->second); else uniq[d->second]++;
+    }
+    for (auto& kv : uniq) { if (kv.second >= (1u << 24)) throw Unsupported("a pod with more than 16M volumes"); out.push_back(0x80000000u | ((uint32_t)kv.first << 24) | kv.second); }
+    std::sort(out.begin(), out.end(), [](uint32_t a, uint32_t b) { const uint32_t da = (a >> 24) & 63u, db = (b >> 24) & 63u; return da != db ? da < db : a < b; });
+    return out;
+  }
+  bool same_pod(const Pod& a, const Pod& b) const { return same_spec(a, b) && (!pods_have_volumes || vol_entries(a) == vol_entries(b)); }
+  // A node whose mounted volumes already exceed one of its limits refuses every pod (Exceeds ranges over the union's drivers, whatever the
+  // pod adds): such nodes carry a taint of their own that no toleration matches.
+  static bool over_volume_limit(const ksp::StateNode& n) {
+    if (n.volume_limits.empty() || n.volumes.empty()) return false;
+    std::map<std::string, std::set<std::string>> u; for (auto& v : n.volumes) u[v.driver].insert(v.pvc);
+    for (auto& kv : n.volume_limits) { auto it = u.find(kv.first); if (it != u.end() && (int64_t)it->second.size() > (int64_t)kv.second) return true; }
+    return false;
+  }
+  uint64_t blocked_mask() {
+    if (blocked_taint < 0) { ksp::Taint t{std::string("\1volume-limits-exceeded"), "", "NoSchedule"}; taint_mask({t}); blocked_taint = taint_id.at(t.key + "\1" + t.value + "\1" + t.effect); }
+    return 1ull << blocked_taint;
+  }
+  void encode_volumes() {
+    const uint32_t NE = (uint32_t)E.existing.size(), ND = pods_have_volumes ? (uint32_t)vol_driver_id.size() : 0u, SW = (uint32_t)((vol_shared.size() + 63) / 64);
+    E.prob.ND = ND; E.prob.SW = ND ? SW : 0;
+    if (E.cls_vol_off.size() != (size_t)E.cls.n + 1) E.cls_vol_off.resize((size_t)E.cls.n + 1, (uint32_t)E.vol_list.size());
+    if (!ND) return;
+    E.en_vol_limit.assign((size_t)NE * ND, INT32_MAX); E.en_vol_count.assign((size_t)NE * ND, 0); E.en_vol_set.assign((size_t)NE * SW, 0);
+    for (uint32_t e = 0; e < NE; ++e) {
+      const auto& n = pr.nodes[E.existing[e]];
+      for (auto& kv : n.volume_limits) E.en_vol_limit[(size_t)e * ND + vol_driver_id.at(kv.first)] = kv.second;
+      std::set<std::string> seen;
+      for (auto& v : n.volumes) {
+        auto d = vol_driver_id.find(v.driver); if (d == vol_driver_id.end()) continue;
+        std::string s2 = vol_pair(v); if (!seen.insert(s2).second) continue;
+        E.en_vol_count[(size_t)e * ND + d->second]++;
+        auto sh = vol_shared.find(s2); if (sh != vol_shared.end()) E.en_vol_set[(size_t)e * SW + sh->second / 64] |= 1ull << (sh->second % 64);
+      }
+    }
+  }
+
   // ---------- existing nodes ----------
   void encode_existing() {
     for (size_t i = 0; i < pr.nodes.size(); ++i) { node_by_name[pr.nodes[i].name] = &pr.nodes[i]; if (node_in_state(i) && pr.nodes[i].owned()) E.existing.push_back((int)i); }
@@ -458,7 +536,7 @@ struct Builder {
   void adopt_base() {
     const Builder& b = *base; const Encoded& B = b.E;
     wellKnown = b.wellKnown; key_id = b.key_id; res_id = b.res_id; taint_id = b.taint_id; taints = b.taints; ip_id = b.ip_id; proto_id = b.proto_id; domains = b.domains;
-    toleratePreferNoSchedule = b.toleratePreferNoSchedule; K = b.K; R = b.R; T = b.T; TW = b.TW;
+    blocked_taint = b.blocked_taint; toleratePreferNoSchedule = b.toleratePreferNoSchedule; K = b.K; R = b.R; T = b.T; TW = b.TW;
     it_reqs = b.it_reqs; it_state_id = b.it_state_id; it_cols = b.it_cols; it_col_id = b.it_col_id;
     E.key_names = B.key_names; E.key_values = B.key_values; E.res_names = B.res_names; E.key_nvalues = B.key_nvalues; E.value_int = B.value_int;
     E.it_present = B.it_present; E.it_complement = B.it_complement; E.it_mask = B.it_mask; E.it_offer = B.it_offer; E.it_price = B.it_price; E.it_price_lo = B.it_price_lo; E.it_alloc = B.it_alloc; E.it_cap = B.it_cap;
@@ -478,7 +556,7 @@ struct Builder {
       Requirements full = Requirements::FromLabels(n.labels);
       Requirements hostless; for (auto& kv : full.m) if (kv.first != ksp::kHostname) hostless.m.emplace(kv.first, kv.second);
       push_reqs(E.en, restrict_to_known_keys(hostless), nullptr, false, false);
-      E.en_taints.push_back(taint_mask(n.taints));
+      E.en_taints.push_back(taint_mask(n.taints) | (over_volume_limit(n) ? blocked_mask() : 0ull));
       res_vec(n.available, E.en_avail, nullptr);
       // daemons that should still land on this node, scheduler.go:229-240 + existingnode.go:41-53
       ksp::ResList dr; int count = 0;
@@ -566,9 +644,11 @@ struct Builder {
   // with them the creation order of topology groups (NewTopology's Update per pod, topology.go:72-78), do not depend on threading.
   void dedupe_specs() {
     if (podp.empty() && !base) { podp.reserve(pr.pods.size()); for (auto& p : pr.pods) podp.push_back(&p); }
-    const uint32_t P = (uint32_t)podp.size(); sublap("(start)");
+    const uint32_t P = (uint32_t)podp.size(); collect_volumes(); sublap("(start)");
     std::vector<Hash128> hs(P); std::vector<uint64_t> uh(P);
-    parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { hs[i] = spec_hash(*podp[i]); uh[i] = str_hash(podp[i]->uid); } });
+    parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) {
+      if (pods_have_volumes) { const std::vector<uint32_t> ve = vol_entries(*podp[i]); hs[i] = spec_hash(*podp[i], &ve); } else hs[i] = spec_hash(*podp[i]);
+      uh[i] = str_hash(podp[i]->uid); } });
     sublap("hash"); uint64_t cap = 64; while (cap < 4ull * P) cap <<= 1;
     batch_uids.pods = &podp; batch_uids.mask = cap - 1; batch_uids.tab.assign(cap, 0);
     for (uint32_t i = 0; i < P; ++i) {
@@ -588,9 +668,9 @@ struct Builder {
     // needs a 2^-128 event).  KSH_CONFIRM_SPECS=1 (the test-suite sets it) additionally confirms every merge field by field; a pod
     // that merely collided would get a spec of its own.
     std::vector<uint8_t> bad(P, 0);
-    if (getenv("KSH_CONFIRM_SPECS")) parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t f = first[pod_spec[i]]; if (f != i && !same_spec(*podp[f], *podp[i])) bad[i] = 1; } });
+    if (getenv("KSH_CONFIRM_SPECS")) parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t f = first[pod_spec[i]]; if (f != i && !same_pod(*podp[f], *podp[i])) bad[i] = 1; } });
     for (uint32_t i = 0; i < P; ++i) if (bad[i]) {
-      int found = -1; for (size_t s2 = 0; s2 < first.size() && found < 0; ++s2) if (same_spec(*podp[first[s2]], *podp[i])) found = (int)s2;
+      int found = -1; for (size_t s2 = 0; s2 < first.size() && found < 0; ++s2) if (same_pod(*podp[first[s2]], *podp[i])) found = (int)s2;
       if (found < 0) { found = (int)first.size(); first.push_back(i); }
       pod_spec[i] = found;
     }
@@ -626,7 +706,7 @@ struct Builder {
     }
     sublap("pass B");
     // classes
-    E.cls_hn_off.assign(1, 0); E.cls_port_off.assign(1, (uint32_t)E.ports.size());
+    E.cls_hn_off.assign(1, 0); E.cls_port_off.assign(1, (uint32_t)E.ports.size()); E.cls_vol_off.assign(1, 0);
     for (auto& si : specs) for (auto& st : si.stages) si.cls.push_back(class_of(st));
     // pods -> stage chains, queue order
     sublap("classes"); E.pod_stage_off.resize((size_t)P + 1); E.pod_stage_off[0] = 0;
@@ -674,8 +754,10 @@ struct Builder {
     std::string sig; sig.reserve(256);
     for (auto& kv : st.reqs.m) { sig += kv.first; sig += '\1'; sig += kv.second.identity(); sig += '\2'; } sig += '\4';
     ksp::ResList req = RequestsForPod(p); sig_res(sig, req);
-    uint64_t tol = 0; for (size_t i = 0; i < taints.size(); ++i) { bool ok = false; for (auto& t : p.tolerations) ok = ok || ToleratesTaint(t, taints[i]); if (ok) tol |= 1ull << i; }
+    uint64_t tol = 0; for (size_t i = 0; i < taints.size(); ++i) { if ((int)i == blocked_taint) continue; bool ok = false; for (auto& t : p.tolerations) ok = ok || ToleratesTaint(t, taints[i]); if (ok) tol |= 1ull << i; }
     sig += std::to_string(tol); sig += '\4';
+    const std::vector<uint32_t> ve = pods_have_volumes ? vol_entries(p) : std::vector<uint32_t>();
+    for (auto e : ve) { sig += std::to_string(e); sig += ','; } sig += '\4';
     std::vector<uint64_t> pe; for (auto& c : p.containers) for (auto& hp : c.ports) if (hp.port != 0) pe.push_back(port_entry(hp.ip, hp.port, hp.proto));
     for (auto e : pe) { sig += std::to_string(e); sig += ','; } sig += '\4';
     sig += std::to_string(lsid); sig += '\4';
@@ -694,6 +776,7 @@ struct Builder {
     uint32_t pm; res_vec(req, E.cls_requests, &pm); E.cls_requests_present.push_back(pm);
     E.cls_tolerated.push_back(tol);
     for (auto e : pe) E.ports.push_back(e); E.cls_port_off.push_back((uint32_t)E.ports.size());
+    for (auto e : ve) E.vol_list.push_back(e); E.cls_vol_off.push_back((uint32_t)E.vol_list.size());
     cls_labelset.push_back(lsid); cls_groups.push_back(st.sg);
     if (mode != 0) for (int g : st.sg.own) if (groups[g]->key == ksp::kHostname && groups[g]->type == 1) throw Unsupported("hostname pod-affinity combined with a hostname node selector");
     class_by_sig.emplace(std::move(sig), c);
@@ -701,7 +784,10 @@ struct Builder {
   }
 
   // the taint universe must be complete before classes compute `tolerated`
-  void collect_taints() { for (auto& p : pr.provisioners) taint_mask(p.taints); for (size_t i = 0; i < pr.nodes.size(); ++i) if (node_in_state(i) && pr.nodes[i].owned()) taint_mask(pr.nodes[i].taints); }
+  void collect_taints() {
+    for (auto& p : pr.provisioners) taint_mask(p.taints);
+    for (size_t i = 0; i < pr.nodes.size(); ++i) if (node_in_state(i) && pr.nodes[i].owned()) { taint_mask(pr.nodes[i].taints); if (over_volume_limit(pr.nodes[i])) blocked_mask(); }
+  }
 
   // ---------- group tables + per-class membership lists ----------
   void encode_groups() {
@@ -826,6 +912,7 @@ struct Builder {
     p.en = E.en.view(); p.en_taints = E.en_taints.data(); p.en_avail = E.en_avail.data(); p.en_requests = E.en_requests.data(); p.en_requests_present = E.en_requests_present.data(); p.en_port_off = E.en_port_off.data();
     p.cls = E.cls.view(); p.cls_hn_mode = E.cls_hn_mode.data(); p.cls_hn_off = E.cls_hn_off.data(); p.hn_list = E.hn_list.data(); p.cls_requests = E.cls_requests.data(); p.cls_requests_present = E.cls_requests_present.data();
     p.cls_tolerated = E.cls_tolerated.data(); p.cls_port_off = E.cls_port_off.data(); p.ports = E.ports.data();
+    p.en_vol_limit = E.en_vol_limit.data(); p.en_vol_count = E.en_vol_count.data(); p.en_vol_set = E.en_vol_set.data(); p.cls_vol_off = E.cls_vol_off.data(); p.vol_list = E.vol_list.data();
     p.cls_own_off = E.cls_own_off.data(); p.own_list = E.own_list.data(); p.cls_sel_off = E.cls_sel_off.data(); p.sel_list = E.sel_list.data();
     p.cls_isel_off = E.cls_isel_off.data(); p.isel_list = E.isel_list.data(); p.cls_iown_off = E.cls_iown_off.data(); p.iown_list = E.iown_list.data();
     p.pod_stage_off = E.pod_stage_off.data(); p.stage_cls = E.stage_cls.data(); p.queue = E.queue.data();
@@ -838,7 +925,7 @@ struct Builder {
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "  encode %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; };
     if (base) {      // a what-if over a shared snapshot: catalogue, universes, templates and state-node rows come from the snapshot's flattening
-      adopt_base(); dedupe_specs(); encode_existing(); encode_pods(); encode_existing_rest_from_base(); encode_groups(); encode_it_states(); finish(); lap("what-if over shared snapshot");
+      adopt_base(); dedupe_specs(); encode_existing(); encode_pods(); encode_existing_rest_from_base(); encode_groups(); encode_it_states(); encode_volumes(); finish(); lap("what-if over shared snapshot");
       return;
     }
     dedupe_specs(); lap("dedupe_specs");
@@ -852,7 +939,7 @@ struct Builder {
     encode_existing_rest(); lap("encode_existing_rest");
     encode_groups(); lap("encode_groups");
     encode_it_states(); lap("encode_it_states");
-    // C == 0 corner: CSR arrays still need their terminating offset
+    encode_volumes();
     finish(); lap("finish");
   }
 };

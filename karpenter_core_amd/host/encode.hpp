@@ -42,6 +42,7 @@ struct Encoded {
   std::vector<uint64_t> en_taints; std::vector<int64_t> en_avail, en_requests; std::vector<uint32_t> en_requests_present, en_port_off;
   std::vector<uint8_t> cls_hn_mode; std::vector<uint32_t> cls_hn_off, hn_list; std::vector<int64_t> cls_requests; std::vector<uint32_t> cls_requests_present;
   std::vector<uint64_t> cls_tolerated; std::vector<uint32_t> cls_port_off; std::vector<uint64_t> ports;
+  std::vector<int32_t> en_vol_limit, en_vol_count; std::vector<uint64_t> en_vol_set; std::vector<uint32_t> cls_vol_off, vol_list;   // volume limits of existing nodes
   std::vector<uint32_t> cls_own_off, own_list, cls_sel_off, sel_list, cls_isel_off, isel_list, cls_iown_off, iown_list;
   std::vector<uint32_t> pod_stage_off, stage_cls, queue;
   std::vector<uint8_t> grp_type, grp_active; std::vector<int32_t> grp_key, grp_max_skew, grp_count, grp_hslot, grph_count, grph_extra_pos; std::vector<uint32_t> grp_filter_off;

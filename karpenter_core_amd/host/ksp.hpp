@@ -71,6 +71,10 @@ struct Taint { std::string key, value, effect; };
 struct HostPort { std::string ip; int32_t port; std::string proto; };
 struct Container { ResList requests, limits; std::vector<HostPort> ports; };
 struct PreferredTerm { int32_t weight; std::vector<Expr> exprs; };
+// One mounted volume after the lookups of VolumeUsage.validate (volumeusage.go:145-195): the CSI driver the claim resolves to (PVC -> bound
+// PV's Spec.CSI.Driver, else StorageClass.Provisioner) and the claim's id ("<namespace>/<claim>", or "<namespace>/<pod>-<volume>" for a
+// generic ephemeral volume).  Volumes that resolve to no CSI driver are not listed (":185-188 might be a non-CSI driver").
+struct Volume { std::string driver, pvc; };
 
 struct Pod {
   std::string uid, ns;
@@ -83,6 +87,8 @@ struct Pod {
   std::vector<Spread> spread;
   std::vector<AffinityTerm> affinity_required, anti_required;
   std::vector<WeightedTerm> affinity_preferred, anti_preferred;
+  std::vector<Volume> volumes;
+  bool volume_error = false;   // a lookup of VolumeUsage.validate failed (claim / storage class / volume not found): ExistingNode.Add returns that error
 };
 
 struct Offering { std::string capacity_type, zone; double price; bool available; };
@@ -105,6 +111,8 @@ struct StateNode {
   StrMap labels; std::vector<Taint> taints;
   ResList available, capacity, daemonset_requests;
   std::vector<HostPort> host_ports;
+  std::vector<std::pair<std::string, int32_t>> volume_limits;   // state.Node.VolumeLimits(): CSINode allocatable count per driver (cluster.go:292-304)
+  std::vector<Volume> volumes;                                   // state.Node.VolumeUsage(): volumes of the pods bound to the node
   bool owned() const { auto it = labels.find(kProvisionerName); return it != labels.end() && !it->second.empty(); }
 };
 struct ClusterPod { std::string uid, ns, node_name; StrMap labels; std::vector<AffinityTerm> anti_required; };
@@ -209,6 +217,8 @@ class Parser {
       for (int n = count(); n > 0; --n) sn.taints.push_back(taint());
       sn.available = reslist(); sn.capacity = reslist(); sn.daemonset_requests = reslist();
       for (int n = count(); n > 0; --n) sn.host_ports.push_back(hostport());
+      if (next_is("VL")) { expect("VL"); for (int n = count(); n > 0; --n) { std::string d = str(); sn.volume_limits.emplace_back(d, (int32_t)integer()); } }
+      if (next_is("VU")) { expect("VU"); for (int n = count(); n > 0; --n) { Volume v; v.driver = str(); v.pvc = str(); sn.volumes.push_back(std::move(v)); } }
       pr.nodes.push_back(std::move(sn));
     }
     expect("CPODS");
@@ -239,6 +249,11 @@ class Parser {
     return std::string(b, p_);
   }
   std::string str() { std::string t = tok(); return t == "~" ? std::string() : t; }
+  bool next_is(const char* s) {   // optional trailing sections (volumes): look at the next token without consuming it
+    const char* save = p_; bool is = false;
+    if (p_ < e_) { try { is = tok() == s; } catch (const Error&) { is = false; } }
+    p_ = save; return is;
+  }
   int64_t integer() {
     std::string t = tok(); char* end = nullptr; long long v = std::strtoll(t.c_str(), &end, 10);
     if (*end != 0 || t.empty()) throw Error("KSP1: expected integer, got " + t);
@@ -288,6 +303,11 @@ class Parser {
     expect("AFP"); for (int n = count(); n > 0; --n) { WeightedTerm w; w.weight = (int32_t)integer(); w.term = term(); p.affinity_preferred.push_back(std::move(w)); }
     expect("ANR"); for (int n = count(); n > 0; --n) p.anti_required.push_back(term());
     expect("ANP"); for (int n = count(); n > 0; --n) { WeightedTerm w; w.weight = (int32_t)integer(); w.term = term(); p.anti_preferred.push_back(std::move(w)); }
+    if (next_is("VOL")) {
+      expect("VOL"); int64_t n = integer();
+      if (n < 0) p.volume_error = true;
+      else for (; n > 0; --n) { Volume v; v.driver = str(); v.pvc = str(); p.volumes.push_back(std::move(v)); }
+    }
     return p;
   }
 };

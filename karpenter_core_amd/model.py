@@ -30,6 +30,9 @@ list is `<count> item*`):
              I ninit {nreq {res qty}* nlim {res qty}*}*
              TS n {maxSkew key whenUnsatisfiable selector}*
              AFR n term*  AFP n {weight term}*  ANR n term*  ANP n {weight term}*
+             [VOL n {driver pvcId}* | VOL -1]          (optional: mounted CSI volumes, see Volume; -1 = a lookup failed)
+  node     : name inState nlabels {k v}* ntaints {key value effect}* available capacity daemonsetRequests
+             nports {ip port proto}*  [VL n {driver count}*]  [VU n {driver pvcId}*]      (optional: volume limits / usage)
 """
 from __future__ import annotations
 
@@ -154,6 +157,14 @@ class HostPort:
 
 
 @dataclass
+class Volume:
+    """One mounted volume AFTER the API-server lookups of VolumeUsage.validate (reference pkg/scheduling/volumeusage.go:145-195):
+    `driver` is the CSI driver the claim resolves to, `pvc_id` the claim's id.  `resolve_pod_volumes` below does the lookups."""
+    driver: str
+    pvc_id: str
+
+
+@dataclass
 class Container:
     requests: Dict[str, str] = field(default_factory=dict)
     limits: Dict[str, str] = field(default_factory=dict)
@@ -185,6 +196,8 @@ class Pod:
     affinity_preferred: List[WeightedPodAffinityTerm] = field(default_factory=list)
     anti_required: List[PodAffinityTerm] = field(default_factory=list)
     anti_preferred: List[WeightedPodAffinityTerm] = field(default_factory=list)
+    volumes: List[Volume] = field(default_factory=list)       # existingnode.go:87-94 (only existing nodes track volumes)
+    volume_error: bool = False                                # VolumeUsage.validate returned an error (a claim / class / volume is missing)
 
     def ksp(self, w):
         w.write(f"{_tok(self.uid)} {_tok(self.namespace)} {int(self.creation_ts)}")
@@ -236,6 +249,12 @@ class Pod:
         for wt in self.anti_preferred:
             w.write(f" {int(wt.weight)}")
             wt.term.ksp(w)
+        if self.volume_error:
+            w.write(" VOL -1")
+        elif self.volumes:
+            w.write(f" VOL {len(self.volumes)}")
+            for v in self.volumes:
+                w.write(f" {_tok(v.driver)} {_tok(v.pvc_id)}")
 
 
 def _ksp_reslist(rl: Dict[str, str], w):
@@ -288,11 +307,55 @@ class StateNode:
     capacity: Dict[str, str] = field(default_factory=dict)
     daemonset_requests: Dict[str, str] = field(default_factory=dict)
     host_ports: List[HostPort] = field(default_factory=list)
+    volume_limits: Dict[str, int] = field(default_factory=dict)   # VolumeLimits(): CSINode driver -> Allocatable.Count (state/cluster.go:292-304)
+    volumes: List[Volume] = field(default_factory=list)           # VolumeUsage(): volumes of the pods bound to the node
     in_state: bool = True       # passed to NewScheduler as a stateNode (helpers.go:48-61 drops candidates)
 
     @property
     def owned(self) -> bool:    # state/node.go Owned(): provisioner-name label non-empty
         return self.labels.get(LABEL_PROVISIONER, "") != ""
+
+
+class VolumeLookupError(Exception):
+    """A Get of VolumeUsage.validate failed (volumeusage.go:152-154,175-184)."""
+
+
+def resolve_pod_volumes(namespace: str, pod_name: str, volume_sources: Sequence[dict], pvcs: Dict[str, dict],
+                        storage_classes: Dict[str, str], pvs: Dict[str, Optional[str]]) -> List[Volume]:
+    """VolumeUsage.validate (reference pkg/scheduling/volumeusage.go:145-195) over plain dictionaries, for callers (and tests) that hold
+    the API objects rather than resolved volumes.
+      volume_sources : the pod's Spec.Volumes, each {"name": ..., "pvc": claimName} | {"name": ..., "ephemeral": {"storage_class": s|None,
+                       "volume_name": v|""}} | anything else (ignored, :169-171)
+      pvcs           : "<namespace>/<claim>" -> {"storage_class": s|None, "volume_name": v|""}
+      storage_classes: name -> Provisioner
+      pvs            : name -> Spec.CSI.Driver, or None for a non-CSI volume
+    Raises VolumeLookupError where the reference returns the Get error (the caller then sets Pod.volume_error)."""
+    out: List[Volume] = []
+    seen = set()
+    for vs in volume_sources:
+        if "pvc" in vs:
+            pvc_id = f"{namespace}/{vs['pvc']}"
+            if pvc_id not in pvcs:
+                raise VolumeLookupError(f"persistentvolumeclaim {pvc_id} not found")
+            sc, vol = pvcs[pvc_id].get("storage_class"), pvcs[pvc_id].get("volume_name", "")
+        elif "ephemeral" in vs:
+            pvc_id = f"{namespace}/{pod_name}-{vs['name']}"      # generated claim name, :165
+            sc, vol = vs["ephemeral"].get("storage_class"), vs["ephemeral"].get("volume_name", "")
+        else:
+            continue
+        driver = ""
+        if vol:                                                   # bound / static: the driver comes from the volume (:176-180)
+            if vol not in pvs:
+                raise VolumeLookupError(f"persistentvolume {vol} not found")
+            driver = pvs[vol] or ""
+        elif sc:                                                  # dynamic: from the storage class (:181-186)
+            if sc not in storage_classes:
+                raise VolumeLookupError(f"storageclass {sc} not found")
+            driver = storage_classes[sc]
+        if driver and (driver, pvc_id) not in seen:               # volumes is a set per driver (:41-48)
+            seen.add((driver, pvc_id))
+            out.append(Volume(driver, pvc_id))
+    return out
 
 
 TAINT_NODE_NOT_READY = "node.kubernetes.io/not-ready"
@@ -383,6 +446,14 @@ class Problem:
             w.write(f" {len(n.host_ports)}")
             for hp in n.host_ports:
                 w.write(f" {_tok(hp.host_ip)} {int(hp.port)} {_tok(hp.protocol)}")
+            if n.volume_limits:
+                w.write(f" VL {len(n.volume_limits)}")
+                for d in sorted(n.volume_limits):
+                    w.write(f" {_tok(d)} {int(n.volume_limits[d])}")
+            if n.volumes:
+                w.write(f" VU {len(n.volumes)}")
+                for v in n.volumes:
+                    w.write(f" {_tok(v.driver)} {_tok(v.pvc_id)}")
             w.write("\n")
         w.write(f"CPODS {len(self.cluster_pods)}\n")
         for cp in self.cluster_pods:

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import List
 
+import dataclasses
+
 import numpy as np
 
 from . import fake
@@ -236,9 +238,7 @@ def whatif(its, prov, nodes, bound, candidates: List[int], with_cluster_pods: bo
     their pods become the pending batch; the cluster still holds the bound pods (excluded by UID,
     topology.go:66-70,249)."""
     cand = set(candidates)
-    ns = [StateNode(name=n.name, labels=n.labels, taints=n.taints, available=n.available, capacity=n.capacity,
-                    daemonset_requests=n.daemonset_requests, host_ports=n.host_ports, in_state=(i not in cand))
-          for i, n in enumerate(nodes)]
+    ns = [dataclasses.replace(n, in_state=(i not in cand)) for i, n in enumerate(nodes)]
     pods = [p for i in candidates for p in bound[i]]
     # the bound pods only matter to countDomains / inverse anti-affinity; a snapshot whose pods carry no
     # topology terms can skip listing them (nothing would be counted)
@@ -256,8 +256,7 @@ def snapshot_problem(its, prov, nodes, bound, with_cluster_pods: bool = True):
         for p in bound[i]:
             pods.append(p)
             pod_node.append(i)
-    ns = [StateNode(name=n.name, labels=n.labels, taints=n.taints, available=n.available, capacity=n.capacity,
-                    daemonset_requests=n.daemonset_requests, host_ports=n.host_ports, in_state=True) for n in nodes]
+    ns = [dataclasses.replace(n, in_state=True) for n in nodes]
     cps = [ClusterPod(uid=p.uid, namespace=p.namespace, node_name=nodes[i].name, labels=p.labels)
            for i in range(len(nodes)) for p in bound[i]] if with_cluster_pods else []
     return Problem(instance_types=its, provisioners=[prov], pods=pods, nodes=ns, cluster_pods=cps,

@@ -664,6 +664,8 @@ struct Node {   // scheduling.Node, node.go:34-107
 struct ExistingNode {   // existingnode.go:28-130
   const ksp::StateNode* sn; Reqs requirements; ResList requests, available; std::vector<ksp::Taint> taints;
   std::vector<int> pods; HostPortUsage ports;
+  std::map<std::string, std::set<std::string>> volumes;   // VolumeUsage.volumes: driver -> claim ids (volumeusage.go:33-40)
+  std::map<std::string, int> volume_limits;                // VolumeCount from the CSINode (cluster.go:292-304); absent = unlimited
 };
 
 struct Scheduler {
@@ -735,6 +737,13 @@ struct Scheduler {
     ksp::Pod& pod = ps.spec;
     if (!taints_tolerates(n.taints, pod)) return false;
     if (!n.ports.validate(pod, nullptr)) return false;
+    // volumeUsage.Validate + VolumeCount.Exceeds, existingnode.go:87-94 / volumeusage.go:102-143
+    if (pod.volume_error) return false;                                     // a lookup failed: Validate returns the error
+    {
+      std::map<std::string, std::set<std::string>> u = n.volumes;           // volumes.union(podVolumes)
+      for (auto& v : pod.volumes) u[v.driver].insert(v.pvc);
+      for (auto& kv : u) { auto lim = n.volume_limits.find(kv.first); if (lim != n.volume_limits.end() && (int)kv.second.size() > lim->second) return false; }   // "would exceed node volume limits"
+    }
     ResList requests = res_merge(n.requests, requests_for_pods({&pod}));
     if (!res_fits(requests, n.available)) return false;
     Reqs nodeReqs = n.requirements;
@@ -747,6 +756,7 @@ struct Scheduler {
     nodeReqs.add_all(topoReqs);
     n.pods.push_back(ps.index); n.requests = requests; n.requirements = nodeReqs;
     topo.record(pod, nodeReqs); n.ports.add(pod);
+    for (auto& v : pod.volumes) n.volumes[v.driver].insert(v.pvc);          // volumeUsage.Add, volumeusage.go:94-100
     return true;
   }
 
@@ -861,6 +871,13 @@ struct Scheduler {
     ksp::Pod& pod = ps.spec;
     if (!taints_tolerates(n.taints, pod)) return false;
     if (!n.ports.validate(pod, nullptr)) return false;
+    // volumeUsage.Validate + VolumeCount.Exceeds, existingnode.go:87-94 / volumeusage.go:102-143
+    if (pod.volume_error) return false;                                     // a lookup failed: Validate returns the error
+    {
+      std::map<std::string, std::set<std::string>> u = n.volumes;           // volumes.union(podVolumes)
+      for (auto& v : pod.volumes) u[v.driver].insert(v.pvc);
+      for (auto& kv : u) { auto lim = n.volume_limits.find(kv.first); if (lim != n.volume_limits.end() && (int)kv.second.size() > lim->second) return false; }   // "would exceed node volume limits"
+    }
     ResList requests = res_merge(n.requests, requests_for_pods({&pod}));
     if (!res_fits(requests, n.available)) return false;
     Reqs nodeReqs = n.requirements; Reqs podReqs = new_pod_requirements(pod);
@@ -1033,6 +1050,8 @@ static std::unique_ptr<Scheduler> build(const ksp::Problem& pr, bool inert_topol
     auto en = std::make_unique<ExistingNode>();
     en->sn = &n; en->available = n.available; en->taints = n.taints; en->requests = remainingDaemon; en->requirements = reqs_from_labels(n.labels);
     for (auto& hp : n.host_ports) { std::string ip = hp.ip.empty() ? "0.0.0.0" : hp.ip; en->ports.reserved["~existing~/" + std::to_string(en->ports.reserved.size())].push_back({canon_ip(ip), hp.port, hp.proto}); }
+    for (auto& v : n.volumes) en->volumes[v.driver].insert(v.pvc);
+    for (auto& kv : n.volume_limits) en->volume_limits[kv.first] = kv.second;
     auto hl = n.labels.find(ksp::kHostname); std::string hostname = (hl == n.labels.end() || hl->second.empty()) ? n.name : hl->second;
     en->requirements.add(new_req(ksp::kHostname, Op::In, {hostname}));
     s->topo.register_domain(s->hostnameKey, s->hn.of(S(hostname)));

@@ -140,6 +140,9 @@ class ClusterSim:
         node.available = {k: format_milli(v) for k, v in avail.items()}
         for c in pod.containers:
             node.host_ports.extend(c.ports)
+        for v in pod.volumes:                                  # state.Node.updateForPod -> volumeUsage.Add (state/node.go:172)
+            if v not in node.volumes:
+                node.volumes.append(v)
         self.cluster_pods.append(ClusterPod(uid=pod.uid, namespace=pod.namespace, node_name=node.name,
                                             labels=dict(pod.labels), anti_required=list(pod.anti_required)))
         self.node_of[pod.uid] = node.name

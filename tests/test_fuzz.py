@@ -1,6 +1,6 @@
 """Randomised small problems that mix every feature the path handles -- existing nodes, weighted provisioners with limits and
 taints, host ports, hostname / instance-type selectors, Gt/Lt, zonal / hostname / capacity-type spread (DoNotSchedule and
-ScheduleAnyway), pod affinity and anti-affinity, preferred terms (relaxation chains), unschedulable pods.
+ScheduleAnyway), pod affinity and anti-affinity, preferred terms (relaxation chains), unschedulable pods, CSI volume limits.
 CPU: the speculation rules hold on every case (oracle.solve_spec).  GPU: bit-identical to the oracle, through the default kernel
 and through the single-wave one."""
 import numpy as np
@@ -9,7 +9,7 @@ import pytest
 from karpenter_core_amd import fake, workloads as W
 from karpenter_core_amd.model import (Container, DO_NOT_SCHEDULE, Expr, HostPort, LABEL_ARCH, LABEL_CAPACITY_TYPE, LABEL_HOSTNAME,
                                       LABEL_INSTANCE_TYPE, LABEL_ZONE, LabelSelector, NO_SCHEDULE, Pod, PodAffinityTerm, PreferredTerm,
-                                      Problem, SCHEDULE_ANYWAY, Taint, Toleration, TopologySpreadConstraint)
+                                      Problem, SCHEDULE_ANYWAY, Taint, Toleration, TopologySpreadConstraint, Volume)
 from oracle import oracle_py as O
 
 SEEDS = list(range(64))
@@ -69,6 +69,26 @@ def fuzz_problem(seed: int) -> Problem:
     if nodes:
         from karpenter_core_amd.model import ClusterPod
         cps = [ClusterPod(uid=q.uid, namespace=q.namespace, node_name=nodes[i].name, labels=q.labels) for i in range(len(nodes)) for q in bound[i]]
+    # volume limits (a stream of its own: the draws above stay what they were): limits on some nodes, claims already mounted, pods with
+    # shared / own / ephemeral-style claims on two drivers, now and then a pod whose claim lookup failed
+    rv = np.random.RandomState(7000 + seed)
+    if nodes and rv.rand() < 0.6:
+        nodes = [__import__("copy").deepcopy(nd) for nd in nodes]
+        drivers = ["ebs.csi", "efs.csi"]
+        for nd in nodes:
+            if rv.rand() < 0.8:
+                nd.volume_limits = {d: int(rv.randint(0, 5)) for d in drivers if rv.rand() < 0.7}
+            nd.volumes = [Volume(drivers[rv.randint(2)], f"default/shared-{rv.randint(6)}") for _ in range(int(rv.randint(0, 4)))]
+        for p in pods:
+            r = rv.rand()
+            if r < 0.35:
+                p.volumes = [Volume(drivers[rv.randint(2)], f"default/shared-{rv.randint(6)}") for _ in range(int(rv.randint(1, 3)))]
+                if rv.rand() < 0.5:
+                    p.volumes.append(Volume(drivers[rv.randint(2)], f"default/{p.uid}-scratch"))
+                if rv.rand() < 0.2:
+                    p.volumes.append(Volume("unlimited.csi", "default/whatever"))
+            elif r < 0.4:
+                p.volume_error = True
     return Problem(instance_types=its, provisioners=provs, pods=pods, nodes=list(nodes), cluster_pods=cps, extra_well_known=fake.EXTRA_WELL_KNOWN)
 
 

@@ -6,7 +6,8 @@ import pytest
 from helpers import BACKENDS, ClusterSim, mkpod, mkpods
 from karpenter_core_amd import fake
 from karpenter_core_amd.model import (Container, Expr, HostPort, LabelSelector, PodAffinityTerm, PreferredTerm, Taint,
-                                      Toleration, TopologySpreadConstraint, WeightedPodAffinityTerm, DO_NOT_SCHEDULE,
+                                      Toleration, TopologySpreadConstraint, Volume, VolumeLookupError, WeightedPodAffinityTerm,
+                                      resolve_pod_volumes, DO_NOT_SCHEDULE,
                                       LABEL_ARCH, LABEL_CAPACITY_TYPE, LABEL_HOSTNAME, LABEL_INSTANCE_TYPE, LABEL_OS,
                                       LABEL_ZONE, SCHEDULE_ANYWAY)
 
@@ -723,3 +724,97 @@ def test_host_port_ip_forms(backend):
         a, b = mkpod(ports=hp(ip1)), mkpod(ports=hp(ip2))
         sim.provision([a, b])
         assert (sim.scheduled(a).name == sim.scheduled(b).name) == together, (ip1, ip2)
+
+
+# ---------------- VolumeUsage (suite_test.go:1994-2270; existingnode.go:87-94, volumeusage.go:102-195) ----------------
+CSI = "fake.csi.provider"
+
+
+def _volume_cluster(backend, limit=10):
+    """S:1997-2029: one huge instance type, an in-flight node from a first pod, then a CSINode giving it `limit` volumes of CSI."""
+    sim = ClusterSim(backend, instance_types=[fake.new_instance_type("instance-type", {"cpu": "1024", "pods": "1024"})],
+                     provisioners=[default_prov(limits=None)])
+    first = mkpod()
+    sim.provision([first])
+    node = sim.scheduled(first)
+    node.volume_limits = {CSI: limit}
+    return sim, node
+
+
+def _claims(pod_name, claims, pvcs, pvs=None):
+    return resolve_pod_volumes("default", pod_name, [{"name": f"v{i}", "pvc": c} for i, c in enumerate(claims)], pvcs,
+                               {"my-storage-class": CSI}, pvs or {})
+
+
+def test_volume_limits_force_a_second_node(backend):
+    # S:1995-2057: 6 pods x 2 dynamic claims each against a limit of 10 -> the in-flight node takes 5, one new node is launched
+    sim, node = _volume_cluster(backend)
+    pvcs = {f"default/my-claim-{ab}-{i}": {"storage_class": "my-storage-class"} for ab in "ab" for i in range(6)}
+    pods = [mkpod(volumes=_claims(f"p{i}", [f"my-claim-a-{i}", f"my-claim-b-{i}"], pvcs)) for i in range(6)]
+    res = sim.provision(pods)
+    assert len(sim.nodes) == 2
+    assert len(res.existing[node.name]) == 5 and len(res.new_nodes) == 1 and len(res.new_nodes[0].pods) == 1
+    assert len(node.volumes) == 10
+
+
+def test_volume_limits_same_claim_counts_once(backend):
+    # S:2058-2123: 100 pods mounting one (bound) claim twice all fit the in-flight node: a claim id counts once per node
+    sim, node = _volume_cluster(backend)
+    pvcs = {"default/my-claim": {"storage_class": "my-storage-class", "volume_name": "my-volume"}}
+    pods = [mkpod(volumes=_claims(f"p{i}", ["my-claim", "my-claim"], pvcs, pvs={"my-volume": CSI})) for i in range(100)]
+    assert all(p.volumes == [Volume(CSI, "default/my-claim")] for p in pods)
+    sim.provision(pods)
+    assert len(sim.nodes) == 1 and len(node.volumes) == 1
+
+
+def test_volume_limits_static_and_non_csi_volumes(backend):
+    # S:2124-2189 non-dynamic PVC (storage class "", driver from the PV); S:2190-2240 an NFS volume has no CSI driver and is not tracked
+    for pv_driver in (CSI, None):
+        sim, node = _volume_cluster(backend)
+        pvcs = {"default/my-claim": {"storage_class": "", "volume_name": "my-volume"}}
+        pods = [mkpod(volumes=_claims(f"p{i}", ["my-claim", "my-claim"], pvcs, pvs={"my-volume": pv_driver})) for i in range(5)]
+        assert all(len(p.volumes) == (1 if pv_driver else 0) for p in pods)
+        sim.provision(pods)
+        assert len(sim.nodes) == 1
+
+
+def test_volume_lookup_errors(backend):
+    # volumeusage.go:152-154,175-184: a failed Get is returned by Validate -> ExistingNode.Add fails on every existing node, new nodes do not look
+    with pytest.raises(VolumeLookupError):
+        resolve_pod_volumes("default", "p", [{"name": "v", "pvc": "missing"}], {}, {}, {})
+    with pytest.raises(VolumeLookupError):       # S:2241-2270's pod: an ephemeral volume of a storage class that does not exist
+        resolve_pod_volumes("default", "p", [{"name": "tmp-ephemeral", "ephemeral": {"storage_class": "non-existent"}}], {}, {}, {})
+    sim, node = _volume_cluster(backend)
+    bad, good = mkpod(volume_error=True), mkpod()
+    res = sim.provision([bad, good])
+    assert sim.scheduled(good).name == node.name
+    assert sim.scheduled(bad) is not None and sim.scheduled(bad).name != node.name and len(res.new_nodes) == 1
+
+
+def test_volume_limits_mixed_claims(backend):
+    # claims shared between pods, claims already on the node, generic ephemeral volumes (unique per pod), two drivers, an unlimited
+    # driver, and a node that is already over its limit (refuses every pod, even one without volumes: Exceeds ranges over the union)
+    other = "other.csi.provider"
+    sim, node = _volume_cluster(backend, limit=4)
+    node.volume_limits[other] = 1
+    warm = mkpod(volumes=[Volume(CSI, "default/shared-0")])
+    sim.provision([warm])
+    assert sim.scheduled(warm).name == node.name and node.volumes == [Volume(CSI, "default/shared-0")]
+    eph = lambda name: resolve_pod_volumes("default", name, [{"name": "scratch", "ephemeral": {"storage_class": "my-storage-class"}}], {}, {"my-storage-class": CSI}, {})
+    pods = [mkpod(volumes=[Volume(CSI, "default/shared-0"), Volume(CSI, "default/shared-1")]),      # +1 (shared-0 is mounted already)
+            mkpod(volumes=[Volume(CSI, "default/shared-1"), Volume("unlimited.csi", "default/x")]),   # +0
+            mkpod(volumes=eph("e1")),                                                                 # +1
+            mkpod(volumes=eph("e2") + [Volume(other, "default/o1")]),                                 # +1, other 1/1
+            mkpod(volumes=[Volume(other, "default/o2")]),                                             # other would be 2/1 -> refused
+            mkpod(volumes=eph("e3")),                                                                 # CSI would be 5/4 -> refused
+            mkpod(volumes=[Volume(CSI, "default/shared-1")])]                                         # +0 -> fits
+    for i, p in enumerate(pods):
+        p.containers[0].requests = {"cpu": f"{100 - i}m"}       # queue order == list order
+    res = sim.provision(pods)
+    assert sorted(res.existing[node.name]) == [0, 1, 2, 3, 6]
+    assert sum(len(n.pods) for n in res.new_nodes) == 2
+    # over the limit: the CSINode's count drops below what is mounted
+    node.volume_limits[CSI] = 2
+    p = mkpod()
+    sim.provision([p])
+    assert sim.scheduled(p).name != node.name

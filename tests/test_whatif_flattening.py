@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from karpenter_core_amd import scheduler as S, workloads as W
-from karpenter_core_amd.model import DO_NOT_SCHEDULE, LABEL_ZONE, LabelSelector, TopologySpreadConstraint
+from karpenter_core_amd.model import DO_NOT_SCHEDULE, LABEL_ZONE, LabelSelector, TopologySpreadConstraint, Volume
 
 SHAPE = ("P", "C", "T", "M", "E", "R", "G", "GH")
 
@@ -23,6 +23,15 @@ def _cases():
             if rs.rand() < 0.3:
                 p.spread = [TopologySpreadConstraint(1, LABEL_ZONE, DO_NOT_SCHEDULE, LabelSelector({"my-label": p.labels["my-label"]}))]
     yield its, prov, nodes, bound, [[0, 1, 2], [5], [7, 3], list(range(10))], True
+    its, prov, nodes, bound = W.cluster_snapshot(existing=24, sizes=5, seed=11)
+    rs = np.random.RandomState(2)
+    for i, pods in enumerate(bound):                      # CSI volume limits: the candidates' pods bring their claims along, the other nodes keep theirs
+        for p in pods:
+            if rs.rand() < 0.5:
+                p.volumes = [Volume("ebs.csi", f"default/shared-{rs.randint(8)}")] + ([Volume("ebs.csi", f"default/{p.uid}-data")] if rs.rand() < 0.5 else [])
+        nodes[i].volumes = [v for j, v in enumerate(x for p in pods for x in p.volumes) if v not in [y for q in pods for y in q.volumes][:j]]
+        nodes[i].volume_limits = {"ebs.csi": int(rs.randint(1, 6))} if rs.rand() < 0.8 else {}
+    yield its, prov, nodes, bound, [[0], [1, 2], [5, 9, 13], list(range(8))], False
 
 
 def _both(its, prov, nodes, bound, sets, with_cluster_pods):
