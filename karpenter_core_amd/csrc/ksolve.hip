@@ -128,6 +128,8 @@ struct DevState {
   u64* pp_entry; i32* pp_next; u32 pp_cap;
   // volumes mounted on the existing nodes (VolumeUsage.volumes as counts + the shared-claim set)
   u32 vol_pad; i32* vol_cnt; u64* vol_set;
+  // per class (index eq-1 for evaluation-equivalent classes): every existing node below it has refused the class (ClsPlan::mono)
+  u32* wm;
   // outputs
   u64* stats; u32* out_counts;   // out_counts: [0]=n_new [1]=n_unscheduled
   u64* batch_meta;               // batched launches: [0]=n_new [1]=n_unscheduled [2..33]=stats of this problem in one batch-wide array (one read-back)
@@ -333,7 +335,7 @@ struct alignas(16) ClsPlan {
   u32 c, present, complement; i32 it_state;
   u32 hn_mode, hn_off, hn_cnt, reqmask;
   u64 tol; u32 port_off, port_cnt;
-  u32 vol_off, vol_cnt, vol_pad0, vol_pad1;
+  u32 vol_off, vol_cnt, mono, vol_pad1;     // mono: an existing node that refused this class once refuses it for the rest of the Solve (see the watermark in ks_pack)
   u32 ntouch, ntopo, nhost, nrec;
   i64 req[KS_MAX_RES];
   PlanTouch touch[KS_MAX_TOUCH];
@@ -438,6 +440,10 @@ __global__ __launch_bounds__(64) void ks_build_plans(DevProb P, ClsPlan* plans, 
   }
   for (u32 j = 0; j < pl.nrec; ++j) pl.rmask |= 1ull << (pl.rec[j].g & 63);
   pl.eq = 0;
+  // Rejections by an EXISTING node are monotone for a class that consults no topology group and whose own requirements are all on
+  // well-known keys: taints are static, host ports / volumes / requests only accumulate, requirement sets only narrow.  (A custom
+  // label the node does not define is the exception -- "label does not have known values" until another pod's NotIn defines it.)
+  pl.mono = (!pl.overflow && pl.ntopo == 0 && pl.nhost == 0 && (pl.present & ~P.wellknown_mask) == 0) ? 1u : 0u;
   plans[c] = pl;
   u64 zmask = 0;
   for (u32 j = 0; j < pl.nhost; ++j) if (pl.host[j].type == 2 || (pl.host[j].type == 0 && (i64)pl.host[j].maxskew - (i64)pl.host[j].self <= 0)) zmask |= 1ull << (pl.host[j].g & 63);
@@ -1106,6 +1112,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     r.porthead() = head;
     for (u32 h = 0; h < tb.GH; ++h) tb.hcnt[(size_t)e * tb.GH + h] = P.grph_count[(size_t)h * tb.E + e];
   }
+  for (u32 i = lane; i < P.C; i += 64) S.wm[i] = 0;
   for (u32 i = lane; i < tb.E * P.ND; i += 64) S.vol_cnt[i] = P.en_vol_count[i];
   for (u32 i = lane; i < tb.E * P.SW; i += 64) S.vol_set[i] = P.en_vol_set[i];
   for (u32 i = lane; i < P.M * tb.R; i += 64) S.remaining[i] = P.tmpl_remaining[i];
@@ -1289,6 +1296,13 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       pf_ok = true;
     }
     u32 pos_base = 0, tm = 0, width = KS_FIRST_WIDTH, why = 0;       // why: one KS_WHY_* per template this pod could not use (scheduler.go:193-217)
+    // Watermark: the existing nodes come first in the visiting order and never move; for a `mono` class every node that refused it
+    // stays refused, so the scan starts where the last pod of the class (or of an evaluation-equivalent one) had to start looking.
+    const bool mono = tb.E != 0 && UF(c.mono) != 0 && !want_stats;
+    const u32 wmi = cr.eq ? cr.eq - 1u : cidx;
+    u32 scan_lo = 0;
+    if (mono) { scan_lo = UF(S.wm[wmi]); pos_base = scan_lo; }
+    const u32 wm0 = scan_lo;
     bool reuse = NW == 1 && r_valid && !want_stats && cr.eq != 0 && cr.eq == r_eq;     // (single-wave kernel only: in the multi-wave one rounds take the runs of equivalent pods)
     if (!want_stats && cr.nhost) {
       // anti-affinity (count == 0) and spread with maxSkew - self == 0 accept a node only if its own hostname counts 0; with no such
@@ -1420,6 +1434,30 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         }
         // ---- commit: node.go:100-105 / existingnode.go:122-129 / scheduler.go:214-216 ----
         visited = win + 1;
+        if (mono && !reuse) scan_lo = ex ? pos_base + (u32)win : tb.E;
+        // Run commit (existing node): the queue entries that follow and are evaluation-equivalent to this pod (same ClsBrief::ev, nothing to
+        // record, never requeued) would each rescan the same refusing nodes and land here while the node has room -- resources.Fits on the
+        // accumulated requests (existingnode.go:99-103) is the only thing that changes between them.  Lane k tests "k+1 more fit".
+        u32 t_extra = 0; u64 run_e = 0;
+        if (ex && mono && cr.eq != 0 && UF(c.nrec) == 0 && q_len != 0) {
+          const u32 avail = min(q_len, 63u), my_ev = UF(briefs[cidx].ev);
+          bool okl = false;
+          if ((u32)lane < avail) {
+            u32 idx = q_head + (u32)lane; if (idx >= nP) idx -= nP;
+            run_e = tb.q[idx];
+            const GA ClsBrief* bq = briefs + ((u32)(run_e >> 32) & 0x7FFFFFFFu);
+            okl = (run_e >> 63) == 0 && bq->ev == my_ev && bq->rmask == 0;
+          }
+          const u64 nok = ~ballot64(okl); const u32 run = nok ? (u32)__builtin_ctzll(nok) : 64u;
+          if (run) {
+            bool fitl = true;
+#pragma unroll
+            for (int i = 0; i < RM; ++i) if (cr.req[i] > 0 && (i64)(lane + 1) * cr.req[i] > pb.room_new[i]) fitl = false;
+            const u64 nfit = ~ballot64(fitl); t_extra = min(run, nfit ? (u32)__builtin_ctzll(nfit) : 64u);
+#pragma unroll
+            for (int i = 0; i < RM; ++i) { pb.req_new[i] += (i64)t_extra * cr.req[i]; pb.room_new[i] -= (i64)t_extra * cr.req[i]; }
+          }
+        }
         if (fresh && lim != 0xFFFFFFFFu) {          // subtractMax, scheduler.go:273-290
           GA u64* const alive = tb.n_alive + (size_t)jw * tb.TW;
           i64 mx[RM];
@@ -1447,6 +1485,11 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           for (u32 i = 0; i < cr.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
           if (!LEAN && ex && cr.vol_cnt) volumes_walk<true>(P, S, c, sw);
           tb.pod_node[pod] = (i32)sw; tb.pod_seq[pod] = (i32)seq; S.pod_reason[pod] = 0;
+        }
+        if (t_extra) {
+          if ((u32)lane < t_extra) { const u32 pd = (u32)run_e; tb.pod_node[pd] = (i32)sw; tb.pod_seq[pd] = (i32)(seq + 1u + (u32)lane); S.pod_reason[pd] = 0; }
+          q_head += t_extra; if (q_head >= nP) q_head -= nP;
+          q_len -= t_extra; seq += t_extra; pf_ok = false;
         }
         PROBE(17);
         if (!ex && !fresh) {
@@ -1486,16 +1529,17 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         PROBE(18);
         break;
       }
-      if (reuse && !placed) { if (NW == 1) CTR(9, 1); reuse = false; r_valid = false; pos_base = 0; continue; }   // window exhausted: evaluate from the top
+      if (reuse && !placed) { if (NW == 1) CTR(9, 1); reuse = false; r_valid = false; pos_base = mono ? scan_lo : 0u; continue; }   // window exhausted: evaluate from the top
       if (want_stats && !fresh) {
         CTR(KS_STAT_REF_ATTEMPTS, visited);
         u32 ty = ((u32)lane < visited && ((reach >> lane) & 1ull)) ? my_alive : 0;
         for (int off = 32; off > 0; off >>= 1) ty += __shfl_xor(ty, off);
         CTR(KS_STAT_REF_TYPES, ty);
       }
-      if (!fresh) { pos_base += width; width = 64; }
+      if (!fresh) { pos_base += width; width = 64; if (mono && !reuse && !placed) scan_lo = min(pos_base, tb.E); }
     }
     if (err) break;
+    if (mono && scan_lo > wm0 && lane == 0) S.wm[wmi] = scan_lo;
 #ifdef KS_PROBES
     if (NW == 1) { const u32 kind = cr.nhost ? 2 : (c.ntopo ? 1 : 0); CTR(27 + kind, __builtin_readcyclecounter() - t_pod); if (kind) CTR(29 + kind, 1); }
     else { CTR(28, __builtin_readcyclecounter() - t_pod); CTR(30, 1); }
@@ -2283,7 +2327,7 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   size_t pp_pool = E ? p->en_port_off[E] : 0;
   for (u32 i = 0; i < P; ++i) { u32 mx = 0; for (u32 st = p->pod_stage_off[i]; st < p->pod_stage_off[i + 1]; ++st) { const u32 c = p->stage_cls[st]; const u32 n = p->cls_port_off[c + 1] - p->cls_port_off[c]; if (n > mx) mx = n; } pp_pool += mx; }
   s.pp_cap = (u32)pp_pool; TRY(dev_alloc(d, pp_pool, &s.pp_entry)); TRY(dev_alloc(d, pp_pool, &s.pp_next));
-  s.vol_pad = 0; TRY(dev_alloc(d, (size_t)E * p->ND, &s.vol_cnt)); TRY(dev_alloc(d, (size_t)E * p->SW, &s.vol_set));
+  s.vol_pad = 0; TRY(dev_alloc(d, (size_t)E * p->ND, &s.vol_cnt)); TRY(dev_alloc(d, (size_t)E * p->SW, &s.vol_set)); TRY(dev_alloc(d, C, &s.wm));
   TRY(dev_alloc(d, 32, &s.stats, 0)); TRY(dev_alloc(d, 4, &s.out_counts, 0)); TRY(dev_alloc(d, P, &s.unscheduled));
   // the two descriptors go last: by now (placing pass) every pointer in them is final
   { const DevProb* dp; const DevState* ds; TRY(dev_copy(d, &d->h, 1, &dp)); TRY(dev_copy(d, &d->hs, 1, &ds)); d->d_prob = (DevProb*)dp; d->d_state = (DevState*)ds; }
