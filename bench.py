@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--cpu-sample-pods", type=int, default=20_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--whatifs", type=int, default=512, help="consolidation what-ifs (BASELINE configs[3]); 0 skips the N=1 what-if leg")
+    ap.add_argument("--whatifs-only", action="store_true", help="diagnostic: only the N=1 what-if leg (prints its object alone, not the contract line)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,6 +89,9 @@ def main():
 
     if world > 1:
         return whatif_fanout(args, rank, world, local_rank, torch, dist, S, W)
+    if args.whatifs_only:
+        print(json.dumps(whatif_leg(args, 0, 1, local_rank, torch, None, S, W), indent=1))
+        return
 
     # ---- the pod list and the cluster objects in host memory (untimed: the caller holds them) ----
     t0 = time.time()
@@ -219,7 +223,8 @@ def whatif_leg(args, rank, world, local_rank, torch, dist, S, W):
         t3 = time.perf_counter()
         return flats, rec, {"flatten_ms": (t1 - t0) * 1e3, "upload_ms": (t2 - t1) * 1e3, "solve_records_ms": (t3 - t2) * 1e3, "kernel_ms": kms, "total_ms": (t3 - t0) * 1e3}
 
-    flats, rec, _ = end_to_end()           # warm-up (device buffer pool, code objects)
+    flats, rec, first = end_to_end()       # first batch over this snapshot: also flattens the snapshot itself (once per snapshot, cached in the
+                                           # parsed object), puts that flattening on the device (shared catalogue + derived tables), warms the pools
     for f in flats:
         f.close()
     runs = []
@@ -241,7 +246,8 @@ def whatif_leg(args, rank, world, local_rank, torch, dist, S, W):
     pods_mine = sum(f.dims["P"] for f in flats)
     out = {"workload": f"{len(flats)} consolidation what-ifs over 2048 existing nodes / {T} instance types (BASELINE configs[3])",
            "whatifs": len(flats), "decisions": pods_mine, "records": int(rec.shape[0]),
-           "end_to_end": dict(ms, what="from the snapshot held as objects: flatten over the shared snapshot base + upload + one batched launch + result records",
+           "first_batch_over_the_snapshot": dict(first, what="cold: + the snapshot's own flattening and its upload (once per snapshot), buffer pools, code objects"),
+           "end_to_end": dict(ms, what="a batch of candidate sets over a snapshot already seen (a consolidation pass probes many): flatten the what-ifs over the shared snapshot base + upload + one batched launch + result records",
                               decisions_per_s=pods_mine / (ms["total_ms"] / 1e3), whatifs_per_s=len(flats) / (ms["total_ms"] / 1e3)),
            "resident": {"kernel_ms": kms, "wall_ms": wms, "decisions_per_s_kernel": pods_mine / (kms / 1e3), "decisions_per_s_wall": pods_mine / (wms / 1e3),
                         "whatifs_per_s_wall": len(flats) / (wms / 1e3)}}

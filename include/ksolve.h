@@ -240,6 +240,12 @@ int ks_current_device(void);                                   /* the calling th
 int ks_problem_device(const ks_dev_problem* d);                /* device an uploaded problem lives on */
 int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem** out);
 void ks_problem_free(ks_dev_problem* d);
+/* Consolidation what-ifs over ONE cluster snapshot (deprovisioning/helpers.go:42-99) differ in their pods and in which state nodes stay, not in
+ * the catalogue.  `base` is a resident problem flattened from the same snapshot (ks_problem_prepare'd): arrays of `p` whose HOST pointers are
+ * the very arrays `base` was uploaded from (instance types, offerings, prices, the instance-type-key lattice) are not copied again, and the
+ * tables derived from the catalogue are shared with it.  `base` must outlive the returned problem.  Anything not shared is uploaded as usual. */
+int ks_problem_upload_shared(const ks_problem* p, const ks_dev_problem* base, ks_dev_problem** out);
+int ks_problem_prepare(ks_dev_problem* d);                     /* build the static tables + feasibility grid now (otherwise the first solve does) */
 /* Solve on the uploaded problem; kernel time (ms, HIP events on the solve stream) is returned in *kernel_ms if non-NULL. */
 int ks_solve_dev(ks_dev_problem* d, ks_result* out, float* kernel_ms);
 /* Convenience: upload + solve + free. */

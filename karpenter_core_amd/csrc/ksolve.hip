@@ -103,7 +103,7 @@ struct DevProb {
   u64* ge_rows;      // [(r*T+i)*TW] types whose Allocatable[r] >= ge_vals[r*T+i]   (resources.Fits as a mask)
   void* plans;       // [C] ClsPlan: per-class plan records (ks_build_plans)
   void* briefs;      // [C] ClsBrief: what the round planner / resolver reads of a class
-  u32* ev_tab; u32 ev_tab_size, ev_pad;   // open-addressing table that interns evaluation classes (ks_link_plans)
+  u32* ev_tab; u32 ev_tab_size, derived_shared;   // open-addressing table that interns evaluation classes (ks_link_ev); derived_shared: kv_types .. ge_rows belong to another problem
   u8* mc_ok;         // [M*C]
   u8* mc_why;        // [M*C]  KS_WHY_* of a fresh node of template m refusing class c before the topology step (0 if mc_ok)
   u32* mc_present; u32* mc_complement; u64* mc_mask; i32* mc_gt; i32* mc_lt; i32* mc_it;   // template ∩ class
@@ -152,7 +152,10 @@ __device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
 // ks_build_type_tables: one wave per table row
 // rows: [0, K*64) -> kv_types[k][v]; [K*64, K*64+K) -> cmplx[k]; [.., +K) -> nidnex[k]; [.., +64) -> pair_types
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ks_build_type_tables(DevProb P) {
+// (Every static-table kernel takes the descriptor array of a batch; blockIdx.y picks the problem.  One Solve launches with grid.y = 1.)
+__global__ __launch_bounds__(256) void ks_build_type_tables(const DevProb* probs) {
+  const DevProb& P = probs[blockIdx.y];
+  if (P.derived_shared) return;      // the catalogue-derived rows are another problem's (ks_problem_upload_shared)
   const int lane = threadIdx.x & 63;
   const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const u32 nrows = P.K * 64 + 2 * P.K + 64;
@@ -187,7 +190,9 @@ __global__ __launch_bounds__(256) void ks_build_type_tables(DevProb P) {
 // Allocatable()[r] >= value.  resources.Fits(requests, allocatable) (resources.go:138-145) for a whole
 // catalogue then is the AND of one row per requested resource.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ks_build_ge_rows(DevProb P) {
+__global__ __launch_bounds__(256) void ks_build_ge_rows(const DevProb* probs) {
+  const DevProb& P = probs[blockIdx.y];
+  if (P.derived_shared) return;
   const int lane = threadIdx.x & 63;
   const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (wave >= P.R * P.T) return;
@@ -207,7 +212,8 @@ __global__ __launch_bounds__(256) void ks_build_ge_rows(DevProb P) {
 // nodeRequirements.Add(podRequirements).  A fresh node's hostname is a placeholder no pod can name
 // (node.go:46), so a pod class with a concrete hostname requirement can never use a new node.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ks_grid_mc(DevProb P) {
+__global__ __launch_bounds__(256) void ks_grid_mc(const DevProb* probs) {
+  const DevProb& P = probs[blockIdx.y];
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)P.M * P.C) return;
   const u32 m = idx / P.C, c = idx % P.C;
@@ -233,6 +239,9 @@ __global__ __launch_bounds__(256) void ks_grid_mc(DevProb P) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// waves = TW * chunks: aim at `wave_target` waves (>= 8 per SIMD on 256 CUs for one Solve) without exceeding the work
+__host__ __device__ inline u32 ks_grid_chunks(size_t MC, u32 TW, u32 wave_target) { const size_t want = (wave_target + TW - 1) / TW; const size_t c = MC < want ? MC : want; return (u32)(c ? c : 1); }
+
 // ks_grid_types: the feasibility grid.  filterInstanceTypesByRequirements (node.go:137-159) for a
 // fresh node of template m receiving a pod of class c:
 //   compatible  = instanceType.Requirements.Intersects(nodeRequirements) == nil     (node.go:143)
@@ -240,7 +249,10 @@ __global__ __launch_bounds__(256) void ks_grid_mc(DevProb P) {
 //   hasOffering = some available offering whose zone / capacity-type the node allows (node.go:151)
 // Wave (w, chunk): lane owns type t = 64*w + lane for the whole kernel; (m,c) records are wave-uniform.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ks_grid_types(DevProb P, u32 chunks) {
+__global__ __launch_bounds__(256) void ks_grid_types(const DevProb* probs, u32 wave_target) {
+  const DevProb& P = probs[blockIdx.y];
+  const size_t MC0 = (size_t)P.M * P.C; if (MC0 == 0) return;
+  const u32 chunks = ks_grid_chunks(MC0, P.TW, wave_target);
   const int lane = threadIdx.x & 63;
   const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const u32 w = wave % P.TW, chunk = wave / P.TW;
@@ -365,7 +377,8 @@ static_assert(sizeof(ClsBrief) == 128, "ClsBrief layout");
 // ks_build_plans: one thread per pod class; everything about a class that does not depend on the
 // Solve state is resolved here once (host/encode.cpp produced the CSR lists).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void ks_build_plans(DevProb P, ClsPlan* plans, ClsBrief* briefs) {
+__global__ __launch_bounds__(64) void ks_build_plans(const DevProb* probs) {
+  const DevProb& P = probs[blockIdx.y]; ClsPlan* const plans = (ClsPlan*)P.plans; ClsBrief* const briefs = (ClsBrief*)P.briefs;
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= P.C) return;
   ClsPlan pl; memset(&pl, 0, sizeof pl);
@@ -476,7 +489,8 @@ __device__ inline u64 ks_plan_eval_hash(const ClsPlan& a) {
   h ^= a.overflow; h *= 0xD6E8FEB86659FD93ull; h ^= a.tkeys; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
   return h;
 }
-__global__ __launch_bounds__(64) void ks_link_ev(const ClsPlan* plans, ClsBrief* briefs, u32* tab, u32 tab_size, u32 C) {
+__global__ __launch_bounds__(64) void ks_link_ev(const DevProb* probs) {
+  const DevProb& P = probs[blockIdx.y]; const ClsPlan* const plans = (const ClsPlan*)P.plans; ClsBrief* const briefs = (ClsBrief*)P.briefs; u32* const tab = P.ev_tab; const u32 tab_size = P.ev_tab_size, C = P.C;
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const ClsPlan& me = plans[c];
@@ -494,7 +508,8 @@ __global__ __launch_bounds__(64) void ks_link_ev(const ClsPlan* plans, ClsBrief*
 // differ only in labels).  For a run of equivalent pods the fit bitmap of one candidate step stays valid:
 // only the node that just received a pod changed, and it moved behind the rest of its count bucket.
 __device__ inline bool ks_plan_eval_eligible(const ClsPlan& p) { return !p.overflow && p.ntopo == 0 && p.nhost == 0 && p.port_cnt == 0 && p.vol_cnt == 0 && p.hn_mode == 0; }
-__global__ __launch_bounds__(64) void ks_link_plans(ClsPlan* plans, u32 C, u32 R) {
+__global__ __launch_bounds__(64) void ks_link_plans(const DevProb* probs) {
+  const DevProb& P = probs[blockIdx.y]; ClsPlan* const plans = (ClsPlan*)P.plans; const u32 C = P.C, R = P.R;
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const ClsPlan& me = plans[c];
@@ -2169,6 +2184,7 @@ struct ks_dev_problem {
   u8* arena = nullptr; size_t arena_bytes = 0; u8* stage = nullptr; size_t stage_bytes = 0;
   hipStream_t stream = nullptr;
   bool tables_built = false;
+  ks_problem src{};              // the host arrays this problem was uploaded from (pointer identity decides what a what-if can share with it)
   bool any_bounds = false;       // some requirement carries Gt/Lt -> the BOUNDS kernel variant
   bool lean_ok = false;          // none of the rarely used features is present -> the LEAN kernel variant (see ks_pack)
   u32 pp_cap = 0;
@@ -2237,12 +2253,20 @@ extern "C" void ks_problem_free(ks_dev_problem* d) {
   delete d;
 }
 
-extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem** out) {
+// `base` (optional): a resident problem flattened from the same cluster snapshot.  Catalogue arrays whose HOST pointers are the ones `base`
+// was uploaded from are not copied again, and if the whole catalogue is shared so are the tables derived from it (kv_types .. ge_rows).
+static int upload_impl(const ks_problem* p, int device, const ks_dev_problem* base, ks_dev_problem** out) {
   *out = nullptr;
   TRY(validate(p));
   if (ks_device_count() <= 0) return fail(KS_ERR_DEVICE, "no gfx950 (MI355X) device visible; libksolve has no CPU path");
   HIPCHK(hipSetDevice(device));
-  ks_dev_problem* d = new ks_dev_problem(); d->device = device;
+  if (base && (base->device != device || !base->tables_built)) return fail(KS_ERR_INVALID, "the shared problem must be resident on the same device with its tables built (ks_problem_prepare)");
+  ks_dev_problem* d = new ks_dev_problem(); d->device = device; d->src = *p;
+  // share X: same host array as the base's -> the base's device copy
+#define SHARED(field) (base && p->field && p->field == base->src.field)
+#define COPY_OR_SHARE(field, count, dst) do { if (SHARED(field)) (dst) = base->h.field; else TRY(dev_copy(d, p->field, (count), &(dst))); } while (0)
+  const bool share_cat = base && p->K == base->h.K && p->T == base->h.T && p->R == base->h.R && SHARED(it_present) && SHARED(it_complement) && SHARED(it_mask) && SHARED(it_alloc) && SHARED(it_offer) &&
+                         memcmp(p->key_nvalues, base->src.key_nvalues, p->K * sizeof(u32)) == 0;
   struct Guard { ks_dev_problem* d; bool ok = false; ~Guard() { if (!ok) ks_problem_free(d); } } guard{d};
   TRY(pool().get_stream(device, &d->stream));
   auto layout = [&]() -> int {
@@ -2258,15 +2282,19 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
     d->lean_ok = lean;
   }
   TRY(dev_copy(d, p->key_nvalues, K, &h.key_nvalues)); TRY(dev_copy(d, p->value_int, (size_t)K * 64, &h.value_int));
-  TRY(dev_copy(d, p->it_present, T, &h.it_present)); TRY(dev_copy(d, p->it_complement, T, &h.it_complement));
-  TRY(dev_copy(d, p->it_mask, (size_t)K * T, &h.it_mask)); TRY(dev_copy(d, p->it_alloc, (size_t)R * T, &h.it_alloc));
-  TRY(dev_copy(d, p->it_cap, (size_t)R * T, &h.it_cap)); TRY(dev_copy(d, p->it_offer, T, &h.it_offer));
+  COPY_OR_SHARE(it_present, T, h.it_present); COPY_OR_SHARE(it_complement, T, h.it_complement);
+  COPY_OR_SHARE(it_mask, (size_t)K * T, h.it_mask); COPY_OR_SHARE(it_alloc, (size_t)R * T, h.it_alloc);
+  COPY_OR_SHARE(it_cap, (size_t)R * T, h.it_cap); COPY_OR_SHARE(it_offer, T, h.it_offer);
   h.it_price = nullptr; h.ct_spot = p->ct_spot; h.ct_ondemand = p->ct_ondemand;
-  if (p->it_price && p->key_zone >= 0 && p->key_ct >= 0) TRY(dev_copy(d, p->it_price, (size_t)T * p->key_nvalues[p->key_zone] * p->n_ct, &h.it_price));
+  const bool same_pairs = base && p->key_zone == base->src.key_zone && p->key_ct == base->src.key_ct && p->n_ct == base->src.n_ct;
+  if (p->it_price && p->key_zone >= 0 && p->key_ct >= 0) { if (same_pairs && SHARED(it_price) && base->h.it_price) h.it_price = base->h.it_price; else TRY(dev_copy(d, p->it_price, (size_t)T * p->key_nvalues[p->key_zone] * p->n_ct, &h.it_price)); }
   h.it_price_lo = h.it_price;
-  if (p->it_price_lo && p->key_zone >= 0 && p->key_ct >= 0) TRY(dev_copy(d, p->it_price_lo, (size_t)T * p->key_nvalues[p->key_zone] * p->n_ct, &h.it_price_lo));
-  TRY(dev_copy(d, p->its_inter, (size_t)h.S * h.SC, &h.its_inter)); TRY(dev_copy(d, p->its_fail, (size_t)h.S * h.SC, &h.its_fail));
-  TRY(dev_copy(d, p->its_nidne, h.S, &h.its_nidne)); TRY(dev_copy(d, p->its_types, (size_t)h.S * TW, &h.its_types));
+  if (p->it_price_lo && p->key_zone >= 0 && p->key_ct >= 0) { if (same_pairs && SHARED(it_price_lo) && base->h.it_price_lo) h.it_price_lo = base->h.it_price_lo; else TRY(dev_copy(d, p->it_price_lo, (size_t)T * p->key_nvalues[p->key_zone] * p->n_ct, &h.it_price_lo)); }
+  const bool same_lattice = base && h.S == base->h.S && h.SC == base->h.SC;
+  if (same_lattice && SHARED(its_inter)) h.its_inter = base->h.its_inter; else TRY(dev_copy(d, p->its_inter, (size_t)h.S * h.SC, &h.its_inter));
+  if (same_lattice && SHARED(its_fail)) h.its_fail = base->h.its_fail; else TRY(dev_copy(d, p->its_fail, (size_t)h.S * h.SC, &h.its_fail));
+  if (same_lattice && SHARED(its_nidne)) h.its_nidne = base->h.its_nidne; else TRY(dev_copy(d, p->its_nidne, h.S, &h.its_nidne));
+  if (same_lattice && SHARED(its_types)) h.its_types = base->h.its_types; else TRY(dev_copy(d, p->its_types, (size_t)h.S * TW, &h.its_types));
   TRY(copy_reqsets(d, p->tmpl, M, K, &h.tmpl)); TRY(dev_copy(d, p->tmpl_taints, M, &h.tmpl_taints));
   TRY(dev_copy(d, p->tmpl_daemon, (size_t)M * R, &h.tmpl_daemon)); TRY(dev_copy(d, p->tmpl_daemon_present, M, &h.tmpl_daemon_present));
   TRY(dev_copy(d, p->tmpl_types, (size_t)M * TW, &h.tmpl_types)); TRY(dev_copy(d, p->tmpl_limit_present, M, &h.tmpl_limit_present));
@@ -2295,6 +2323,11 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   TRY(dev_copy(d, p->grp_count, (size_t)G * 64, &h.grp_count)); TRY(dev_copy(d, p->grp_hslot, G, &h.grp_hslot));
   TRY(dev_copy(d, p->grph_count, (size_t)p->GH * E, &h.grph_count)); TRY(dev_copy(d, p->grph_extra_pos, p->GH, &h.grph_extra_pos));
   // derived tables
+  h.derived_shared = share_cat ? 1u : 0u;
+  if (share_cat) {
+    h.kv_types = base->h.kv_types; h.cmplx_types = base->h.cmplx_types; h.nidnex_types = base->h.nidnex_types; h.pair_types = base->h.pair_types;
+    h.ge_vals = base->h.ge_vals; h.ge_cnt = base->h.ge_cnt; h.ge_rows = base->h.ge_rows; h.ge_max = base->h.ge_max;
+  } else {
   TRY(dev_alloc(d, (size_t)K * 64 * TW, &h.kv_types, 0)); TRY(dev_alloc(d, (size_t)K * TW, &h.cmplx_types, 0)); TRY(dev_alloc(d, (size_t)K * TW, &h.nidnex_types, 0));
   TRY(dev_alloc(d, (size_t)64 * TW, &h.pair_types, 0));
   {   // ascending distinct Allocatable values per resource (host sort; the rows are built on the device)
@@ -2304,9 +2337,10 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
     h.ge_max = 1; for (u32 r = 0; r < R; ++r) h.ge_max = std::max(h.ge_max, cnt[r]);
     TRY(dev_alloc(d, (size_t)R * T * TW, &h.ge_rows, 0));
   }
+  }
   { u8* pl = nullptr; TRY(dev_alloc(d, (size_t)C * sizeof(ClsPlan), &pl, 0)); h.plans = pl; }
   { u8* br = nullptr; TRY(dev_alloc(d, (size_t)C * sizeof(ClsBrief), &br, 0)); h.briefs = br;
-    h.ev_tab_size = 64; while (h.ev_tab_size < 2 * C) h.ev_tab_size <<= 1; h.ev_pad = 0; TRY(dev_alloc(d, (size_t)h.ev_tab_size, &h.ev_tab, 0)); }
+    h.ev_tab_size = 64; while (h.ev_tab_size < 2 * C) h.ev_tab_size <<= 1; TRY(dev_alloc(d, (size_t)h.ev_tab_size, &h.ev_tab, 0)); }
   const size_t MC = (size_t)M * C;
   TRY(dev_alloc(d, MC, &h.mc_ok, 0)); TRY(dev_alloc(d, MC, &h.mc_why, 0)); TRY(dev_alloc(d, MC, &h.mc_present)); TRY(dev_alloc(d, MC, &h.mc_complement));
   TRY(dev_alloc(d, MC * K, &h.mc_mask)); TRY(dev_alloc(d, MC * K, &h.mc_gt)); TRY(dev_alloc(d, MC * K, &h.mc_lt)); TRY(dev_alloc(d, MC, &h.mc_it));
@@ -2342,35 +2376,55 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
   if (d->sz[1]) HIPCHK(hipMemsetAsync(d->base[1], 0, d->sz[1], d->stream));
   if (d->sz[2]) HIPCHK(hipMemsetAsync(d->base[2], 0xFF, d->sz[2], d->stream));
   guard.ok = true; *out = d; return KS_OK;
+#undef SHARED
+#undef COPY_OR_SHARE
+}
+extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem** out) { return upload_impl(p, device, nullptr, out); }
+extern "C" int ks_problem_upload_shared(const ks_problem* p, const ks_dev_problem* base, ks_dev_problem** out) {
+  if (!base) return fail(KS_ERR_INVALID, "null shared problem");
+  return upload_impl(p, base->device, base, out);
 }
 
 // Build the derived tables + the feasibility grid (idempotent).  Returns the grid kernels' time.
-static int build_static(ks_dev_problem* d, float* grid_ms, bool async = false) {
-  HIPCHK(hipSetDevice(d->device));
-  const DevProb& h = d->h;
-  hipEvent_t e0 = nullptr, e1 = nullptr; if (!async) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); }
-  const u32 rows = h.K * 64 + 2 * h.K + 64;
-  hipLaunchKernelGGL(ks_build_type_tables, dim3((rows * 64 + 255) / 256), dim3(256), 0, d->stream, h);
-  if (h.C) hipLaunchKernelGGL(ks_build_plans, dim3((h.C + 63) / 64), dim3(64), 0, d->stream, h, (ClsPlan*)h.plans, (ClsBrief*)h.briefs);
-  if (h.C) { HIPCHK(hipMemsetAsync(h.ev_tab, 0, (size_t)h.ev_tab_size * sizeof(u32), d->stream)); hipLaunchKernelGGL(ks_link_ev, dim3((h.C + 63) / 64), dim3(64), 0, d->stream, (const ClsPlan*)h.plans, (ClsBrief*)h.briefs, h.ev_tab, h.ev_tab_size, h.C); }
-  if (h.C) hipLaunchKernelGGL(ks_link_plans, dim3((h.C + 63) / 64), dim3(64), 0, d->stream, (ClsPlan*)h.plans, h.C, h.R);
-  hipLaunchKernelGGL(ks_build_ge_rows, dim3((u32)(((size_t)h.R * h.T * 64 + 255) / 256)), dim3(256), 0, d->stream, h);
-  const size_t MC = (size_t)h.M * h.C;
-  if (!async) HIPCHK(hipEventRecord(e0, d->stream));
-  if (MC) {
-    hipLaunchKernelGGL(ks_grid_mc, dim3((u32)((MC + 255) / 256)), dim3(256), 0, d->stream, h);
-    // waves = TW * chunks; aim at >= 8 waves per SIMD on 256 CUs (8192 waves) without exceeding the work
-    u32 chunks = (u32)std::min<size_t>(MC, std::max<size_t>(1, (8192 + h.TW - 1) / h.TW));
-    const size_t waves = (size_t)h.TW * chunks;
-    hipLaunchKernelGGL(ks_grid_types, dim3((u32)((waves * 64 + 255) / 256)), dim3(256), 0, d->stream, h, chunks);
+// Launch the static-table kernels for the problems behind `probs` (device descriptor array, n of them) on one stream.
+struct StaticDims { u32 rows = 0, C = 0, RT = 0, TW = 1; size_t MC = 0; };
+static void static_dims_of(const DevProb& h, StaticDims& a) {
+  if (!h.derived_shared) { a.rows = std::max(a.rows, h.K * 64 + 2 * h.K + 64); a.RT = std::max(a.RT, h.R * h.T); }
+  a.C = std::max(a.C, h.C); a.MC = std::max(a.MC, (size_t)h.M * h.C); a.TW = std::max(a.TW, h.TW);
+}
+static void launch_static(const DevProb* probs, u32 n, const StaticDims& a, u32 wave_target, hipStream_t st, hipEvent_t before_grid) {
+  if (a.rows) hipLaunchKernelGGL(ks_build_type_tables, dim3((a.rows * 64 + 255) / 256, n), dim3(256), 0, st, probs);
+  if (a.C) {
+    hipLaunchKernelGGL(ks_build_plans, dim3((a.C + 63) / 64, n), dim3(64), 0, st, probs);
+    hipLaunchKernelGGL(ks_link_ev, dim3((a.C + 63) / 64, n), dim3(64), 0, st, probs);      // (ev_tab comes zero-filled from the upload; a repeated build finds its own entries again)
+    hipLaunchKernelGGL(ks_link_plans, dim3((a.C + 63) / 64, n), dim3(64), 0, st, probs);
   }
+  if (a.RT) hipLaunchKernelGGL(ks_build_ge_rows, dim3((u32)(((size_t)a.RT * 64 + 255) / 256), n), dim3(256), 0, st, probs);
+  if (before_grid) hipEventRecord(before_grid, st);
+  if (a.MC) {
+    hipLaunchKernelGGL(ks_grid_mc, dim3((u32)((a.MC + 255) / 256), n), dim3(256), 0, st, probs);
+    const size_t waves = (size_t)a.TW * ks_grid_chunks(a.MC, a.TW, wave_target);      // (an upper bound over the batch: a problem's surplus waves return at once)
+    hipLaunchKernelGGL(ks_grid_types, dim3((u32)((waves * 64 + 255) / 256), n), dim3(256), 0, st, probs, wave_target);
+  }
+}
+// Build the derived tables + the feasibility grid (idempotent).  Returns the grid kernels' time.
+static int build_static(ks_dev_problem* d, float* grid_ms) {
+  HIPCHK(hipSetDevice(d->device));
+  hipEvent_t e0 = nullptr, e1 = nullptr; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  StaticDims a; static_dims_of(d->h, a);
+  launch_static(d->d_prob, 1, a, 8192, d->stream, e0);
   d->tables_built = true;
-  if (async) return KS_OK;            // the caller waits for the device once, after queueing every problem of a batch
   HIPCHK(hipEventRecord(e1, d->stream));
   HIPCHK(hipStreamSynchronize(d->stream));
   HIPCHK(hipGetLastError());
   if (grid_ms) HIPCHK(hipEventElapsedTime(grid_ms, e0, e1));
   hipEventDestroy(e0); hipEventDestroy(e1);
+  return KS_OK;
+}
+
+extern "C" int ks_problem_prepare(ks_dev_problem* d) {
+  if (!d) return fail(KS_ERR_INVALID, "null device problem");
+  if (!d->tables_built) TRY(build_static(d, nullptr));
   return KS_OK;
 }
 
@@ -2474,9 +2528,9 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   if (!ds || !outs) return fail(KS_ERR_INVALID, "null batch");
   const int device = ds[0]->device;
   HIPCHK(hipSetDevice(device));
-  bool queued = false;
-  for (u32 i = 0; i < n; ++i) { if (ds[i]->device != device) return fail(KS_ERR_INVALID, "batch spans devices"); if (!ds[i]->tables_built) { TRY(build_static(ds[i], nullptr, n > 1)); queued = n > 1; } }
-  if (queued) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipGetLastError()); }      // every what-if built its tables on its own stream: one wait for all of them
+  u32 unbuilt = 0;
+  for (u32 i = 0; i < n; ++i) { if (ds[i]->device != device) return fail(KS_ERR_INVALID, "batch spans devices"); if (!ds[i]->tables_built) ++unbuilt; }
+  if (n == 1 && unbuilt) TRY(build_static(ds[0], nullptr));
   std::vector<DevProb> hp(n); std::vector<DevState> hs(n);
   for (u32 i = 0; i < n; ++i) { hp[i] = ds[i]->h; hs[i] = ds[i]->hs; }
   DevProb* dp = nullptr; DevState* dsv = nullptr; u64* d_meta = nullptr;
@@ -2489,6 +2543,14 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
     HIPCHK(hipMemcpy(dp, hp.data(), n * sizeof(DevProb), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dsv, hs.data(), n * sizeof(DevState), hipMemcpyHostToDevice));
   }
   hipStream_t st = ds[0]->stream;
+  if (n > 1 && unbuilt) {
+    // The static tables of the whole batch in seven launches (grid.y = what-if) instead of seven per what-if.  The uploads were queued on
+    // the what-ifs' own streams: one wait for all of them first.  (Problems built earlier are rebuilt in place: the build is idempotent.)
+    HIPCHK(hipDeviceSynchronize());
+    StaticDims a; for (u32 i = 0; i < n; ++i) static_dims_of(ds[i]->h, a);
+    launch_static(dp, n, a, std::max(64u, 16384u / n), st, nullptr);
+    for (u32 i = 0; i < n; ++i) ds[i]->tables_built = true;
+  }
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipEventRecord(e0, st));
   // dynamic LDS: Allocatable table + visiting-order array.  One Solve gets most of the CU's 160 KiB;

@@ -4,6 +4,7 @@
 // ksh_open == NewScheduler (+NewTopology) + flattening + upload; ksh_solve == Solve through the
 // libksolve C ABI (HIP kernels).  There is no CPU scheduling path in this library.
 #include <atomic>
+#include <mutex>
 #include <chrono>
 #include <cstring>
 #include <string>
@@ -14,6 +15,7 @@
 namespace {
 struct Handle {
   std::unique_ptr<ksh::Encoded> enc; ks_dev_problem* dev = nullptr; std::unique_ptr<ksh::Encoded::ResultBuf> rb;
+  std::shared_ptr<void> base_dev;      // what-ifs over a snapshot: the snapshot's own flattening, resident on the device (shared catalogue + derived tables)
   ~Handle() { if (dev) ks_problem_free(dev); }
 };
 thread_local std::string g_err;
@@ -50,7 +52,13 @@ const ks_problem* ksh_problem(void* h) { return &((Handle*)h)->enc->prob; }
 // ksh_parse turns KSP1 text into the C++ objects (the analogue of the []*v1.Pod, []*cloudprovider.InstanceType, []*state.Node a Go
 // caller holds); ksh_solve_from_pods then does what the reference does from that point: NewScheduler's flattening incl. NewQueue's
 // sort and every per-pod computation, upload, the HIP kernels, read-back -- the window bench.py times as "solve_from_pods".
-struct Parsed { std::shared_ptr<const ksp::Problem> pr; };
+// The caller's objects in memory.  A cluster snapshot additionally keeps its flattening (ksh::SnapshotBase) once a what-if batch asked for
+// it: a consolidation pass probes many candidate sets against the same snapshot (multinodeconsolidation.go:86-114 binary search,
+// singlenodeconsolidation.go:54 scan), and everything that does not depend on the candidate set is flattened once.
+struct Parsed {
+  std::shared_ptr<const ksp::Problem> pr;
+  std::mutex mu; std::shared_ptr<const ksh::SnapshotBase> sb; std::vector<int32_t> sb_pod_node; uint32_t sb_flags = 0;
+};
 int ksh_parse(const char* ksp_text, size_t len, void** out) {
   *out = nullptr;
   try { auto p = std::make_unique<Parsed>(); p->pr = std::make_shared<const ksp::Problem>(ksp::Parser(ksp_text, len).parse()); *out = p.release(); return KS_OK; }
@@ -99,12 +107,20 @@ int ksh_result_summary(void* hv, uint64_t* out, uint32_t words) {
 // cand_off[w+1]) leave the state-node list (helpers.go:48-61), their pods, in candidate order, become the pending batch, the
 // flattening (NewScheduler / NewTopology host half) runs on `nthreads` host threads.  out_handles[w] is a ksh_open handle.
 static int open_whatifs_over(std::shared_ptr<const ksp::Problem> snapshot, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand,
-                             const int32_t* pod_node, uint32_t nthreads, void** out_handles) {
+                             const int32_t* pod_node, uint32_t nthreads, void** out_handles, Parsed* cache = nullptr) {
   for (uint32_t w = 0; w < n; ++w) out_handles[w] = nullptr;
   try {
     for (uint32_t i = 0; i < cand_off[n]; ++i) if (cand[i] >= snapshot->nodes.size()) return set_err(KS_ERR_INVALID, "candidate node out of range");
     // the snapshot is flattened ONCE (catalogue, universes, templates, every state node's row); a what-if adds only what its candidate set decides
-    auto sb = ksh::make_snapshot_base(snapshot, pod_node, flags);
+    const bool timing = getenv("KSH_TIMING") != nullptr; auto t0 = std::chrono::steady_clock::now();
+    std::shared_ptr<const ksh::SnapshotBase> sb;
+    if (cache) {
+      std::lock_guard<std::mutex> g(cache->mu);
+      const size_t np = snapshot->pods.size();
+      if (cache->sb && cache->sb_flags == flags && cache->sb_pod_node.size() == np && std::equal(pod_node, pod_node + np, cache->sb_pod_node.begin())) sb = cache->sb;
+      else { sb = ksh::make_snapshot_base(snapshot, pod_node, flags); cache->sb = sb; cache->sb_flags = flags; cache->sb_pod_node.assign(pod_node, pod_node + np); }
+    } else sb = ksh::make_snapshot_base(snapshot, pod_node, flags);
+    if (timing) { auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "  what-ifs: snapshot base %8.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; }
     std::atomic<uint32_t> next{0}; std::atomic<int> rc{KS_OK}; std::vector<std::string> errs(n);
     auto work = [&]() {
       for (;;) {
@@ -121,6 +137,7 @@ static int open_whatifs_over(std::shared_ptr<const ksp::Problem> snapshot, uint3
     const uint32_t nt = std::max(1u, std::min(nthreads ? nthreads : default_threads(), n));
     std::vector<std::thread> pool; for (uint32_t t = 1; t < nt; ++t) pool.emplace_back(work);
     work(); for (auto& t : pool) t.join();
+    if (timing) { auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "  what-ifs: %u flattened on %u threads %8.2f ms\n", n, nt, std::chrono::duration<double, std::milli>(t1 - t0).count()); }
     if (rc != KS_OK) { std::string m; for (auto& e : errs) if (!e.empty()) { m = e; break; } for (uint32_t w = 0; w < n; ++w) { delete (Handle*)out_handles[w]; out_handles[w] = nullptr; } return set_err(rc, m); }
     return KS_OK;
   } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());
@@ -137,7 +154,7 @@ int ksh_open_whatifs(const char* base_text, size_t len, uint32_t flags, uint32_t
 }
 // The same over a snapshot the caller already holds as objects (ksh_parse): every node of it is a state node, every pod a bound pod.
 int ksh_open_whatifs_parsed(void* parsed, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand, const int32_t* pod_node, uint32_t nthreads, void** out_handles) {
-  return open_whatifs_over(((Parsed*)parsed)->pr, flags, n, cand_off, cand, pod_node, nthreads, out_handles);
+  return open_whatifs_over(((Parsed*)parsed)->pr, flags, n, cand_off, cand, pod_node, nthreads, out_handles, (Parsed*)parsed);
 }
 
 // FNV-1a over every array behind the handle's ks_problem: two construction routes produced the same flat problem iff equal.
@@ -147,8 +164,9 @@ uint64_t ksh_fingerprint(void* hv) {
   auto vec = [&](const auto& v) { uint64_t n = v.size(); mix(&n, 8); if (n) mix(v.data(), n * sizeof(v[0])); };
   auto rs = [&](const ksh::ReqSetsStore& r) { vec(r.present); vec(r.complement); vec(r.mask); vec(r.gt); vec(r.lt); vec(r.it_state); };
   const ks_problem& p = E.prob; const uint32_t dims[16] = {p.P, p.C, p.T, p.M, p.E, p.K, p.R, p.G, p.GH, p.S, p.SC, p.max_new_nodes, p.flags, p.wellknown_mask, p.n_ct, p.n_topologies}; mix(dims, sizeof dims);
-  vec(E.key_nvalues); vec(E.value_int); vec(E.it_present); vec(E.it_complement); vec(E.it_mask); vec(E.it_offer); vec(E.it_price); vec(E.it_alloc); vec(E.it_cap);
-  vec(E.its_inter); vec(E.its_fail); vec(E.its_nidne); vec(E.its_types); rs(E.tmpl); rs(E.en); rs(E.cls); rs(E.flt);
+  const ksh::Encoded& C = E.catalogue(); const ksh::Encoded& L = E.lattice();
+  vec(E.key_nvalues); vec(E.value_int); vec(C.it_present); vec(C.it_complement); vec(C.it_mask); vec(C.it_offer); vec(C.it_price); vec(C.it_alloc); vec(C.it_cap);
+  vec(L.its_inter); vec(L.its_fail); vec(L.its_nidne); vec(L.its_types); rs(E.tmpl); rs(E.en); rs(E.cls); rs(E.flt);
   vec(E.tmpl_taints); vec(E.tmpl_types); vec(E.tmpl_daemon); vec(E.tmpl_remaining); vec(E.tmpl_daemon_present); vec(E.tmpl_limit_present);
   vec(E.en_taints); vec(E.en_avail); vec(E.en_requests); vec(E.en_requests_present); vec(E.en_port_off);
   vec(E.cls_hn_mode); vec(E.cls_hn_off); vec(E.hn_list); vec(E.cls_requests); vec(E.cls_requests_present); vec(E.cls_tolerated); vec(E.cls_port_off); vec(E.ports);
@@ -163,7 +181,27 @@ uint64_t ksh_fingerprint(void* hv) {
 int ksh_upload(void* hv, int device) {
   Handle* h = (Handle*)hv;
   if (h->dev) return ks_problem_device(h->dev) == device ? KS_OK : set_err(KS_ERR_INVALID, "problem already resident on another device");
-  int rc = ks_problem_upload(&h->enc->prob, device, &h->dev);
+  int rc;
+  if (const ksh::Encoded* base = h->enc->shared.get()) {
+    // A what-if flattened over a shared snapshot: the snapshot's flattening goes to the device once (catalogue, prices, lattice, the tables
+    // derived from them); the what-if then uploads only what its candidate set decides.
+    std::shared_ptr<void> bd;
+    {
+      std::lock_guard<std::mutex> g(base->dev_mu);
+      auto it = base->dev_resident.find(device);
+      if (it != base->dev_resident.end()) bd = it->second;
+      else {
+        ks_dev_problem* raw = nullptr;
+        rc = ks_problem_upload(&base->prob, device, &raw);
+        if (rc == KS_OK) rc = ks_problem_prepare(raw);
+        if (rc != KS_OK) { if (raw) ks_problem_free(raw); return set_err(rc, ks_last_error()); }
+        bd = std::shared_ptr<void>(raw, [](void* p) { ks_problem_free((ks_dev_problem*)p); });
+        base->dev_resident[device] = bd;
+      }
+    }
+    rc = ks_problem_upload_shared(&h->enc->prob, (const ks_dev_problem*)bd.get(), &h->dev);
+    if (rc == KS_OK) h->base_dev = bd;
+  } else rc = ks_problem_upload(&h->enc->prob, device, &h->dev);
   if (rc != KS_OK) return set_err(rc, ks_last_error());
   return KS_OK;
 }

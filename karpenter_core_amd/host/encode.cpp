@@ -203,7 +203,18 @@ struct Builder {
   std::map<std::string, int> taint_id;
   std::map<std::string, uint32_t> ip_id, proto_id;
   std::map<std::string, std::set<std::string>> domains;   // topology domain universe, provisioner.go:267-276
-  std::map<std::string, int> hostname_to_existing;
+  std::map<std::string, int> hostname_to_existing;                   // hostname -> row of the existing-node tables (single problems and the snapshot base)
+  std::map<std::string, int> hostname_to_node;                       // base only: hostname -> node index (what-ifs translate through existing_row)
+  std::vector<int> existing_row;                                     // what-if mode: node index -> row of THIS what-if's existing-node tables (-1: left / not owned)
+  std::vector<uint8_t> node_owned;                                   // base only: state.Node.Owned() per node
+  bool any_volume_limits = false;                                    // base only
+  int existing_of_hostname(const std::string& h) const {
+    if (base) { auto it = base->hostname_to_node.find(h); return it == base->hostname_to_node.end() ? -1 : existing_row[it->second]; }
+    auto it = hostname_to_existing.find(h); return it == hostname_to_existing.end() ? -1 : it->second;
+  }
+  const ksp::StateNode* node_named(const std::string& n) const {
+    const auto& m = base ? base->node_by_name : node_by_name; auto it = m.find(n); return it == m.end() ? nullptr : it->second;
+  }
   std::vector<std::unique_ptr<Group>> groups; std::map<std::string, int> topo_by_id, inverse_by_id;   // creation order; inverse flagged
   std::vector<Requirement> it_reqs; std::map<std::string, int> it_state_id;   // node-side instance-type states (index 0 = absent)
   std::vector<Requirement> it_cols; std::map<std::string, int> it_col_id;     // pod-side instance-type requirements (classes, topology filters; 0 = none)
@@ -224,6 +235,7 @@ struct Builder {
   const Builder* base = nullptr;                      // what-if mode: the finished flattening of the whole snapshot
   const std::vector<uint8_t>* removed = nullptr;      // what-if mode: nodes that leave the state-node list (helpers.go:48-61)
   bool node_in_state(size_t i) const { return removed ? !(*removed)[i] : pr.nodes[i].in_state; }
+  std::vector<uint32_t> pod_rank;                     // base only: a pod's position in the snapshot-wide queue order
   std::vector<int> base_existing_of;                  // base only: node index -> row of the base's existing-node tables (-1: not owned)
   std::vector<ksp::ResList> base_remaining;           // base only: remainingResources with every node in state
 
@@ -314,13 +326,20 @@ struct Builder {
   }
 
   // ---------- requirement encoding ----------
+  // What-if mode: the snapshot's lattice is consulted in place; it is copied only if the what-if needs a state / column the snapshot lacks.
+  bool lattice_adopted = false;
+  void adopt_lattice() { it_reqs = base->it_reqs; it_state_id = base->it_state_id; it_cols = base->it_cols; it_col_id = base->it_col_id; lattice_adopted = true; }
   int it_state_of(const Requirement& r) {
-    std::string id = r.identity(); auto it = it_state_id.find(id); if (it != it_state_id.end()) return it->second;
+    std::string id = r.identity();
+    if (base && !lattice_adopted) { auto bt = base->it_state_id.find(id); if (bt != base->it_state_id.end()) return bt->second; adopt_lattice(); }
+    auto it = it_state_id.find(id); if (it != it_state_id.end()) return it->second;
     if (it_reqs.size() >= KS_MAX_ITSTATES) throw Unsupported("more than 65534 distinct instance-type requirements (closure)");
     int s = (int)it_reqs.size(); it_reqs.push_back(r); it_state_id[id] = s; return s;
   }
   int it_col_of(const Requirement& r) {
-    std::string id = r.identity(); auto it = it_col_id.find(id); if (it != it_col_id.end()) return it->second;
+    std::string id = r.identity();
+    if (base && !lattice_adopted) { auto bt = base->it_col_id.find(id); if (bt != base->it_col_id.end()) return bt->second; adopt_lattice(); }
+    auto it = it_col_id.find(id); if (it != it_col_id.end()) return it->second;
     if (it_cols.size() >= KS_MAX_ITSTATES) throw Unsupported("more than 65534 distinct pod-side instance-type requirements");
     int s = (int)it_cols.size(); it_cols.push_back(r); it_col_id[id] = s; return s;
   }
@@ -432,6 +451,7 @@ struct Builder {
   bool pods_have_volumes = false; int blocked_taint = -1;
   static std::string vol_pair(const ksp::Volume& v) { return v.driver + '\1' + v.pvc; }
   void collect_volumes() {
+    if (base && !base->any_volume_limits) { for (auto* p : podp) if (p->volume_error) { pods_have_volumes = true; break; } return; }      // no node limits a volume: only a failed lookup matters
     for (size_t i = 0; i < pr.nodes.size(); ++i) if (node_in_state(i) && pr.nodes[i].owned()) for (auto& kv : pr.nodes[i].volume_limits) if (!vol_driver_id.count(kv.first)) { const int id = (int)vol_driver_id.size(); vol_driver_id[kv.first] = id; }
     if (vol_driver_id.size() > 64) throw Unsupported("more than 64 CSI drivers with volume limits");
     for (auto* p : podp) if (p->volume_error || !p->volumes.empty()) { pods_have_volumes = true; break; }
@@ -500,13 +520,21 @@ struct Builder {
 
   // ---------- existing nodes ----------
   void encode_existing() {
-    for (size_t i = 0; i < pr.nodes.size(); ++i) { node_by_name[pr.nodes[i].name] = &pr.nodes[i]; if (node_in_state(i) && pr.nodes[i].owned()) E.existing.push_back((int)i); }
+    if (base) {      // the name / hostname indices are the snapshot's; only the row numbering depends on which nodes left
+      existing_row.assign(pr.nodes.size(), -1);
+      for (size_t i = 0; i < pr.nodes.size(); ++i) if (!(*removed)[i] && base->node_owned[i]) { existing_row[i] = (int)E.existing.size(); E.existing.push_back((int)i); }
+      E.en_port_off.assign(1, 0);
+      for (int i : E.existing) { for (auto& hp : pr.nodes[i].host_ports) E.ports.push_back(port_entry(hp.ip, hp.port, hp.proto)); E.en_port_off.push_back((uint32_t)E.ports.size()); }
+      return;
+    }
+    node_owned.assign(pr.nodes.size(), 0);
+    for (size_t i = 0; i < pr.nodes.size(); ++i) { node_by_name[pr.nodes[i].name] = &pr.nodes[i]; node_owned[i] = pr.nodes[i].owned() ? 1 : 0; if (node_in_state(i) && node_owned[i]) E.existing.push_back((int)i); if (!pr.nodes[i].volume_limits.empty()) any_volume_limits = true; }
     const uint32_t NE = (uint32_t)E.existing.size();
     E.en_port_off.assign(1, 0);
     for (uint32_t e = 0; e < NE; ++e) {
       const auto& n = pr.nodes[E.existing[e]];
       auto hl = n.labels.find(ksp::kHostname); std::string hostname = (hl == n.labels.end() || hl->second.empty()) ? n.name : hl->second;
-      hostname_to_existing[hostname] = (int)e;
+      hostname_to_existing[hostname] = (int)e; hostname_to_node[hostname] = E.existing[e];
       // existing host-port reservations come first in ports[] (the kernel seeds its pool from them)
       for (auto& hp : n.host_ports) E.ports.push_back(port_entry(hp.ip, hp.port, hp.proto));
       E.en_port_off.push_back((uint32_t)E.ports.size());
@@ -527,7 +555,7 @@ struct Builder {
       std::copy_n(&B.en_avail[(size_t)b * R], R, &E.en_avail[(size_t)e * R]); std::copy_n(&B.en_requests[(size_t)b * R], R, &E.en_requests[(size_t)e * R]);
     }
     std::vector<ksp::ResList> remaining = base->base_remaining;
-    for (size_t i = 0; i < pr.nodes.size(); ++i) if ((*removed)[i] && pr.nodes[i].owned()) {
+    for (size_t i = 0; i < pr.nodes.size(); ++i) if ((*removed)[i] && base->node_owned[i]) {
       auto pl = pr.nodes[i].labels.find(ksp::kProvisionerName);
       for (uint32_t m = 0; m < M; ++m) if (E.templates[m]->has_limits && E.templates[m]->name == pl->second) for (auto& kv : remaining[m]) { auto c = pr.nodes[i].capacity.find(kv.first); if (c != pr.nodes[i].capacity.end()) kv.second += c->second; }
     }
@@ -535,11 +563,10 @@ struct Builder {
   }
   void adopt_base() {
     const Builder& b = *base; const Encoded& B = b.E;
-    wellKnown = b.wellKnown; key_id = b.key_id; res_id = b.res_id; taint_id = b.taint_id; taints = b.taints; ip_id = b.ip_id; proto_id = b.proto_id; domains = b.domains;
+    wellKnown = b.wellKnown; key_id = b.key_id; res_id = b.res_id; taint_id = b.taint_id; taints = b.taints; ip_id = b.ip_id; proto_id = b.proto_id;      // (domains: read in place)
     blocked_taint = b.blocked_taint; toleratePreferNoSchedule = b.toleratePreferNoSchedule; K = b.K; R = b.R; T = b.T; TW = b.TW;
-    it_reqs = b.it_reqs; it_state_id = b.it_state_id; it_cols = b.it_cols; it_col_id = b.it_col_id;
     E.key_names = B.key_names; E.key_values = B.key_values; E.res_names = B.res_names; E.key_nvalues = B.key_nvalues; E.value_int = B.value_int;
-    E.it_present = B.it_present; E.it_complement = B.it_complement; E.it_mask = B.it_mask; E.it_offer = B.it_offer; E.it_price = B.it_price; E.it_price_lo = B.it_price_lo; E.it_alloc = B.it_alloc; E.it_cap = B.it_cap;
+    // the catalogue arrays (it_*) stay the snapshot's: Encoded::shared keeps them alive, finish() points ks_problem at them
     E.templates = B.templates; E.tmpl = B.tmpl; E.tmpl_taints = B.tmpl_taints; E.tmpl_types = B.tmpl_types; E.tmpl_daemon = B.tmpl_daemon; E.tmpl_daemon_present = B.tmpl_daemon_present;
     E.tmpl_limit_present = B.tmpl_limit_present;
   }
@@ -588,8 +615,8 @@ struct Builder {
       if (!g.namespaces.count(cp.ns)) continue;
       if (!(g.selector.nil || SelectorMatches(g.selector, cp.labels))) continue;   // TopologyListOptions: nil selector lists everything
       if (batch_uids.count(cp.uid)) continue;
-      auto nit = node_by_name.find(cp.node_name); if (nit == node_by_name.end()) continue;
-      const auto& node = *nit->second;
+      const ksp::StateNode* nptr = node_named(cp.node_name); if (!nptr) continue;
+      const auto& node = *nptr;
       auto lt = node.labels.find(g.key); bool ok = lt != node.labels.end(); std::string domain = ok ? lt->second : "";
       if (!ok && g.key == ksp::kHostname) { domain = node.name; ok = true; }
       if (!ok) continue;
@@ -609,7 +636,8 @@ struct Builder {
     }
     auto g = std::make_unique<Group>(); g->type = type; g->key = key; g->namespaces = nss; g->selector = sel; g->max_skew = max_skew; g->filter = f; g->inverse = inverse; g->active = active_now;
     g->filter_sig = filter_content(f);
-    auto d = domains.find(key); if (d != domains.end()) for (auto& v : d->second) g->counts[v] = 0;   // NewTopologyGroup, topologygroup.go:64-68
+    const auto& doms = base ? base->domains : domains;
+    auto d = doms.find(key); if (d != doms.end()) for (auto& v : d->second) g->counts[v] = 0;   // NewTopologyGroup, topologygroup.go:64-68
     if (!inverse) count_domains(*g);
     int idx = (int)groups.size(); groups.push_back(std::move(g)); index[id] = idx; return idx;
   }
@@ -645,6 +673,22 @@ struct Builder {
   void dedupe_specs() {
     if (podp.empty() && !base) { podp.reserve(pr.pods.size()); for (auto& p : pr.pods) podp.push_back(&p); }
     const uint32_t P = (uint32_t)podp.size(); collect_volumes(); sublap("(start)");
+    if (base) {
+      // What-if over a snapshot: its pods ARE snapshot pods, and the snapshot's flattening already knows which of them share a spec (a partition
+      // at least as fine as this what-if needs).  Local spec ids in order of first occurrence, as always.
+      const Pod* p0 = pr.pods.data();
+      std::vector<int32_t> local(base->specs.size(), -1); std::vector<uint32_t> first; pod_spec.assign(P, -1);
+      for (uint32_t i = 0; i < P; ++i) { const int bs = base->pod_spec[podp[i] - p0]; if (local[bs] < 0) { local[bs] = (int32_t)first.size(); first.push_back(i); } pod_spec[i] = local[bs]; }
+      if (!pr.cluster_pods.empty()) {      // countDomains / inverse anti-affinity ask which cluster pods are in the batch
+        uint64_t cap = 64; while (cap < 4ull * P) cap <<= 1;
+        batch_uids.pods = &podp; batch_uids.mask = cap - 1; batch_uids.tab.assign(cap, 0);
+        for (uint32_t i = 0; i < P; ++i) { uint64_t j = str_hash(podp[i]->uid) & batch_uids.mask; while (batch_uids.tab[j]) j = (j + 1) & batch_uids.mask; batch_uids.tab[j] = i + 1; }
+      }
+      specs.resize(first.size());
+      for (size_t s2 = 0; s2 < first.size(); ++s2) { StageInfo st; st.spec = *podp[first[s2]]; st.spec.uid.clear(); specs[s2].stages.push_back(std::move(st)); }
+      sublap("specs from the snapshot");
+      return;
+    }
     std::vector<Hash128> hs(P); std::vector<uint64_t> uh(P);
     parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) {
       if (pods_have_volumes) { const std::vector<uint32_t> ve = vol_entries(*podp[i]); hs[i] = spec_hash(*podp[i], &ve); } else hs[i] = spec_hash(*podp[i]);
@@ -683,11 +727,11 @@ struct Builder {
     // updateInverseAffinities, topology.go:181-199 (cluster pods with required anti-affinity, not in the batch)
     for (auto& cp : pr.cluster_pods) {
       if (cp.anti_required.empty() || batch_uids.count(cp.uid)) continue;
-      auto nit = node_by_name.find(cp.node_name); if (nit == node_by_name.end()) continue;
+      const ksp::StateNode* nptr = node_named(cp.node_name); if (!nptr) continue;
       Pod dummy; dummy.ns = cp.ns;
       for (auto& t : cp.anti_required) {
         int gi = get_group(true, 2, t.topology_key, ns_list(cp.ns, t.namespaces), t.selector, INT32_MAX, dummy, true);
-        auto lt = nit->second->labels.find(groups[gi]->key); if (lt != nit->second->labels.end()) groups[gi]->counts[lt->second]++;
+        auto lt = nptr->labels.find(groups[gi]->key); if (lt != nptr->labels.end()) groups[gi]->counts[lt->second]++;
       }
     }
     sublap("inverse affinities");
@@ -714,6 +758,13 @@ struct Builder {
     E.stage_cls.resize(E.pod_stage_off[P]);
     parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const auto& cl = specs[pod_spec[i]].cls; std::copy(cl.begin(), cl.end(), E.stage_cls.begin() + E.pod_stage_off[i]); } });
     // NewQueue: byCPUAndMemoryDescending, queue.go:74-110
+    if (base) {      // the order is a total order on pods: a what-if's queue is its pods in the snapshot's order
+      const Pod* p0 = pr.pods.data(); std::vector<std::pair<uint32_t, uint32_t>> k(P);
+      for (uint32_t i = 0; i < P; ++i) k[i] = {base->pod_rank[podp[i] - p0], i};
+      std::sort(k.begin(), k.end());
+      E.queue.resize(P); for (uint32_t i = 0; i < P; ++i) E.queue[i] = k[i].second; sublap("queue from the snapshot's order");
+      return;
+    }
     const int rc = res_id.at("cpu"), rm = res_id.at("memory");
     // The order is total (UIDs are unique), so any correct sort gives the reference's queue: chunks are sorted on the host threads
     // and merged pairwise.  Keys are gathered first so a comparison touches one 32-byte record per side and the uid only on ties.
@@ -743,6 +794,7 @@ struct Builder {
       }
     }
     E.queue.resize(P); for (uint32_t i = 0; i < P; ++i) E.queue[i] = keys[i].pod; sublap("queue sort");
+    pod_rank.resize(P); for (uint32_t i = 0; i < P; ++i) pod_rank[E.queue[i]] = i;
   }
 
   uint32_t class_of(const StageInfo& st) {
@@ -770,7 +822,7 @@ struct Builder {
     if (hn) {
       if (hn->greaterThan || hn->lessThan) throw Unsupported("Gt/Lt on kubernetes.io/hostname");
       mode = hn->complement ? 2 : 1;
-      for (auto& v : hn->values) { auto e = hostname_to_existing.find(v); if (e != hostname_to_existing.end()) E.hn_list.push_back((uint32_t)e->second); }
+      for (auto& v : hn->values) { const int e = existing_of_hostname(v); if (e >= 0) E.hn_list.push_back((uint32_t)e); }
     }
     E.cls_hn_mode.push_back(mode); E.cls_hn_off.push_back((uint32_t)E.hn_list.size());
     uint32_t pm; res_vec(req, E.cls_requests, &pm); E.cls_requests_present.push_back(pm);
@@ -811,7 +863,7 @@ struct Builder {
       if (g.key == ksp::kHostname) {
         E.grp_key.push_back(KS_KEY_HOSTNAME); E.grp_hslot.push_back((int32_t)GH); ++GH;
         int32_t extra = 0; std::vector<int32_t> row(NE, g.active ? 0 : -1);   // NewExistingNode registers its hostname in every group that exists (existingnode.go:73)
-        for (auto& kv : g.counts) { auto e = hostname_to_existing.find(kv.first); if (e != hostname_to_existing.end()) row[e->second] = kv.second; else if (kv.second > 0) ++extra; }
+        for (auto& kv : g.counts) { const int e = existing_of_hostname(kv.first); if (e >= 0) row[e] = kv.second; else if (kv.second > 0) ++extra; }
         E.grph_count.insert(E.grph_count.end(), row.begin(), row.end()); E.grph_extra_pos.push_back(extra);
       } else {
         int k = key_id.at(g.key); E.grp_key.push_back(k); E.grp_hslot.push_back(-1);
@@ -849,9 +901,8 @@ struct Builder {
 
   // ---------- instance-type-key lattice ----------
   void encode_it_states() {
-    if (base && it_cols.size() == base->it_cols.size() && it_reqs.size() == base->it_reqs.size()) {      // every class / filter / node state of the what-if is one the snapshot already has
-      const Encoded& B = base->E;
-      E.its_inter = B.its_inter; E.its_fail = B.its_fail; E.its_nidne = B.its_nidne; E.its_types = B.its_types; E.it_states = B.it_states; E.prob.S = B.prob.S; E.prob.SC = B.prob.SC;
+    if (base && !lattice_adopted) {      // every class / filter / node state of the what-if is one the snapshot already has: its tables are used in place
+      E.shared_lattice = true; E.prob.S = base->E.prob.S; E.prob.SC = base->E.prob.SC;
       return;
     }
     const std::vector<Requirements>& it_requirements = base ? base->it_requirements : this->it_requirements;
@@ -905,8 +956,9 @@ struct Builder {
     p.max_new_nodes = p.P ? p.P : 1; p.flags = flags | ((pr.simulation_mode || base) ? KS_FLAG_SIMULATION : 0);
     p.wellknown_mask = 0; for (uint32_t k = 0; k < K; ++k) if (wellKnown.count(E.key_names[k])) p.wellknown_mask |= 1u << k;
     p.key_nvalues = E.key_nvalues.data(); p.value_int = E.value_int.data(); p.key_zone = key_id.at(ksp::kZone); p.key_ct = key_id.at(ksp::kCapacityType); p.n_ct = E.key_nvalues[p.key_ct];
-    p.it_present = E.it_present.data(); p.it_complement = E.it_complement.data(); p.it_mask = E.it_mask.data(); p.it_alloc = E.it_alloc.data(); p.it_cap = E.it_cap.data(); p.it_offer = E.it_offer.data(); p.it_price = E.it_price.data(); p.it_price_lo = E.it_price_lo.data(); p.ct_spot = value_id(p.key_ct, "spot"); p.ct_ondemand = value_id(p.key_ct, "on-demand");
-    p.its_inter = E.its_inter.data(); p.its_fail = E.its_fail.data(); p.its_nidne = E.its_nidne.data(); p.its_types = E.its_types.data();
+    const Encoded& CAT = E.catalogue(); const Encoded& LAT = E.lattice();
+    p.it_present = CAT.it_present.data(); p.it_complement = CAT.it_complement.data(); p.it_mask = CAT.it_mask.data(); p.it_alloc = CAT.it_alloc.data(); p.it_cap = CAT.it_cap.data(); p.it_offer = CAT.it_offer.data(); p.it_price = CAT.it_price.data(); p.it_price_lo = CAT.it_price_lo.data(); p.ct_spot = value_id(p.key_ct, "spot"); p.ct_ondemand = value_id(p.key_ct, "on-demand");
+    p.its_inter = LAT.its_inter.data(); p.its_fail = LAT.its_fail.data(); p.its_nidne = LAT.its_nidne.data(); p.its_types = LAT.its_types.data();
     p.tmpl = E.tmpl.view(); p.tmpl_taints = E.tmpl_taints.data(); p.tmpl_daemon = E.tmpl_daemon.data(); p.tmpl_daemon_present = E.tmpl_daemon_present.data(); p.tmpl_types = E.tmpl_types.data();
     p.tmpl_limit_present = E.tmpl_limit_present.data(); p.tmpl_remaining = E.tmpl_remaining.data();
     p.en = E.en.view(); p.en_taints = E.en_taints.data(); p.en_avail = E.en_avail.data(); p.en_requests = E.en_requests.data(); p.en_requests_present = E.en_requests_present.data(); p.en_port_off = E.en_port_off.data();
@@ -953,19 +1005,19 @@ std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> pr, uint32_t
 }
 
 struct SnapshotBase {
-  std::shared_ptr<const ksp::Problem> snapshot; std::unique_ptr<Encoded> enc; std::unique_ptr<Builder> builder;
+  std::shared_ptr<const ksp::Problem> snapshot; std::shared_ptr<Encoded> enc; std::unique_ptr<Builder> builder;
   std::vector<std::vector<uint32_t>> by_node;      // pods bound to each node, in pod order
 };
 std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp::Problem> snapshot, const int32_t* pod_node, uint32_t flags) {
   auto sb = std::make_shared<SnapshotBase>(); sb->snapshot = snapshot;
   sb->by_node.resize(snapshot->nodes.size());
   for (size_t i = 0; i < snapshot->pods.size(); ++i) { if (pod_node[i] < 0 || (size_t)pod_node[i] >= snapshot->nodes.size()) throw ksp::Error("pod_node out of range"); sb->by_node[pod_node[i]].push_back((uint32_t)i); }
-  sb->enc = std::make_unique<Encoded>(); sb->enc->src = snapshot;
+  sb->enc = std::make_shared<Encoded>(); sb->enc->src = snapshot;
   sb->builder = std::make_unique<Builder>(*sb->enc, flags); sb->builder->run();
   return sb;
 }
 std::unique_ptr<Encoded> encode_whatif(const SnapshotBase& sb, const uint32_t* cand, uint32_t ncand, uint32_t flags) {
-  auto e = std::make_unique<Encoded>(); e->src = sb.snapshot;
+  auto e = std::make_unique<Encoded>(); e->src = sb.snapshot; e->shared = sb.enc;
   std::vector<uint8_t> removed(sb.snapshot->nodes.size(), 0);
   Builder b(*e, flags); b.base = sb.builder.get(); b.removed = &removed;
   for (uint32_t i = 0; i < ncand; ++i) { if (cand[i] >= removed.size()) throw ksp::Error("candidate node out of range"); removed[cand[i]] = 1; for (uint32_t p : sb.by_node[cand[i]]) b.podp.push_back(&sb.snapshot->pods[p]); }
@@ -1013,7 +1065,7 @@ std::string Encoded::decode(const ks_result& r, double solve_seconds) const {
       reqs[key_names[k]] = std::move(x);
     }
     if (r.node_it_state[j] > 0) {
-      const Requirement& q = it_states[r.node_it_state[j]]; Out x; x.c = q.complement; x.vals.assign(q.values.begin(), q.values.end());
+      const Requirement& q = lattice().it_states[r.node_it_state[j]]; Out x; x.c = q.complement; x.vals.assign(q.values.begin(), q.values.end());
       x.gt = q.greaterThan ? std::to_string(*q.greaterThan) : "-"; x.lt = q.lessThan ? std::to_string(*q.lessThan) : "-"; reqs[ksp::kInstanceType] = std::move(x);
     }
     o << " " << reqs.size();

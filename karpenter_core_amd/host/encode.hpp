@@ -6,7 +6,9 @@
 // (topology.go:56-80, countDomains :231-276), scheduling.NewScheduler (scheduler.go:42-94) and
 // NewQueue (queue.go:35-41) before handing the flat structure-of-arrays problem to the GPU.
 #pragma once
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -47,6 +49,13 @@ struct Encoded {
   std::vector<uint32_t> pod_stage_off, stage_cls, queue;
   std::vector<uint8_t> grp_type, grp_active; std::vector<int32_t> grp_key, grp_max_skew, grp_count, grp_hslot, grph_count, grph_extra_pos; std::vector<uint32_t> grp_filter_off;
   ks_problem prob{};
+  // A what-if flattened over a shared snapshot (encode_whatif) does not copy the snapshot's catalogue arrays (it_*) nor, when it needs no
+  // instance-type state of its own, its lattice tables (its_*, it_states): `shared` keeps the snapshot's flattening alive and these pick it.
+  std::shared_ptr<const Encoded> shared; bool shared_lattice = false;
+  // (snapshot flattenings only) the same problem resident on a device, per device: what-ifs upload against it (ks_problem_upload_shared)
+  mutable std::mutex dev_mu; mutable std::map<int, std::shared_ptr<void>> dev_resident;
+  const Encoded& catalogue() const { return shared ? *shared : *this; }
+  const Encoded& lattice() const { return shared && shared_lattice ? *shared : *this; }
 
   // ---- result buffers ----
   // Worst-case sized (max_new_nodes rows) but never zero-filled: untouched pages cost nothing, the library writes what it fills.

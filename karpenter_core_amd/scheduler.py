@@ -217,13 +217,17 @@ def open_whatifs(snapshot, pod_node: Sequence[int], candidate_sets: Sequence[Seq
     topology groups, remainingResources) runs on `threads` host threads (0 = all usable cores)."""
     kh = libs()[1]
     n = len(candidate_sets)
-    off = [0]
-    for cs in candidate_sets:
-        off.append(off[-1] + len(cs))
-    flat = [int(c) for cs in candidate_sets for c in cs]
-    c_off = (ctypes.c_uint32 * (n + 1))(*off)
-    c_cand = (ctypes.c_uint32 * max(1, len(flat)))(*flat)
-    c_pn = (ctypes.c_int32 * max(1, len(pod_node)))(*[int(x) for x in pod_node])
+    import numpy as np
+    lens = np.fromiter((len(cs) for cs in candidate_sets), dtype=np.int64, count=n)
+    off = np.zeros(n + 1, dtype=np.uint32)
+    np.cumsum(lens, out=off[1:])
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(cs, dtype=np.uint32) for cs in candidate_sets]) if n else np.zeros(1, dtype=np.uint32))
+    if flat.size == 0:
+        flat = np.zeros(1, dtype=np.uint32)
+    pn = np.ascontiguousarray(np.asarray(pod_node, dtype=np.int32)) if len(pod_node) else np.zeros(1, dtype=np.int32)
+    c_off = off.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    c_cand = flat.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    c_pn = pn.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
     hs = (ctypes.c_void_p * max(1, n))()
     if isinstance(snapshot, ParsedProblem):
         rc = kh.ksh_open_whatifs_parsed(snapshot._p, 0, n, c_off, c_cand, c_pn, threads, hs)
