@@ -1,20 +1,20 @@
 #!/bin/bash
-# rocprofv3 evidence for bench.py (run on the GPU box through gpurun): kernel trace + stats, then HBM
-# traffic counters in their own passes (never combined with tracing domains other than --kernel-trace).
+# rocprofv3 evidence for bench.py, run on the GPU box through gpurun:   tools/profile_bench.sh <tag>      (tag e.g. r02)
+#   1. the contract command itself (`python bench.py`, default arguments) -> the JSON line
+#   2. the same command under `rocprofv3 --kernel-trace --stats`          -> per-kernel durations
+#   3. counters in their OWN passes (kernel-trace only, never with other tracing domains): FETCH_SIZE | WRITE_SIZE | SQ instruction mix,
+#      on the Solve leg only (`--no-cpu-baseline --whatifs 0`: same pack kernel, same problem)
+# then tools/summarize_profile.py gpurun_out/prof_<tag> <tag> (here, in the build container) writes the files kept under profiles/.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_$1; mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --whatifs 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py $ARGS > $OUT/bench_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- python $R/bench.py $ARGS > $OUT/bench_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- python $R/bench.py $ARGS > $OUT/bench_write.log 2>&1
-find $OUT -name "*.csv" | head -20
-python - <<PY
-import csv, glob, collections
-for kind in ("fetch", "write"):
-    agg = collections.defaultdict(lambda: [0.0, 0])
-    for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % kind, recursive=True):
-        for row in csv.DictReader(open(f)):
-            a = agg[(row["Kernel_Name"][:30], row["Counter_Name"])]; a[0] += float(row["Counter_Value"]); a[1] += 1
-    for k, v in sorted(agg.items()): print(kind, k, "sum", v[0], "dispatches", v[1])
-PY
-for f in $(find $OUT/stats -name "*kernel_stats.csv"); do echo "== $f"; cat $f; done
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_$1; rm -rf $OUT; mkdir -p $OUT
+SOLVE="--steps 3 --warmup 1 --no-cpu-baseline --whatifs 0"
+python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py > $OUT/bench_under_rocprof.json 2> $OUT/bench_stats.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- python $R/bench.py $SOLVE > $OUT/bench_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- python $R/bench.py $SOLVE > $OUT/bench_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_BRANCH --output-format csv -d $OUT/insts -o bench -- python $R/bench.py $SOLVE > $OUT/bench_insts.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/cycles -o bench -- python $R/bench.py $SOLVE > $OUT/bench_cycles.log 2>&1
+# keep only what the summariser reads (gpurun_out is capped at 64 MiB)
+find $OUT -name "*.csv" ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -delete
+find $OUT -name "*.db" -delete
+du -sh $OUT; tail -c 600 $OUT/bench.json
