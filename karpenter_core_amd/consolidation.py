@@ -44,6 +44,24 @@ def to_record(whatif_id: int, res: SolveResult, type_index: dict, width: int) ->
     return rec
 
 
+def all_gather_records(records: torch.Tensor, per_rank: int) -> torch.Tensor:
+    """The single exchange step of the sharded what-if path: this rank's [m, width] int64 result records (column 0 = what-if id, m <= per_rank)
+    are padded to per_rank rows with id -1, all-gathered once, and returned as the full table ordered by what-if id (on `records`' device).
+    Used by `solve_whatifs` and by `bench.py --gpus N`; a world of one returns the records sorted."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    width = records.shape[1]
+    local = torch.full((per_rank, width), -1, dtype=torch.int64, device=records.device)
+    local[: records.shape[0]] = records
+    if world > 1:
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        table = torch.cat(gathered, 0)
+    else:
+        table = local
+    table = table[table[:, 0] >= 0]
+    return table[torch.argsort(table[:, 0])]
+
+
 def solve_whatifs(problems: Sequence[Problem], solve_many: Callable[[List[Problem]], List[SolveResult]],
                   device: str = "cpu") -> torch.Tensor:
     """Solve all what-ifs across the process group; every rank returns the full [n, width] record table."""
@@ -55,19 +73,10 @@ def solve_whatifs(problems: Sequence[Problem], solve_many: Callable[[List[Proble
     mine = shard(n, rank, world)
     results = solve_many([problems[i] for i in mine]) if mine else []
     per_rank = (n + world - 1) // world
-    local = torch.full((per_rank, width), -1, dtype=torch.int64)
+    local = torch.full((len(mine), width), -1, dtype=torch.int64)
     for slot, (i, res) in enumerate(zip(mine, results)):
         local[slot] = to_record(i, res, type_index, width)
-    local = local.to(device)
-    if world > 1:
-        gathered = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(gathered, local)                 # the single exchange step of the path
-        table = torch.stack(gathered, 0).reshape(world * per_rank, width)
-    else:
-        table = local
-    table = table[table[:, 0] >= 0]
-    order = torch.argsort(table[:, 0])
-    return table[order].cpu()
+    return all_gather_records(local.to(device), per_rank).cpu()
 
 
 def gpu_solve_many(problems: List[Problem], device: Optional[int] = None) -> List[SolveResult]:

@@ -56,6 +56,28 @@ def test_two_rank_gloo_matches_serial():
     assert out[0] == serial and out[1] == serial
 
 
+def _gather_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # what `bench.py --gpus N` hands over: binary records [id, n_new, n_unscheduled, InstanceTypeOptions words] of this rank's share, i mod N
+        ids = C.shard(5, rank, world)
+        rec = torch.tensor([[i, i % 2, 0, (1 << i) - 1, -(i + 1)] for i in ids], dtype=torch.int64).reshape(len(ids), 5)
+        out[rank] = C.all_gather_records(rec, (5 + world - 1) // world).tolist()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_record_gather():
+    """The record builder of the sharded path: uneven shares (3 + 2 records), padding rows dropped, rows in what-if order on every rank."""
+    want = [[i, i % 2, 0, (1 << i) - 1, -(i + 1)] for i in range(5)]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gather_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] == want and out[1] == want
+    assert C.all_gather_records(torch.tensor(want[::-1], dtype=torch.int64), 5).tolist() == want      # world of one: sorted by id
+
+
 @pytest.mark.gpu
 def test_whatif_records_gpu():
     probs = _problems()
