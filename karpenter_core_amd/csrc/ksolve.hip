@@ -103,6 +103,9 @@ struct DevProb {
   u64* ge_rows;      // [(r*T+i)*TW] types whose Allocatable[r] >= ge_vals[r*T+i]   (resources.Fits as a mask)
   void* plans;       // [C] ClsPlan: per-class plan records (ks_build_plans)
   void* briefs;      // [C] ClsBrief: what the round planner / resolver reads of a class
+  // Spread groups the round resolver follows exactly (ks_pack, "dynamic spread"): unfiltered, initially active spread groups on ONE narrow key
+  // (the key with the most of them, <= 8 values): bit g of dyn_groups, slot(g) = popcount(dyn_groups below g), at most 16.
+  u64 dyn_groups; i32 dyn_key; u32 dyn_nz;
   u32* ev_tab; u32 ev_tab_size, derived_shared;   // open-addressing table that interns evaluation classes (ks_link_ev); derived_shared: kv_types .. ge_rows belong to another problem
   u8* mc_ok;         // [M*C]
   u8* mc_why;        // [M*C]  KS_WHY_* of a fresh node of template m refusing class c before the topology step (0 if mc_ok)
@@ -347,7 +350,7 @@ struct alignas(16) ClsPlan {
   u32 c, present, complement; i32 it_state;
   u32 hn_mode, hn_off, hn_cnt, reqmask;
   u64 tol; u32 port_off, port_cnt;
-  u32 vol_off, vol_cnt, mono, vol_pad1;     // mono: an existing node that refused this class once refuses it for the rest of the Solve (see the watermark in ks_pack)
+  u32 vol_off, vol_cnt, mono, dyn;     // mono: an existing node that refused this class once refuses it for the rest of the Solve (see the watermark in ks_pack); dyn: see ClsBrief::dyn
   u32 ntouch, ntopo, nhost, nrec;
   i64 req[KS_MAX_RES];
   PlanTouch touch[KS_MAX_TOUCH];
@@ -366,10 +369,14 @@ struct alignas(16) ClsBrief {
   u64 rmask;    // groups Topology.Record may update
   u32 ev;       // evaluation class: classes with equal ids are evaluated identically by eval_node (they may differ in what they record)
   u32 flags;    // bit 0: may take part in rounds (plan fits the kernel's limits, no host ports, no volumes)
-  u32 reqmask, pad;
+  u32 reqmask;
+  u32 dyn;      // != 0: the evaluation's only topology item is a spread over a group of DevProb::dyn_groups and the pod has no requirement of its own on that
+                // key: 1 | g << 8 | selfSelecting << 16.  On a node whose requirement on the key is a single value the item then depends on that value
+                // and the group's counts alone, so the resolver can apply it against counts it keeps for the round.
   i64 req[KS_MAX_RES];
   u64 zmask;    // hostname-keyed groups whose item accepts a node only while the node's own counter is 0 (anti-affinity; spread with maxSkew - self == 0)
   u64 rsure;    // hostname-keyed groups this class records into for certain (group present from the start, no node filter): subset of rmask
+  i32 dyn_maxskew; u32 dyn_pd;      // dyn: maxSkew and the pod's domains (PlanTopo::PD) over the key's <= 8 values
 };
 static_assert(sizeof(ClsBrief) == 128, "ClsBrief layout");
 
@@ -457,6 +464,9 @@ __global__ __launch_bounds__(64) void ks_build_plans(const DevProb* probs) {
   // well-known keys: taints are static, host ports / volumes / requests only accumulate, requirement sets only narrow.  (A custom
   // label the node does not define is the exception -- "label does not have known values" until another pod's NotIn defines it.)
   pl.mono = (!pl.overflow && pl.ntopo == 0 && pl.nhost == 0 && (pl.present & ~P.wellknown_mask) == 0) ? 1u : 0u;
+  pl.dyn = 0;
+  if (!pl.overflow && pl.ntopo == 1 && pl.nhost == 0 && pl.topo[0].type == 0 && !pl.topo[0].pod_has && pl.topo[0].g < 64 && ((P.dyn_groups >> pl.topo[0].g) & 1ull) &&
+      pl.topo[0].maxskew >= 0 && pl.topo[0].maxskew < (1 << 30)) pl.dyn = 1u | ((u32)pl.topo[0].g << 8) | ((u32)pl.topo[0].self << 16);
   plans[c] = pl;
   u64 zmask = 0;
   for (u32 j = 0; j < pl.nhost; ++j) if (pl.host[j].type == 2 || (pl.host[j].type == 0 && (i64)pl.host[j].maxskew - (i64)pl.host[j].self <= 0)) zmask |= 1ull << (pl.host[j].g & 63);
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(64) void ks_build_plans(const DevProb* probs) {
   for (u32 j = 0; j < pl.nrec; ++j) { const PlanRec& r = pl.rec[j]; if (r.key == KS_KEY_HOSTNAME && (r.owned_inverse || (P.grp_active[r.g] != 0 && !r.filtered))) rsure |= 1ull << (r.g & 63); }
   ClsBrief b; b.zmask = zmask; b.rsure = rsure; b.tmask = pl.tmask; b.tfull = tfull; b.rmask = pl.rmask; bool late_host = false;       // a record into a hostname-keyed group a relaxation creates later: such hostnames may be unregistered
   for (u32 j = 0; j < pl.nrec; ++j) if (pl.rec[j].key == KS_KEY_HOSTNAME && !pl.rec[j].owned_inverse && P.grp_active[pl.rec[j].g] == 0) late_host = true;
-  b.ev = 0; b.flags = (!pl.overflow && pl.port_cnt == 0 && pl.vol_cnt == 0 && !late_host) ? 1u : 0u; b.reqmask = pl.reqmask; b.pad = 0;
+  b.ev = 0; b.flags = (!pl.overflow && pl.port_cnt == 0 && pl.vol_cnt == 0 && !late_host) ? 1u : 0u; b.reqmask = pl.reqmask; b.dyn = pl.dyn; b.dyn_maxskew = pl.dyn ? pl.topo[0].maxskew : 0; b.dyn_pd = pl.dyn ? (u32)pl.topo[0].PD : 0u;
   for (u32 r = 0; r < KS_MAX_RES; ++r) b.req[r] = pl.req[r];
   briefs[c] = b;
 }
@@ -595,6 +605,11 @@ template <int RM> struct RoundCtlT {   // speculation-round hand-off between the
   u32 ortmp[4];                                  // scratch of the resolver's mask reductions
   u8 lastpod[64], firstpod[64], npods[64];       // per candidate: last / first round pod placed on it, how many
   u32 rmsk_new[64]; i64 roomrem[RM][64];         // per candidate after the round's pods: requested-resource mask, headroom
+  // dynamic spread (DevProb::dyn_groups)
+  u64 mo[KS_MAX_WAVES];                          // per worker: candidates that accept its class if the skew test is left aside (superset of m)
+  u8 zone[64];                                   // per candidate: the single value its requirement on dyn_key allows (In [v]), 0xFF if it is not of that form
+  u32 dynq[2][64];                               // per round pod of a ClsBrief::dyn class: maxSkew | PD << 24 (the dyn word itself rides in the leader's b_flags)
+  i32 dd[64][8];                                 // what the round's pods have recorded so far: [group][domain] (rows of dyn_groups only)
 };
 
 // ---- slot record (AoS).  Offsets in bytes; stride = ks_rec_stride(R,K) ----
@@ -694,8 +709,11 @@ template <int RM> struct EvT {
 // `merged`: the pod's own requirements are already folded into the record (a fresh node materialised
 // from the template∩class record), only topology is evaluated on top.
 template <bool BOUNDS, bool LEAN, int RM>
-__device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, const Tabs& tb, WaveShared& sh, WaveBounds& wb, u32 slot, bool existing, bool merged, EvT<RM>& ev, int lane, u64& tprobe, const ClsRT<RM>& cr) {
-  const ClsPlan& c = sh.cls;
+__device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, const Tabs& tb, WaveShared& sh, WaveBounds& wb, u32 slot, bool existing, bool merged, EvT<RM>& ev, int lane, u64& tprobe, const ClsRT<RM>& cr, const bool relax_skew = false) {
+  // relax_skew (round evaluation of a ClsBrief::dyn class only): a spread item no domain of the node satisfies does not end the evaluation -- it
+  // goes on as if every registered domain of the node were allowed and the result is flagged (rc |= 4): "accepts but for the skew", which the
+  // resolver re-decides against the counts of the moment.
+  const ClsPlan& c = sh.cls; bool skew_failed = false;
   const Rec r = slot_rec(S, tb, slot);
   ev.rc = 0; ev.tpres = 0; ev.tcomp = 0; ev.tchg = 0; ev.tnar = 0;
   // ---- gather: header, requests/capacity, first touched key, hostname counters (independent loads) ----
@@ -783,6 +801,7 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
             if ((i64)cnt - (i64)d.minc <= (i64)tt.maxskew && cnt < best) { best = cnt; bestv = dd; }
           }
           if (bestv >= 0) options = 1ull << bestv;
+          else if (relax_skew) { skew_failed = true; options = d.reg & ND; }
         } else if (tt.type == 1) {                                // affinity: nextDomainAffinity :202-233
           options = d.reg & tt.PD & d.pos;
           if (!options && tt.self) {
@@ -809,7 +828,7 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
     if (kreq_differs(a, orig)) ev.tchg |= 1u << i;
     sh.la_mask[i][lane] = a.mask; if constexpr (BOUNDS) { wb.la_gt[i][lane] = a.gt; wb.la_lt[i][lane] = a.lt; }
   }
-  ev.rc = fit ? 2 : 1;
+  ev.rc = (fit ? 2 : 1) | (skew_failed ? 4 : 0);
 }
 
 // Synchronisation.  The sequential path runs on wave 0 alone:
@@ -963,6 +982,14 @@ __device__ __forceinline__ u32 wave_min_u32(u32 v) {
   v = min(v, (u32)__builtin_amdgcn_update_dpp(id, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 into rows 1 and 3
   v = min(v, (u32)__builtin_amdgcn_update_dpp(id, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 into rows 2 and 3
   return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+// ... over lanes 0..7 only (three row shifts; the result sits in lane 7)
+__device__ __forceinline__ u32 lanes8_min_u32(u32 v) {
+  const int id = (int)0xFFFFFFFFu;
+  v = min(v, (u32)__builtin_amdgcn_update_dpp(id, (int)v, 0x111, 0xF, 0xF, false));
+  v = min(v, (u32)__builtin_amdgcn_update_dpp(id, (int)v, 0x112, 0xF, 0xF, false));
+  v = min(v, (u32)__builtin_amdgcn_update_dpp(id, (int)v, 0x114, 0xF, 0xF, false));
+  return (u32)__builtin_amdgcn_readlane((int)v, 7);
 }
 __device__ __forceinline__ i64 wave_max_i64(i64 v) { for (int off = 32; off > 0; off >>= 1) { const i64 o = __shfl_xor(v, off); if (o > v) v = o; } return v; }
 
@@ -1222,7 +1249,10 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           const GA i64* rqp = (const GA i64*)((const GA u8*)bp + 40);
 #pragma unroll
           for (int i = 0; i < RM; ++i) b_req[i] = rqp[i];
-          b_e = e; b_tmask = (u64)v0.x | ((u64)v0.y << 32); b_tfull = (u64)v0.z | ((u64)v0.w << 32); b_rmask = (u64)v1.x | ((u64)v1.y << 32); b_flags = v1.w; b_reqmask = rqm; b_zmask = *(const GA u64*)((const GA u8*)bp + 104); b_rsure = *(const GA u64*)((const GA u8*)bp + 112);
+          u32 dynw_l = 0;
+          { const u32 dynw = *(const GA u32*)((const GA u8*)bp + 36); const u32 dms = *(const GA u32*)((const GA u8*)bp + 120), dpd = *(const GA u32*)((const GA u8*)bp + 124);
+            rc.dynq[wpar][lane] = (dms & 0xFFFFFFu) | (dpd << 24); dynw_l = dynw; }
+          b_e = e; b_tmask = (u64)v0.x | ((u64)v0.y << 32); b_tfull = (u64)v0.z | ((u64)v0.w << 32); b_rmask = (u64)v1.x | ((u64)v1.y << 32); b_flags = (v1.w & 1u) | (dynw_l << 1) /* bit 0: round-eligible; bits 1..: ClsBrief::dyn */; b_reqmask = rqm; b_zmask = *(const GA u64*)((const GA u8*)bp + 104); b_rsure = *(const GA u64*)((const GA u8*)bp + 112);
           const u32 evc = v1.z;
           u32 rn = cap;
           { const u64 rq_bits = ballot64((u32)lane < cap && (e >> 63) != 0); if (rq_bits) rn = min(rn, (u32)__builtin_ctzll(rq_bits)); }
@@ -1667,10 +1697,19 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         ev.rc = 0; ev.count = 0; ev.reqmask = 0; ev.tchg = 0; ev.tpres = 0; ev.tcomp = 0; ev.present = 0; ev.complement = 0; ev.it_state = 0; ev.it0 = 0;
 #pragma unroll
         for (int i = 0; i < RM; ++i) { ev.room[i] = 0; ev.req[i] = 0; ev.low[i] = INT64_MIN; }
-        if (slot != 0xFFFFFFFFu) eval_node<BOUNDS, LEAN, RM>(P, S, tb, sh, wb, slot, slot < tb.E, false, ev, lane, tprobe, cr);
+        const bool dync = UF(c.dyn) != 0;
+        u32 zl = 0xFFu;        // (worker 0) this candidate's single value on dyn_key, if its requirement is In [v]
+        if (kw == 0 && (i32)UF(P.dyn_key) >= 0 && slot != 0xFFFFFFFFu) {
+          const Rec rz = slot_rec(S, tb, slot); const u32 dk = UF((u32)P.dyn_key);
+          const u64 zm = rz.mask()[dk];
+          if (((rz.present() >> dk) & 1u) && !((rz.complement() >> dk) & 1u) && __builtin_popcountll(zm) == 1) zl = (u32)__builtin_ctzll(zm);
+        }
+        if (slot != 0xFFFFFFFFu) eval_node<BOUNDS, LEAN, RM>(P, S, tb, sh, wb, slot, slot < tb.E, false, ev, lane, tprobe, cr, dync);
+        const u64 mo = ballot64((ev.rc & 3) == 2 && ev.rc > 0);
         const u64 m = ballot64(ev.rc == 2);
-        const u64 chgb = ballot64(ev.rc == 2 && (ev.tchg != 0 || ev.it_state != ev.it0));
-        if (lane == 0) { rc.m[kw] = m; rc.chg[kw] = chgb; }
+        const u64 chgb = ballot64((ev.rc & 3) == 2 && ev.rc > 0 && (ev.tchg != 0 || ev.it_state != ev.it0));
+        if (lane == 0) { rc.m[kw] = m; rc.chg[kw] = chgb; rc.mo[kw] = mo; }
+        if (kw == 0) rc.zone[lane] = (u8)zl;
         if (kw == 0) {
           rc.cnt[lane] = ev.count; rc.rmsk[lane] = ev.reqmask;
 #pragma unroll
@@ -1700,19 +1739,55 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         u64 closedmask = 0, rall = 0;
         const bool exact_masks = nG <= 64;      // group bits (g & 63) do not alias: a set bit names one group
         // OR of two per-lane masks over the lanes of `in` (LDS atomics: cheaper than twelve cross-lane steps for what is a rare, amortised call)
-        auto or_masks = [&](bool in, u64& o_r, u64& o_s) {
+        auto or_masks = [&](bool in, u64 v_r, u64 v_s, u64& o_r, u64& o_s) {
           if (lane == 0) { rc.ortmp[0] = 0; rc.ortmp[1] = 0; rc.ortmp[2] = 0; rc.ortmp[3] = 0; }
           LSYNC();
-          if (in) { atomicOr(&rc.ortmp[0], (u32)b_rmask); atomicOr(&rc.ortmp[1], (u32)(b_rmask >> 32)); atomicOr(&rc.ortmp[2], (u32)b_rsure); atomicOr(&rc.ortmp[3], (u32)(b_rsure >> 32)); }
+          if (in) { atomicOr(&rc.ortmp[0], (u32)v_r); atomicOr(&rc.ortmp[1], (u32)(v_r >> 32)); atomicOr(&rc.ortmp[2], (u32)v_s); atomicOr(&rc.ortmp[3], (u32)(v_s >> 32)); }
           LSYNC();
           o_r = UF64((u64)rc.ortmp[0] | ((u64)rc.ortmp[1] << 32)); o_s = UF64((u64)rc.ortmp[2] | ((u64)rc.ortmp[3] << 32));
         };
+        // Dynamic spread: records into a group of dyn_groups are followed exactly where that is possible.  `mine`: this lane applies the
+        // record masks `rm` of one pod placed on a candidate whose single value on dyn_key is `zb` (0xFF: not of that form) and whose
+        // requirements the pod changes iff `chg`.  Returns the part of rm that was NOT accounted for exactly (it goes into `rall`).
+        const u64 dyn_groups = exact_masks ? UF64(P.dyn_groups) : 0ull; const bool dyn_on = dyn_groups != 0;
+        u32 c_zone = 0xFFu;
+        if (dyn_on) { c_zone = rc.zone[lane]; if ((dyn_groups >> lane) & 1ull) { u32x4* row = (u32x4*)&rc.dd[lane][0]; const u32x4 z4 = {0, 0, 0, 0}; row[0] = z4; row[1] = z4; } LSYNC(); }
+        auto track_records = [&](bool mine, u64 rm, u32 zb, bool chg) -> u64 {
+          const u64 db = rm & dyn_groups;
+          if (!mine || !db) return rm;
+          if (zb != 0xFFu) { for (u64 b = db; b; b &= b - 1) atomicAdd(&rc.dd[__builtin_ctzll(b)][zb & 7u], 1); return rm & ~dyn_groups; }
+          return chg ? rm : (rm & ~dyn_groups);      // a node whose requirement on the key is not In [v] and stays as it is: nothing is counted (topology.go:120-133)
+        };
+        // the same for ONE pod (wave-uniform arguments): lane g carries group g
+        auto track_one = [&](u64 rm, u32 zb) { if (zb != 0xFFu && ((rm & dyn_groups) >> lane) & 1ull) atomicAdd(&rc.dd[lane][zb & 7u], 1); };
         u32 k = 0;
         P2T(12);
         while (k < rn) {
           P2C(15, 1);
           if (RL64(b_tmask, k) & rall) { CUT(13); break; }
-          const u64 mk = RL64(mk_l, k), tfk = RL64(b_tfull, k), chgk = RL64(chg_l, k); const u32 rmk = RL(b_reqmask, k);
+          u64 mk = RL64(mk_l, k), tfk = RL64(b_tfull, k); const u64 chgk = RL64(chg_l, k); const u32 rmk = RL(b_reqmask, k);
+          u64 unk = 0;      // candidates whose answer under the counts of the moment is not known (their requirement on dyn_key is not In [v])
+          if (dyn_on) {
+            const u32 dynk = RL(b_flags, k) >> 1;
+            if (dynk) {
+              // nextDomainTopologySpread (topologygroup.go:155-182) for a node with ONE domain z: z registered and count(z) + self - min <= maxSkew,
+              // with the counts as the round has left them; min over the registered domains the pod allows.
+              const u32 g = (dynk >> 8) & 0xFFu, self = (dynk >> 16) & 1u, q = UF(rc.dynq[par][k]), pd = q >> 24; const i32 maxskew = (i32)(q & 0xFFFFFFu);
+              const u64 reg = tb.g_reg[g];
+              LSYNC();
+              i32 cz = 0, dz = 0; const bool zin = (u32)lane < 8u && ((reg >> lane) & 1ull);
+              if ((u32)lane < 8u) { dz = rc.dd[g][lane]; cz = tb.gcnt[(size_t)g * 64 + lane] + dz; }
+              const u32 minc = lanes8_min_u32((zin && ((pd >> lane) & 1u)) ? (u32)cz : 0xFFFFFFFFu);
+              const u64 VZ = ballot64(zin && (i64)cz + (i64)self - (i64)minc <= (i64)maxskew);
+              const bool anyd = ballot64((u32)lane < 8u && dz != 0) != 0;
+              const u64 mok = UF64(rc.mo[RL(b_w, k) & (KS_MAX_WAVES - 1)]);
+              const u64 pinned = ballot64(c_zone != 0xFFu);
+              const u64 okz = ballot64(c_zone != 0xFFu && ((VZ >> (c_zone & 63u)) & 1ull));
+              if (anyd) unk = mok & ~pinned;
+              mk = (mok & okz) | (anyd ? unk : (mk & ~pinned));
+              tfk &= ~(1ull << g);
+            }
+          }
           i64 rqk[RM];
 #pragma unroll
           for (int i = 0; i < RM; ++i) rqk[i] = (i64)RL64(b_req[i], k);
@@ -1743,6 +1818,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           const u32 best = wave_min_u32(inA ? c_key : 0xFFFFFFFFu);
           const int bu = __builtin_ctzll(ballot64(inA && c_key == best));
           const bool bu_moved = (movedmask >> bu) & 1ull;
+          if ((unk >> bu) & 1ull) { CUT(13); break; }
           if (bu_moved) {
             if ((u32)bu >= tb.E && !window_complete && (best >> 8) > cnt_last) { CUT(15); break; }        // nodes beyond the window may precede it
             if ((closedmask >> bu) & 1ull) { CUT(15); break; }                                              // its requirements changed in this round
@@ -1768,7 +1844,8 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
                 rc.win[pidx] = (u8)lane;
               }
               const u64 S = ballot64(inS);
-              u64 orr, ors; or_masks((u32)lane >= k && (u32)lane < k + sN, orr, ors);
+              const u64 inx = track_records(inS, prm, c_zone, (chgk >> lane) & 1ull);
+              u64 orr, ors; or_masks(inS, inx, psu, orr, ors);
               movedmask = UF64(movedmask | S); closedmask = UF64(closedmask | (S & chgk)); rall = UF64(rall | orr);
               k += sN; n_ok = k;
               continue;
@@ -1793,8 +1870,16 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             const u32 t_res = ~bal ? (u32)__builtin_ctzll(~bal) : 64u;
             t = max(1u, min(min(r, t_order), t_res));
           }
-          u64 orr = RL64(b_rmask, k), ors = RL64(b_rsure, k);
-          if (t >= 2) or_masks((u32)lane >= k && (u32)lane < k + t, orr, ors);
+          u64 orr = RL64(b_rmask, k), ors = RL64(b_rsure, k), inx = orr;
+          {
+            const u32 zb = RL(c_zone, bu); const bool chg_bu = (chgk >> bu) & 1ull;
+            if (t >= 2) {
+              const bool inrun = (u32)lane >= k && (u32)lane < k + t;
+              u64 o_full, o_s; or_masks(inrun, b_rmask, b_rsure, o_full, o_s);
+              orr = o_full; ors = o_s; inx = o_full;
+              if (dyn_on && (o_full & dyn_groups)) { (void)track_records(inrun, b_rmask, zb, chg_bu); inx = (zb != 0xFFu || !chg_bu) ? (o_full & ~dyn_groups) : o_full; }
+            } else if (dyn_on && (orr & dyn_groups)) { track_one(orr, zb); inx = (zb != 0xFFu || !chg_bu) ? (orr & ~dyn_groups) : orr; }
+          }
           if (lane == bu) {
 #pragma unroll
             for (int i = 0; i < RM; ++i) c_room[i] -= (i64)t * rqk[i];
@@ -1804,7 +1889,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           if ((u32)lane >= k && (u32)lane < k + t) rc.win[lane] = (u8)bu;
           movedmask = UF64(movedmask | (1ull << bu));
           if ((chgk >> bu) & 1ull) closedmask = UF64(closedmask | (1ull << bu));
-          rall = UF64(rall | orr);
+          rall = UF64(rall | inx);
           k += t; n_ok = k;
         }
         P2T(13);
@@ -2274,6 +2359,24 @@ static int upload_impl(const ks_problem* p, int device, const ks_dev_problem* ba
   h.P = p->P; h.C = p->C; h.T = p->T; h.TW = (p->T + 63) / 64; h.M = p->M; h.E = p->E; h.K = p->K; h.R = p->R; h.G = p->G; h.GH = p->GH; h.S = p->S; h.SC = p->SC;
   h.NMAX = p->max_new_nodes ? p->max_new_nodes : 1; h.flags = p->flags; h.n_topologies = p->n_topologies;
   h.wellknown_mask = p->wellknown_mask; h.key_zone = p->key_zone; h.key_ct = p->key_ct; h.n_ct = p->n_ct;
+  {   // groups the round resolver may follow exactly (DevProb::dyn_groups)
+    h.dyn_groups = 0; h.dyn_key = -1; h.dyn_nz = 0;
+    if (p->G <= 64 && !getenv("KS_NO_DYN")) {
+      u64 per_key[KS_MAX_KEYS]; for (u32 k = 0; k < KS_MAX_KEYS; ++k) per_key[k] = 0;
+      for (u32 g = 0; g < p->n_topologies && g < p->G; ++g) {
+        const i32 k = p->grp_key[g];
+        if (p->grp_type[g] != 0 || k < 0 || (u32)k >= p->K || !p->grp_active[g] || p->key_nvalues[k] > 8) continue;
+        bool unfiltered = p->grp_filter_off[g] == p->grp_filter_off[g + 1];
+        for (u32 f = p->grp_filter_off[g]; f < p->grp_filter_off[g + 1]; ++f) if (p->flt.present[f] == 0 && p->flt.it_state[f] == 0) unfiltered = true;      // an empty term matches every node
+        if (unfiltered) per_key[k] |= 1ull << g;
+      }
+      int best = -1; for (u32 k = 0; k < p->K; ++k) if (per_key[k] && (best < 0 || __builtin_popcountll(per_key[k]) > __builtin_popcountll(per_key[best]))) best = (int)k;
+      if (best >= 0) {
+        u64 m = per_key[best]; while (__builtin_popcountll(m) > 16) m &= ~(1ull << (63 - __builtin_clzll(m)));
+        h.dyn_groups = m; h.dyn_key = best; h.dyn_nz = p->key_nvalues[best];
+      }
+    }
+  }
   const u32 K = h.K, R = h.R, T = h.T, TW = h.TW, C = h.C, M = h.M, E = h.E, G = h.G, P = h.P;
   {   // LEAN kernel variant eligibility (see ks_pack)
     bool lean = R <= 4 && h.SC == 1 && !(p->flags & KS_FLAG_STATS);
@@ -2570,9 +2673,9 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
     if ((size_t)device >= attr_done.size()) attr_done.resize(device + 1, 0);
     if (!attr_done[device]) {
       for (int i = 0; i < 8; ++i) HIPCHK(hipFuncSetAttribute((const void*)variants[i], hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, true, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 44 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 44 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)ks_pack<true, true, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 44 * 1024));
       attr_done[device] = 1;
     }
   }
