@@ -1541,7 +1541,14 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           // visiting order: the node leaves position p of bucket `cnt` for the FRONT of bucket cnt+1
           const u32 p = pos_base + win - tb.E;
           const u32 endc = UF(BST(cnt + 1));                         // one past the last node with `cnt` pods
-          for (u32 i = p + 1; i < endc; i += 64) { const u32 ii = i + lane; u32 v = 0; if (ii < endc) v = ORD_RD(ii); if (ord_in_lds) LSYNC(); else GSYNC(); if (ii < endc) ORD_WR(ii - 1, v); }
+          for (u32 i = p + 1; i < endc; i += 256) {       // shift left by one: reads may run ahead of the writes (four chunks in flight)
+            u32 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const u32 ii = i + 64u * (u32)u + (u32)lane; v[u] = 0; if (ii < endc) v[u] = ORD_RD(ii); }
+            if (ord_in_lds) LSYNC(); else GSYNC();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const u32 ii = i + 64u * (u32)u + (u32)lane; if (ii < endc) ORD_WR(ii - 1, v[u]); }
+          }
           if (ord_in_lds) LSYNC(); else GSYNC();
           if (lane == 0) { ORD_WR(endc - 1, jw); BST(cnt + 1) = endc - 1; if (cnt + 1 > maxc) BST(cnt + 2) = nnew; }
           if (cnt + 1 > maxc) maxc = cnt + 1;
@@ -1562,7 +1569,16 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           if (maxc == 0) { if (lane == 0) { BST(1) = 0; BST(2) = 1; ORD_WR(0, jw); } maxc = 1; }
           else {
             const u32 ins = UF(BST(2));
-            for (u32 hi = nnew; hi > ins; ) { const u32 lo = hi > ins + 64 ? hi - 64 : ins; const u32 ii = lo + lane; u32 v = 0; if (ii < hi) v = ORD_RD(ii); if (ord_in_lds) LSYNC(); else GSYNC(); if (ii < hi) ORD_WR(ii + 1, v); if (ord_in_lds) LSYNC(); else GSYNC(); hi = lo; }
+            for (u32 hi = nnew; hi > ins; ) {            // shift right by one, from the top down: four chunks in flight (the reads run ahead towards lower positions, the writes go up)
+              const u32 lo = hi > ins + 256 ? hi - 256 : ins; u32 v[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) { const u32 ii = lo + 64u * (u32)u + (u32)lane; v[u] = 0; if (ii < hi) v[u] = ORD_RD(ii); }
+              if (ord_in_lds) LSYNC(); else GSYNC();
+#pragma unroll
+              for (int u = 0; u < 4; ++u) { const u32 ii = lo + 64u * (u32)u + (u32)lane; if (ii < hi) ORD_WR(ii + 1, v[u]); }
+              if (ord_in_lds) LSYNC(); else GSYNC();
+              hi = lo;
+            }
             if (lane == 0) ORD_WR(ins, jw);
             for (u32 cc = 2 + lane; cc <= maxc + 1; cc += 64) BST(cc) += 1;
           }
@@ -2113,6 +2129,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           }
         }
       }
+#ifdef KS_P2PROBES
+      u64 t2p = __builtin_readcyclecounter();
+#endif
       if (wv == 0) {
         if (!cancelled && n_ok) {
           // ---- visiting order: every moved node leaves its place and enters the FRONT of the bucket of its final count (the
@@ -2127,21 +2146,47 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             for (u64 b = M; b; b &= b - 1) { const int x = __builtin_ctzll(b); cmin = min(cmin, RL(c_cnt0, x)); cmax = max(cmax, RL(c_cnt, x)); }
             const u32 pmin = (u32)__builtin_ctzll(Mpos);
             auto oldstart = [&](u32 b) -> u32 { return b <= maxc + 1 ? UF(BST(b)) : nnew; };
-            // relocate the untouched elements, bucket by bucket (within a bucket the shift depends only on how many moved nodes stood before)
-            for (u32 b = cmin; b <= cmax; ++b) {
-              const u32 s0 = max(oldstart(b), pmin), s1 = oldstart(b + 1);
-              u32 ins = 0; for (u64 q = M; q; q &= q - 1) { const int x = __builtin_ctzll(q); if (RL(c_cnt, x) <= b) ++ins; }      // moved nodes that end up at or before this bucket's front
-              for (u32 base = s0; base < s1; base += 64) {
-                const u32 ii = base + lane; u32 v = 0; const bool in = ii < s1;
-                if (in) v = ORD_RD(ii);
-                if (ord_in_lds) LSYNC(); else GSYNC();
-                if (in) {
-                  const bool is_m = ii < 64 && ((Mpos >> ii) & 1ull);
-                  const u32 rem_before = ii >= 64 ? nM : (u32)__builtin_popcountll(Mpos & ((1ull << ii) - 1ull));
-                  if (!is_m) ORD_WR(ii - rem_before + ins, v);
+            // Relocate the untouched elements of [pmin, end of bucket cmax): an element of bucket b moves left by (moved nodes that stood before it) -
+            // (moved nodes that end up at or before bucket b's front).  Every net shift is <= 0 -- a moved node that lands at or before b's front
+            // came from a lower bucket, i.e. from before b -- so reading ahead of the writes is safe: four chunks of 64 are in flight at a time
+            // (one LDS round trip per four chunks instead of one each; the LDS unit executes a wave's instructions in order).
+            const u32 nb = cmax - cmin + 2;                                  // buckets cmin .. cmax+1 (the last one only bounds the range)
+            if (nb > 64) {        // (more count buckets than lanes -- a window spanning very different pod counts: bucket by bucket, one chunk at a time)
+              for (u32 b = cmin; b <= cmax; ++b) {
+                const u32 s0 = max(oldstart(b), pmin), s1 = oldstart(b + 1);
+                u32 ins = 0; for (u64 q = M; q; q &= q - 1) { const int x = __builtin_ctzll(q); if (RL(c_cnt, x) <= b) ++ins; }
+                for (u32 base = s0; base < s1; base += 64) {
+                  const u32 ii = base + lane; u32 v = 0; const bool in = ii < s1;
+                  if (in) v = ORD_RD(ii);
+                  if (ord_in_lds) LSYNC(); else GSYNC();
+                  if (in) {
+                    const bool is_m = ii < 64 && ((Mpos >> ii) & 1ull);
+                    const u32 rem_before = ii >= 64 ? nM : (u32)__builtin_popcountll(Mpos & ((1ull << ii) - 1ull));
+                    if (!is_m) ORD_WR(ii - rem_before + ins, v);
+                  }
+                  if (ord_in_lds) LSYNC(); else GSYNC();
                 }
-                if (ord_in_lds) LSYNC(); else GSYNC();
               }
+            } else {
+            u32 st_l = 0xFFFFFFFFu, ins_l = 0;                               // lane j < nb: old start of bucket cmin+j, moved nodes whose final count is <= cmin+j
+            if ((u32)lane < nb) { const u32 bb = cmin + (u32)lane; st_l = bb <= maxc + 1 ? BST(bb) : nnew; }      // (per lane: oldstart() is the wave-uniform form)
+            for (u64 q = M; q; q &= q - 1) { const u32 fc = RL(c_cnt, __builtin_ctzll(q)); if ((u32)lane < nb && fc <= cmin + (u32)lane) ++ins_l; }
+            const u32 endp = RL(st_l, (int)(nb - 1));
+            for (u32 base = pmin; base < endp; base += 256) {
+              u32 v[4]; bool in[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) { const u32 ii = base + 64u * (u32)u + (u32)lane; in[u] = ii < endp; v[u] = 0; if (in[u]) v[u] = ORD_RD(ii); }
+              if (ord_in_lds) LSYNC(); else GSYNC();
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const u32 ii = base + 64u * (u32)u + (u32)lane;
+                u32 ins = 0; for (u32 j = 1; j + 1 < nb; ++j) { if (ii >= RL(st_l, (int)j)) ins = RL(ins_l, (int)j); }
+                const bool is_m = ii < 64 && ((Mpos >> ii) & 1ull);
+                const u32 rem_before = ii >= 64 ? nM : (u32)__builtin_popcountll(Mpos & ((1ull << ii) - 1ull));
+                if (in[u] && !is_m) ORD_WR(ii - rem_before + ins, v[u]);
+              }
+            }
+            if (ord_in_lds) LSYNC(); else GSYNC();
             }
             // new bucket starts for the counts in (cmin, cmax + 1]
             for (u32 b = cmin + 1 + lane; b <= cmax + 1; b += 64) {
@@ -2159,6 +2204,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             }
             if (ord_in_lds) LSYNC(); else GSYNC();
           }
+          if (wv == 0) { P2T(16); }
           q_head = sp_head; q_len = sp_len; seq = sp_seq; CTR(KS_STAT_POPS, n_ok); CTR(21, 1);
           CTR(KS_STAT_FULLCHECKS, (u32)__builtin_popcountll(M));
         }
@@ -2175,6 +2221,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         }
       }
       __syncthreads();
+      if (wv == 0) { P2T(17); }
     }
   }
 
