@@ -2172,18 +2172,26 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             if ((u32)lane < nb) { const u32 bb = cmin + (u32)lane; st_l = bb <= maxc + 1 ? BST(bb) : nnew; }      // (per lane: oldstart() is the wave-uniform form)
             for (u64 q = M; q; q &= q - 1) { const u32 fc = RL(c_cnt, __builtin_ctzll(q)); if ((u32)lane < nb && fc <= cmin + (u32)lane) ++ins_l; }
             const u32 endp = RL(st_l, (int)(nb - 1));
-            for (u32 base = pmin; base < endp; base += 256) {
-              u32 v[4]; bool in[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) { const u32 ii = base + 64u * (u32)u + (u32)lane; in[u] = ii < endp; v[u] = 0; if (in[u]) v[u] = ORD_RD(ii); }
+            if (pmin < 64) {      // the window's own positions: a moved node leaves a hole, the others close up
+              const u32 ii = (u32)lane; const bool in = ii >= pmin && ii < endp; u32 v = 0;
+              if (in) v = ORD_RD(ii);
               if (ord_in_lds) LSYNC(); else GSYNC();
+              u32 ins = 0; for (u32 j = 1; j + 1 < nb; ++j) { if (ii >= RL(st_l, (int)j)) ins = RL(ins_l, (int)j); }
+              const bool is_m = (Mpos >> ii) & 1ull;
+              const u32 rem_before = (u32)__builtin_popcountll(Mpos & ((1ull << ii) - 1ull));
+              if (in && !is_m) ORD_WR(ii - rem_before + ins, v);
+            }
+            // beyond the window every moved node stood before: inside bucket b the shift is the same for all, nM - ins_b (nothing to do where it is 0)
+            for (u32 j = 0; j + 1 < nb; ++j) {
+              const u32 lo = max(max(RL(st_l, (int)j), 64u), pmin), hi = RL(st_l, (int)(j + 1)), d = nM - RL(ins_l, (int)j);
+              if (d == 0 || lo >= hi) continue;
+              for (u32 base = lo; base < hi; base += 256) {
+                u32 v[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const u32 ii = base + 64u * (u32)u + (u32)lane;
-                u32 ins = 0; for (u32 j = 1; j + 1 < nb; ++j) { if (ii >= RL(st_l, (int)j)) ins = RL(ins_l, (int)j); }
-                const bool is_m = ii < 64 && ((Mpos >> ii) & 1ull);
-                const u32 rem_before = ii >= 64 ? nM : (u32)__builtin_popcountll(Mpos & ((1ull << ii) - 1ull));
-                if (in[u] && !is_m) ORD_WR(ii - rem_before + ins, v[u]);
+                for (int u = 0; u < 4; ++u) { const u32 ii = base + 64u * (u32)u + (u32)lane; v[u] = 0; if (ii < hi) v[u] = ORD_RD(ii); }
+                if (ord_in_lds) LSYNC(); else GSYNC();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const u32 ii = base + 64u * (u32)u + (u32)lane; if (ii < hi) ORD_WR(ii - d, v[u]); }
               }
             }
             if (ord_in_lds) LSYNC(); else GSYNC();
