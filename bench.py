@@ -215,8 +215,7 @@ def whatif_leg(args, rank, world, local_rank, torch, dist, S, W):
         t0 = time.perf_counter()
         flats = S.open_whatifs(parsed, pod_node, [sets[i] for i in mine])
         t1 = time.perf_counter()
-        for f in flats:
-            f.upload(local_rank)
+        S.upload_batch(flats, local_rank)
         t2 = time.perf_counter()
         _, kms, _ = S.solve_batch(flats, decode=False)
         rec = S.result_records(flats, mine, words)
@@ -262,8 +261,7 @@ def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
     total_whatifs = len(sets)
     mine = list(range(rank, total_whatifs, world))
     flats = S.open_whatifs(parsed, pod_node, [sets[i] for i in mine])
-    for f in flats:
-        f.upload(local_rank)
+    S.upload_batch(flats, local_rank)
     words = (T + 63) // 64
     per = (total_whatifs + world - 1) // world
     pods_mine = sum(f.dims["P"] for f in flats)

@@ -56,6 +56,7 @@ const ks_problem* ksh_problem(void* handle);                                    
 void ksh_dims(void* handle, uint32_t dims[10]);                                        /* P,C,T,M,E,K,R,G,GH,S */
 uint64_t ksh_fingerprint(void* handle);                                                /* hash of every array of the flat problem */
 int ksh_upload(void* handle, int device);                                              /* idempotent; a second call with another device is an error */
+int ksh_upload_batch(void** handles, uint32_t n, int device, uint32_t nthreads);       /* the same for a batch, on host threads (0 = all usable cores) */
 /* Solve / grid on a handle that was not uploaded yet use the calling thread's current HIP device. */
 int ksh_solve(void* handle, char** out_text /* KSR1 or NULL */, float* kernel_ms, double* wall_ms);
 int ksh_solve_batch(void** handles, uint32_t n, char** out_texts /* n entries or NULL */, float* kernel_ms, double* wall_ms);
@@ -65,6 +66,7 @@ int ksh_solve_ksp(const char* ksp_text, size_t len, uint32_t flags, char** out_t
 /* ---- results ---- */
 int ksh_result_text(void* handle, char** out_text);
 int ksh_result_summary(void* handle, uint64_t* out /* [2 + words]: n_new, n_unscheduled, new node 0's InstanceTypeOptions */, uint32_t words);
+int ksh_result_summaries(void** handles, uint32_t n, uint64_t* out /* [n][2 + words] */, uint32_t words);
 
 /* ---- consolidation ---- */
 int ksh_open_whatifs(const char* snapshot_text, size_t len, uint32_t flags, uint32_t n, const uint32_t* cand_off /* [n+1] */, const uint32_t* cand,

@@ -206,6 +206,30 @@ int ksh_upload(void* hv, int device) {
   return KS_OK;
 }
 
+// Upload a batch (what-ifs of one snapshot) on host threads: the per-problem cost is packing its arrays into the pinned staging buffer.
+int ksh_upload_batch(void** handles, uint32_t n, int device, uint32_t nthreads) {
+  if (!n) return KS_OK;
+  int rc0 = ksh_upload(handles[0], device); if (rc0 != KS_OK) return rc0;      // the first one also makes the snapshot resident (once)
+  std::atomic<uint32_t> next{1}; std::atomic<int> rc{KS_OK}; std::mutex emu; std::string emsg;
+  auto work = [&]() {
+    for (;;) {
+      const uint32_t i = next.fetch_add(1); if (i >= n) return;
+      const int r = ksh_upload(handles[i], device);
+      if (r != KS_OK) { rc = r; std::lock_guard<std::mutex> g(emu); if (emsg.empty()) emsg = g_err; }
+    }
+  };
+  const uint32_t nt = std::max(1u, std::min(nthreads ? nthreads : default_threads(), n - 1));
+  std::vector<std::thread> pool; for (uint32_t t = 1; t < nt; ++t) pool.emplace_back(work);
+  work(); for (auto& t : pool) t.join();
+  if (rc != KS_OK) return set_err(rc, emsg);
+  return KS_OK;
+}
+// The fixed-size records of a batch in one call: out[i*(2+words) ..] as ksh_result_summary.
+int ksh_result_summaries(void** handles, uint32_t n, uint64_t* out, uint32_t words) {
+  for (uint32_t i = 0; i < n; ++i) { const int rc = ksh_result_summary(handles[i], out + (size_t)i * (2 + words), words); if (rc != KS_OK) return rc; }
+  return KS_OK;
+}
+
 // Solve (device-resident inputs).  out_text may be NULL (skip decode).
 int ksh_solve(void* hv, char** out_text, float* kernel_ms, double* wall_ms) {
   Handle* h = (Handle*)hv;

@@ -1,7 +1,9 @@
 // encode.cpp -- see encode.hpp.  Reference citations are relative to aws/karpenter-core pkg/.
 #include "encode.hpp"
 
+#include <atomic>
 #include <chrono>
+#include <exception>
 #include <cstdio>
 #include <cstring>
 #include <sstream>
@@ -126,14 +128,16 @@ uint32_t host_threads() {
   return n;
 }
 namespace {
-// fn(begin, end, thread) over [0, n) in contiguous chunks
-template <class F> void parallel_chunks(size_t n, F&& fn) {
-  const uint32_t nt = (uint32_t)std::max<size_t>(1, std::min<size_t>(host_threads(), n / 2048));
+// fn(begin, end, thread) over [0, n) in contiguous chunks of at least `grain` items; an exception in a chunk is rethrown after the join
+template <class F> void parallel_chunks(size_t n, F&& fn, size_t grain = 2048) {
+  const uint32_t nt = (uint32_t)std::max<size_t>(1, std::min<size_t>(host_threads(), n / grain));
   if (nt == 1) { fn((size_t)0, n, 0u); return; }
-  std::vector<std::thread> pool; const size_t per = (n + nt - 1) / nt;
-  for (uint32_t t = 1; t < nt; ++t) pool.emplace_back([&, t] { fn(std::min(n, t * per), std::min(n, (t + 1) * per), t); });
-  fn((size_t)0, std::min(n, per), 0u);
+  std::vector<std::thread> pool; const size_t per = (n + nt - 1) / nt; std::vector<std::exception_ptr> errs(nt);
+  auto guarded = [&](uint32_t t) { try { fn(std::min(n, t * per), std::min(n, (t + 1) * per), t); } catch (...) { errs[t] = std::current_exception(); } };
+  for (uint32_t t = 1; t < nt; ++t) pool.emplace_back(guarded, t);
+  guarded(0u);
   for (auto& th : pool) th.join();
+  for (auto& e : errs) if (e) std::rethrow_exception(e);
 }
 
 // ---- 128-bit streaming hash of everything of a pod spec that Solve can read (everything but uid and creationTimestamp).
@@ -394,7 +398,7 @@ struct Builder {
     if ((uint64_t)E.key_nvalues[kz] * nct > 64 || nct > 32) throw Unsupported("more than 64 zone x capacity-type pairs");
     const uint32_t NP = (uint32_t)E.key_nvalues[kz] * nct; E.it_price.assign((size_t)T * NP, -1.0); E.it_price_lo.assign((size_t)T * NP, 1.7976931348623157e308);
     it_requirements.resize(T);
-    for (uint32_t t = 0; t < T; ++t) {
+    parallel_chunks(T, [&](size_t tb_, size_t te_, uint32_t) { for (uint32_t t = (uint32_t)tb_; t < (uint32_t)te_; ++t) {      // (a type only writes its own column / row)
       const auto& it = pr.instance_types[t];
       Requirements rs = Requirements::FromExprs(it.requirements); it_requirements[t] = rs;
       for (auto& kv : rs.m) {
@@ -415,7 +419,7 @@ struct Builder {
       ksp::ResList alloc = Subtract(it.capacity, it.overhead);   // Allocatable(), types.go:87-89
       for (auto& kv : alloc) E.it_alloc[(size_t)res_id.at(kv.first) * T + t] = kv.second;
       for (auto& kv : it.capacity) E.it_cap[(size_t)res_id.at(kv.first) * T + t] = kv.second;
-    }
+    } }, 128);
   }
 
   // ---------- templates ----------
@@ -694,11 +698,14 @@ struct Builder {
       if (pods_have_volumes) { const std::vector<uint32_t> ve = vol_entries(*podp[i]); hs[i] = spec_hash(*podp[i], &ve); } else hs[i] = spec_hash(*podp[i]);
       uh[i] = str_hash(podp[i]->uid); } });
     sublap("hash"); uint64_t cap = 64; while (cap < 4ull * P) cap <<= 1;
-    batch_uids.pods = &podp; batch_uids.mask = cap - 1; batch_uids.tab.assign(cap, 0);
-    for (uint32_t i = 0; i < P; ++i) {
-      uint64_t j = uh[i] & batch_uids.mask;
-      for (;; j = (j + 1) & batch_uids.mask) { const uint32_t e = batch_uids.tab[j]; if (!e) break; if (podp[e - 1]->uid == podp[i]->uid) throw ksp::Error("pod UIDs must be unique (queue.go:102-108 needs a total order)"); }
-      batch_uids.tab[j] = i + 1;
+    if (!pr.cluster_pods.empty()) {      // countDomains / inverse anti-affinity ask which cluster pods are in the batch; without cluster pods nobody asks, and the
+                                         // uniqueness of the UIDs is checked on the sorted queue instead (encode_pods)
+      batch_uids.pods = &podp; batch_uids.mask = cap - 1; batch_uids.tab.assign(cap, 0);
+      for (uint32_t i = 0; i < P; ++i) {
+        uint64_t j = uh[i] & batch_uids.mask;
+        for (;; j = (j + 1) & batch_uids.mask) { const uint32_t e = batch_uids.tab[j]; if (!e) break; if (podp[e - 1]->uid == podp[i]->uid) throw ksp::Error("pod UIDs must be unique (queue.go:102-108 needs a total order)"); }
+        batch_uids.tab[j] = i + 1;
+      }
     }
     sublap("uid table"); pod_spec.assign(P, -1);
     std::vector<int32_t> tab(cap, -1); std::vector<uint32_t> first;      // table of spec ids; first[s] = first pod with spec s
@@ -793,6 +800,11 @@ struct Builder {
         keys.swap(tmp);
       }
     }
+    // equal UIDs end up next to each other (everything before the UID in the order is a function of the spec and the timestamp)
+    { std::atomic<bool> dup{false};
+      parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = std::max<size_t>(b, 1); i < e; ++i) if (keys[i].u0 == keys[i - 1].u0 && keys[i].u1 == keys[i - 1].u1 && keys[i].ulen == keys[i - 1].ulen && keys[i].ts == keys[i - 1].ts &&
+                                                                                                                 keys[i].cpu == keys[i - 1].cpu && keys[i].mem == keys[i - 1].mem && podp[keys[i].pod]->uid == podp[keys[i - 1].pod]->uid) dup = true; });
+      if (dup) throw ksp::Error("pod UIDs must be unique (queue.go:102-108 needs a total order)"); }
     E.queue.resize(P); for (uint32_t i = 0; i < P; ++i) E.queue[i] = keys[i].pod; sublap("queue sort");
     pod_rank.resize(P); for (uint32_t i = 0; i < P; ++i) pod_rank[E.queue[i]] = i;
   }

@@ -56,6 +56,8 @@ def libs():
         kh.ksh_open.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
         kh.ksh_close.argtypes = [ctypes.c_void_p]
         kh.ksh_upload.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        kh.ksh_upload_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
+        kh.ksh_result_summaries.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
         kh.ksh_solve.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
         kh.ksh_solve_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
         kh.ksh_grid.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
@@ -263,15 +265,26 @@ def result_records(flats: Sequence[FlatProblem], ids: Sequence[int], words: int)
     InstanceTypeOptions]` straight from the binary results (no text round trip): what the ranks exchange after a what-if batch."""
     import numpy as np
     kh = libs()[1]
-    out = np.zeros((len(flats), 3 + words), dtype=np.uint64)
-    row = np.zeros(2 + words, dtype=np.uint64)
-    for i, f in enumerate(flats):
-        rc = kh.ksh_result_summary(f._h, row.ctypes.data, words)
-        if rc != KS_OK:
-            raise KSolveError(rc, kh.ksh_last_error().decode())
-        out[i, 0] = ids[i]
-        out[i, 1:] = row
+    n = len(flats)
+    rows = np.zeros((n, 2 + words), dtype=np.uint64)
+    hs = (ctypes.c_void_p * max(1, n))(*[f._h for f in flats])
+    rc = kh.ksh_result_summaries(hs, n, rows.ctypes.data_as(ctypes.c_void_p), words)
+    if rc != KS_OK:
+        raise KSolveError(rc, kh.ksh_last_error().decode())
+    out = np.empty((n, 3 + words), dtype=np.uint64)
+    out[:, 0] = np.asarray(ids, dtype=np.uint64)
+    out[:, 1:] = rows
     return out.view(np.int64)
+
+
+def upload_batch(flats: Sequence[FlatProblem], device: int = 0, threads: int = 0):
+    """Upload a batch of problems (typically the what-ifs of one snapshot) on host threads."""
+    kh = libs()[1]
+    n = len(flats)
+    hs = (ctypes.c_void_p * max(1, n))(*[f._h for f in flats])
+    rc = kh.ksh_upload_batch(hs, n, device, threads)
+    if rc != KS_OK:
+        raise KSolveError(rc, kh.ksh_last_error().decode())
 
 
 def price_filter(flats: Sequence[FlatProblem], nodes: Sequence[int], max_prices: Sequence[float], spot_only: Optional[Sequence[bool]] = None) -> List[List[int]]:

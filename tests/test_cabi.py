@@ -105,6 +105,19 @@ def test_unsupported_is_loud():
     assert ei.value.code == S.KS_ERR_UNSUPPORTED
 
 
+def test_ambiguous_queue_order_is_refused():
+    """queue.go:102-108 breaks ties by UID: two pods that tie on cpu, memory, creation timestamp AND UID leave the order undefined -- refused at
+    flattening time, with or without cluster pods (two code paths: the UID table, or the check on the sorted queue)."""
+    from karpenter_core_amd.model import ClusterPod
+    base = W.config3(pods=70, sizes=4, seed=3)
+    base.pods[5].uid = base.pods[40].uid
+    base.pods[5].containers, base.pods[5].creation_ts = base.pods[40].containers, base.pods[40].creation_ts
+    for cps in ([], [ClusterPod(uid="bound-1", namespace="default", node_name="nowhere")]):
+        base.cluster_pods = cps
+        with pytest.raises(S.KSolveError):
+            S.FlatProblem(base)
+
+
 @pytest.mark.gpu
 def test_two_concurrent_solves():
     """The provisioner and the deprovisioner are two goroutines that may call Solve at the same time (provisioner.go:102-104,
