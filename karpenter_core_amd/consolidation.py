@@ -124,6 +124,8 @@ class Snapshot:
     provisioner: Provisioner
     nodes: List[StateNode]
     bound: List[list]                      # pods bound to each node
+    pending: list = field(default_factory=list)      # provisioner.GetPendingPods (helpers.go:76-79): they join the batch of every simulation
+    deleting: tuple = ()                   # indices of nodes that are MarkedForDeletion (helpers.go:48-61): not state nodes, their pods join the batch
 
 
 @dataclass
@@ -147,6 +149,11 @@ class Command:
 
     def canonical(self):
         return (self.action, tuple(self.nodes_to_remove), tuple(self.replacement_types), tuple(sorted(self.replacement_requirements.items())))
+
+
+class _NoProblem:
+    def close(self):
+        pass
 
 
 def candidate(snapshot: Snapshot, i: int) -> CandidateNode:
@@ -199,16 +206,37 @@ def compute_consolidations(snapshot: Snapshot, candidate_sets: Sequence[Sequence
     types = {it.name: it for it in snapshot.instance_types}
     tindex = {it.name: i for i, it in enumerate(snapshot.instance_types)}
     # one snapshot, flattened natively per what-if on all host cores (scheduler.open_whatifs)
-    snap, pod_node = workloads.snapshot_problem(snapshot.instance_types, snapshot.provisioner, snapshot.nodes, snapshot.bound)
-    flats = scheduler.open_whatifs(snap, pod_node, [list(cs) for cs in candidate_sets])
-    results, _, _ = scheduler.solve_batch(flats)
+    # simulateScheduling's batch is pending pods + the candidates' pods + the pods of nodes that are already deleting (helpers.go:76-84), and
+    # deleting nodes are no state nodes (:48-55).  Over the shared snapshot: the pending pods sit on a node of their own that no provisioner owns
+    # (it is never an existing node) and that every candidate set removes first; the deleting nodes are removed last.
+    PENDING = "~pending~"
+    deleting = [int(j) for j in snapshot.deleting]
+    nodes, bound = list(snapshot.nodes), list(snapshot.bound)
+    pend_idx = None
+    if snapshot.pending:
+        pend_idx = len(nodes)
+        nodes.append(StateNode(name=PENDING)); bound.append(list(snapshot.pending))
+    snap, pod_node = workloads.snapshot_problem(snapshot.instance_types, snapshot.provisioner, nodes, bound)
+    snap.cluster_pods = [cp for cp in snap.cluster_pods if cp.node_name != PENDING]      # pending pods are bound nowhere: countDomains does not see them
     cmds = [Command() for _ in candidate_sets]
+    live = [i for i, cs in enumerate(candidate_sets) if not (set(cs) & set(deleting))]
+    for i in range(len(candidate_sets)):
+        if i not in set(live):
+            cmds[i] = Command(error="candidate node is deleting")       # errCandidateNodeDeleting, helpers.go:62-67
+    sets = [([pend_idx] if pend_idx is not None else []) + list(candidate_sets[i]) + deleting for i in live]
+    flats_live = scheduler.open_whatifs(snap, pod_node, sets)
+    results_live, _, _ = scheduler.solve_batch(flats_live) if flats_live else ([], 0, 0)
+    flats = [_NoProblem()] * len(candidate_sets); results = [None] * len(candidate_sets)       # (a refused candidate set has nothing on the device)
+    for i, f, r in zip(live, flats_live, results_live):
+        flats[i], results[i] = f, r
     need, prices = [], []
     for i, (cs, res) in enumerate(zip(candidate_sets, results)):
+        if res is None:
+            continue
         cands = [candidate(snapshot, j) for j in cs]
         # simulateScheduling, helpers.go:102-111: the simulation must not lean on a node that is not ready yet -- Solve returns EVERY
         # in-state existing node (scheduler.go:132), so one uninitialised node that stays in the cluster fails the simulation
-        removed = set(cs)
+        removed = set(cs) | set(deleting)
         if any(n.owned and n.labels.get(LABEL_INITIALIZED) != "true" for j, n in enumerate(snapshot.nodes) if j not in removed and n.in_state):
             continue
         if res.unscheduled:                                     # "not all pods would schedule"

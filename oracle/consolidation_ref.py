@@ -95,11 +95,18 @@ def compute_consolidation(snapshot, cand_idx):
     """-> (action, nodes_to_remove, options, requirements dict of requirement-like objects)"""
     types = {it.name: it for it in snapshot.instance_types}
     cands = [Cand(snapshot, i) for i in cand_idx]
-    res = oracle_py.solve(workloads.whatif(snapshot.instance_types, snapshot.provisioner, snapshot.nodes, snapshot.bound, list(cand_idx)))
+    # simulateScheduling, helpers.go:42-99: nodes marked for deletion are no state nodes; a candidate that is itself deleting is an error; the batch
+    # is the pending pods, then the candidates' pods, then the pods of the deleting nodes
+    deleting = [int(j) for j in getattr(snapshot, "deleting", ())]
+    if set(cand_idx) & set(deleting):
+        raise ValueError("candidate node is deleting")
+    problem = workloads.whatif(snapshot.instance_types, snapshot.provisioner, snapshot.nodes, snapshot.bound, list(cand_idx) + deleting)
+    problem.pods = list(getattr(snapshot, "pending", [])) + problem.pods
+    res = oracle_py.solve(problem)
     # helpers.go:102-111: `for _, n := range ifn { if n.Node.Labels[LabelNodeInitialized] != "true" { return nil, false, nil } }` -- ifn is every
     # in-state (owned) existing node Solve was given, whether or not it received a pod
     for j, n in enumerate(snapshot.nodes):
-        if j not in set(cand_idx) and n.in_state and n.owned and n.labels.get("karpenter.sh/initialized") != "true":
+        if j not in set(cand_idx) and j not in set(deleting) and n.in_state and n.owned and n.labels.get("karpenter.sh/initialized") != "true":
             return ("do-nothing", [], [], {})
     if res.unscheduled:
         return ("do-nothing", [], [], {})

@@ -155,6 +155,30 @@ def test_oracle_offering_error_skips_the_candidate():
     assert cmd[0] in ("replace", "delete") and cmd[1] == ("n1",)
 
 
+def _pending_and_deleting():
+    """simulateScheduling's batch (helpers.go:76-84): pending pods + the candidates' pods + the pods of nodes that are already deleting, which are
+    no state nodes either (:48-55).  Three half-empty nodes: alone, n0's pod fits elsewhere (delete); with a deleting neighbour and pending
+    pods competing for the same room it does not."""
+    its = fake.instance_types_assorted()
+    big, big_of = most_expensive(its)
+    nodes = [node(f"n{i}", big, big_of.capacity_type, big_of.zone, cpu="2") for i in range(3)]          # Available(): 2 cpu free on each
+    bound = [[pod("p0", "2")], [pod("p1", "2")], [pod("p2", "2")]]
+    return snapshot(its, nodes, bound)
+
+
+def test_oracle_pending_pods_and_deleting_nodes():
+    snap = _pending_and_deleting()
+    assert CR.compute_consolidation(snap, [0])[0] == "delete"                    # p0 moves next to p1 or p2
+    snap.deleting = (2,)                                                            # n2 is going away: p2 needs a home too -> n1 takes p0 XOR p2
+    assert CR.compute_consolidation(snap, [0])[0] != "delete"
+    with pytest.raises(ValueError):
+        CR.compute_consolidation(snap, [2])                                         # errCandidateNodeDeleting
+    snap.deleting = ()
+    snap.pending = [pod("q0", "2"), pod("q1", "2")]                                 # the pending pods take the free halves of n1 and n2 first
+    assert CR.compute_consolidation(snap, [0])[0] != "delete"
+    assert CR.single_node_consolidation_option(snap, [0, 1, 2])[0] in ("do-nothing", "replace")
+
+
 def test_worst_launch_price_prefers_spot_then_on_demand():
     """helpers.go:292-315 on the reference's own offering lists (suite_test.go:1166-1186, :1254-1280)."""
     from karpenter_core_amd.model import RequirementOut
@@ -253,6 +277,33 @@ def test_gpu_uninitialized_node_and_offering_error():
     assert cmds[0].action == "do-nothing"
     snap, cands = _missing_offering()
     assert C.single_node_consolidation_option(snap, cands).canonical() == CR.single_node_consolidation_option(snap, cands)
+
+
+@pytest.mark.gpu
+def test_gpu_pending_pods_and_deleting_nodes():
+    from karpenter_core_amd import consolidation as C
+    for deleting, pending in (((), []), ((2,), []), ((), [pod("q0", "2"), pod("q1", "2")]), ((1,), [pod("q0", "1")])):
+        snap = _pending_and_deleting()
+        snap.deleting, snap.pending = deleting, pending
+        cands = [[0], [1], [2], [0, 1]]
+        cmds, flats, _ = C.compute_consolidations(snap, cands)
+        for f in flats:
+            f.close()
+        for cs, cmd in zip(cands, cmds):
+            try:
+                want = CR.canonical(CR.compute_consolidation(snap, cs))
+            except ValueError:
+                assert cmd.error is not None
+                continue
+            assert cmd.error is None and cmd.canonical() == want
+        assert C.single_node_consolidation_option(snap, [0, 1, 2]).canonical() == CR.single_node_consolidation_option(snap, [0, 1, 2])
+    # busy cluster with pending pods and two deleting nodes: the searches agree with the one-Solve-per-probe restatement
+    snap = busy_cluster(24, 5, util=(0.9, 0.99))
+    snap.deleting = (3, 17)
+    snap.pending = [pod(f"pend-{i}", "1") for i in range(6)]
+    cands = [i for i in range(12) if i not in snap.deleting]
+    assert C.single_node_consolidation_option(snap, cands).canonical() == CR.single_node_consolidation_option(snap, cands)
+    assert C.first_n_node_consolidation_option(snap, cands, max_nodes=100).canonical() == CR.first_n_node_consolidation_option(snap, cands, 100)
 
 
 @pytest.mark.gpu
