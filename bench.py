@@ -77,8 +77,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # KS_BENCH_BACKEND=gloo is a rehearsal hook for boxes with fewer GPUs than ranks (the ranks then share devices and the records are
+        # gathered through host memory); the driver's runs use the default: one GPU per rank, RCCL.
+        backend = os.environ.get("KS_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")       # RCCL on ROCm
+        dist.init_process_group(backend)       # "nccl" is RCCL on ROCm
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -268,10 +273,12 @@ def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
 
     from karpenter_core_amd import consolidation as C
 
+    on_device = dist.get_backend() == "nccl"
+
     def step():
         S.solve_batch(flats, decode=False)
-        rec = torch.from_numpy(S.result_records(flats, mine, words)).cuda()
-        return C.all_gather_records(rec, per)           # the single collective of the path (RCCL all-gather)
+        rec = torch.from_numpy(S.result_records(flats, mine, words))
+        return C.all_gather_records(rec.cuda() if on_device else rec, per)           # the single collective of the path (RCCL all-gather)
 
     for _ in range(args.warmup):
         step()
@@ -283,10 +290,11 @@ def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    red_dev = "cuda" if on_device else "cpu"
+    tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
-    tp = torch.tensor([pods_mine], device="cuda", dtype=torch.int64)
+    tp = torch.tensor([pods_mine], device=red_dev, dtype=torch.int64)
     dist.all_reduce(tp)
     total_pods = int(tp.item())
     if rank != 0:
