@@ -297,8 +297,22 @@ def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
     tp = torch.tensor([pods_mine], device=red_dev, dtype=torch.int64)
     dist.all_reduce(tp)
     total_pods = int(tp.item())
+    # kernel time of the batched launch (HIP events on the solve stream inside ks_solve_batch_dev), mean over a few launches
+    kms = []
+    for _ in range(3):
+        _, k, _ = S.solve_batch(flats, decode=False)
+        kms.append(k)
     if rank != 0:
         return
+    # roofline of the dominant kernel of this leg (the single-wave batch kernel): algorithmic bytes of the REFERENCE algorithm for rank 0's
+    # what-ifs (attempts / scanned types from an untimed KS_FLAG_STATS batch), SURVEY 8d formula with the fixed R = 4, K = 8
+    sflats = S.open_whatifs(parsed, pod_node, [sets[i] for i in mine], stats=True)
+    S.upload_batch(sflats, local_rank)
+    sres, _, _ = S.solve_batch(sflats)
+    abytes = sum(algorithmic_bytes(T, r.stats, f.dims["P"]) for r, f in zip(sres, sflats))
+    for f in sflats:
+        f.close()
+    k_s = statistics.mean(kms) / 1e3
     got = int(table.shape[0])
     out = {"metric": "pod-placement decisions/sec (Solve())", "value": total_pods * args.steps / elapsed, "unit": "decisions/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -306,7 +320,11 @@ def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
            "config": {"workload": f"BASELINE configs[3]: {total_whatifs} consolidation what-ifs over 2048 existing nodes / {T} instance types, dealt out i mod {world}; "
                                   "one batched launch per rank + ONE RCCL all-gather of result records", "whatifs": total_whatifs, "decisions_per_step": total_pods,
                       "records_gathered": got, "parallelism": f"{world} ranks x {per} what-ifs",
-                      "n1_reference": "the `whatif_batch` object of the --gpus 1 line (same workload on one GPU); a single Solve() does not shard (replicas only)"}}
+                      "n1_reference": "the `whatif_batch` object of the --gpus 1 line (same workload on one GPU); a single Solve() does not shard (replicas only)"},
+           "roofline": {"kernel": "ks_pack<single wave> x what-ifs of rank 0 in one launch", "bound": "hbm", "achieved": abytes / k_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": abytes / k_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": abytes, "kernel_ms_mean": k_s * 1e3,
+                        "formula": f"SURVEY 8d with R={ROOFLINE_R}, K={ROOFLINE_K}, summed over rank 0's {len(mine)} what-ifs",
+                        "note": "a batch takes as long as its longest what-if (one wave each); the watermark / run commit skip most of the attempts the reference makes"}}
     print(json.dumps(out))
 
 

@@ -211,7 +211,7 @@ def solve_from_pods(parsed: ParsedProblem, device: int = 0, stats: bool = False,
     return fp, dict(zip(TIMING_KEYS, [float(x) for x in ms]))
 
 
-def open_whatifs(snapshot, pod_node: Sequence[int], candidate_sets: Sequence[Sequence[int]], threads: int = 0) -> List[FlatProblem]:
+def open_whatifs(snapshot, pod_node: Sequence[int], candidate_sets: Sequence[Sequence[int]], threads: int = 0, stats: bool = False) -> List[FlatProblem]:
     """Flatten N consolidation what-ifs over one cluster snapshot natively (simulateScheduling, deprovisioning/helpers.go:42-115):
     `snapshot` (a `Problem`, or a `ParsedProblem` already held as objects) lists every state node and, as its pod batch, every bound pod
     (full spec); pod_node[i] = node index of pod i.  What-if w removes candidate_sets[w] from the state nodes and makes their pods
@@ -232,10 +232,10 @@ def open_whatifs(snapshot, pod_node: Sequence[int], candidate_sets: Sequence[Seq
     c_pn = pn.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
     hs = (ctypes.c_void_p * max(1, n))()
     if isinstance(snapshot, ParsedProblem):
-        rc = kh.ksh_open_whatifs_parsed(snapshot._p, 0, n, c_off, c_cand, c_pn, threads, hs)
+        rc = kh.ksh_open_whatifs_parsed(snapshot._p, KS_FLAG_STATS if stats else 0, n, c_off, c_cand, c_pn, threads, hs)
     else:
         text = snapshot.to_ksp().encode()
-        rc = kh.ksh_open_whatifs(text, len(text), 0, n, c_off, c_cand, c_pn, threads, hs)
+        rc = kh.ksh_open_whatifs(text, len(text), KS_FLAG_STATS if stats else 0, n, c_off, c_cand, c_pn, threads, hs)
     if rc != KS_OK:
         raise KSolveError(rc, kh.ksh_last_error().decode())
     return [FlatProblem(None, _handle=ctypes.c_void_p(hs[i])) for i in range(n)]
