@@ -370,7 +370,10 @@ struct alignas(16) ClsBrief {
   u32 ev;       // evaluation class: classes with equal ids are evaluated identically by eval_node (they may differ in what they record)
   u32 flags;    // bit 0: may take part in rounds (plan fits the kernel's limits, no host ports, no volumes)
   u32 reqmask;
-  u32 dyn;      // != 0: the evaluation's only topology item is a spread over a group of DevProb::dyn_groups and the pod has no requirement of its own on that
+  u32 dyn;      // bit 1 (2 | hslot << 8 | (g & 63) << 16): the evaluation's only topology item is a hostname-keyed spread / anti-affinity (row hslot < 16
+                // of the hostname tables): whether a candidate still takes the pod depends on how many pods the round has recorded into that group
+                // on it, which the resolver counts.
+                // bit 0: the evaluation's only topology item is a spread over a group of DevProb::dyn_groups and the pod has no requirement of its own on that
                 // key: 1 | g << 8 | selfSelecting << 16.  On a node whose requirement on the key is a single value the item then depends on that value
                 // and the group's counts alone, so the resolver can apply it against counts it keeps for the round.
   i64 req[KS_MAX_RES];
@@ -467,6 +470,8 @@ __global__ __launch_bounds__(64) void ks_build_plans(const DevProb* probs) {
   pl.dyn = 0;
   if (!pl.overflow && pl.ntopo == 1 && pl.nhost == 0 && pl.topo[0].type == 0 && !pl.topo[0].pod_has && pl.topo[0].g < 64 && ((P.dyn_groups >> pl.topo[0].g) & 1ull) &&
       pl.topo[0].maxskew >= 0 && pl.topo[0].maxskew < (1 << 30)) pl.dyn = 1u | ((u32)pl.topo[0].g << 8) | ((u32)pl.topo[0].self << 16);
+  else if (!pl.overflow && pl.ntopo == 0 && pl.nhost == 1 && pl.host[0].type != 1 && pl.host[0].hslot < 24 && pl.host[0].g >= 0 && pl.host[0].g < 64 && P.G <= 64 && P.GH <= 24)
+    pl.dyn = 2u | ((u32)pl.host[0].hslot << 8) | ((u32)pl.host[0].g << 16);
   plans[c] = pl;
   u64 zmask = 0;
   for (u32 j = 0; j < pl.nhost; ++j) if (pl.host[j].type == 2 || (pl.host[j].type == 0 && (i64)pl.host[j].maxskew - (i64)pl.host[j].self <= 0)) zmask |= 1ull << (pl.host[j].g & 63);
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(64) void ks_build_plans(const DevProb* probs) {
   for (u32 j = 0; j < pl.nrec; ++j) { const PlanRec& r = pl.rec[j]; if (r.key == KS_KEY_HOSTNAME && (r.owned_inverse || (P.grp_active[r.g] != 0 && !r.filtered))) rsure |= 1ull << (r.g & 63); }
   ClsBrief b; b.zmask = zmask; b.rsure = rsure; b.tmask = pl.tmask; b.tfull = tfull; b.rmask = pl.rmask; bool late_host = false;       // a record into a hostname-keyed group a relaxation creates later: such hostnames may be unregistered
   for (u32 j = 0; j < pl.nrec; ++j) if (pl.rec[j].key == KS_KEY_HOSTNAME && !pl.rec[j].owned_inverse && P.grp_active[pl.rec[j].g] == 0) late_host = true;
-  b.ev = 0; b.flags = (!pl.overflow && pl.port_cnt == 0 && pl.vol_cnt == 0 && !late_host) ? 1u : 0u; b.reqmask = pl.reqmask; b.dyn = pl.dyn; b.dyn_maxskew = pl.dyn ? pl.topo[0].maxskew : 0; b.dyn_pd = pl.dyn ? (u32)pl.topo[0].PD : 0u;
+  b.ev = 0; b.flags = (!pl.overflow && pl.port_cnt == 0 && pl.vol_cnt == 0 && !late_host) ? 1u : 0u; b.reqmask = pl.reqmask; b.dyn = pl.dyn; b.dyn_maxskew = (pl.dyn & 1u) ? pl.topo[0].maxskew : 0; b.dyn_pd = (pl.dyn & 1u) ? (u32)pl.topo[0].PD : 0u;
   for (u32 r = 0; r < KS_MAX_RES; ++r) b.req[r] = pl.req[r];
   briefs[c] = b;
 }
@@ -587,6 +592,7 @@ struct alignas(16) WaveShared {      // one per wave of the workgroup
 struct WaveBounds { i32 la_gt[KS_MAX_TOUCH][64]; i32 la_lt[KS_MAX_TOUCH][64]; };            // ... their Gt/Lt halves (BOUNDS variants only)
 struct LeaderShared {                // owned by wave 0, which carries the Solve's sequential state
   u32 hard[8];          // 256-bit hashed set of classes whose last pod found nothing in the first candidate window (heuristic only)
+  u8 hslot_of[64];      // group g (< 64) -> row of the hostname tables (grp_hslot), 0xFF if its key is not the hostname
   u32 bstart[KS_BST_LDS];
   u64 ctr[32];          // statistics + (KS_PROBES builds) per-phase cycle counters; slot numbers = ks_result.stats[]
 };
@@ -609,7 +615,10 @@ template <int RM> struct RoundCtlT {   // speculation-round hand-off between the
   u64 mo[KS_MAX_WAVES];                          // per worker: candidates that accept its class if the skew test is left aside (superset of m)
   u8 zone[64];                                   // per candidate: the single value its requirement on dyn_key allows (In [v]), 0xFF if it is not of that form
   u32 dynq[2][64];                               // per round pod of a ClsBrief::dyn class: maxSkew | PD << 24 (the dyn word itself rides in the leader's b_flags)
-  i32 dd[64][8];                                 // what the round's pods have recorded so far: [group][domain] (rows of dyn_groups only)
+  i32 dd[16][8];                                 // what the round's pods have recorded so far: [slot of the group in dyn_groups][domain]
+  // hostname-keyed items that tolerate more than zero pods (ClsBrief::dyn tag 2): the round's certain records per candidate and group
+  u32 hrec32[64][6];                             // [candidate][hslot / 4]: 8-bit counters, hslot < 24
+  u8 hslack[KS_MAX_WAVES][64];                   // per worker: how many more pods of its group candidate i takes (maxSkew - self - count at the snapshot)
 };
 
 // ---- slot record (AoS).  Offsets in bytes; stride = ks_rec_stride(R,K) ----
@@ -1194,6 +1203,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     }
     for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h], nz = 0; for (u32 e = 0; e < tb.E; ++e) { const i32 c = P.grph_count[(size_t)h * tb.E + e]; if (c > 0) ++np; if (c == 0) ++nz; } S.g_hpos[h] = np; S.g_hzero[h] = nz; }
   }
+  if (wv == 0) ls.hslot_of[lane] = ((u32)lane < P.G && P.grp_hslot[lane] >= 0 && P.grp_hslot[lane] < 255) ? (u8)P.grp_hslot[lane] : (u8)0xFF;
   if (wv == 0 && lane < 32) ls.ctr[lane] = 0;
   if (wv == 0 && lane < 8) ls.hard[lane] = 0;
   __threadfence_block();
@@ -1713,7 +1723,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         ev.rc = 0; ev.count = 0; ev.reqmask = 0; ev.tchg = 0; ev.tpres = 0; ev.tcomp = 0; ev.present = 0; ev.complement = 0; ev.it_state = 0; ev.it0 = 0;
 #pragma unroll
         for (int i = 0; i < RM; ++i) { ev.room[i] = 0; ev.req[i] = 0; ev.low[i] = INT64_MIN; }
-        const bool dync = UF(c.dyn) != 0;
+        const bool dync = (UF(c.dyn) & 1u) != 0;
         u32 zl = 0xFFu;        // (worker 0) this candidate's single value on dyn_key, if its requirement is In [v]
         if (kw == 0 && (i32)UF(P.dyn_key) >= 0 && slot != 0xFFFFFFFFu) {
           const Rec rz = slot_rec(S, tb, slot); const u32 dk = UF((u32)P.dyn_key);
@@ -1726,6 +1736,12 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         const u64 chgb = ballot64((ev.rc & 3) == 2 && ev.rc > 0 && (ev.tchg != 0 || ev.it_state != ev.it0));
         if (lane == 0) { rc.m[kw] = m; rc.chg[kw] = chgb; rc.mo[kw] = mo; }
         if (kw == 0) rc.zone[lane] = (u8)zl;
+        if (UF(c.dyn) & 2u) {      // how many more pods of the item's group this candidate takes
+          const PlanTopo& th = c.host[0]; const u32 f = UF(*(const u32*)&th.type); const u32 ty = f & 0xFF, self = (f >> 8) & 0xFF;
+          i32 slack = 0;
+          if (slot != 0xFFFFFFFFu && ty == 0) { const i32 cnt = tb.hcnt[(size_t)slot * tb.GH + UF(th.hslot)]; slack = (i32)UF(th.maxskew) - (i32)self - cnt; }
+          rc.hslack[kw][lane] = (u8)(slack < 0 ? 0 : (slack > 255 ? 255 : slack));
+        }
         if (kw == 0) {
           rc.cnt[lane] = ev.count; rc.rmsk[lane] = ev.reqmask;
 #pragma unroll
@@ -1767,32 +1783,46 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         // requirements the pod changes iff `chg`.  Returns the part of rm that was NOT accounted for exactly (it goes into `rall`).
         const u64 dyn_groups = exact_masks ? UF64(P.dyn_groups) : 0ull; const bool dyn_on = dyn_groups != 0;
         u32 c_zone = 0xFFu;
-        if (dyn_on) { c_zone = rc.zone[lane]; if ((dyn_groups >> lane) & 1ull) { u32x4* row = (u32x4*)&rc.dd[lane][0]; const u32x4 z4 = {0, 0, 0, 0}; row[0] = z4; row[1] = z4; } LSYNC(); }
+        auto dslot = [&](u32 g) -> u32 { return (u32)__builtin_popcountll(dyn_groups & ((1ull << g) - 1ull)) & 15u; };
+        const bool hrec_on = exact_masks && tb.GH <= 24 && tb.GH != 0;
+        if (dyn_on) { c_zone = rc.zone[lane]; ((i32*)rc.dd)[lane] = 0; ((i32*)rc.dd)[lane + 64] = 0; }
+        if (hrec_on) { for (int i = 0; i < 6; ++i) rc.hrec32[lane][i] = 0; }
+        if (dyn_on || hrec_on) LSYNC();
+        u64 c_unsure = 0;      // groups an earlier pod of the round MAY have recorded into on this candidate (a record that is not certain: node filter, late group)
+        // the round's certain hostname records on candidate `cand` (wave-uniform): lane g carries group g
+        auto count_host_one = [&](u64 sure, u32 cand) {
+          if (hrec_on && ((sure >> lane) & 1ull)) { const u32 hs = ls.hslot_of[lane]; if (hs < 24u) atomicAdd(&rc.hrec32[cand][hs >> 2], 1u << (8u * (hs & 3u))); }
+        };
+        // ... of one pod per lane (`mine`), on candidate `cand` (per lane)
+        auto count_host_lanes = [&](bool mine, u64 sure, u32 cand) {
+          if (hrec_on && mine) for (u64 b = sure; b; b &= b - 1) { const u32 hs = ls.hslot_of[__builtin_ctzll(b)]; if (hs < 24u) atomicAdd(&rc.hrec32[cand & 63u][hs >> 2], 1u << (8u * (hs & 3u))); }
+        };
         auto track_records = [&](bool mine, u64 rm, u32 zb, bool chg) -> u64 {
           const u64 db = rm & dyn_groups;
           if (!mine || !db) return rm;
-          if (zb != 0xFFu) { for (u64 b = db; b; b &= b - 1) atomicAdd(&rc.dd[__builtin_ctzll(b)][zb & 7u], 1); return rm & ~dyn_groups; }
+          if (zb != 0xFFu) { for (u64 b = db; b; b &= b - 1) atomicAdd(&rc.dd[dslot((u32)__builtin_ctzll(b))][zb & 7u], 1); return rm & ~dyn_groups; }
           return chg ? rm : (rm & ~dyn_groups);      // a node whose requirement on the key is not In [v] and stays as it is: nothing is counted (topology.go:120-133)
         };
         // the same for ONE pod (wave-uniform arguments): lane g carries group g
-        auto track_one = [&](u64 rm, u32 zb) { if (zb != 0xFFu && ((rm & dyn_groups) >> lane) & 1ull) atomicAdd(&rc.dd[lane][zb & 7u], 1); };
+        auto track_one = [&](u64 rm, u32 zb) { if (zb != 0xFFu && ((rm & dyn_groups) >> lane) & 1ull) atomicAdd(&rc.dd[dslot((u32)lane)][zb & 7u], 1); };
         u32 k = 0;
         P2T(12);
         while (k < rn) {
           P2C(15, 1);
-          if (RL64(b_tmask, k) & rall) { CUT(13); break; }
+          if (RL64(b_tmask, k) & rall) { CUT(13); CUT(17); break; }
           u64 mk = RL64(mk_l, k), tfk = RL64(b_tfull, k); const u64 chgk = RL64(chg_l, k); const u32 rmk = RL(b_reqmask, k);
           u64 unk = 0;      // candidates whose answer under the counts of the moment is not known (their requirement on dyn_key is not In [v])
+          const u32 hsw = hrec_on ? (RL(b_flags, k) >> 1) : 0u; const bool hsk = (hsw & 2u) != 0;      // ClsBrief::dyn tag 2: hslot = bits 8.., group = bits 16..
           if (dyn_on) {
             const u32 dynk = RL(b_flags, k) >> 1;
-            if (dynk) {
+            if (dynk & 1u) {
               // nextDomainTopologySpread (topologygroup.go:155-182) for a node with ONE domain z: z registered and count(z) + self - min <= maxSkew,
               // with the counts as the round has left them; min over the registered domains the pod allows.
               const u32 g = (dynk >> 8) & 0xFFu, self = (dynk >> 16) & 1u, q = UF(rc.dynq[par][k]), pd = q >> 24; const i32 maxskew = (i32)(q & 0xFFFFFFu);
               const u64 reg = tb.g_reg[g];
               LSYNC();
               i32 cz = 0, dz = 0; const bool zin = (u32)lane < 8u && ((reg >> lane) & 1ull);
-              if ((u32)lane < 8u) { dz = rc.dd[g][lane]; cz = tb.gcnt[(size_t)g * 64 + lane] + dz; }
+              if ((u32)lane < 8u) { dz = rc.dd[dslot(g)][lane]; cz = tb.gcnt[(size_t)g * 64 + lane] + dz; }
               const u32 minc = lanes8_min_u32((zin && ((pd >> lane) & 1u)) ? (u32)cz : 0xFFFFFFFFu);
               const u64 VZ = ballot64(zin && (i64)cz + (i64)self - (i64)minc <= (i64)maxskew);
               const bool anyd = ballot64((u32)lane < 8u && dz != 0) != 0;
@@ -1819,7 +1849,10 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             bool ok = true;
 #pragma unroll
             for (int i = 0; i < RM; ++i) if ((((c_rm | rmk) >> i) & 1u) && rqk[i] > c_room[i]) ok = false;
-            if (exact_masks && (tfk & zm & c_rsure)) ok = false;
+            if (hsk) {       // the candidate took `extra` certain pods of the item's group since the snapshot: it accepts while that stays within its slack
+              const u32 hsl = (hsw >> 8) & 31u; const u32 extra = (rc.hrec32[lane][hsl >> 2] >> (8u * (hsl & 3u))) & 255u;
+              if (extra > (u32)rc.hslack[RL(b_w, k) & (KS_MAX_WAVES - 1)][lane]) ok = false;
+            } else if (exact_masks && (tfk & zm & c_rsure)) ok = false;
             A = mk & (~movedmask | ballot64(ok));
           }
           if (!A) {
@@ -1834,11 +1867,11 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           const u32 best = wave_min_u32(inA ? c_key : 0xFFFFFFFFu);
           const int bu = __builtin_ctzll(ballot64(inA && c_key == best));
           const bool bu_moved = (movedmask >> bu) & 1ull;
-          if ((unk >> bu) & 1ull) { CUT(13); break; }
+          if ((unk >> bu) & 1ull) { CUT(13); CUT(18); break; }
           if (bu_moved) {
             if ((u32)bu >= tb.E && !window_complete && (best >> 8) > cnt_last) { CUT(15); break; }        // nodes beyond the window may precede it
             if ((closedmask >> bu) & 1ull) { CUT(15); break; }                                              // its requirements changed in this round
-            if (tfk & RL64(c_racc, bu)) { CUT(13); break; }                                                 // a counter of that node the evaluation reads may have changed (the certain cases were answered above)
+            if (tfk & (hsk ? RL64(c_unsure, bu) : RL64(c_racc, bu))) { CUT(13); CUT(19); break; }                                                 // a counter of that node the evaluation reads may have changed (the certain cases were answered above)
           }
           const u32 cnt_bu = RL(c_cnt, bu);
           if (r >= 2 && !bu_moved && (u32)bu >= tb.E) {
@@ -1856,10 +1889,11 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
               if (inS) {
 #pragma unroll
                 for (int i = 0; i < RM; ++i) c_room[i] -= rqk[i];
-                c_rm |= rmk; c_racc |= prm; c_rsure |= psu; c_np = 1; c_first = pidx; c_last = pidx; ++c_cnt; c_key = (c_cnt << 8) | (63u - pidx);
+                c_rm |= rmk; c_racc |= prm; c_rsure |= psu; c_unsure |= prm & ~psu; c_np = 1; c_first = pidx; c_last = pidx; ++c_cnt; c_key = (c_cnt << 8) | (63u - pidx);
                 rc.win[pidx] = (u8)lane;
               }
               const u64 S = ballot64(inS);
+              count_host_lanes(inS, psu, (u32)lane);
               const u64 inx = track_records(inS, prm, c_zone, (chgk >> lane) & 1ull);
               u64 orr, ors; or_masks(inS, inx, psu, orr, ors);
               movedmask = UF64(movedmask | S); closedmask = UF64(closedmask | (S & chgk)); rall = UF64(rall | orr);
@@ -1886,20 +1920,24 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             const u32 t_res = ~bal ? (u32)__builtin_ctzll(~bal) : 64u;
             t = max(1u, min(min(r, t_order), t_res));
           }
-          u64 orr = RL64(b_rmask, k), ors = RL64(b_rsure, k), inx = orr;
+          u64 orr = RL64(b_rmask, k), ors = RL64(b_rsure, k), inx = orr, uns = 0;
           {
             const u32 zb = RL(c_zone, bu); const bool chg_bu = (chgk >> bu) & 1ull;
             if (t >= 2) {
               const bool inrun = (u32)lane >= k && (u32)lane < k + t;
               u64 o_full, o_s; or_masks(inrun, b_rmask, b_rsure, o_full, o_s);
+              if (hrec_on && o_full) { u64 o_u, o_d; or_masks(inrun, b_rmask & ~b_rsure, 0ull, o_u, o_d); uns = o_u; count_host_lanes(inrun, b_rsure, (u32)bu); }
               orr = o_full; ors = o_s; inx = o_full;
               if (dyn_on && (o_full & dyn_groups)) { (void)track_records(inrun, b_rmask, zb, chg_bu); inx = (zb != 0xFFu || !chg_bu) ? (o_full & ~dyn_groups) : o_full; }
-            } else if (dyn_on && (orr & dyn_groups)) { track_one(orr, zb); inx = (zb != 0xFFu || !chg_bu) ? (orr & ~dyn_groups) : orr; }
+            } else {
+              uns = orr & ~ors; count_host_one(ors, (u32)bu);
+              if (dyn_on && (orr & dyn_groups)) { track_one(orr, zb); inx = (zb != 0xFFu || !chg_bu) ? (orr & ~dyn_groups) : orr; }
+            }
           }
           if (lane == bu) {
 #pragma unroll
             for (int i = 0; i < RM; ++i) c_room[i] -= (i64)t * rqk[i];
-            c_rm |= rmk; c_racc |= orr; c_rsure |= ors; if (c_np == 0) c_first = k; c_np += t; c_last = k + t - 1;
+            c_rm |= rmk; c_racc |= orr; c_rsure |= ors; c_unsure |= uns; if (c_np == 0) c_first = k; c_np += t; c_last = k + t - 1;
             if ((u32)bu >= tb.E) { c_cnt += t; c_key = (c_cnt << 8) | (63u - (k + t - 1)); }
           }
           if ((u32)lane >= k && (u32)lane < k + t) rc.win[lane] = (u8)bu;
