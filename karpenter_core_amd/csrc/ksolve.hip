@@ -33,6 +33,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <type_traits>
 
 #include "../../include/ksolve.h"
 #include "ks_algebra.h"
@@ -608,7 +609,6 @@ template <int RM> struct RoundCtlT {   // speculation-round hand-off between the
   u64 m[KS_MAX_WAVES], chg[KS_MAX_WAVES];        // per worker: candidates that accept its class / whose requirements a commit of that class would change
   u32 cnt[64], rmsk[64]; i64 room[RM][64], req0[RM][64], low0[RM][64];   // per candidate, class independent (published by worker 0): pods, requested-resource mask, headroom, requests, filter thresholds (Rec::low)
   u8 win[64];                                    // candidate (window lane) of round pod i
-  u32 ortmp[4];                                  // scratch of the resolver's mask reductions
   u8 lastpod[64], firstpod[64], npods[64];       // per candidate: last / first round pod placed on it, how many
   u32 rmsk_new[64]; i64 roomrem[RM][64];         // per candidate after the round's pods: requested-resource mask, headroom
   // dynamic spread (DevProb::dyn_groups)
@@ -992,6 +992,16 @@ __device__ __forceinline__ u32 wave_min_u32(u32 v) {
   v = min(v, (u32)__builtin_amdgcn_update_dpp(id, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 into rows 2 and 3
   return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
+// Bitwise OR of a 32-bit value over the wave, wave-uniform (same path; lanes that do not count pass 0).
+__device__ __forceinline__ u32 wave_or_u32(u32 v) {
+  v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+  v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+  v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+  v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+  v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+  v |= (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+  return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
 // ... over lanes 0..7 only (three row shifts; the result sits in lane 7)
 __device__ __forceinline__ u32 lanes8_min_u32(u32 v) {
   const int id = (int)0xFFFFFFFFu;
@@ -1121,6 +1131,17 @@ __device__ __forceinline__ void write_record(const Tabs& tb, const Rec& r, const
   if (lane == 63) { r.present() = pb.present; r.complement() = pb.complement; r.it_state() = pb.it_state; r.reqmask() = reqmask_new; }
 }
 
+// FAST variant: the small hot tables of one Solve as true LDS arrays
+struct alignas(16) FastTabs {
+  u64 g_reg[KS_FAST_G]; u64 g_pos[KS_FAST_G]; i32 g_hpos[KS_FAST_G]; i32 g_hzero[KS_FAST_G]; u32 key_nvalues[KS_MAX_KEYS]; u32 ge_cnt[KS_MAX_RES];
+  u16 its_inter[KS_FAST_S * KS_FAST_S]; u8 its_fail[KS_FAST_S * KS_FAST_S]; u8 g_active[KS_FAST_G];
+  i32 gcnt[KS_FAST_G * 64]; i32 value_int[KS_MAX_KEYS * 64];
+};
+struct alignas(16) NoTabs { u32 pad[4]; };
+template <bool FAST, bool BOUNDS, int NW, int RM> struct alignas(16) PackLds {
+  alignas(16) unsigned char rc_raw[NW > 1 ? sizeof(RoundCtlT<RM>) : 16]; LeaderShared ls; typename std::conditional<FAST, FastTabs, NoTabs>::type ft; DevProb P; DevState S;
+  alignas(16) unsigned char wbs_raw[BOUNDS ? sizeof(WaveBounds) * NW : 16]; WaveShared shw[NW];      // (no Gt/Lt anywhere in the problem: the bounds slots are never touched)
+};
 extern __shared__ __attribute__((aligned(16))) unsigned char ks_dyn_lds[];
 
 // LEAN: no class has host ports, a hostname selector or an instance-type requirement, no provisioner has limits,
@@ -1132,8 +1153,13 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
   using ClsR = ClsRT<RM>; using Ev = EvT<RM>; using Pub = PubT<RM>;
   static_assert(NW >= 1 && NW <= KS_MAX_WAVES, "wave count");
   // descriptors are copied to LDS: loads from them can then be CSE'd across global stores (no aliasing)
-  __shared__ DevProb P_lds; __shared__ DevState S_lds;
-  __shared__ WaveShared shw[NW]; __shared__ WaveBounds wbs[BOUNDS ? NW : 1]; __shared__ LeaderShared ls; __shared__ RoundCtlT<RM> rc;
+  // ONE static LDS object, hot lane-indexed arrays first: a ds instruction carries a 16-bit immediate offset, so everything in the first
+  // 64 KiB is addressed as lane*stride + immediate; an array beyond that needs its base in a register of its own, which the compiler hoists
+  // out of the Solve loop and -- the 8-wave kernel sits at its 256-VGPR budget -- spills to scratch (a memory round trip per reload).
+  __shared__ PackLds<FAST, BOUNDS, NW, RM> L;
+  DevProb& P_lds = L.P; DevState& S_lds = L.S;
+  WaveShared (&shw)[NW] = L.shw; WaveBounds* const wbs = (WaveBounds*)L.wbs_raw; LeaderShared& ls = L.ls;
+  RoundCtlT<RM>& rc = *(RoundCtlT<RM>*)L.rc_raw;      // (single-wave kernels have no rounds: nothing of rc is touched)
   const int lane = threadIdx.x & 63; const u32 wv = NW > 1 ? UF(threadIdx.x >> 6) : 0u;
   WaveShared& sh = shw[wv]; WaveBounds& wb = wbs[BOUNDS ? wv : 0];
   { const u32* src = (const u32*)&probs[blockIdx.x]; u32* dst = (u32*)&P_lds; for (u32 i = threadIdx.x; i < sizeof(DevProb) / 4; i += 64 * NW) dst[i] = src[i]; }
@@ -1172,10 +1198,11 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
   // ---------------- small hot tables: true LDS arrays in the FAST variant, global memory otherwise ----------------
   u32 lds_used = 0;
   if constexpr (FAST) {
-    __shared__ u32 sm_key_nvalues[KS_MAX_KEYS]; __shared__ i32 sm_value_int[KS_MAX_KEYS * 64];
-    __shared__ u8 sm_its_fail[KS_FAST_S * KS_FAST_S]; __shared__ u16 sm_its_inter[KS_FAST_S * KS_FAST_S];
-    __shared__ i32 sm_gcnt[KS_FAST_G * 64]; __shared__ u64 sm_g_reg[KS_FAST_G]; __shared__ u64 sm_g_pos[KS_FAST_G]; __shared__ u8 sm_g_active[KS_FAST_G]; __shared__ i32 sm_g_hpos[KS_FAST_G]; __shared__ i32 sm_g_hzero[KS_FAST_G];
-    __shared__ u32 sm_ge_cnt[KS_MAX_RES];
+    FastTabs& ft = L.ft;
+    u32 (&sm_key_nvalues)[KS_MAX_KEYS] = ft.key_nvalues; i32 (&sm_value_int)[KS_MAX_KEYS * 64] = ft.value_int;
+    u8 (&sm_its_fail)[KS_FAST_S * KS_FAST_S] = ft.its_fail; u16 (&sm_its_inter)[KS_FAST_S * KS_FAST_S] = ft.its_inter;
+    i32 (&sm_gcnt)[KS_FAST_G * 64] = ft.gcnt; u64 (&sm_g_reg)[KS_FAST_G] = ft.g_reg; u64 (&sm_g_pos)[KS_FAST_G] = ft.g_pos; u8 (&sm_g_active)[KS_FAST_G] = ft.g_active;
+    i32 (&sm_g_hpos)[KS_FAST_G] = ft.g_hpos; i32 (&sm_g_hzero)[KS_FAST_G] = ft.g_hzero; u32 (&sm_ge_cnt)[KS_MAX_RES] = ft.ge_cnt;
     i64* ge = (i64*)ks_dyn_lds;
     const u32 gs = UF(P.ge_max);            // the Allocatable ladders are stored with the longest one's stride
     if (wv == 0) {
@@ -1770,13 +1797,13 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         const u32 cnt_last = nwin ? RL(c_cnt, (int)(nwin - 1)) : 0u; const bool window_complete = total <= 64;
         u64 closedmask = 0, rall = 0;
         const bool exact_masks = nG <= 64;      // group bits (g & 63) do not alias: a set bit names one group
-        // OR of two per-lane masks over the lanes of `in` (LDS atomics: cheaper than twelve cross-lane steps for what is a rare, amortised call)
+        // OR of two per-lane masks over the lanes of `in`: row shifts and row broadcasts on the data-parallel-primitive path (no LDS round trips);
+        // with at most 32 groups the upper halves are zero
+        const bool groups_hi = nG > 32;
         auto or_masks = [&](bool in, u64 v_r, u64 v_s, u64& o_r, u64& o_s) {
-          if (lane == 0) { rc.ortmp[0] = 0; rc.ortmp[1] = 0; rc.ortmp[2] = 0; rc.ortmp[3] = 0; }
-          LSYNC();
-          if (in) { atomicOr(&rc.ortmp[0], (u32)v_r); atomicOr(&rc.ortmp[1], (u32)(v_r >> 32)); atomicOr(&rc.ortmp[2], (u32)v_s); atomicOr(&rc.ortmp[3], (u32)(v_s >> 32)); }
-          LSYNC();
-          o_r = UF64((u64)rc.ortmp[0] | ((u64)rc.ortmp[1] << 32)); o_s = UF64((u64)rc.ortmp[2] | ((u64)rc.ortmp[3] << 32));
+          const u32 rl = wave_or_u32(in ? (u32)v_r : 0u), sl = wave_or_u32(in ? (u32)v_s : 0u); u32 rh = 0, sh_ = 0;
+          if (groups_hi) { rh = wave_or_u32(in ? (u32)(v_r >> 32) : 0u); sh_ = wave_or_u32(in ? (u32)(v_s >> 32) : 0u); }
+          o_r = (u64)rl | ((u64)rh << 32); o_s = (u64)sl | ((u64)sh_ << 32);
         };
         // Dynamic spread: records into a group of dyn_groups are followed exactly where that is possible.  `mine`: this lane applies the
         // record masks `rm` of one pod placed on a candidate whose single value on dyn_key is `zb` (0xFF: not of that form) and whose
@@ -1790,8 +1817,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         if (dyn_on || hrec_on) LSYNC();
         u64 c_unsure = 0;      // groups an earlier pod of the round MAY have recorded into on this candidate (a record that is not certain: node filter, late group)
         // the round's certain hostname records on candidate `cand` (wave-uniform): lane g carries group g
+        const u32 my_hs = hrec_on ? (u32)ls.hslot_of[lane] : 0xFFu;      // group `lane`'s row of the hostname tables
         auto count_host_one = [&](u64 sure, u32 cand) {
-          if (hrec_on && ((sure >> lane) & 1ull)) { const u32 hs = ls.hslot_of[lane]; if (hs < 24u) atomicAdd(&rc.hrec32[cand][hs >> 2], 1u << (8u * (hs & 3u))); }
+          if (hrec_on && ((sure >> lane) & 1ull) && my_hs < 24u) atomicAdd(&rc.hrec32[cand][my_hs >> 2], 1u << (8u * (my_hs & 3u)));
         };
         // ... of one pod per lane (`mine`), on candidate `cand` (per lane)
         auto count_host_lanes = [&](bool mine, u64 sure, u32 cand) {
@@ -1804,9 +1832,14 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           return chg ? rm : (rm & ~dyn_groups);      // a node whose requirement on the key is not In [v] and stays as it is: nothing is counted (topology.go:120-133)
         };
         // the same for ONE pod (wave-uniform arguments): lane g carries group g
-        auto track_one = [&](u64 rm, u32 zb) { if (zb != 0xFFu && ((rm & dyn_groups) >> lane) & 1ull) atomicAdd(&rc.dd[dslot((u32)lane)][zb & 7u], 1); };
+        const u32 my_ds = dslot((u32)lane);
+        auto track_one = [&](u64 rm, u32 zb) { if (zb != 0xFFu && ((rm & dyn_groups) >> lane) & 1ull) atomicAdd(&rc.dd[my_ds][zb & 7u], 1); };
+        // runs: bit i of run_next = round pods i and i+1 belong to one evaluation class and neither evaluation reads a topology counter
+        u64 run_next;
+        { const u32 w_nx = (u32)__shfl_down((int)b_w, 1); const u64 tf_nx = (u64)(u32)__shfl_down((int)(u32)b_tfull, 1) | ((u64)(u32)__shfl_down((int)(u32)(b_tfull >> 32), 1) << 32);
+          run_next = ballot64((u32)lane + 1u < rn && b_tfull == 0 && tf_nx == 0 && w_nx == b_w); }
         u32 k = 0;
-        P2T(12);
+        P2T(19);
         while (k < rn) {
           P2C(15, 1);
           if (RL64(b_tmask, k) & rall) { CUT(13); CUT(17); break; }
@@ -1834,13 +1867,14 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
               tfk &= ~(1ull << g);
             }
           }
+          P2T(13);
           i64 rqk[RM];
 #pragma unroll
           for (int i = 0; i < RM; ++i) rqk[i] = (i64)RL64(b_req[i], k);
           // r: consecutive pods of this evaluation class whose evaluation reads no topology counter -- they differ at most in what
           // they record, so where one goes is decided by the same bitmap and the same requests
           u32 r = 1;
-          if (tfk == 0) { const u32 wk_ = RL(b_w, k); const u64 same = ballot64(b_w == wk_ && b_tfull == 0 && (u32)lane < rn) >> k; r = ~same ? (u32)__builtin_ctzll(~same) : 64u; }
+          if (tfk == 0) { const u64 nx = ~(run_next >> k); r = 1u + (nx ? (u32)__builtin_ctzll(nx) : 63u); }
           u64 A = mk;
           if (mk & movedmask) {      // candidates the round already used
             const u64 zm = RL64(b_zmask, k);
@@ -1855,6 +1889,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             } else if (exact_masks && (tfk & zm & c_rsure)) ok = false;
             A = mk & (~movedmask | ballot64(ok));
           }
+          P2T(18);
           if (!A) {
             // nothing in the window takes this pod (and a window only loses acceptors as the round goes on): it needs a deeper scan or a new
             // node -- remember its class so that the next plan hands it to the sequential path instead of opening a round that ends at once
@@ -1873,6 +1908,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             if ((closedmask >> bu) & 1ull) { CUT(15); break; }                                              // its requirements changed in this round
             if (tfk & (hsk ? RL64(c_unsure, bu) : RL64(c_racc, bu))) { CUT(13); CUT(19); break; }                                                 // a counter of that node the evaluation reads may have changed (the certain cases were answered above)
           }
+          P2T(19);
           const u32 cnt_bu = RL(c_cnt, bu);
           if (r >= 2 && !bu_moved && (u32)bu >= tb.E) {
             // SWEEP: the untouched acceptors that share bu's pod count follow it in window order, and a node that takes a pod goes BEHIND them
@@ -1897,7 +1933,8 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
               const u64 inx = track_records(inS, prm, c_zone, (chgk >> lane) & 1ull);
               u64 orr, ors; or_masks(inS, inx, psu, orr, ors);
               movedmask = UF64(movedmask | S); closedmask = UF64(closedmask | (S & chgk)); rall = UF64(rall | orr);
-              k += sN; n_ok = k;
+              k += sN; n_ok = k; P2C(20, 1);
+              P2T(26);
               continue;
             }
           }
@@ -1945,6 +1982,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           if ((chgk >> bu) & 1ull) closedmask = UF64(closedmask | (1ull << bu));
           rall = UF64(rall | inx);
           k += t; n_ok = k;
+          P2T(26);
         }
         P2T(13);
         if (n_ok == rn) CUT(16);
@@ -2067,6 +2105,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         }
         filtered = (filtmask >> lane) & 1ull; failedmask = failed;
         if ((failed >> lane) & 1ull) atomicMin(&rc.fail_at, (u32)rc.firstpod[lane]);
+#ifdef KS_P2PROBES
+        if (wv == 1) { const u64 now_ = __builtin_readcyclecounter(); if (lane == 0) ls.ctr[12] += now_ - t_ph; }      // worker 1's filters
+#endif
       }
       u32 sp_head = q_head, sp_len = q_len, sp_seq = seq;
       if (wv == 0) {
@@ -2078,6 +2119,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         { u32 idx = sp_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; pq_e = tb.q[idx]; pq_ok = true; }
         if (n_ok == 0) seq_credit = 1;                 // the head pod needs more than the window offers: take it sequentially
         plan(sp_head, sp_len, sp_seq);
+#ifdef KS_P2PROBES
+        { const u64 now_ = __builtin_readcyclecounter(); if (lane == 0) ls.ctr[14] += now_ - t_ph; }      // the leader's own share of the filter phase
+#endif
       }
       __syncthreads();
 #ifdef KS_PROBES
@@ -2148,34 +2192,15 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           }
         }
       }
-      __syncthreads();      // records read node records; the node commits below rewrite them
-      if (wv != 0 && n_ok && !cancelled && committer) {
-        const Rec r = slot_rec(S, tb, wslot);
-#pragma unroll
-        for (int i = 0; i < RM; ++i) if ((u32)i < tb.R) {
-          const i64 rem = rc.roomrem[i][lane];
-          r.req()[i] = rc.req0[i][lane] + (rc.room[i][lane] - rem); r.room()[i] = rem;
-          if (filtered && ((n_rm >> i) & 1u)) r.low()[i] = tb.ge_vals[(size_t)i * tb.ge_stride + n_idx[i]];
-        }
-        r.reqmask() = n_rm;
-        if (wslot >= tb.E) r.count() = rc.cnt[lane] + n_np;
-        if (my_chg) {
-          r.present() = n_pres; r.complement() = n_comp; r.it_state() = ev.it_state;
-          for (u32 i = 0; i < cr.ntouch; ++i) if ((ev.tchg >> i) & 1u) {
-            const u32 k = (u32)(cr.tkeys >> (5 * i)) & 31u; r.mask()[k] = sh.la_mask[i][lane];
-            if constexpr (BOUNDS) { r.gt()[k] = wb.la_gt[i][lane]; r.lt()[k] = wb.la_lt[i][lane]; }
-          }
-        }
-      }
+      u64 M_moved = 0;
+      if (wv == 0 && !cancelled && n_ok) {      // (while the workers record: the order array and the bucket starts are the leader's alone)
 #ifdef KS_P2PROBES
-      u64 t2p = __builtin_readcyclecounter();
+          u64 t2p = __builtin_readcyclecounter();
 #endif
-      if (wv == 0) {
-        if (!cancelled && n_ok) {
           // ---- visiting order: every moved node leaves its place and enters the FRONT of the bucket of its final count (the
           // most recently moved one in front); untouched nodes keep their relative order.  One pass over the affected range. ----
           const bool mvd = (u32)lane >= tb.E && (u32)lane < nwin && c_np != 0;
-          const u64 M = ballot64(mvd);                                   // by window lane
+          const u64 M = ballot64(mvd); M_moved = M;                       // by window lane
           if (M) {
             const u32 nM = (u32)__builtin_popcountll(M);
             const u64 Mpos = tb.E >= 64 ? 0ull : (M >> tb.E);            // by position in `ord`
@@ -2250,9 +2275,34 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             }
             if (ord_in_lds) LSYNC(); else GSYNC();
           }
-          if (wv == 0) { P2T(16); }
+          P2T(16);
+      }
+      __syncthreads();      // records read node records; the node commits below rewrite them
+      if (wv != 0 && n_ok && !cancelled && committer) {
+        const Rec r = slot_rec(S, tb, wslot);
+#pragma unroll
+        for (int i = 0; i < RM; ++i) if ((u32)i < tb.R) {
+          const i64 rem = rc.roomrem[i][lane];
+          r.req()[i] = rc.req0[i][lane] + (rc.room[i][lane] - rem); r.room()[i] = rem;
+          if (filtered && ((n_rm >> i) & 1u)) r.low()[i] = tb.ge_vals[(size_t)i * tb.ge_stride + n_idx[i]];
+        }
+        r.reqmask() = n_rm;
+        if (wslot >= tb.E) r.count() = rc.cnt[lane] + n_np;
+        if (my_chg) {
+          r.present() = n_pres; r.complement() = n_comp; r.it_state() = ev.it_state;
+          for (u32 i = 0; i < cr.ntouch; ++i) if ((ev.tchg >> i) & 1u) {
+            const u32 k = (u32)(cr.tkeys >> (5 * i)) & 31u; r.mask()[k] = sh.la_mask[i][lane];
+            if constexpr (BOUNDS) { r.gt()[k] = wb.la_gt[i][lane]; r.lt()[k] = wb.la_lt[i][lane]; }
+          }
+        }
+      }
+#ifdef KS_P2PROBES
+      u64 t2p = __builtin_readcyclecounter();
+#endif
+      if (wv == 0) {
+        if (!cancelled && n_ok) {
           q_head = sp_head; q_len = sp_len; seq = sp_seq; CTR(KS_STAT_POPS, n_ok); CTR(21, 1);
-          CTR(KS_STAT_FULLCHECKS, (u32)__builtin_popcountll(M));
+          CTR(KS_STAT_FULLCHECKS, (u32)__builtin_popcountll(M_moved));
         }
         const u32 n_commit = cancelled ? 0u : n_ok;
 #ifdef KS_PROBES

@@ -1089,7 +1089,7 @@ std::string Encoded::decode(const ks_result& r, double solve_seconds) const {
   o << "UNSCHEDULED " << r.n_unscheduled; for (uint32_t i = 0; i < r.n_unscheduled; ++i) o << " " << r.unscheduled[i]; o << "\n";
   o << "STAGES " << p.P; for (uint32_t i = 0; i < p.P; ++i) o << " " << r.pod_stage[i]; o << "\n";
   o << "REASONS " << r.n_unscheduled; for (uint32_t i = 0; i < r.n_unscheduled; ++i) o << " " << r.unscheduled[i] << " " << r.pod_reason[r.unscheduled[i]]; o << "\n";
-  o << "STATS 32 eq_pods " << r.stats[8] << " reuse_exhausted " << r.stats[9] << " reuse_seeds " << r.stats[10] << " reuse_hits " << r.stats[11] << " cyc_kind0 " << r.stats[27] << " cyc_kind1 " << r.stats[28] << " cyc_kind2 " << r.stats[29] << " n_kind1 " << r.stats[30] << " n_kind2 " << r.stats[31] << " p22 " << r.stats[22] << " p23 " << r.stats[23] << " p24 " << r.stats[24] << " p25 " << r.stats[25] << " p26 " << r.stats[26] << " cyc_pop " << r.stats[12] << " cyc_stage " << r.stats[13] << " cyc_scan " << r.stats[14] << " cyc_evalout " << r.stats[15] << " cyc_full " << r.stats[16]
+  o << "STATS 33 p20 " << r.stats[20] << " eq_pods " << r.stats[8] << " reuse_exhausted " << r.stats[9] << " reuse_seeds " << r.stats[10] << " reuse_hits " << r.stats[11] << " cyc_kind0 " << r.stats[27] << " cyc_kind1 " << r.stats[28] << " cyc_kind2 " << r.stats[29] << " n_kind1 " << r.stats[30] << " n_kind2 " << r.stats[31] << " p22 " << r.stats[22] << " p23 " << r.stats[23] << " p24 " << r.stats[24] << " p25 " << r.stats[25] << " p26 " << r.stats[26] << " cyc_pop " << r.stats[12] << " cyc_stage " << r.stats[13] << " cyc_scan " << r.stats[14] << " cyc_evalout " << r.stats[15] << " cyc_full " << r.stats[16]
     << " cyc_commit " << r.stats[17] << " cyc_order " << r.stats[18] << " cyc_new " << r.stats[19] << " scan_chunks " << r.stats[21]
     << " queue_pops " << r.stats[KS_STAT_POPS] << " relaxations " << r.stats[KS_STAT_RELAX] << " full_checks " << r.stats[KS_STAT_FULLCHECKS] << " full_fails " << r.stats[KS_STAT_FULLFAILS]
     << " attempts " << r.stats[KS_STAT_REF_ATTEMPTS] << " types_scanned " << r.stats[KS_STAT_REF_TYPES] << " kernel_cycles " << r.stats[KS_STAT_CYCLES]
