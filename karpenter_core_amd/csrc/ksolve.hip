@@ -121,6 +121,7 @@ struct DevState {
   // node records (AoS, see Rec): slots [0,E) existing nodes, [E,E+NMAX) new nodes
   u8* rec; u32 rec_stride;
   i32* n_tmpl; u64* n_alive;          // new nodes only, indexed by j = slot-E; n_alive has one spare row
+  u64* lowi;                          // [E+NMAX][2] per node: index of Rec::low[r] in resource r's Allocatable ladder, 16 bits each (0xFFFF: none yet; word r/4) -- the rounds' filters resume from it
   u64* round_scratch;                 // [KS_MAX_WAVES*64][TW]: InstanceTypeOptions rows as they were before a round's filters (restored if the round is cancelled)
   u32* bstart;                        // [P+3] count-bucket boundaries of the visiting-order array
   u32* order_g;                       // [NMAX] global-memory home of the visiting order once it outgrows LDS
@@ -587,7 +588,7 @@ struct TopoDyn { u64 reg, pos; i32 minc; i32 pad; };
 struct alignas(16) WaveShared {      // one per wave of the workgroup
   ClsPlan cls; ReqOut rq;
   TopoDyn dyn[KS_MAX_TOPO]; i32 host_anypos[KS_MAX_HOST]; i32 host_zero[KS_MAX_HOST]; i32 pad_hz[2];
-  i64 low_new[KS_MAX_RES];
+  i64 low_new[KS_MAX_RES]; u32 low_idx[KS_MAX_RES];
   u64 la_mask[KS_MAX_TOUCH][64];                                                            // per-lane requirement slots of eval_node
 };
 struct WaveBounds { i32 la_gt[KS_MAX_TOUCH][64]; i32 la_lt[KS_MAX_TOUCH][64]; };            // ... their Gt/Lt halves (BOUNDS variants only)
@@ -1078,7 +1079,7 @@ __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, c
   word[0] = 0; word[1] = 0;
   if (none) { if (alive_out) for (u32 w = lane; w < tb.TW; w += 64) alive_out[w] = 0; LSYNC(); return false; }   // nothing has that much of some resource
 #pragma unroll
-  for (int i = 0; i < RM; ++i) if (lane == 0 && ((reqmask_new >> i) & 1u)) sh.low_new[i] = tb.ge_vals[(size_t)i * tb.ge_stride + ridx[i]];
+  for (int i = 0; i < RM; ++i) if (lane == 0) { if ((reqmask_new >> i) & 1u) { sh.low_new[i] = tb.ge_vals[(size_t)i * tb.ge_stride + ridx[i]]; sh.low_idx[i] = ridx[i]; } else sh.low_idx[i] = 0xFFFFu; }
   bool any = false;
   for (u32 wbase = 0; wbase < tb.TW; wbase += 64) {
     const u32 w = wbase + lane; u64 a = 0;
@@ -1233,6 +1234,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
   if (wv == 0) ls.hslot_of[lane] = ((u32)lane < P.G && P.grp_hslot[lane] >= 0 && P.grp_hslot[lane] < 255) ? (u8)P.grp_hslot[lane] : (u8)0xFF;
   if (wv == 0 && lane < 32) ls.ctr[lane] = 0;
   if (wv == 0 && lane < 8) ls.hard[lane] = 0;
+  if (lane == 0) sh.cls.c = 0xFFFFFFFFu;      // no plan staged yet
   __threadfence_block();
   __syncthreads();
   const GA ClsPlan* plans = (const GA ClsPlan*)UF64((u64)P.plans);
@@ -1512,6 +1514,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             if (inreg) { if ((u32)lane < tb.TW) alive[lane] = aw[0]; if ((u32)lane + 64 < tb.TW) alive[lane + 64] = aw[1]; }
             else if (!fresh) for (u32 w = lane; w < tb.TW; w += 64) alive[w] = scratch[w];
             if ((u32)lane < tb.R && ((rm >> lane) & 1u)) r.low()[lane] = sh.low_new[lane];
+            if constexpr (NW > 1) if (lane < 2 && 4 * lane < RM) { u64 li = 0; for (int i = 0; i < 4; ++i) li |= (u64)((u32)(4 * lane + i) < tb.R ? (sh.low_idx[4 * lane + i] & 0xFFFFu) : 0xFFFFu) << (16 * i); ((GA u64*)S.lowi)[2 * (size_t)sw + lane] = li; }
           }
         }
         // ---- commit: node.go:100-105 / existingnode.go:122-129 / scheduler.go:214-216 ----
@@ -1738,7 +1741,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       // ---- P1: one evaluation per class ----
       if (wv != 0 && kw < nwk) {
         const u32 cidx = UF(rc.wcls[par][kw]);
-        { const GA u32x4* src = (const GA u32x4*)(plans + cidx); u32x4* dst = (u32x4*)&sh.cls; dst[lane] = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = src[lane + 64]; }
+        if (UF(sh.cls.c) != cidx) { const GA u32x4* src = (const GA u32x4*)(plans + cidx); u32x4* dst = (u32x4*)&sh.cls; dst[lane] = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = src[lane + 64]; }      // (usually staged at the end of the last round, below)
         stage_class(tb, sh, lane);
         const ClsPlan& c = sh.cls;
         cr.tol = UF64(c.tol); cr.reqmask = UF(c.reqmask); cr.ntouch = UF(c.ntouch); cr.nhost = UF(c.nhost); cr.hn_mode = UF(c.hn_mode); cr.port_cnt = UF(c.port_cnt); cr.vol_cnt = UF(c.vol_cnt); cr.it_state = (i32)UF(c.it_state); cr.tkeys = UF64(c.tkeys); cr.eq = UF(c.eq);
@@ -1783,6 +1786,20 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       // ---- P2: the leader resolves the round.  Lane i plays two parts: round pod i (b_*) and window candidate i (c_*). ----
       u32 c_cnt = 0, c_cnt0 = 0, c_rm = 0, c_np = 0, c_last = 0, c_first = 0, c_key = 0xFFFFFFFFu; u64 c_racc = 0, c_rsure = 0; i64 c_room[RM];
       u64 movedmask = 0; u32 n_ok = 0, nocand_cls = 0xFFFFFFFFu;
+      // Workers: what the filter phase and the commit read from global memory is requested NOW and arrives while the leader resolves --
+      // lane l as window candidate l: its slot and the ladder indices of its filter thresholds (DevState::lowi);
+      // lane l as round pod l (if this wave evaluated its class): the first groups Topology.Record will visit.
+      u32 wslot = 0xFFFFFFFFu; u64 li[2] = {~0ull, ~0ull}; u32 pr_nrec = 0, pr_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (wv != 0) {
+        if ((u32)lane < nwin) wslot = (u32)lane < tb.E ? (u32)lane : tb.E + (ord_lds_r ? ord_l[lane - tb.E] : ord_g[lane - tb.E]);
+        if (wslot != 0xFFFFFFFFu && wslot >= tb.E) { li[0] = ((const GA u64*)S.lowi)[2 * (size_t)wslot]; if constexpr (RM > 4) li[1] = ((const GA u64*)S.lowi)[2 * (size_t)wslot + 1]; }
+        if (kw < nwk && (u32)lane < rn && rc.pw[par][lane] == kw) {
+          const GA ClsPlan* pl = plans + ((u32)(rc.qe[par][lane] >> 32) & 0x7FFFFFFFu);
+          pr_nrec = pl->nrec; const GA u32* rp = (const GA u32*)&pl->rec[0];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) pr_w[i] = rp[i];
+        }
+      }
       if (wv == 0) {
 #ifdef KS_P2PROBES
         u64 t2p = __builtin_readcyclecounter();
@@ -1849,6 +1866,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           if (dyn_on) {
             const u32 dynk = RL(b_flags, k) >> 1;
             if (dynk & 1u) {
+              P2T(13);
               // nextDomainTopologySpread (topologygroup.go:155-182) for a node with ONE domain z: z registered and count(z) + self - min <= maxSkew,
               // with the counts as the round has left them; min over the registered domains the pod allows.
               const u32 g = (dynk >> 8) & 0xFFu, self = (dynk >> 16) & 1u, q = UF(rc.dynq[par][k]), pd = q >> 24; const i32 maxskew = (i32)(q & 0xFFFFFFu);
@@ -1865,6 +1883,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
               if (anyd) unk = mok & ~pinned;
               mk = (mok & okz) | (anyd ? unk : (mk & ~pinned));
               tfk &= ~(1ull << g);
+              P2T(21);
             }
           }
           P2T(13);
@@ -1933,7 +1952,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
               const u64 inx = track_records(inS, prm, c_zone, (chgk >> lane) & 1ull);
               u64 orr, ors; or_masks(inS, inx, psu, orr, ors);
               movedmask = UF64(movedmask | S); closedmask = UF64(closedmask | (S & chgk)); rall = UF64(rall | orr);
-              k += sN; n_ok = k; P2C(20, 1);
+              k += sN; n_ok = k;
               P2T(26);
               continue;
             }
@@ -2001,18 +2020,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       //      they are dealt out over ALL worker waves (a run of equivalent pods would otherwise leave six of seven waves idle) ----
       n_ok = UF(rc.n_ok);
       // worker lane u as candidate u:
-      bool committer = false, filtered = false, my_chg = false; u32 n_np = 0, n_rm = 0, n_pres = 0, n_comp = 0, n_chgkeys = 0, wslot = 0xFFFFFFFFu; u32 n_idx[RM];
+      bool committer = false, filtered = false, my_chg = false; u32 n_np = 0, n_rm = 0, n_pres = 0, n_comp = 0, n_chgkeys = 0; u32 n_idx[RM];
       u64 filtmask = 0, ranmask = 0, failedmask = 0;     // (little state crosses the barriers: requests / thresholds are re-read from LDS where they are needed)
-      // lane l as round pod l (if this wave evaluated its class): what Topology.Record will visit -- requested now, a whole phase before the commit uses it
-      u32 pr_nrec = 0, pr_w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (wv != 0 && kw < nwk && (u32)lane < n_ok && rc.pw[par][lane] == kw) {
-        const GA ClsPlan* pl = plans + ((u32)(rc.qe[par][lane] >> 32) & 0x7FFFFFFFu);
-        pr_nrec = pl->nrec; const GA u32* rp = (const GA u32*)&pl->rec[0];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pr_w[i] = rp[i];
-      }
       if (wv != 0 && n_ok) {
-        if ((u32)lane < nwin) wslot = (u32)lane < tb.E ? (u32)lane : tb.E + (ord_lds_r ? ord_l[lane - tb.E] : ord_g[lane - tb.E]);
         n_np = (u32)lane < nwin ? rc.npods[lane] : 0u;
         const u32 lastw = rc.pw[par][rc.lastpod[lane] & 63];
         const bool changing = n_np != 0 && ((rc.chg[lastw & (KS_MAX_WAVES - 1)] >> lane) & 1ull);
@@ -2033,24 +2043,62 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         bool none = false;
 #pragma unroll
         for (int i = 0; i < RM; ++i) n_idx[i] = 0;
-        if (committer && wslot >= tb.E) {
-          i64 tot[RM]; u32 lo[RM], hi[RM];
+#ifdef KS_P2PROBES
+        u64 t3p = __builtin_readcyclecounter();
+        if (wv == 1 && lane == 0) ls.ctr[17] += t3p - t_ph;        // worker 1: up to the totals
+#endif
+        {
+          // Totals per candidate, then lower_bound over the ascending distinct Allocatable values of every requested resource.  A resource whose
+          // total stays under its threshold keeps its ladder index; one that crosses it resumes from that index: three probes in flight (one
+          // LDS round trip) settle almost every case, a branch-free binary search with a wave-uniform trip count the rest.
+          // (Every read below is unconditional -- rows past R are clamped to row R-1 and their results ignored -- so that the reads of a step are
+          // issued together: a wave-uniform branch around a read ends the scheduling region and costs one LDS round trip per read.)
+          i64 tot[RM]; u32 lo[RM], hi[RM]; const bool cw = committer && wslot >= tb.E; bool more = false; const u32 Rm1 = tb.R - 1u;
+          i64 rq0[RM], rm0[RM], rr0[RM], lw0[RM];
 #pragma unroll
-          for (int i = 0; i < RM; ++i) { tot[i] = 0; lo[i] = 0; hi[i] = 0; if ((u32)i < tb.R) { tot[i] = rc.req0[i][lane] + (rc.room[i][lane] - rc.roomrem[i][lane]); if (((n_rm >> i) & 1u) && tot[i] > rc.low0[i][lane]) need = true; } }
-          if (need) {      // lower_bound over the ascending distinct Allocatable values of every requested resource; the searches advance together so their LDS reads overlap
+          for (int i = 0; i < RM; ++i) { rq0[i] = rc.req0[i][lane]; rm0[i] = rc.room[i][lane]; rr0[i] = rc.roomrem[i][lane]; lw0[i] = rc.low0[i][lane]; }
 #pragma unroll
-            for (int i = 0; i < RM; ++i) if ((u32)i < tb.R && ((n_rm >> i) & 1u)) hi[i] = tb.ge_cnt[i];
-            for (;;) {
-              bool busy = false;
+          for (int i = 0; i < RM; ++i) { tot[i] = rq0[i] + (rm0[i] - rr0[i]); lo[i] = 0; hi[i] = 0; if ((u32)i < tb.R && cw && ((n_rm >> i) & 1u) && tot[i] > lw0[i]) { need = true; hi[i] = 1; } }
+          if (ballot64(need)) {
+            u32 gc[RM], gmax = 0, row[RM];
 #pragma unroll
-              for (int i = 0; i < RM; ++i) if (lo[i] < hi[i]) { busy = true; const u32 mid = (lo[i] + hi[i]) >> 1; if (tb.ge_vals[(size_t)i * tb.ge_stride + mid] >= tot[i]) hi[i] = mid; else lo[i] = mid + 1; }
-              if (!busy) break;
+            for (int i = 0; i < RM; ++i) { row[i] = min((u32)i, Rm1) * tb.ge_stride; gc[i] = tb.ge_cnt[min((u32)i, Rm1)]; }
+#pragma unroll
+            for (int i = 0; i < RM; ++i) { gc[i] = UF(gc[i]); gmax = max(gmax, gc[i]); }
+            i64 pv[RM][3]; u32 ixs[RM][3];
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+              const u32 old = (u32)(li[i >> 2] >> (16 * (i & 3))) & 0xFFFFu; const bool crossing = hi[i] != 0;
+              lo[i] = crossing ? (old == 0xFFFFu ? 0u : old + 1u) : old; hi[i] = crossing ? gc[i] : lo[i];      // (lo == hi: settled)
+#pragma unroll
+              for (int j = 0; j < 3; ++j) { ixs[i][j] = lo[i] + (u32)j; pv[i][j] = tb.ge_vals[(size_t)(row[i] + (ixs[i][j] < gc[i] ? ixs[i][j] : 0u))]; }
             }
 #pragma unroll
-            for (int i = 0; i < RM; ++i) if ((u32)i < tb.R && ((n_rm >> i) & 1u)) { n_idx[i] = lo[i]; if (lo[i] >= tb.ge_cnt[i]) none = true; }
+            for (int i = 0; i < RM; ++i) {
+#pragma unroll
+              for (int j = 0; j < 3; ++j) if (ixs[i][j] >= gc[i]) pv[i][j] = INT64_MAX;
+              const bool act = lo[i] < hi[i];
+              const u32 adv = pv[i][0] >= tot[i] ? 0u : (pv[i][1] >= tot[i] ? 1u : (pv[i][2] >= tot[i] ? 2u : 3u));
+              if (act) { if (adv < 3u) { lo[i] += adv; hi[i] = lo[i]; } else { lo[i] = min(lo[i] + 3u, hi[i]); if (lo[i] < hi[i]) more = true; } }
+            }
+            if (ballot64(more)) {
+              const u32 steps = 32u - (u32)__builtin_clz(gmax | 1u);
+              for (u32 st = 0; st < steps; ++st) {
+                i64 v[RM]; u32 mid[RM];
+#pragma unroll
+                for (int i = 0; i < RM; ++i) { mid[i] = (lo[i] + hi[i]) >> 1; v[i] = tb.ge_vals[(size_t)(row[i] + (lo[i] < hi[i] ? mid[i] : 0u))]; }
+#pragma unroll
+                for (int i = 0; i < RM; ++i) if (lo[i] < hi[i]) { if (v[i] >= tot[i]) hi[i] = mid[i]; else lo[i] = mid[i] + 1; }
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < RM; ++i) if (need && (u32)i < tb.R && ((n_rm >> i) & 1u)) { n_idx[i] = lo[i]; if (lo[i] >= gc[i]) none = true; }
           }
         }
         filtmask = ballot64(need);
+#ifdef KS_P2PROBES
+        { const u64 now_ = __builtin_readcyclecounter(); if (wv == 1 && lane == 0) ls.ctr[20] += now_ - t3p; }      // worker 1: totals + lower bounds
+#endif
         u64 failed = ballot64(need && none);
         ranmask = filtmask & ~failed;
         u32 nf = 0;
@@ -2286,6 +2334,12 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           r.req()[i] = rc.req0[i][lane] + (rc.room[i][lane] - rem); r.room()[i] = rem;
           if (filtered && ((n_rm >> i) & 1u)) r.low()[i] = tb.ge_vals[(size_t)i * tb.ge_stride + n_idx[i]];
         }
+        if (filtered) {
+          u64 lw[2] = {0, 0};
+#pragma unroll
+          for (int i = 0; i < RM; ++i) lw[i >> 2] |= (u64)(((u32)i < tb.R && ((n_rm >> i) & 1u)) ? (n_idx[i] & 0xFFFFu) : 0xFFFFu) << (16 * (i & 3));
+          ((GA u64*)S.lowi)[2 * (size_t)wslot] = lw[0]; if constexpr (RM > 4) ((GA u64*)S.lowi)[2 * (size_t)wslot + 1] = lw[1];
+        }
         r.reqmask() = n_rm;
         if (wslot >= tb.E) r.count() = rc.cnt[lane] + n_np;
         if (my_chg) {
@@ -2316,8 +2370,12 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           pq_ok = false; plan(q_head, q_len, seq);
         }
       }
+      else if (!cancelled && UF(rc.mode2[stepc & 1u]) == 2u && kw < UF(rc.nwk)) {
+        // the plan made during the filter phase stands: stage the class this wave evaluates next while the leader finishes the order moves
+        const u32 cnx = UF(rc.wcls[UF(rc.par) & 1u][kw]);
+        if (UF(sh.cls.c) != cnx) { const GA u32x4* src = (const GA u32x4*)(plans + cnx); u32x4* dst = (u32x4*)&sh.cls; dst[lane] = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = src[lane + 64]; }
+      }
       __syncthreads();
-      if (wv == 0) { P2T(17); }
     }
   }
 
@@ -2596,7 +2654,7 @@ static int upload_impl(const ks_problem* p, int device, const ks_dev_problem* ba
   TRY(dev_alloc(d, P, &s.q)); TRY(dev_alloc(d, P, &s.lastlen)); TRY(dev_alloc(d, P, &s.lastgen)); TRY(dev_alloc(d, P, &s.pod_stage)); TRY(dev_alloc(d, P, &s.pod_node)); TRY(dev_alloc(d, P, &s.pod_seq)); TRY(dev_alloc(d, P, &s.pod_reason));
   s.rec_stride = ks_rec_stride(R, K);
   TRY(dev_alloc(d, NS * s.rec_stride, &s.rec, 0));
-  TRY(dev_alloc(d, (size_t)h.NMAX, &s.n_tmpl)); TRY(dev_alloc(d, ((size_t)h.NMAX + 1) * TW, &s.n_alive)); TRY(dev_alloc(d, (size_t)8 * 64 * TW, &s.round_scratch));
+  TRY(dev_alloc(d, (size_t)h.NMAX, &s.n_tmpl)); TRY(dev_alloc(d, ((size_t)h.NMAX + 1) * TW, &s.n_alive)); TRY(dev_alloc(d, (size_t)8 * 64 * TW, &s.round_scratch)); TRY(dev_alloc(d, 2 * NS, &s.lowi));
   TRY(dev_alloc(d, (size_t)P + 4, &s.bstart, 0)); TRY(dev_alloc(d, (size_t)h.NMAX, &s.order_g));
   TRY(dev_alloc(d, (size_t)G * 64, &s.gcnt)); TRY(dev_alloc(d, G, &s.g_reg)); TRY(dev_alloc(d, G, &s.g_pos)); TRY(dev_alloc(d, G, &s.g_active));
   TRY(dev_alloc(d, (size_t)p->GH * NS, &s.hcnt, 0xFF)); TRY(dev_alloc(d, p->GH, &s.g_hpos)); TRY(dev_alloc(d, p->GH, &s.g_hzero)); TRY(dev_alloc(d, (size_t)M * R, &s.remaining));
