@@ -563,6 +563,12 @@ struct Tabs {
 #define G_lastgen ((GA u32*)S.lastgen)
 #define G_lastlen ((GA u32*)S.lastlen)
 #define G_pod_stage ((GA i32*)S.pod_stage)
+#define G_pod_reason ((GA u32*)S.pod_reason)
+#define G_n_tmpl ((GA i32*)S.n_tmpl)
+#define G_wm ((GA u32*)S.wm)
+#define G_remaining ((GA i64*)S.remaining)
+#define G_bstart ((GA u32*)S.bstart)
+#define GC(T, p) ((const GA T*)(p))   /* a descriptor pointer read as global memory */
 #define G_stage_cls ((const GA u32*)P.stage_cls)
 #define G_pod_stage_off ((const GA u32*)P.pod_stage_off)
 #define G_grp_filter_off ((const GA u32*)P.grp_filter_off)
@@ -1073,8 +1079,8 @@ __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, c
   bool none = false;
 #pragma unroll
   for (int i = 0; i < RM; ++i) {
-    rows[i] = nullptr;
-    if ((reqmask_new >> i) & 1u) { if (ridx[i] >= tb.ge_cnt[i]) none = true; rows[i] = tb.ge_rows + ((size_t)i * tb.T + ridx[i]) * tb.TW; }
+    rows[i] = tb.ge_rows;      // (a resource that is not requested reads row 0 and ignores it: every row read is unconditional, so they are in flight together)
+    if ((reqmask_new >> i) & 1u) { if (ridx[i] >= tb.ge_cnt[i]) none = true; else rows[i] = tb.ge_rows + ((size_t)i * tb.T + ridx[i]) * tb.TW; }
   }
   word[0] = 0; word[1] = 0;
   if (none) { if (alive_out) for (u32 w = lane; w < tb.TW; w += 64) alive_out[w] = 0; LSYNC(); return false; }   // nothing has that much of some resource
@@ -1085,9 +1091,12 @@ __device__ __forceinline__ bool filter_types(const DevProb& P, const Tabs& tb, c
     const u32 w = wbase + lane; u64 a = 0;
     if (w < tb.TW) {
       // every load below is independent of the others: one memory round trip, not one per term
+      u64 gr[RM];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) gr[i] = rows[i][w];
       a = alive_in[w];
 #pragma unroll
-      for (int i = 0; i < RM; ++i) if (rows[i]) a &= rows[i][w];
+      for (int i = 0; i < RM; ++i) a &= ((reqmask_new >> i) & 1u) ? gr[i] : ~0ull;
       u64 x = ~0ull;
       for (u32 bits = changed_keys; bits; bits &= bits - 1) { const int k = __builtin_ctz(bits); x &= pass_types_word(P, tb, k, new_req(pb, sh, r, k), w); }
       if (check_it) x &= G_its_types[(size_t)pb.it_state * tb.TW + w];
@@ -1179,7 +1188,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
 
   // ---------------- initialise state (global memory); wave 0 alone, it is a one-off ----------------
   if (wv == 0) {
-  for (u32 i = lane; i < P.P; i += 64) { const u32 pd = P.queue[i]; tb.q[i] = (u64)pd | ((u64)P.stage_cls[P.pod_stage_off[pd]] << 32); G_lastgen[i] = 0xFFFFFFFFu; G_lastlen[i] = 0; G_pod_stage[i] = 0; tb.pod_node[i] = -1; tb.pod_seq[i] = -1; S.pod_reason[i] = 0; }
+  for (u32 i = lane; i < P.P; i += 64) { const u32 pd = P.queue[i]; tb.q[i] = (u64)pd | ((u64)P.stage_cls[P.pod_stage_off[pd]] << 32); G_lastgen[i] = 0xFFFFFFFFu; G_lastlen[i] = 0; G_pod_stage[i] = 0; tb.pod_node[i] = -1; tb.pod_seq[i] = -1; G_pod_reason[i] = 0; }
   for (u32 e = lane; e < tb.E; e += 64) {
     const Rec r = slot_rec(S, tb, e);
     r.taints() = P.en_taints[e]; r.present() = P.en.present[e]; r.complement() = P.en.complement[e]; r.it_state() = P.en.it_state[e];
@@ -1190,10 +1199,10 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     r.porthead() = head;
     for (u32 h = 0; h < tb.GH; ++h) tb.hcnt[(size_t)e * tb.GH + h] = P.grph_count[(size_t)h * tb.E + e];
   }
-  for (u32 i = lane; i < P.C; i += 64) S.wm[i] = 0;
+  for (u32 i = lane; i < P.C; i += 64) G_wm[i] = 0;
   for (u32 i = lane; i < tb.E * P.ND; i += 64) S.vol_cnt[i] = P.en_vol_count[i];
   for (u32 i = lane; i < tb.E * P.SW; i += 64) S.vol_set[i] = P.en_vol_set[i];
-  for (u32 i = lane; i < P.M * tb.R; i += 64) S.remaining[i] = P.tmpl_remaining[i];
+  for (u32 i = lane; i < P.M * tb.R; i += 64) G_remaining[i] = P.tmpl_remaining[i];
   }
 
   // ---------------- small hot tables: true LDS arrays in the FAST variant, global memory otherwise ----------------
@@ -1245,7 +1254,8 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
   const u32 ord_cap = (lds_bytes - lds_used) / 4;
   bool ord_in_lds = true;
   // count-bucket boundaries: bstart[c] (1 <= c <= maxc+1) = first position in `ord` whose node has >= c pods
-#define BST(c) (*((c) < KS_BST_LDS ? &ls.bstart[(c)] : &S.bstart[(c)]))
+  auto bst_rd = [&](u32 c) -> u32 { u32 v; if (c < KS_BST_LDS) v = ls.bstart[c]; else v = G_bstart[c]; return v; };      // (a pointer chosen between LDS and global memory would be generic: FLAT accesses wait on both counters)
+  auto bst_wr = [&](u32 c, u32 v) { if (c < KS_BST_LDS) ls.bstart[c] = v; else G_bstart[c] = v; };
 
   // The Solve's sequential state lives in wave 0's registers (SGPRs); the other waves of the workgroup only take
   // part in speculation rounds (below) and otherwise wait at the barriers.
@@ -1331,7 +1341,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             const u32 cc = slot_rec(S, tb, tb.E + j).count();
             if (cc == 0 || cc > maxc) { bad = 3; continue; }
             if (i + 1 < nnew) { const u32 j2 = ORD_RD(i + 1); if (j2 < nnew && slot_rec(S, tb, tb.E + j2).count() < cc) bad = 2; }
-            if (i < BST(cc) || i >= BST(cc + 1)) bad = 4;
+            if (i < bst_rd(cc) || i >= bst_rd(cc + 1)) bad = 4;
           }
           const u64 bb = ballot64(bad != 0);
           if (bb) err = 100u + RL(bad, __builtin_ctzll(bb));
@@ -1385,7 +1395,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     const bool mono = tb.E != 0 && UF(c.mono) != 0 && !want_stats;
     const u32 wmi = cr.eq ? cr.eq - 1u : cidx;
     u32 scan_lo = 0;
-    if (mono) { scan_lo = UF(S.wm[wmi]); pos_base = scan_lo; }
+    if (mono) { scan_lo = UF(G_wm[wmi]); pos_base = scan_lo; }
     const u32 wm0 = scan_lo;
     bool reuse = NW == 1 && r_valid && !want_stats && cr.eq != 0 && cr.eq == r_eq;     // (single-wave kernel only: in the multi-wave one rounds take the runs of equivalent pods)
     if (!want_stats && cr.nhost) {
@@ -1433,12 +1443,12 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           bool lany = false; ltypes = 0;
           for (u32 wbase = 0; wbase < tb.TW; wbase += 64) {
             const u32 w = wbase + lane; u64 a = 0;
-            if (w < tb.TW) a = P.tmpl_types[(size_t)m_t * tb.TW + w];
+            if (w < tb.TW) a = GC(u64, P.tmpl_types)[(size_t)m_t * tb.TW + w];
             if (lim != 0xFFFFFFFFu) {
               for (u64 nz = ballot64(a != 0); nz; nz &= nz - 1) {
                 const int b = __builtin_ctzll(nz); const u64 aw = __shfl(a, b); const u32 t = (wbase + b) * 64 + lane;
                 bool ok = (aw >> lane) & 1ull;
-                if (ok) for (u32 bits = lim; bits; bits &= bits - 1) { const int r = __builtin_ctz(bits); if (P.it_cap[(size_t)r * tb.T + t] > S.remaining[(size_t)m_t * tb.R + r]) { ok = false; break; } }
+                if (ok) for (u32 bits = lim; bits; bits &= bits - 1) { const int r = __builtin_ctz(bits); if (P.it_cap[(size_t)r * tb.T + t] > G_remaining[(size_t)m_t * tb.R + r]) { ok = false; break; } }
                 const u64 bw = ballot64(ok); if (lane == b) a = bw;
               }
             }
@@ -1448,17 +1458,17 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           }
           if (!lany) { if (m_t < 8) why |= (u32)KS_WHY_LIMITS << (4 * m_t); continue; }                  // "all available instance types exceed provisioner limits" (before NewNode)
           if (want_stats) CTR(KS_STAT_REF_ATTEMPTS, 1);    // NewNode + node.Add is attempted for this template
-          if (!UF(P.mc_ok[mc])) { if (m_t < 8) why |= (u32)UF(P.mc_why[mc]) << (4 * m_t); continue; }           // taints / Compatible fail inside Add
+          if (!UF(GC(u8, P.mc_ok)[mc])) { if (m_t < 8) why |= (u32)UF(GC(u8, P.mc_why)[mc]) << (4 * m_t); continue; }           // taints / Compatible fail inside Add
           have = true;
         }
         if (err) break;
         if (!have) { PROBE(19); break; }     // every template failed -> relax / requeue
         // NewNode (node.go:44-60): materialise the fresh node's record from template∩class, register its hostname
         const u32 fs = tb.E + nnew; const Rec fr = slot_rec(S, tb, fs);
-        if ((u32)lane < tb.K) { fr.mask()[lane] = P.mc_mask[mc * tb.K + lane]; fr.gt()[lane] = P.mc_gt[mc * tb.K + lane]; fr.lt()[lane] = P.mc_lt[mc * tb.K + lane]; }
-        if (lane >= 32 && (u32)lane < 32 + tb.R) { fr.req()[lane - 32] = P.tmpl_daemon[(size_t)m_t * tb.R + lane - 32]; fr.room()[lane - 32] = INT64_MAX / 2; fr.low()[lane - 32] = INT64_MIN; }
-        if (lane == 63) { fr.taints() = P.tmpl_taints[m_t]; fr.present() = P.mc_present[mc]; fr.complement() = P.mc_complement[mc]; fr.it_state() = P.mc_it[mc]; fr.reqmask() = P.tmpl_daemon_present[m_t]; fr.porthead() = -1; fr.count() = 0; }
-        for (u32 g = lane; g < nG; g += 64) if (P.grp_hslot[g] >= 0) tb.hcnt[(size_t)fs * tb.GH + P.grp_hslot[g]] = tb.g_active[g] ? 0 : -1;   // Topology.Register(hostname), node.go:47
+        if ((u32)lane < tb.K) { fr.mask()[lane] = GC(u64, P.mc_mask)[mc * tb.K + lane]; fr.gt()[lane] = GC(i32, P.mc_gt)[mc * tb.K + lane]; fr.lt()[lane] = GC(i32, P.mc_lt)[mc * tb.K + lane]; }
+        if (lane >= 32 && (u32)lane < 32 + tb.R) { fr.req()[lane - 32] = GC(i64, P.tmpl_daemon)[(size_t)m_t * tb.R + lane - 32]; fr.room()[lane - 32] = INT64_MAX / 2; fr.low()[lane - 32] = INT64_MIN; }
+        if (lane == 63) { fr.taints() = GC(u64, P.tmpl_taints)[m_t]; fr.present() = GC(u32, P.mc_present)[mc]; fr.complement() = GC(u32, P.mc_complement)[mc]; fr.it_state() = GC(i32, P.mc_it)[mc]; fr.reqmask() = GC(u32, P.tmpl_daemon_present)[m_t]; fr.porthead() = -1; fr.count() = 0; }
+        for (u32 g = lane; g < nG; g += 64) { const i32 hs = GC(i32, P.grp_hslot)[g]; if (hs >= 0) tb.hcnt[(size_t)fs * tb.GH + hs] = tb.g_active[g] ? 0 : -1; }   // Topology.Register(hostname), node.go:47
         __threadfence_block();
         GSYNC();
         if (lane == 0) slot = fs;
@@ -1554,10 +1564,10 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             for (int rr = 0; rr < RM; ++rr) if ((u32)rr < tb.R && on) { const i64 cp = P.it_cap[(size_t)rr * tb.T + t]; if (cp > mx[rr]) mx[rr] = cp; }
           }
 #pragma unroll
-          for (int rr = 0; rr < RM; ++rr) if ((u32)rr < tb.R) { const i64 v = wave_max_i64(mx[rr]); if (lane == 0 && ((lim >> rr) & 1u)) S.remaining[(size_t)m_t * tb.R + rr] -= v; }
+          for (int rr = 0; rr < RM; ++rr) if ((u32)rr < tb.R) { const i64 v = wave_max_i64(mx[rr]); if (lane == 0 && ((lim >> rr) & 1u)) G_remaining[(size_t)m_t * tb.R + rr] -= v; }
         }
         if (fresh) {        // the node exists from here on: its registered hostnames join the zero-count census (before this pod is recorded)
-          for (u32 g = lane; g < nG; g += 64) { const i32 hs = P.grp_hslot[g]; if (hs >= 0 && tb.hcnt[(size_t)sw * tb.GH + hs] == 0) tb.g_hzero[hs]++; }
+          for (u32 g = lane; g < nG; g += 64) { const i32 hs = GC(i32, P.grp_hslot)[g]; if (hs >= 0 && tb.hcnt[(size_t)sw * tb.GH + hs] == 0) tb.g_hzero[hs]++; }
           LSYNC();
         }
         topology_record<false>(P, S, tb, pb, sh, r, sw, lane);      // (the sequential path commits alone: nothing else records meanwhile)
@@ -1566,13 +1576,13 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         write_record<BOUNDS, RM>(tb, r, pb, sh, rm, lane);
         if (lane == 0) {
           if (!ex) r.count() = cnt + 1;
-          if (fresh) S.n_tmpl[jw] = (i32)m_t;
+          if (fresh) G_n_tmpl[jw] = (i32)m_t;
           for (u32 i = 0; i < cr.port_cnt; ++i) { S.pp_entry[pp_used + i] = P.ports[c.port_off + i]; S.pp_next[pp_used + i] = r.porthead(); r.porthead() = (i32)(pp_used + i); }
           if (!LEAN && ex && cr.vol_cnt) volumes_walk<true>(P, S, c, sw);
-          tb.pod_node[pod] = (i32)sw; tb.pod_seq[pod] = (i32)seq; S.pod_reason[pod] = 0;
+          tb.pod_node[pod] = (i32)sw; tb.pod_seq[pod] = (i32)seq; G_pod_reason[pod] = 0;
         }
         if (t_extra) {
-          if ((u32)lane < t_extra) { const u32 pd = (u32)run_e; tb.pod_node[pd] = (i32)sw; tb.pod_seq[pd] = (i32)(seq + 1u + (u32)lane); S.pod_reason[pd] = 0; }
+          if ((u32)lane < t_extra) { const u32 pd = (u32)run_e; tb.pod_node[pd] = (i32)sw; tb.pod_seq[pd] = (i32)(seq + 1u + (u32)lane); G_pod_reason[pd] = 0; }
           q_head += t_extra; if (q_head >= nP) q_head -= nP;
           q_len -= t_extra; seq += t_extra; pf_ok = false;
         }
@@ -1580,7 +1590,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         if (!ex && !fresh) {
           // visiting order: the node leaves position p of bucket `cnt` for the FRONT of bucket cnt+1
           const u32 p = pos_base + win - tb.E;
-          const u32 endc = UF(BST(cnt + 1));                         // one past the last node with `cnt` pods
+          const u32 endc = UF(bst_rd(cnt + 1));                         // one past the last node with `cnt` pods
           for (u32 i = p + 1; i < endc; i += 256) {       // shift left by one: reads may run ahead of the writes (four chunks in flight)
             u32 v[4];
 #pragma unroll
@@ -1590,7 +1600,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             for (int u = 0; u < 4; ++u) { const u32 ii = i + 64u * (u32)u + (u32)lane; if (ii < endc) ORD_WR(ii - 1, v[u]); }
           }
           if (ord_in_lds) LSYNC(); else GSYNC();
-          if (lane == 0) { ORD_WR(endc - 1, jw); BST(cnt + 1) = endc - 1; if (cnt + 1 > maxc) BST(cnt + 2) = nnew; }
+          if (lane == 0) { ORD_WR(endc - 1, jw); bst_wr(cnt + 1, endc - 1); if (cnt + 1 > maxc) bst_wr(cnt + 2, nnew); }
           if (cnt + 1 > maxc) maxc = cnt + 1;
           // keep the step's remaining fit bits for the next pod if it is evaluation-equivalent: valid for the lanes
           // whose nodes share the winner's count bucket (they now precede it in the visiting order)
@@ -1606,9 +1616,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             for (u32 i = lane; i < nnew; i += 64) ord_g[i] = ord_l[i];
             GSYNC(); ord_in_lds = false;
           }
-          if (maxc == 0) { if (lane == 0) { BST(1) = 0; BST(2) = 1; ORD_WR(0, jw); } maxc = 1; }
+          if (maxc == 0) { if (lane == 0) { bst_wr(1, 0); bst_wr(2, 1); ORD_WR(0, jw); } maxc = 1; }
           else {
-            const u32 ins = UF(BST(2));
+            const u32 ins = UF(bst_rd(2));
             for (u32 hi = nnew; hi > ins; ) {            // shift right by one, from the top down: four chunks in flight (the reads run ahead towards lower positions, the writes go up)
               const u32 lo = hi > ins + 256 ? hi - 256 : ins; u32 v[4];
 #pragma unroll
@@ -1620,7 +1630,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
               hi = lo;
             }
             if (lane == 0) ORD_WR(ins, jw);
-            for (u32 cc = 2 + lane; cc <= maxc + 1; cc += 64) BST(cc) += 1;
+            for (u32 cc = 2 + lane; cc <= maxc + 1; cc += 64) bst_wr(cc, bst_rd(cc) + 1u);
           }
           nnew = jw + 1;
         }
@@ -1640,7 +1650,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       if (!fresh) { pos_base += width; width = 64; if (mono && !reuse && !placed) scan_lo = min(pos_base, tb.E); }
     }
     if (err) break;
-    if (mono && scan_lo > wm0 && lane == 0) S.wm[wmi] = scan_lo;
+    if (mono && scan_lo > wm0 && lane == 0) G_wm[wmi] = scan_lo;
 #ifdef KS_PROBES
     if (NW == 1) { const u32 kind = cr.nhost ? 2 : (c.ntopo ? 1 : 0); CTR(27 + kind, __builtin_readcyclecounter() - t_pod); if (kind) CTR(29 + kind, 1); }
     else { CTR(28, __builtin_readcyclecounter() - t_pod); CTR(30, 1); }
@@ -1654,7 +1664,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       u32 tail = q_head + q_len; if (tail >= nP) tail -= nP;
       q_len++; pf_ok = false;
       if (lane == 0) {
-        S.pod_reason[pod] = why;
+        G_pod_reason[pod] = why;
         const u32 ncls = relaxed ? G_stage_cls[G_pod_stage_off[pod] + stg + 1] : cidx;
         tb.q[tail] = (u64)pod | ((u64)ncls << 32) | (relaxed ? 0ull : (1ull << 63));
         if (relaxed) {
@@ -2130,9 +2140,13 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           for (u32 wbase = 0; wbase < tb.TW; wbase += 64) {
             const u32 w = wbase + lane; u64 a = 0;
             if (w < tb.TW) {
+              // (the rows are read unconditionally and together -- a branch around each read would cost one memory round trip per row)
+              u64 gr[RM];
+#pragma unroll
+              for (int i = 0; i < RM; ++i) gr[i] = tb.ge_rows[((size_t)min((u32)i, tb.R - 1u) * tb.T + idx_u[i]) * tb.TW + w];
               const u64 old = alive[w]; a = old;
 #pragma unroll
-              for (int i = 0; i < RM; ++i) if ((u32)i < tb.R && ((rmu >> i) & 1u)) a &= tb.ge_rows[((size_t)i * tb.T + idx_u[i]) * tb.TW + w];
+              for (int i = 0; i < RM; ++i) a &= ((u32)i < tb.R && ((rmu >> i) & 1u)) ? gr[i] : ~0ull;
               u64 x = ~0ull;
               for (u32 bits = chk; bits; bits &= bits - 1) { const int k = __builtin_ctz(bits); x &= pass_types_word(P, tb, k, node_req(k), w); }
               if (itc) x &= G_its_types[(size_t)its_u * tb.TW + w];
@@ -2199,7 +2213,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           const u32 su = (u32)__shfl((int)wslot, u), pres_u = (u32)__shfl((int)n_pres, u), comp_u = (u32)__shfl((int)n_comp, u); const i32 its_u = __shfl(ev.it_state, u);
           if (mine) {
             const u64 qe = rc.qe[par][lane]; const u32 pod = (u32)qe, cidx = (u32)(qe >> 32) & 0x7FFFFFFFu;
-            tb.pod_node[pod] = (i32)su; tb.pod_seq[pod] = (i32)(seq0 + (u32)lane); S.pod_reason[pod] = 0;
+            tb.pod_node[pod] = (i32)su; tb.pod_seq[pod] = (i32)(seq0 + (u32)lane); G_pod_reason[pod] = 0;
             const Rec ru = slot_rec(S, tb, su);
             auto node_req = [&](int k) {
               KReq q; q.present = (pres_u >> k) & 1u; q.complement = (comp_u >> k) & 1u; q.gt = KS_NOGT; q.lt = KS_NOLT; q.mask = 0; bool hit = false;
@@ -2256,7 +2270,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             u32 cmin = 0xFFFFFFFFu, cmax = 0;
             for (u64 b = M; b; b &= b - 1) { const int x = __builtin_ctzll(b); cmin = min(cmin, RL(c_cnt0, x)); cmax = max(cmax, RL(c_cnt, x)); }
             const u32 pmin = (u32)__builtin_ctzll(Mpos);
-            auto oldstart = [&](u32 b) -> u32 { return b <= maxc + 1 ? UF(BST(b)) : nnew; };
+            auto oldstart = [&](u32 b) -> u32 { return b <= maxc + 1 ? UF(bst_rd(b)) : nnew; };
             // Relocate the untouched elements of [pmin, end of bucket cmax): an element of bucket b moves left by (moved nodes that stood before it) -
             // (moved nodes that end up at or before bucket b's front).  Every net shift is <= 0 -- a moved node that lands at or before b's front
             // came from a lower bucket, i.e. from before b -- so reading ahead of the writes is safe: four chunks of 64 are in flight at a time
@@ -2280,7 +2294,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
               }
             } else {
             u32 st_l = 0xFFFFFFFFu, ins_l = 0;                               // lane j < nb: old start of bucket cmin+j, moved nodes whose final count is <= cmin+j
-            if ((u32)lane < nb) { const u32 bb = cmin + (u32)lane; st_l = bb <= maxc + 1 ? BST(bb) : nnew; }      // (per lane: oldstart() is the wave-uniform form)
+            if ((u32)lane < nb) { const u32 bb = cmin + (u32)lane; st_l = bb <= maxc + 1 ? bst_rd(bb) : nnew; }      // (per lane: oldstart() is the wave-uniform form)
             for (u64 q = M; q; q &= q - 1) { const u32 fc = RL(c_cnt, __builtin_ctzll(q)); if ((u32)lane < nb && fc <= cmin + (u32)lane) ++ins_l; }
             const u32 endp = RL(st_l, (int)(nb - 1));
             if (pmin < 64) {      // the window's own positions: a moved node leaves a hole, the others close up
@@ -2309,17 +2323,17 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             }
             // new bucket starts for the counts in (cmin, cmax + 1]
             for (u32 b = cmin + 1 + lane; b <= cmax + 1; b += 64) {
-              const u32 os = b <= maxc + 1 ? BST(b) : nnew;
+              const u32 os = b <= maxc + 1 ? bst_rd(b) : nnew;
               const u32 rem_before = os >= 64 ? nM : (u32)__builtin_popcountll(Mpos & ((1ull << os) - 1ull));
               u32 below = 0; for (u64 q = M; q; q &= q - 1) { const int x = __builtin_ctzll(q); if (RL(c_cnt, x) < b) ++below; }
-              BST(b) = os - rem_before + below;
+              bst_wr(b, os - rem_before + below);
             }
             if (ord_in_lds) LSYNC(); else GSYNC();
             if (cmax > maxc) maxc = cmax;
             // the moved nodes: front of their final bucket, the most recent move first
             if (mvd) {
               u32 rank = 0; for (u64 q = M; q; q &= q - 1) { const int x = __builtin_ctzll(q); if (RL(c_cnt, x) == c_cnt && RL(c_last, x) > c_last) ++rank; }
-              ORD_WR(BST(c_cnt) + rank, jw_l);
+              ORD_WR(bst_rd(c_cnt) + rank, jw_l);
             }
             if (ord_in_lds) LSYNC(); else GSYNC();
           }
