@@ -2267,8 +2267,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             const u32 nM = (u32)__builtin_popcountll(M);
             const u64 Mpos = tb.E >= 64 ? 0ull : (M >> tb.E);            // by position in `ord`
             u32 jw_l = 0; if (mvd) jw_l = ORD_RD((u32)lane - tb.E);
-            u32 cmin = 0xFFFFFFFFu, cmax = 0;
-            for (u64 b = M; b; b &= b - 1) { const int x = __builtin_ctzll(b); cmin = min(cmin, RL(c_cnt0, x)); cmax = max(cmax, RL(c_cnt, x)); }
+            const u32 cmin = wave_min_u32(mvd ? c_cnt0 : 0xFFFFFFFFu), cmax = ~wave_min_u32(mvd ? ~c_cnt : 0xFFFFFFFFu);      // lowest count a moved node had, highest one has now
             const u32 pmin = (u32)__builtin_ctzll(Mpos);
             auto oldstart = [&](u32 b) -> u32 { return b <= maxc + 1 ? UF(bst_rd(b)) : nnew; };
             // Relocate the untouched elements of [pmin, end of bucket cmax): an element of bucket b moves left by (moved nodes that stood before it) -
@@ -2276,6 +2275,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             // came from a lower bucket, i.e. from before b -- so reading ahead of the writes is safe: four chunks of 64 are in flight at a time
             // (one LDS round trip per four chunks instead of one each; the LDS unit executes a wave's instructions in order).
             const u32 nb = cmax - cmin + 2;                                  // buckets cmin .. cmax+1 (the last one only bounds the range)
+            u32 ins_keep = 0;                                                // (nb <= 64) lane j: moved nodes whose final count is <= cmin+j
             if (nb > 64) {        // (more count buckets than lanes -- a window spanning very different pod counts: bucket by bucket, one chunk at a time)
               for (u32 b = cmin; b <= cmax; ++b) {
                 const u32 s0 = max(oldstart(b), pmin), s1 = oldstart(b + 1);
@@ -2295,7 +2295,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             } else {
             u32 st_l = 0xFFFFFFFFu, ins_l = 0;                               // lane j < nb: old start of bucket cmin+j, moved nodes whose final count is <= cmin+j
             if ((u32)lane < nb) { const u32 bb = cmin + (u32)lane; st_l = bb <= maxc + 1 ? bst_rd(bb) : nnew; }      // (per lane: oldstart() is the wave-uniform form)
-            for (u64 q = M; q; q &= q - 1) { const u32 fc = RL(c_cnt, __builtin_ctzll(q)); if ((u32)lane < nb && fc <= cmin + (u32)lane) ++ins_l; }
+            if (nb <= nM) { for (u32 j = 0; j < nb; ++j) { const u32 cj = (u32)__builtin_popcountll(ballot64(mvd && c_cnt <= cmin + j)); if ((u32)lane == j) ins_l = cj; } }      // (one ballot per bucket ...)
+            else for (u64 q = M; q; q &= q - 1) { const u32 fc = RL(c_cnt, __builtin_ctzll(q)); if ((u32)lane < nb && fc <= cmin + (u32)lane) ++ins_l; }                          // (... or one step per moved node)
+            ins_keep = ins_l;
             const u32 endp = RL(st_l, (int)(nb - 1));
             if (pmin < 64) {      // the window's own positions: a moved node leaves a hole, the others close up
               const u32 ii = (u32)lane; const bool in = ii >= pmin && ii < endp; u32 v = 0;
@@ -2325,7 +2327,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             for (u32 b = cmin + 1 + lane; b <= cmax + 1; b += 64) {
               const u32 os = b <= maxc + 1 ? bst_rd(b) : nnew;
               const u32 rem_before = os >= 64 ? nM : (u32)__builtin_popcountll(Mpos & ((1ull << os) - 1ull));
-              u32 below = 0; for (u64 q = M; q; q &= q - 1) { const int x = __builtin_ctzll(q); if (RL(c_cnt, x) < b) ++below; }
+              u32 below = 0;      // moved nodes whose final count is < b
+              if (nb <= 64) below = ins_keep;       // (b = cmin + 1 + lane: the count of final counts <= cmin + lane is this lane's ins_l)
+              else for (u64 q = M; q; q &= q - 1) { const int x = __builtin_ctzll(q); if (RL(c_cnt, x) < b) ++below; }
               bst_wr(b, os - rem_before + below);
             }
             if (ord_in_lds) LSYNC(); else GSYNC();
