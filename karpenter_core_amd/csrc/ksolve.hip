@@ -1285,7 +1285,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
   u32 round_lim = 64;              // after a cancelled round: the next one stops short of the pod whose node failed
   u32 plan_par = 0, stepc = 0;     // stepc: loop iterations started (every wave counts them alike)
   u32 spec_mode = 0;               // what the plan made during a round's filter phase chose (undone if the round is cancelled)
-  auto plan = [&](const u32 q_head, const u32 q_len, const u32 seq) {      // (the queue as it will be when the planned step starts)
+  auto plan = [&](const u32 q_head_, const u32 q_len_, const u32 seq_) {      // (the queue as it will be when the planned step starts)
+        const u32 q_head = UF(q_head_), q_len = UF(q_len_), seq = UF(seq_);
+        plan_par = UF(plan_par); round_lim = UF(round_lim); seq_credit = UF(seq_credit); nnew = UF(nnew);
         u32 mode = 1; const u32 wpar = plan_par ^ 1u;
         if (++iters > 8u * nP + 4096u) err = (u32)(-KS_ERR_INTERNAL);      // watchdog: a Solve needs at most a few steps per pod
         if (done || err || q_len == 0) mode = 0;
@@ -1349,6 +1351,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
 #endif
     if (mode == 1) {
     if (wv == 0) do {
+    // The leader's sequential state is wave-uniform by construction; say so (the compiler's uniformity analysis gives up on the Solve loop,
+    // and a state it takes for divergent lives in vector registers, every use behind a v_readfirstlane and an exec-masked branch).
+    q_head = UF(q_head); q_len = UF(q_len); q_gen = UF(q_gen); nnew = UF(nnew); seq = UF(seq); maxc = UF(maxc); err = UF(err); pp_used = UF(pp_used);
     // Queue.Pop, queue.go:44-58
     if (q_len == 0) { done = true; break; }
     PROBE(20);
@@ -1962,7 +1967,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
               const u64 inx = track_records(inS, prm, c_zone, (chgk >> lane) & 1ull);
               u64 orr, ors; or_masks(inS, inx, psu, orr, ors);
               movedmask = UF64(movedmask | S); closedmask = UF64(closedmask | (S & chgk)); rall = UF64(rall | orr);
-              k += sN; n_ok = k;
+              k = UF(k + sN); n_ok = k;
               P2T(26);
               continue;
             }
@@ -2010,7 +2015,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           movedmask = UF64(movedmask | (1ull << bu));
           if ((chgk >> bu) & 1ull) closedmask = UF64(closedmask | (1ull << bu));
           rall = UF64(rall | inx);
-          k += t; n_ok = k;
+          k = UF(k + t); n_ok = k;
           P2T(26);
         }
         P2T(13);
