@@ -1572,7 +1572,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           for (int rr = 0; rr < RM; ++rr) if ((u32)rr < tb.R) { const i64 v = wave_max_i64(mx[rr]); if (lane == 0 && ((lim >> rr) & 1u)) G_remaining[(size_t)m_t * tb.R + rr] -= v; }
         }
         if (fresh) {        // the node exists from here on: its registered hostnames join the zero-count census (before this pod is recorded)
-          for (u32 g = lane; g < nG; g += 64) { const i32 hs = GC(i32, P.grp_hslot)[g]; if (hs >= 0 && tb.hcnt[(size_t)sw * tb.GH + hs] == 0) tb.g_hzero[hs]++; }
+          for (u32 g = lane; g < nG; g += 64) { const i32 hs = GC(i32, P.grp_hslot)[g]; if (hs >= 0 && tb.g_active[g]) tb.g_hzero[hs]++; }      // (its counters were set a moment ago: 0 for the groups that exist, see Topology.Register above)
           LSYNC();
         }
         topology_record<false>(P, S, tb, pb, sh, r, sw, lane);      // (the sequential path commits alone: nothing else records meanwhile)
@@ -1769,22 +1769,23 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
 #pragma unroll
         for (int i = 0; i < RM; ++i) { ev.room[i] = 0; ev.req[i] = 0; ev.low[i] = INT64_MIN; }
         const bool dync = (UF(c.dyn) & 1u) != 0;
+        // (what this wave publishes besides the evaluation is requested BEFORE it and used after: the loads travel with the evaluation's own)
         u32 zl = 0xFFu;        // (worker 0) this candidate's single value on dyn_key, if its requirement is In [v]
-        if (kw == 0 && (i32)UF(P.dyn_key) >= 0 && slot != 0xFFFFFFFFu) {
-          const Rec rz = slot_rec(S, tb, slot); const u32 dk = UF((u32)P.dyn_key);
-          const u64 zm = rz.mask()[dk];
-          if (((rz.present() >> dk) & 1u) && !((rz.complement() >> dk) & 1u) && __builtin_popcountll(zm) == 1) zl = (u32)__builtin_ctzll(zm);
-        }
+        const bool want_zl = kw == 0 && (i32)UF(P.dyn_key) >= 0 && slot != 0xFFFFFFFFu; const u32 dk = want_zl ? UF((u32)P.dyn_key) : 0u;
+        u64 zm_pre = 0; if (want_zl) zm_pre = slot_rec(S, tb, slot).mask()[dk];
+        const u32 dyn2 = UF(c.dyn) & 2u; u32 h0f = 0, h0slot = 0; i32 h0max = 0, hc_pre = 0;
+        if (dyn2) { const PlanTopo& th = c.host[0]; h0f = UF(*(const u32*)&th.type); h0slot = UF(th.hslot); h0max = (i32)UF(th.maxskew); if (slot != 0xFFFFFFFFu) hc_pre = tb.hcnt[(size_t)slot * tb.GH + h0slot]; }
         if (slot != 0xFFFFFFFFu) eval_node<BOUNDS, LEAN, RM>(P, S, tb, sh, wb, slot, slot < tb.E, false, ev, lane, tprobe, cr, dync);
+        if (want_zl && ((ev.present >> dk) & 1u) && !((ev.complement >> dk) & 1u) && __builtin_popcountll(zm_pre) == 1) zl = (u32)__builtin_ctzll(zm_pre);
         const u64 mo = ballot64((ev.rc & 3) == 2 && ev.rc > 0);
         const u64 m = ballot64(ev.rc == 2);
         const u64 chgb = ballot64((ev.rc & 3) == 2 && ev.rc > 0 && (ev.tchg != 0 || ev.it_state != ev.it0));
         if (lane == 0) { rc.m[kw] = m; rc.chg[kw] = chgb; rc.mo[kw] = mo; }
         if (kw == 0) rc.zone[lane] = (u8)zl;
-        if (UF(c.dyn) & 2u) {      // how many more pods of the item's group this candidate takes
-          const PlanTopo& th = c.host[0]; const u32 f = UF(*(const u32*)&th.type); const u32 ty = f & 0xFF, self = (f >> 8) & 0xFF;
+        if (dyn2) {      // how many more pods of the item's group this candidate takes
+          const u32 ty = h0f & 0xFF, self = (h0f >> 8) & 0xFF;
           i32 slack = 0;
-          if (slot != 0xFFFFFFFFu && ty == 0) { const i32 cnt = tb.hcnt[(size_t)slot * tb.GH + UF(th.hslot)]; slack = (i32)UF(th.maxskew) - (i32)self - cnt; }
+          if (slot != 0xFFFFFFFFu && ty == 0) slack = h0max - (i32)self - hc_pre;
           rc.hslack[kw][lane] = (u8)(slack < 0 ? 0 : (slack > 255 ? 255 : slack));
         }
         if (kw == 0) {
