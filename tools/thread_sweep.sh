@@ -1,0 +1,1 @@
+for t in 8 16 32 64; do echo "threads $t"; KSH_THREADS=$t python tools/time_from_pods.py 100000 5 2>&1 | grep -E "flatten|total_ms|decisions"; done
