@@ -145,3 +145,30 @@ def test_two_concurrent_solves():
         t.join()
     assert not errs, errs
     assert got == wants
+
+
+def test_concurrent_flattening_matches_serial():
+    """The host flattening runs its parallel phases on a shared pool of worker threads; a second caller arriving while the pool is busy
+    spawns threads of its own.  Four threads flattening different problems at once (provisioner and deprovisioner goroutines do) must
+    produce the flat problems a serial run produces, fingerprint for fingerprint, run after run."""
+    import threading
+    problems = [W.config3(pods=6000, sizes=10, seed=3), W.config2(pods=5000, sizes=8, seed=4), W.config5(pods=5000, sizes=50, seed=5),
+                W.config1(pods=7000, types=40, seed=6)]
+    parsed = [S.ParsedProblem(p) for p in problems]
+
+    def flatten(i):
+        fp = S.FlatProblem(problems[i])
+        f = fp.fingerprint()
+        fp.close()
+        return f
+
+    serial = [flatten(i) for i in range(len(problems))]
+    for _ in range(3):
+        got = [None] * len(problems)
+        ths = [threading.Thread(target=lambda i=i: got.__setitem__(i, flatten(i))) for i in range(len(problems))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert got == serial
+    del parsed
