@@ -526,22 +526,13 @@ __global__ __launch_bounds__(64) void ks_link_ev(const DevProb* probs) {
 // only the node that just received a pod changed, and it moved behind the rest of its count bucket.
 __device__ inline bool ks_plan_eval_eligible(const ClsPlan& p) { return !p.overflow && p.ntopo == 0 && p.nhost == 0 && p.port_cnt == 0 && p.vol_cnt == 0 && p.hn_mode == 0; }
 __global__ __launch_bounds__(64) void ks_link_plans(const DevProb* probs) {
-  const DevProb& P = probs[blockIdx.y]; ClsPlan* const plans = (ClsPlan*)P.plans; const u32 C = P.C, R = P.R;
+  const DevProb& P = probs[blockIdx.y]; ClsPlan* const plans = (ClsPlan*)P.plans; const ClsBrief* const briefs = (const ClsBrief*)P.briefs;
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const ClsPlan& me = plans[c];
-  if (!ks_plan_eval_eligible(me)) return;
-  u32 eq = c + 1;
-  for (u32 o = 0; o < c; ++o) {
-    const ClsPlan& p = plans[o];
-    if (!ks_plan_eval_eligible(p) || p.present != me.present || p.complement != me.complement || p.it_state != me.it_state || p.reqmask != me.reqmask ||
-        p.tol != me.tol || p.ntouch != me.ntouch || p.tkeys != me.tkeys) continue;
-    bool same = true;
-    for (u32 r = 0; r < R && same; ++r) same = p.req[r] == me.req[r];
-    for (u32 i = 0; i < me.ntouch && same; ++i) { const PlanTouch &a = p.touch[i], &b = me.touch[i]; same = a.mask == b.mask && a.gt == b.gt && a.lt == b.lt && a.own == b.own && a.complement == b.complement; }
-    if (same) { eq = o + 1; break; }
-  }
-  plans[c].eq = eq;   // the first equivalent class represents the set (no other thread reads this field)
+  if (c >= P.C) return;
+  // For plans that consult no topology, carry no ports / volumes / hostname selector, "evaluated identically" (ks_link_ev: every word of the
+  // evaluation part equal) IS "Node.Add reads the same inputs": the evaluation class interned there -- one hash-table probe per class instead
+  // of a scan over every earlier class -- names the set (which member represents it is immaterial: the id only indexes the watermark).
+  if (ks_plan_eval_eligible(plans[c])) plans[c].eq = briefs[c].ev;
 }
 
 // Hot, small tables and scalars of one Solve, held in registers.  In the FAST kernel variant every
