@@ -818,3 +818,31 @@ def test_volume_limits_mixed_claims(backend):
     p = mkpod()
     sim.provision([p])
     assert sim.scheduled(p).name != node.name
+
+
+# ---------------- label normalisation (pkg/scheduling/requirement_test.go:44-80, apis/v1alpha5/labels.go:84-110) ----------------
+def test_beta_labels_are_normalised(backend):
+    """NewLabelRequirements / NewNodeSelectorRequirements / NewPodRequirements map the deprecated label keys to their stable names
+    (the reference asserts r.Keys() == {arch, os, instance-type, region, zone} for all three constructors).  Restated through Solve:
+    a pod that names the BETA keys in its node selector, in a required node-affinity term and in a preferred one lands on a node whose
+    requirements carry the STABLE keys with those values -- and none of the beta keys."""
+    beta = {"failure-domain.beta.kubernetes.io/zone": "test-zone-2", "failure-domain.beta.kubernetes.io/region": "test",
+            "beta.kubernetes.io/arch": "arm64", "beta.kubernetes.io/os": "linux", "beta.kubernetes.io/instance-type": "arm-instance-type"}
+    stable = {LABEL_ZONE: "test-zone-2", "topology.kubernetes.io/region": "test", LABEL_ARCH: "arm64", LABEL_OS: "linux",
+              LABEL_INSTANCE_TYPE: "arm-instance-type"}
+    exprs = [Expr(k, "In", [v]) for k, v in beta.items()]
+    pods = [mkpod(node_selector=dict(beta)),                                                   # NewLabelRequirements
+            mkpod(required_affinity=[list(exprs)]),                                            # NewNodeSelectorRequirements (required term)
+            mkpod(node_selector=dict(beta), required_affinity=[list(exprs)], preferred_affinity=[PreferredTerm(1, list(exprs))])]
+    for p in pods:
+        sim = ClusterSim(backend)
+        sim.provision([p])
+        node = sim.scheduled(p)
+        assert node is not None
+        nn = [n for n in sim.last.new_nodes if n.pods][0]
+        for k, v in stable.items():
+            r = nn.requirements[k]
+            assert not r.complement and list(r.values) == [v], (k, r)
+        assert not any(k in nn.requirements for k in beta)
+        assert nn.instance_types == ["arm-instance-type"]
+        assert node.labels[LABEL_ZONE] == "test-zone-2" and node.labels[LABEL_ARCH] == "arm64"
