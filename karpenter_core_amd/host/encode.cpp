@@ -790,7 +790,7 @@ struct Builder {
       pod_spec[i] = found;
     }
     sublap("confirm"); specs.resize(first.size());
-    for (size_t s2 = 0; s2 < first.size(); ++s2) { StageInfo st; st.spec = *podp[first[s2]]; st.spec.uid.clear(); specs[s2].stages.push_back(std::move(st)); }
+    parallel_chunks(first.size(), [&](size_t b, size_t e, uint32_t) { for (size_t s2 = b; s2 < e; ++s2) { StageInfo st; st.spec = *podp[first[s2]]; st.spec.uid.clear(); specs[s2].stages.push_back(std::move(st)); } }, 128);      // (a spec is a deep copy of a pod: strings, vectors)
   }
 
   void encode_pods() {
