@@ -806,19 +806,22 @@ struct Builder {
       }
     }
     sublap("inverse affinities");
-    // pass A: NewTopology's Update(pod) over the distinct stage-0 specs in order of first occurrence
-    for (auto& si : specs) { StageInfo& st = si.stages[0]; st.reqs = NewPodRequirements(st.spec); st.sg = groups_of(st.spec, true); }
-    sublap("pass A");
-    // pass B: relaxation chains (Preferences.Relax + Topology.Update after each relaxation)
-    for (auto& si : specs) {
+    // The pure halves of both passes -- NewPodRequirements of every stage, Preferences.Relax down each spec's chain -- run on the worker pool;
+    // what registers topology groups (groups_of) then runs serially in the reference's order.
+    parallel_chunks(specs.size(), [&](size_t b, size_t e, uint32_t) { for (size_t s2 = b; s2 < e; ++s2) {
+      SpecInfo& si = specs[s2]; si.stages[0].reqs = NewPodRequirements(si.stages[0].spec);
       for (;;) {
         Pod next = si.stages.back().spec;
         if (!Relax(next, toleratePreferNoSchedule)) break;
-        StageInfo st; st.spec = std::move(next); st.reqs = NewPodRequirements(st.spec); st.sg = groups_of(st.spec, false);
+        StageInfo st; st.spec = std::move(next); st.reqs = NewPodRequirements(st.spec);
         si.stages.push_back(std::move(st));
         if (si.stages.size() > 64) throw Unsupported("more than 64 relaxation stages");
-      }
-    }
+      } } }, 64);
+    // pass A: NewTopology's Update(pod) over the distinct stage-0 specs in order of first occurrence
+    for (auto& si : specs) si.stages[0].sg = groups_of(si.stages[0].spec, true);
+    sublap("pass A");
+    // pass B: relaxation chains (Topology.Update after each relaxation)
+    for (auto& si : specs) for (size_t k = 1; k < si.stages.size(); ++k) si.stages[k].sg = groups_of(si.stages[k].spec, false);
     sublap("pass B");
     // classes
     E.cls_hn_off.assign(1, 0); E.cls_port_off.assign(1, (uint32_t)E.ports.size()); E.cls_vol_off.assign(1, 0);

@@ -172,3 +172,15 @@ def test_concurrent_flattening_matches_serial():
             t.join()
         assert got == serial
     del parsed
+
+
+def test_flattening_fingerprints_are_pinned():
+    """The host flattening of a fixed problem set hashes to the committed fingerprints (tests/golden/make_flat_fingerprints.py): changes of
+    the host code that are meant to be result-neutral -- threading, caching, the order work is done in -- are caught on the CPU."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_flat_fingerprints as M
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "flat_fingerprints.json")))
+    got = M.compute()
+    assert got == want, sorted(k for k in want if got.get(k) != want[k])
