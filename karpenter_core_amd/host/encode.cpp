@@ -825,10 +825,7 @@ struct Builder {
     sublap("pass B");
     // classes
     E.cls_hn_off.assign(1, 0); E.cls_port_off.assign(1, (uint32_t)E.ports.size()); E.cls_vol_off.assign(1, 0);
-    { std::vector<const StageInfo*> flat; for (auto& si : specs) for (auto& st : si.stages) flat.push_back(&st);
-      std::vector<ClassPre> pre(flat.size());
-      parallel_chunks(flat.size(), [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) pre[i] = class_pre(*flat[i]); }, 128);
-      size_t i = 0; for (auto& si : specs) for (auto& st : si.stages) si.cls.push_back(class_of(st, pre[i++])); }
+    for (auto& si : specs) for (auto& st : si.stages) si.cls.push_back(class_of(st));
     // pods -> stage chains, queue order
     sublap("classes"); E.pod_stage_off.resize((size_t)P + 1); E.pod_stage_off[0] = 0;
     for (uint32_t i = 0; i < P; ++i) E.pod_stage_off[i + 1] = E.pod_stage_off[i] + (uint32_t)specs[pod_spec[i]].cls.size();
@@ -879,26 +876,20 @@ struct Builder {
     pod_rank.resize(P); for (uint32_t i = 0; i < P; ++i) pod_rank[E.queue[i]] = i;
   }
 
-  // The half of a class signature that reads nothing the flattening still mutates: computed for every (spec, stage) on the worker pool.
-  struct ClassPre { std::string ls, sig_a; ksp::ResList req; uint64_t tol = 0; std::vector<uint32_t> ve; };
-  ClassPre class_pre(const StageInfo& st) const {
-    const Pod& p = st.spec; ClassPre c;
-    c.ls = p.ns; c.ls += '\3'; sig_map(c.ls, p.labels);      // label set (namespace + labels decide which selectors select the pod)
-    c.sig_a.reserve(256);                                     // signature of everything Node.Add reads
-    for (auto& kv : st.reqs.m) { c.sig_a += kv.first; c.sig_a += '\1'; c.sig_a += kv.second.identity(); c.sig_a += '\2'; } c.sig_a += '\4';
-    c.req = RequestsForPod(p); sig_res(c.sig_a, c.req);
-    for (size_t i = 0; i < taints.size(); ++i) { if ((int)i == blocked_taint) continue; bool ok = false; for (auto& t : p.tolerations) ok = ok || ToleratesTaint(t, taints[i]); if (ok) c.tol |= 1ull << i; }
-    c.sig_a += std::to_string(c.tol); c.sig_a += '\4';
-    if (pods_have_volumes) c.ve = vol_entries(p);
-    for (auto e : c.ve) { c.sig_a += std::to_string(e); c.sig_a += ','; } c.sig_a += '\4';
-    return c;
-  }
-  uint32_t class_of(const StageInfo& st, ClassPre& pre) {
+  uint32_t class_of(const StageInfo& st) {
     const Pod& p = st.spec;
-    const std::string& ls = pre.ls;
+    // label set (namespace + labels decide which selectors select the pod)
+    std::string ls = p.ns; ls += '\3'; sig_map(ls, p.labels);
     int lsid; auto li = labelset_id.find(ls); if (li == labelset_id.end()) { lsid = (int)labelsets.size(); labelsets.emplace_back(p.ns, p.labels); labelset_id[ls] = lsid; } else lsid = li->second;
-    std::string sig = std::move(pre.sig_a); const ksp::ResList& req = pre.req; const uint64_t tol = pre.tol; const std::vector<uint32_t>& ve = pre.ve;
-    std::vector<uint64_t> pe; for (auto& c : p.containers) for (auto& hp : c.ports) if (hp.port != 0) pe.push_back(port_entry(hp.ip, hp.port, hp.proto));      // (interns addresses and protocols: serial)
+    // signature of everything Node.Add reads
+    std::string sig; sig.reserve(256);
+    for (auto& kv : st.reqs.m) { sig += kv.first; sig += '\1'; sig += kv.second.identity(); sig += '\2'; } sig += '\4';
+    ksp::ResList req = RequestsForPod(p); sig_res(sig, req);
+    uint64_t tol = 0; for (size_t i = 0; i < taints.size(); ++i) { if ((int)i == blocked_taint) continue; bool ok = false; for (auto& t : p.tolerations) ok = ok || ToleratesTaint(t, taints[i]); if (ok) tol |= 1ull << i; }
+    sig += std::to_string(tol); sig += '\4';
+    const std::vector<uint32_t> ve = pods_have_volumes ? vol_entries(p) : std::vector<uint32_t>();
+    for (auto e : ve) { sig += std::to_string(e); sig += ','; } sig += '\4';
+    std::vector<uint64_t> pe; for (auto& c : p.containers) for (auto& hp : c.ports) if (hp.port != 0) pe.push_back(port_entry(hp.ip, hp.port, hp.proto));
     for (auto e : pe) { sig += std::to_string(e); sig += ','; } sig += '\4';
     sig += std::to_string(lsid); sig += '\4';
     for (int g : st.sg.own) { sig += std::to_string(g); sig += ','; } sig += '\4';
