@@ -70,9 +70,17 @@ def main():
     ap.add_argument("--whatifs-only", action="store_true", help="diagnostic: only the N=1 what-if leg (prints its object alone, not the contract line)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)      # `python bench.py --gpus N` launches its own N ranks (one per GPU); under torchrun the ranks arrive here with WORLD_SIZE set
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)")
+    if os.environ.get("KS_BENCH_DRY"):
+        return dry_fanout(args, rank, world)
     import torch
     if world > 1:
         import torch.distributed as dist
@@ -82,6 +90,8 @@ def main():
         backend = os.environ.get("KS_BENCH_BACKEND", "nccl")
         if backend != "nccl":
             local_rank = local_rank % max(1, torch.cuda.device_count())
+        elif torch.cuda.device_count() < world:
+            sys.exit(f"bench.py: --gpus {world} needs {world} GPUs on this node, {torch.cuda.device_count()} visible (rank {rank} would have no device of its own)")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend)       # "nccl" is RCCL on ROCm
 
@@ -203,6 +213,44 @@ def main():
     print(json.dumps(out))
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1."""
+    import socket
+    import subprocess
+    if not os.environ.get("KS_BENCH_DRY") and os.environ.get("KS_BENCH_BACKEND", "nccl") == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs on this node, {have} visible")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def dry_fanout(args, rank, world):
+    """KS_BENCH_DRY=1 (CPU rehearsal of the launch + exchange plumbing, tests/test_distributed.py): the ranks deal the what-if ids out exactly as the
+    real leg does and all-gather id-only records over gloo; nothing is solved and the line says so (`dry`: it is not a measurement)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    from karpenter_core_amd import consolidation as C
+    total = args.whatifs or 512
+    mine = list(range(rank, total, world))
+    per = (total + world - 1) // world
+    rec = torch.zeros((len(mine), 3), dtype=torch.int64)
+    rec[:, 0] = torch.tensor(mine, dtype=torch.int64)
+    table = C.all_gather_records(rec, per)
+    if rank == 0:
+        print(json.dumps({"metric": "pod-placement decisions/sec (Solve())", "value": None, "dry": True, "n_gpus": world,
+                          "config": {"whatifs": total, "records_gathered": int(table.shape[0]), "ids_in_order": bool((table[:, 0] == torch.arange(total)).all())}}))
+    dist.destroy_process_group()
+
+
 def whatif_snapshot(args, S, W):
     """BASELINE configs[3]'s cluster: 2048 existing nodes with their bound pods, held as objects in host memory (untimed, like the pod list)."""
     c_its, c_prov, c_nodes, c_bound = W.cluster_snapshot(2048, args.sizes, 45)
@@ -239,22 +287,37 @@ def whatif_leg(args, rank, world, local_rank, torch, dist, S, W):
             for f in flats:
                 f.close()
     ms = sorted(runs, key=lambda r: r["total_ms"])[1]
-    # resident: the batch already in HBM, launch + read-back only (round 1's what-if window)
+    # resident: the batch already in HBM -- exactly the step of the N>1 fan-out at world size 1: one batched launch with the results left on the
+    # device, the fixed-size records built there (no host hop), nothing else
+    rec_dev = torch.full((len(flats), 3 + words), -1, dtype=torch.int64, device=f"cuda:{local_rank}")
     res = []
-    for _ in range(3):
+    for _ in range(5):
         t1 = time.perf_counter()
-        _, kms, _ = S.solve_batch(flats, decode=False)
-        S.result_records(flats, mine, words)
+        kms, _ = S.solve_batch_resident(flats)
+        S.result_records_dev(flats, mine, words, rec_dev)
         res.append(((time.perf_counter() - t1) * 1e3, kms))
-    wms, kms = sorted(res)[1]
+    wms, kms = sorted(res)[2]
+    assert (rec_dev.cpu().numpy() == rec).all(), "device-built records differ from the host-built ones"
     pods_mine = sum(f.dims["P"] for f in flats)
+    # roofline of the batch kernel: the REFERENCE algorithm's bytes for these what-ifs (untimed KS_FLAG_STATS batch) over the launch's HIP-event time
+    sflats = S.open_whatifs(parsed, pod_node, [sets[i] for i in mine], stats=True)
+    S.upload_batch(sflats, local_rank)
+    sres, _, _ = S.solve_batch(sflats)
+    abytes = sum(algorithmic_bytes(T, r.stats, f.dims["P"]) for r, f in zip(sres, sflats))
+    for f in sflats:
+        f.close()
     out = {"workload": f"{len(flats)} consolidation what-ifs over 2048 existing nodes / {T} instance types (BASELINE configs[3])",
            "whatifs": len(flats), "decisions": pods_mine, "records": int(rec.shape[0]),
            "first_batch_over_the_snapshot": dict(first, what="cold: + the snapshot's own flattening and its upload (once per snapshot), buffer pools, code objects"),
            "end_to_end": dict(ms, what="a batch of candidate sets over a snapshot already seen (a consolidation pass probes many): flatten the what-ifs over the shared snapshot base + upload + one batched launch + result records",
                               decisions_per_s=pods_mine / (ms["total_ms"] / 1e3), whatifs_per_s=len(flats) / (ms["total_ms"] / 1e3)),
-           "resident": {"kernel_ms": kms, "wall_ms": wms, "decisions_per_s_kernel": pods_mine / (kms / 1e3), "decisions_per_s_wall": pods_mine / (wms / 1e3),
-                        "whatifs_per_s_wall": len(flats) / (wms / 1e3)}}
+           "resident": {"what": "the N>1 fan-out's step at world size 1: batched launch, results left on the device, records built there",
+                        "kernel_ms": kms, "wall_ms": wms, "decisions_per_s_kernel": pods_mine / (kms / 1e3), "decisions_per_s_wall": pods_mine / (wms / 1e3),
+                        "whatifs_per_s_wall": len(flats) / (wms / 1e3)},
+           "roofline": {"kernel": "ks_pack<single wave> x what-ifs in one launch", "bound": "hbm", "achieved": abytes / (kms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": abytes / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": abytes, "kernel_ms": kms,
+                        "formula": f"SURVEY 8d with R={ROOFLINE_R}, K={ROOFLINE_K}, summed over the what-ifs",
+                        "note": "a batch takes as long as its longest what-if (one wave each); the watermark / run commit skip most of the attempts the reference makes"}}
     for f in flats:
         f.close()
     return out
@@ -274,11 +337,20 @@ def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
     from karpenter_core_amd import consolidation as C
 
     on_device = dist.get_backend() == "nccl"
+    dev = f"cuda:{local_rank}"
+    width = 3 + words
+    local = torch.full((per, width), -1, dtype=torch.int64, device=dev)               # rows [0, len(mine)) are rewritten by every step; padding rows keep id -1
+    gathered = torch.empty((world * per, width), dtype=torch.int64, device=dev)
 
     def step():
-        S.solve_batch(flats, decode=False)
-        rec = torch.from_numpy(S.result_records(flats, mine, words))
-        return C.all_gather_records(rec.cuda() if on_device else rec, per)           # the single collective of the path (RCCL all-gather)
+        S.solve_batch_resident(flats)                                                  # one batched launch; the results stay on the device
+        S.result_records_dev(flats, mine, words, local)                               # [id, n_new, n_unscheduled, options] built on the device, complete on return
+        if on_device:
+            dist.all_gather_into_tensor(gathered, local)                              # the single collective of the path: RCCL all-gather of the device buffer as is
+            return gathered
+        parts = [torch.empty_like(local) for _ in range(world)]                       # (gloo rehearsal on a box with fewer GPUs than ranks)
+        dist.all_gather(parts, local)
+        return torch.cat(parts, 0)
 
     for _ in range(args.warmup):
         step()
@@ -297,11 +369,33 @@ def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
     tp = torch.tensor([pods_mine], device=red_dev, dtype=torch.int64)
     dist.all_reduce(tp)
     total_pods = int(tp.item())
+    table = table[table[:, 0] >= 0]
+    table = table[torch.argsort(table[:, 0])]
     # kernel time of the batched launch (HIP events on the solve stream inside ks_solve_batch_dev), mean over a few launches
     kms = []
     for _ in range(3):
-        _, k, _ = S.solve_batch(flats, decode=False)
+        k, _ = S.solve_batch_resident(flats)
         kms.append(k)
+    # the same total work on ONE GPU of this box (rank 0 alone, the others wait): the strong-scaling reference measured beside the N-rank number
+    n1 = None
+    if rank == 0:
+        allf = S.open_whatifs(parsed, pod_node, sets)
+        S.upload_batch(allf, local_rank)
+        one = torch.full((total_whatifs, width), -1, dtype=torch.int64, device=dev)
+        ids = list(range(total_whatifs))
+        for _ in range(max(1, args.warmup)):
+            S.solve_batch_resident(allf); S.result_records_dev(allf, ids, words, one)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            S.solve_batch_resident(allf); S.result_records_dev(allf, ids, words, one)
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        n1 = {"what": "all what-ifs on rank 0's GPU alone, same step without the collective", "ms_per_step": e1 / args.steps * 1e3,
+              "decisions_per_s": sum(f.dims["P"] for f in allf) * args.steps / e1, "records_equal_gathered": bool((one == table).all().item())}
+        for f in allf:
+            f.close()
+    dist.barrier()
     if rank != 0:
         return
     # roofline of the dominant kernel of this leg (the single-wave batch kernel): algorithmic bytes of the REFERENCE algorithm for rank 0's
@@ -319,7 +413,7 @@ def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
            "vs_baseline": None, "dtype": "int64", "data": "synthetic",
            "config": {"workload": f"BASELINE configs[3]: {total_whatifs} consolidation what-ifs over 2048 existing nodes / {T} instance types, dealt out i mod {world}; "
                                   "one batched launch per rank + ONE RCCL all-gather of result records", "whatifs": total_whatifs, "decisions_per_step": total_pods,
-                      "records_gathered": got, "parallelism": f"{world} ranks x {per} what-ifs",
+                      "records_gathered": got, "parallelism": f"{world} ranks x {per} what-ifs", "single_gpu_same_workload": n1,
                       "n1_reference": "the `whatif_batch` object of the --gpus 1 line (same workload on one GPU); a single Solve() does not shard (replicas only)"},
            "roofline": {"kernel": "ks_pack<single wave> x what-ifs of rank 0 in one launch", "bound": "hbm", "achieved": abytes / k_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": abytes / k_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": abytes, "kernel_ms_mean": k_s * 1e3,

@@ -68,6 +68,12 @@ int ksh_result_text(void* handle, char** out_text);
 int ksh_result_summary(void* handle, uint64_t* out /* [2 + words]: n_new, n_unscheduled, new node 0's InstanceTypeOptions */, uint32_t words);
 int ksh_result_summaries(void** handles, uint32_t n, uint64_t* out /* [n][2 + words] */, uint32_t words);
 
+/* the batched launch with the results LEFT ON THE DEVICE (only error words come back), and the batch's fixed-size records built there into a
+ * caller-owned device buffer d_out[n][3 + words] of uint64: [ids[i], n_new, n_unscheduled, new node 0's InstanceTypeOptions] -- the payload of
+ * the one all-gather a what-if fan-out needs, with no host hop */
+int ksh_solve_batch_resident(void** handles, uint32_t n, float* kernel_ms, double* wall_ms);
+int ksh_result_records_dev(void** handles, uint32_t n, const uint64_t* ids, uint32_t words, void* d_out);
+
 /* ---- consolidation ---- */
 int ksh_open_whatifs(const char* snapshot_text, size_t len, uint32_t flags, uint32_t n, const uint32_t* cand_off /* [n+1] */, const uint32_t* cand,
                      const int32_t* pod_node /* node index of every snapshot pod */, uint32_t nthreads /* 0 = all usable cores */, void** out_handles /* [n] */);

@@ -251,7 +251,13 @@ int ks_solve_dev(ks_dev_problem* d, ks_result* out, float* kernel_ms);
 /* Convenience: upload + solve + free. */
 int ks_solve(const ks_problem* p, ks_result* out);
 /* N independent problems (consolidation what-ifs): one workgroup each, one launch. */
+/* out == NULL: the results stay on the device (only the error words are read back) for ks_batch_records_dev / ks_price_filter_dev / ... */
 int ks_solve_batch_dev(ks_dev_problem* const* d, uint32_t n, ks_result* const* out, float* kernel_ms);
+/* The fixed-size records a what-if fan-out exchanges (deprovisioning: what consolidation reads of a simulation, consolidation.go:190-260;
+ * multinodeconsolidation.go:74-114 probes many candidate sets), built on the device from the results the last ks_solve*_dev left there, into a
+ * caller-owned DEVICE buffer d_out[n][3 + words] of uint64: [ids[i], n_new, n_unscheduled, new node 0's InstanceTypeOptions (zero if none)].
+ * The buffer is complete when the call returns -- it can be handed to RCCL as is (no host hop). */
+int ks_batch_records_dev(ks_dev_problem* const* ds, uint32_t n, const uint64_t* ids, uint32_t words, void* d_out);
 int ks_solve_batch(const ks_problem* const* p, uint32_t n, ks_result* const* out);
 
 /* The static pod-class x instance-type feasibility grid for fresh nodes of every template:

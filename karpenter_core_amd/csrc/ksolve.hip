@@ -1163,6 +1163,10 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
   RoundCtlT<RM>& rc = *(RoundCtlT<RM>*)L.rc_raw;      // (single-wave kernels have no rounds: nothing of rc is touched)
   const int lane = threadIdx.x & 63; const u32 wv = NW > 1 ? UF(threadIdx.x >> 6) : 0u;
   WaveShared& sh = shw[wv]; WaveBounds& wb = wbs[BOUNDS ? wv : 0];
+#ifdef KS_CHECK   /* debug builds: LDS starts out as garbage from whatever ran before -- make that garbage deterministic and hostile */
+  { u32* z = (u32*)&L; for (u32 i = threadIdx.x; i < sizeof(L) / 4; i += 64 * NW) z[i] = 0xA5A5A5A5u; u32* y = (u32*)ks_dyn_lds; for (u32 i = threadIdx.x; i < lds_bytes / 4; i += 64 * NW) y[i] = 0xA5A5A5A5u; }
+  __syncthreads();
+#endif
   { const u32* src = (const u32*)&probs[blockIdx.x]; u32* dst = (u32*)&P_lds; for (u32 i = threadIdx.x; i < sizeof(DevProb) / 4; i += 64 * NW) dst[i] = src[i]; }
   { const u32* src = (const u32*)&states[blockIdx.x]; u32* dst = (u32*)&S_lds; for (u32 i = threadIdx.x; i < sizeof(DevState) / 4; i += 64 * NW) dst[i] = src[i]; }
   __syncthreads();
@@ -1863,6 +1867,38 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         { const u32 w_nx = (u32)__shfl_down((int)b_w, 1); const u64 tf_nx = (u64)(u32)__shfl_down((int)(u32)b_tfull, 1) | ((u64)(u32)__shfl_down((int)(u32)(b_tfull >> 32), 1) << 32);
           run_next = ballot64((u32)lane + 1u < rn && b_tfull == 0 && tf_nx == 0 && w_nx == b_w); }
         u32 k = 0;
+        // ---- Scalar selection (KS_FASTSEL).  Most single pods of a round take a candidate the round has not touched yet that stands in front of
+        // every candidate it HAS touched: then the pod's node is the first set bit of its snapshot bitmap minus the touched candidates -- base rules
+        // (a) / (b) of the rounds, decided on the scalar unit (a wave's vector instructions issue once per 4 cycles, its scalar ones every cycle) --
+        // and nothing of the per-candidate bookkeeping below is needed to CHOOSE.  The bookkeeping of the candidates taken that way (`pend`, the
+        // pod of each in `pod_of`) is deferred to ONE vector pass (flush) before the general path next needs it.
+        //   mc_min: lower bound of the pod counts of the NEW nodes the round has moved (every move event's count; counts only grow)
+        u64 pend = 0; u32 mc_min = 0xFFFFFFFFu, pod_of = 0;
+        const u64 emask = tb.E >= 64u ? ~0ull : ((1ull << tb.E) - 1ull);      // window lanes holding existing nodes (they keep their place when they take a pod)
+#ifndef KS_NO_FASTSEL
+        const bool fast_on = true;
+#else
+        const bool fast_on = false;
+#endif
+        auto shfl64 = [&](u64 v, int src) -> u64 { return (u64)(u32)__shfl((int)(u32)v, src) | ((u64)(u32)__shfl((int)(u32)(v >> 32), src) << 32); };
+        auto flush = [&]() {
+          const bool inT = (pend >> lane) & 1ull;
+          const int src = inT ? (int)pod_of : lane;
+          i64 rq[RM];
+#pragma unroll
+          for (int i = 0; i < RM; ++i) rq[i] = (i64)shfl64((u64)b_req[i], src);
+          const u32 rmq = (u32)__shfl((int)b_reqmask, src);
+          const u64 prm = shfl64(b_rmask, src), psu = shfl64(b_rsure, src);
+          if (inT) {
+#pragma unroll
+            for (int i = 0; i < RM; ++i) c_room[i] -= rq[i];
+            c_rm |= rmq; c_racc |= prm; c_rsure |= psu; c_unsure |= prm & ~psu; c_np = 1; c_first = pod_of; c_last = pod_of;
+            if ((u32)lane >= tb.E) { ++c_cnt; c_key = (c_cnt << 8) | (63u - pod_of); }
+            rc.win[pod_of & 63u] = (u8)lane;
+          }
+          count_host_lanes(inT, psu, (u32)lane);
+          pend = 0;
+        };
         P2T(19);
         while (k < rn) {
           P2C(15, 1);
@@ -1894,6 +1930,32 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             }
           }
           P2T(13);
+          if (fast_on && !((run_next >> k) & 1ull)) {      // (a run of equivalent pods is SWEEP's / CLIMB's: one step for the lot)
+            const u64 un = mk & ~movedmask;
+            if (un) {
+              const u32 u = (u32)__builtin_ctzll(un); const u64 ubit = 1ull << u;
+              bool ok = (movedmask & emask & (ubit - 1ull)) == 0;      // no touched existing node stands before it (they keep their place)
+              u32 cu = 0;
+              if (u >= tb.E) { cu = RL(c_cnt0, u); ok = ok && mc_min > cu; }      // every touched new node holds more pods: it stands behind
+              if (ok) {
+                if ((unk >> u) & 1ull) { CUT(13); CUT(18); break; }
+                const bool chgb = (chgk & ubit) != 0; const u64 rmk64 = RL64(b_rmask, k); u64 inx = rmk64;
+                if (rmk64 & dyn_groups) {      // (track_records / track_one for one pod on candidate u)
+                  const u32 zb = RL(c_zone, u);
+                  if (zb != 0xFFu) { track_one(rmk64, zb); inx = rmk64 & ~dyn_groups; }
+                  else if (!chgb) inx = rmk64 & ~dyn_groups;
+                }
+                rall = UF64(rall | inx); movedmask = UF64(movedmask | ubit); pend = UF64(pend | ubit); if (chgb) closedmask = UF64(closedmask | ubit);
+                if (u >= tb.E) mc_min = UF(min(mc_min, cu + 1u));
+                if ((u32)lane == u) pod_of = k;
+                k = UF(k + 1u); n_ok = k;
+                P2C(29, 1);
+                P2T(26);
+                continue;
+              }
+            }
+          }
+          if (pend) flush();
           i64 rqk[RM];
 #pragma unroll
           for (int i = 0; i < RM; ++i) rqk[i] = (i64)RL64(b_req[i], k);
@@ -1959,6 +2021,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
               const u64 inx = track_records(inS, prm, c_zone, (chgk >> lane) & 1ull);
               u64 orr, ors; or_masks(inS, inx, psu, orr, ors);
               movedmask = UF64(movedmask | S); closedmask = UF64(closedmask | (S & chgk)); rall = UF64(rall | orr);
+              mc_min = UF(min(mc_min, cnt_bu + 1u));
               k = UF(k + sN); n_ok = k;
               P2T(26);
               continue;
@@ -2004,12 +2067,14 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             if ((u32)bu >= tb.E) { c_cnt += t; c_key = (c_cnt << 8) | (63u - (k + t - 1)); }
           }
           if ((u32)lane >= k && (u32)lane < k + t) rc.win[lane] = (u8)bu;
+          if ((u32)bu >= tb.E) mc_min = UF(min(mc_min, cnt_bu + 1u));
           movedmask = UF64(movedmask | (1ull << bu));
           if ((chgk >> bu) & 1ull) closedmask = UF64(closedmask | (1ull << bu));
           rall = UF64(rall | inx);
           k = UF(k + t); n_ok = k;
           P2T(26);
         }
+        if (pend) flush();
         P2T(13);
         if (n_ok == rn) CUT(16);
         rc.npods[lane] = (u8)c_np; rc.lastpod[lane] = (u8)c_last; rc.firstpod[lane] = (u8)c_first; rc.rmsk_new[lane] = c_rm;
@@ -2694,6 +2759,9 @@ static int upload_impl(const ks_problem* p, int device, const ks_dev_problem* ba
   HIPCHK(hipMemcpyAsync(d->base[0], d->stage, d->sz[0], hipMemcpyHostToDevice, d->stream));
   if (d->sz[1]) HIPCHK(hipMemsetAsync(d->base[1], 0, d->sz[1], d->stream));
   if (d->sz[2]) HIPCHK(hipMemsetAsync(d->base[2], 0xFF, d->sz[2], d->stream));
+  // Diagnostic: KS_POISON=<byte> fills the region the kernels must initialise themselves before reading (queue, node records' tails, alive rows,
+  // ladder indices, order array, ...).  Results must not depend on it (tests/test_parity.py::test_poisoned_arena, tools/stress_cold.py).
+  if (const char* pz = getenv("KS_POISON")) { if (d->sz[3]) HIPCHK(hipMemsetAsync(d->base[3], (int)strtol(pz, nullptr, 0) & 0xFF, d->sz[3], d->stream)); }
   guard.ok = true; *out = d; return KS_OK;
 #undef SHARED
 #undef COPY_OR_SHARE
@@ -2844,7 +2912,7 @@ static int download(ks_dev_problem* d, ks_result* out) {
 
 extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_result* const* outs, float* kernel_ms) {
   if (!n) return KS_OK;
-  if (!ds || !outs) return fail(KS_ERR_INVALID, "null batch");
+  if (!ds) return fail(KS_ERR_INVALID, "null batch");
   const int device = ds[0]->device;
   HIPCHK(hipSetDevice(device));
   u32 unbuilt = 0;
@@ -2915,9 +2983,42 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   if (kernel_ms) HIPCHK(hipEventElapsedTime(kernel_ms, e0, e1));
   hipEventDestroy(e0); hipEventDestroy(e1);
   int rc = KS_OK;
+  if (!outs) {       // results stay on the device (ks_batch_records_dev / ks_price_filter_dev / ... read them there): only the error words come back
+    if (n > 1) { std::vector<u64> meta((size_t)n * 34); HIPCHK(hipMemcpy(meta.data(), d_meta, meta.size() * sizeof(u64), hipMemcpyDeviceToHost)); for (u32 i = 0; i < n && rc == KS_OK; ++i) rc = ks_stats_error(&meta[(size_t)i * 34 + 2]); }
+    else { u64 st[32]; HIPCHK(hipMemcpy(st, ds[0]->hs.stats, sizeof st, hipMemcpyDeviceToHost)); rc = ks_stats_error(st); }
+    return rc;
+  }
   if (n > 1) rc = download_batch(ds, n, dsv, d_meta, outs);
   else rc = download(ds[0], outs[0]);
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fixed-size result records of a batch, built ON the device into a caller-owned device buffer: what the ranks of a what-if fan-out exchange
+// (one RCCL all-gather, no host hop).  Record i = [ids[i], n_new, n_unscheduled, InstanceTypeOptions of new node 0 (words x u64, zero if none)].
+// ------------------------------------------------------------------------------------------------
+struct RecordDesc { const u32* counts; const u64* alive; u64 id; u32 TW, pad; };
+__global__ __launch_bounds__(64) void ks_records(const RecordDesc* descs, u64* out, u32 words) {
+  const RecordDesc d = descs[blockIdx.x]; u64* row = out + (size_t)blockIdx.x * (3 + words);
+  const u32 n_new = d.counts[0];
+  if (threadIdx.x == 0) { row[0] = d.id; row[1] = n_new; row[2] = d.counts[1]; }
+  for (u32 w = threadIdx.x; w < words; w += 64) row[3 + w] = (n_new && w < d.TW) ? d.alive[w] : 0ull;
+}
+extern "C" int ks_batch_records_dev(ks_dev_problem* const* ds, uint32_t n, const uint64_t* ids, uint32_t words, void* d_out) {
+  if (!n) return KS_OK;
+  if (!ds || !ids || !d_out) return fail(KS_ERR_INVALID, "null argument");
+  const int device = ds[0]->device; HIPCHK(hipSetDevice(device));
+  std::vector<RecordDesc> hd(n);
+  for (u32 i = 0; i < n; ++i) {
+    if (ds[i]->device != device) return fail(KS_ERR_INVALID, "batch spans devices");
+    if (ds[i]->h.TW > words) return fail(KS_ERR_INVALID, "record row too short");
+    hd[i] = RecordDesc{ds[i]->hs.out_counts, ds[i]->hs.n_alive, ids[i], ds[i]->h.TW, 0};
+  }
+  TmpDev t_desc(device); TRY(t_desc.alloc(n * sizeof(RecordDesc)));
+  HIPCHK(hipMemcpyAsync(t_desc.p, hd.data(), n * sizeof(RecordDesc), hipMemcpyHostToDevice, ds[0]->stream));
+  hipLaunchKernelGGL(ks_records, dim3(n), dim3(64), 0, ds[0]->stream, t_desc.as<RecordDesc>(), (u64*)d_out, words);
+  HIPCHK(hipStreamSynchronize(ds[0]->stream)); HIPCHK(hipGetLastError());      // the buffer is complete when this returns: the caller's own stream may read it
+  return KS_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -16,6 +16,8 @@ namespace {
 struct Handle {
   std::unique_ptr<ksh::Encoded> enc; ks_dev_problem* dev = nullptr; std::unique_ptr<ksh::Encoded::ResultBuf> rb;
   std::shared_ptr<void> base_dev;      // what-ifs over a snapshot: the snapshot's own flattening, resident on the device (shared catalogue + derived tables)
+  bool solved = false;                 // rb holds the result of a successful solve (the result buffers are raw memory until then)
+  bool dev_result = false;             // the device holds the result of a successful solve (price filter / launch pick / records read it there)
   ~Handle() { if (dev) ks_problem_free(dev); }
 };
 thread_local std::string g_err;
@@ -80,6 +82,7 @@ int ksh_solve_from_pods(void* parsed, int device, uint32_t flags, void** out_han
     float grid_ms = 0; rc = ks_feasibility_grid(h->dev, nullptr, &grid_ms); if (rc != KS_OK) return set_err(rc, ks_last_error());
     auto t3 = now();
     float kms = 0; rc = ks_solve_dev(h->dev, &h->rb->r, &kms); if (rc != KS_OK) return set_err(rc, ks_last_error());
+    h->solved = true; h->dev_result = true;
     auto t4 = now();
     if (ms) { ms[0] = since(t0, t1); ms[1] = since(t1, t2); ms[2] = since(t2, t3); ms[3] = kms; ms[4] = since(t3, t4); ms[5] = since(t0, t4); }
     if (out_handle) *out_handle = h.release();
@@ -88,13 +91,21 @@ int ksh_solve_from_pods(void* parsed, int device, uint32_t flags, void** out_han
   } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
 }
 // KSR1 text of the result a handle holds (after ksh_solve / ksh_solve_from_pods)
-int ksh_result_text(void* hv, char** out_text) { Handle* h = (Handle*)hv; std::string s = h->enc->decode(h->rb->r, 0.0); *out_text = strdup(s.c_str()); return KS_OK; }
+int ksh_result_text(void* hv, char** out_text) {
+  Handle* h = (Handle*)hv; if (out_text) *out_text = nullptr;
+  if (!h || !out_text) return set_err(KS_ERR_INVALID, "null argument");
+  if (!h->solved) return set_err(KS_ERR_INVALID, "the handle holds no result: solve it first (or the last solve failed)");
+  try { std::string s = h->enc->decode(h->rb->r, 0.0); *out_text = strdup(s.c_str()); return KS_OK; }
+  catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
+}
 
 // Fixed-size record of the result a handle holds -- what consolidation reads of a simulation (consolidation.go:190-260):
 // out[0] = number of new nodes, out[1] = number of unscheduled pods, out[2..2+words) = InstanceTypeOptions of new node 0 as a bitmask
 // (zero if there is none).  No text, no per-pod data: this is what the ranks all-gather.
 int ksh_result_summary(void* hv, uint64_t* out, uint32_t words) {
-  Handle* h = (Handle*)hv; const ks_result& r = h->rb->r; const uint32_t TW = (h->enc->prob.T + 63) / 64;
+  Handle* h = (Handle*)hv; if (!h || !out) return set_err(KS_ERR_INVALID, "null argument");
+  if (!h->solved) return set_err(KS_ERR_INVALID, "the handle holds no result: solve it first (or the last solve failed)");
+  const ks_result& r = h->rb->r; const uint32_t TW = (h->enc->prob.T + 63) / 64;
   if (words < TW) return set_err(KS_ERR_INVALID, "summary row too short");
   out[0] = r.n_new; out[1] = r.n_unscheduled;
   for (uint32_t w = 0; w < words; ++w) out[2 + w] = (r.n_new && w < TW) ? r.node_types[w] : 0;
@@ -235,11 +246,14 @@ int ksh_solve(void* hv, char** out_text, float* kernel_ms, double* wall_ms) {
   Handle* h = (Handle*)hv;
   int rc = h->dev ? KS_OK : ksh_upload(hv, ks_current_device()); if (rc != KS_OK) return rc;      // not uploaded yet: the calling thread's current HIP device
   auto t0 = std::chrono::steady_clock::now();
+  h->solved = false; h->dev_result = false;
   rc = ks_solve_dev(h->dev, &h->rb->r, kernel_ms);
   double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (wall_ms) *wall_ms = dt * 1e3;
   if (rc != KS_OK) return set_err(rc, ks_last_error());
-  if (out_text) { std::string s = h->enc->decode(h->rb->r, dt); *out_text = strdup(s.c_str()); }
+  h->solved = true; h->dev_result = true;
+  try { if (out_text) { std::string s = h->enc->decode(h->rb->r, dt); *out_text = strdup(s.c_str()); } }
+  catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
   return KS_OK;
 }
 
@@ -249,11 +263,37 @@ int ksh_solve_batch(void** hv, uint32_t n, char** out_texts, float* kernel_ms, d
   const int dev = ks_current_device();
   for (uint32_t i = 0; i < n; ++i) { int rc = ((Handle*)hv[i])->dev ? KS_OK : ksh_upload(hv[i], dev); if (rc != KS_OK) return rc; ds[i] = ((Handle*)hv[i])->dev; rs[i] = &((Handle*)hv[i])->rb->r; }
   auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t i = 0; i < n; ++i) { ((Handle*)hv[i])->solved = false; ((Handle*)hv[i])->dev_result = false; }
   int rc = ks_solve_batch_dev(ds.data(), n, rs.data(), kernel_ms);
   double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (wall_ms) *wall_ms = dt * 1e3;
   if (rc != KS_OK) return set_err(rc, ks_last_error());
-  if (out_texts) for (uint32_t i = 0; i < n; ++i) { std::string s = ((Handle*)hv[i])->enc->decode(*rs[i], dt); out_texts[i] = strdup(s.c_str()); }
+  for (uint32_t i = 0; i < n; ++i) { ((Handle*)hv[i])->solved = true; ((Handle*)hv[i])->dev_result = true; }
+  try { if (out_texts) for (uint32_t i = 0; i < n; ++i) { std::string s = ((Handle*)hv[i])->enc->decode(*rs[i], dt); out_texts[i] = strdup(s.c_str()); } }
+  catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
+  return KS_OK;
+}
+
+// The same launch with the results left on the device (no read-back but the error words), and the fixed-size records of the batch built there
+// into a caller-owned DEVICE buffer [n][3 + words] of uint64 -- [ids[i], n_new, n_unscheduled, new node 0's InstanceTypeOptions] -- which a
+// fan-out hands to its one all-gather as is (multinodeconsolidation.go:74-114: many candidate sets, one decision record each).
+int ksh_solve_batch_resident(void** hv, uint32_t n, float* kernel_ms, double* wall_ms) {
+  std::vector<ks_dev_problem*> ds(n);
+  const int dev = ks_current_device();
+  for (uint32_t i = 0; i < n; ++i) { int rc = ((Handle*)hv[i])->dev ? KS_OK : ksh_upload(hv[i], dev); if (rc != KS_OK) return rc; ds[i] = ((Handle*)hv[i])->dev; }
+  auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t i = 0; i < n; ++i) { ((Handle*)hv[i])->solved = false; ((Handle*)hv[i])->dev_result = false; }
+  int rc = ks_solve_batch_dev(ds.data(), n, nullptr, kernel_ms);
+  if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (rc != KS_OK) return set_err(rc, ks_last_error());
+  for (uint32_t i = 0; i < n; ++i) ((Handle*)hv[i])->dev_result = true;
+  return KS_OK;
+}
+int ksh_result_records_dev(void** hv, uint32_t n, const uint64_t* ids, uint32_t words, void* d_out) {
+  std::vector<ks_dev_problem*> ds(n);
+  for (uint32_t i = 0; i < n; ++i) { Handle* h = (Handle*)hv[i]; if (!h->dev || !h->dev_result) return set_err(KS_ERR_INVALID, "records before solve"); ds[i] = h->dev; }
+  int rc = ks_batch_records_dev(ds.data(), n, ids, words, d_out);
+  if (rc != KS_OK) return set_err(rc, ks_last_error());
   return KS_OK;
 }
 
@@ -263,7 +303,7 @@ int ksh_solve_batch(void** hv, uint32_t n, char** out_texts, float* kernel_ms, d
 int ksh_price_filter(void** hv, uint32_t n, const uint32_t* node, const double* max_price, const uint32_t* spot_only, uint64_t* out_masks, uint32_t stride_words, uint32_t* out_counts) {
   std::vector<ks_dev_problem*> ds(n); std::vector<uint64_t*> outs(n);
   for (uint32_t i = 0; i < n; ++i) {
-    Handle* h = (Handle*)hv[i]; if (!h->dev) return set_err(KS_ERR_INVALID, "price filter before solve");
+    Handle* h = (Handle*)hv[i]; if (!h->dev || !h->dev_result) return set_err(KS_ERR_INVALID, "price filter before solve");
     if ((h->enc->prob.T + 63) / 64 > stride_words) return set_err(KS_ERR_INVALID, "mask row too short");
     ds[i] = h->dev; outs[i] = out_masks + (size_t)i * stride_words;
   }
@@ -277,7 +317,7 @@ int ksh_price_filter(void** hv, uint32_t n, const uint32_t* node, const double* 
 // capacity-type universes (ksh_key_value resolves them), out_price.
 int ksh_launch_pick(void** hv, uint32_t n, const uint32_t* node, int32_t* out_type, int32_t* out_zone, int32_t* out_ct, double* out_price) {
   std::vector<ks_dev_problem*> ds(n); std::vector<int32_t> pair(n);
-  for (uint32_t i = 0; i < n; ++i) { Handle* h = (Handle*)hv[i]; if (!h->dev) return set_err(KS_ERR_INVALID, "launch pick before solve"); ds[i] = h->dev; }
+  for (uint32_t i = 0; i < n; ++i) { Handle* h = (Handle*)hv[i]; if (!h->dev || !h->dev_result) return set_err(KS_ERR_INVALID, "launch pick before solve"); ds[i] = h->dev; }
   int rc = ks_launch_pick_dev(ds.data(), n, node, out_type, pair.data(), out_price);
   if (rc != KS_OK) return set_err(rc, ks_last_error());
   for (uint32_t i = 0; i < n; ++i) { const uint32_t nct = ((Handle*)hv[i])->enc->prob.n_ct; out_zone[i] = pair[i] < 0 ? -1 : pair[i] / (int32_t)nct; out_ct[i] = pair[i] < 0 ? -1 : pair[i] % (int32_t)nct; }
@@ -291,7 +331,7 @@ const char* ksh_key_value(void* hv, int which, int32_t v) {
 }
 int ksh_types_subset(void** hv, uint32_t n, const uint32_t* node, const uint64_t* lhs, uint32_t stride_words, uint32_t* out) {
   std::vector<ks_dev_problem*> ds(n);
-  for (uint32_t i = 0; i < n; ++i) { Handle* h = (Handle*)hv[i]; if (!h->dev) return set_err(KS_ERR_INVALID, "subset test before solve"); ds[i] = h->dev; }
+  for (uint32_t i = 0; i < n; ++i) { Handle* h = (Handle*)hv[i]; if (!h->dev || !h->dev_result) return set_err(KS_ERR_INVALID, "subset test before solve"); ds[i] = h->dev; }
   int rc = ks_types_subset_dev(ds.data(), n, node, lhs, stride_words, out);
   if (rc != KS_OK) return set_err(rc, ks_last_error());
   return KS_OK;

@@ -780,10 +780,11 @@ struct Builder {
     }
     sublap("spec table");
     // Two pods share a spec when their 128-bit spec hashes agree (two independent 64-bit lanes over every field: a false merge
-    // needs a 2^-128 event).  KSH_CONFIRM_SPECS=1 (the test-suite sets it) additionally confirms every merge field by field; a pod
+    // needs a 2^-128 event for random inputs, but pod specs are tenant-supplied).  Every merge is therefore confirmed field by field (on the
+    // worker pool; KSH_NO_CONFIRM_SPECS=1 skips it for A/B timing only); a pod
     // that merely collided would get a spec of its own.
     std::vector<uint8_t> bad(P, 0);
-    if (getenv("KSH_CONFIRM_SPECS")) parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t f = first[pod_spec[i]]; if (f != i && !same_pod(*podp[f], *podp[i])) bad[i] = 1; } });
+    if (!getenv("KSH_NO_CONFIRM_SPECS")) parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t f = first[pod_spec[i]]; if (f != i && !same_pod(*podp[f], *podp[i])) bad[i] = 1; } });
     for (uint32_t i = 0; i < P; ++i) if (bad[i]) {
       int found = -1; for (size_t s2 = 0; s2 < first.size() && found < 0; ++s2) if (same_pod(*podp[first[s2]], *podp[i])) found = (int)s2;
       if (found < 0) { found = (int)first.size(); first.push_back(i); }

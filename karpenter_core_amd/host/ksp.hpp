@@ -249,7 +249,9 @@ class Parser {
     return std::string(b, p_);
   }
   std::string str() { std::string t = tok(); return t == "~" ? std::string() : t; }
-  bool next_is(const char* s) {   // optional trailing sections (volumes): look at the next token without consuming it
+  // optional trailing sections (volumes): look at the next token without consuming it.  Unambiguous: every record of the grammar opens with a
+  // keyword (POD / NODE / CPOD / ...), so the token after a pod's ANP list or a node's host ports is a keyword, never a free-form uid or name.
+  bool next_is(const char* s) {
     const char* save = p_; bool is = false;
     if (p_ < e_) { try { is = tok() == s; } catch (const Error&) { is = false; } }
     p_ = save; return is;

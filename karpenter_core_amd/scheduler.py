@@ -79,6 +79,8 @@ def libs():
         kh.ksh_key_value.restype = ctypes.c_char_p
         kh.ksh_types_subset.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32,
                                         ctypes.POINTER(ctypes.c_uint32)]
+        kh.ksh_solve_batch_resident.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
+        kh.ksh_result_records_dev.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32, ctypes.c_void_p]
         kh.ksh_fingerprint.argtypes = [ctypes.c_void_p]
         kh.ksh_fingerprint.restype = ctypes.c_uint64
         kh.ksh_free.argtypes = [ctypes.c_void_p]
@@ -277,6 +279,31 @@ def result_records(flats: Sequence[FlatProblem], ids: Sequence[int], words: int)
     return out.view(np.int64)
 
 
+def solve_batch_resident(flats: Sequence[FlatProblem]):
+    """The batched launch with the results left on the device (nothing but the error words is read back).  Returns (kernel ms, wall ms)."""
+    kh = libs()[1]
+    n = len(flats)
+    hs = (ctypes.c_void_p * max(1, n))(*[f._h for f in flats])
+    kms, wms = ctypes.c_float(), ctypes.c_double()
+    rc = kh.ksh_solve_batch_resident(hs, n, ctypes.byref(kms), ctypes.byref(wms))
+    if rc != KS_OK:
+        raise KSolveError(rc, kh.ksh_last_error().decode())
+    return float(kms.value), float(wms.value)
+
+
+def result_records_dev(flats: Sequence[FlatProblem], ids: Sequence[int], words: int, out_tensor):
+    """The records of `result_records`, built ON the device from the results a `solve_batch_resident` left there, into `out_tensor`: a contiguous
+    int64 / uint64 device tensor [len(flats), 3 + words] on the problems' device (anything with .data_ptr()).  Complete on return."""
+    kh = libs()[1]
+    n = len(flats)
+    hs = (ctypes.c_void_p * max(1, n))(*[f._h for f in flats])
+    c_ids = (ctypes.c_uint64 * max(1, n))(*[int(x) for x in ids])
+    rc = kh.ksh_result_records_dev(hs, n, c_ids, words, ctypes.c_void_p(int(out_tensor.data_ptr())))
+    if rc != KS_OK:
+        raise KSolveError(rc, kh.ksh_last_error().decode())
+    return out_tensor
+
+
 def upload_batch(flats: Sequence[FlatProblem], device: int = 0, threads: int = 0):
     """Upload a batch of problems (typically the what-ifs of one snapshot) on host threads."""
     kh = libs()[1]
@@ -317,7 +344,11 @@ def price_filter(flats: Sequence[FlatProblem], nodes: Sequence[int], max_prices:
 def launch_pick(flats: Sequence[FlatProblem], nodes: Sequence[int]):
     """The launch-time instance-type pick of the reference's in-memory provider (cloudprovider/fake/cloudprovider.go:79-84) on the device, over
     the results the last solve of `flats` left there: for flats[i]'s new node nodes[i], (instance-type index, zone, capacity type, price) of the
-    option whose cheapest available offering under the node's zone / capacity-type requirements is cheapest (ties: lowest type index), or None."""
+    option whose cheapest available offering under the node's zone / capacity-type requirements is cheapest (ties: lowest type index), or None.
+    The (zone, capacity type) returned are THAT cheapest offering's.  The in-memory provider labels the launched node with the first
+    available offering, in the type's own Offerings order, that is compatible with the requirements (fake/cloudprovider.go:92-102) -- not
+    necessarily the cheapest one; the flat problem does not keep the offering order, so callers that need the provider's label choice take
+    (type, price) from here and walk the type's Offerings themselves (tests/helpers.py's cluster simulator does)."""
     kh = libs()[1]
     n = len(flats)
     if n == 0:

@@ -731,7 +731,7 @@ struct Scheduler {
     topo.record(pod, nodeReqs); m.ports.add(pod);
     return true;
   }
-  // ---- ExistingNode.Add, existingnode.go:77-130 (volume limits not modelled: no PVC-backed pods in the fixtures) ----
+  // ---- ExistingNode.Add, existingnode.go:77-130 (incl. the volume limits of :87-94; PVC -> driver lookups arrive resolved) ----
   bool existing_add(ExistingNode& n, PodState& ps) {
     st.attempts++;
     ksp::Pod& pod = ps.spec;

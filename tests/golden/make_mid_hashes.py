@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Golden fingerprints of the mid-scale fuzz family (tests/test_fuzz_mid.py), produced by the CPU oracle (a few minutes in all; some
+seeds take the oracle a minute or two, which is why the GPU test compares fingerprints instead of re-running it on the GPU box).
+    python tests/golden/make_mid_hashes.py        # rewrites tests/golden/mid_hashes.json"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import oracle_py as O  # noqa: E402
+import test_fuzz_mid as T  # noqa: E402
+
+out = {}
+for seed in T.MID_SEEDS:
+    p = T.mid_problem(seed)
+    t = time.time()
+    r = O.solve(p)
+    out[str(seed)] = dict(T.fingerprints(r), pods=len(p.pods), instance_types=len(p.instance_types), new_nodes=len(r.new_nodes),
+                          unscheduled=len(r.unscheduled), relaxed_pods=sum(1 for s in r.final_stage if s > 0) if isinstance(r.final_stage, list) else None,
+                          oracle_seconds=round(time.time() - t, 1))
+    print(seed, out[str(seed)], flush=True)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "mid_hashes.json"), "w"), indent=1, sort_keys=True)

@@ -84,3 +84,44 @@ def test_whatif_records_gpu():
     want = C.solve_whatifs(probs, _oracle_many).tolist()
     got = C.solve_whatifs(probs, C.gpu_solve_many).tolist()
     assert got == want
+
+
+def _run_bench(extra_env, *argv, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **extra_env)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_spawns_two_ranks():
+    """`python bench.py --gpus 2` with no launcher must start two ranks itself (the driver's command shape).  KS_BENCH_DRY=1: the launch and the
+    exchange plumbing over gloo without a GPU -- ids dealt out i mod N, ONE all-gather, 512 records back in what-if order on rank 0."""
+    out = _run_bench({"KS_BENCH_DRY": "1"}, "--gpus", "2", "--steps", "1", "--warmup", "0", timeout=300)
+    assert out["n_gpus"] == 2 and out["dry"] is True
+    assert out["config"]["records_gathered"] == 512 and out["config"]["ids_in_order"] is True
+
+
+def test_bench_gpus_mismatch_is_loud():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0", KS_BENCH_DRY="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_fanout_on_one_gpu():
+    """The whole N>1 leg as the driver launches it, rehearsed on a 1-GPU box: two ranks share the device, records are built on the device and
+    gathered over gloo.  512 records, equal to what one GPU computes alone for the same what-ifs."""
+    out = _run_bench({"KS_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert out["n_gpus"] == 2 and out["config"]["records_gathered"] == 512
+    assert out["config"]["single_gpu_same_workload"]["records_equal_gathered"] is True
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
