@@ -49,6 +49,29 @@ void ksh_parsed_free(void* parsed);
  * out_handle (may be NULL) receives a ksh_open-style handle holding the problem and its result (ksh_result_text, ksh_solve again, ...). */
 int ksh_solve_from_pods(void* parsed, int device, uint32_t flags /* KS_FLAG_* */, void** out_handle, double* ms);
 
+/* ---- binary pod ingress: the pending pods as flat arrays (no text) ----
+ * What provisioner.go:301-307 hands to NewScheduler / Solve is a []*v1.Pod.  A cgo shim walks its pods once (one goroutine per block) and
+ * fills, per BLOCK: a table of interned strings, per pod one record of u32 words (string ids, counts, int64 milli-quantities as two words;
+ * grammar in karpenter_core_amd/host/kspb.hpp, field for field the KSP1 POD record), the uid (a string id) and the creationTimestamp.
+ * ksh_pods_ingest copies what it keeps (the buffers are only read during the call -- the cgo pointer rule) and never builds one object
+ * per pod: records that are equal word for word share one decoded spec.  The environment -- instance types, provisioners, state nodes,
+ * cluster pods, daemonsets -- comes from ksh_parse (of a KSP1 text with `PODS 0`); it changes far less often than the pending batch.
+ * ksh_solve_from_batch == ksh_solve_from_pods for that batch: same flat problem (ksh_fingerprint), same result. */
+typedef struct ksh_pod_block {
+  uint32_t n_pods, n_strings;
+  const uint32_t* str_off;      /* [n_strings + 1] byte offsets into str_bytes */
+  const char* str_bytes;
+  const uint32_t* spec_off;     /* [n_pods + 1] word offsets into spec_words */
+  const uint32_t* spec_words;
+  const uint32_t* uid;          /* [n_pods] string ids */
+  const int64_t* creation_ts;   /* [n_pods] */
+} ksh_pod_block;
+int ksh_pods_ingest(const ksh_pod_block* blocks, uint32_t n_blocks, void** out_batch, double* ms /* ingest time or NULL */);
+void ksh_pods_free(void* batch);
+int ksh_pods_count(void* batch, uint32_t* n_pods, uint32_t* n_specs);
+int ksh_solve_from_batch(void* parsed_env, void* batch, int device, uint32_t flags, void** out_handle, double* ms /* as ksh_solve_from_pods */);
+int ksh_open_batch(void* parsed_env, void* batch, uint32_t flags, void** out_handle);   /* flatten only (no GPU needed) */
+
 /* ---- the same in steps ---- */
 int ksh_open(const char* ksp_text, size_t len, uint32_t flags, void** out_handle);      /* parse + flatten (no GPU needed) */
 void ksh_close(void* handle);

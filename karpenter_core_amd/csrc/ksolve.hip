@@ -471,7 +471,7 @@ __global__ __launch_bounds__(64) void ks_build_plans(const DevProb* probs) {
   pl.mono = (!pl.overflow && pl.ntopo == 0 && pl.nhost == 0 && (pl.present & ~P.wellknown_mask) == 0) ? 1u : 0u;
   pl.dyn = 0;
   if (!pl.overflow && pl.ntopo == 1 && pl.nhost == 0 && pl.topo[0].type == 0 && !pl.topo[0].pod_has && pl.topo[0].g < 64 && ((P.dyn_groups >> pl.topo[0].g) & 1ull) &&
-      pl.topo[0].maxskew >= 0 && pl.topo[0].maxskew < (1 << 30)) pl.dyn = 1u | ((u32)pl.topo[0].g << 8) | ((u32)pl.topo[0].self << 16);
+      pl.topo[0].maxskew >= 0 && pl.topo[0].maxskew < (1 << 24) /* RoundCtl::dynq packs it into 24 bits */) pl.dyn = 1u | ((u32)pl.topo[0].g << 8) | ((u32)pl.topo[0].self << 16);
   else if (!pl.overflow && pl.ntopo == 0 && pl.nhost == 1 && pl.host[0].type != 1 && pl.host[0].hslot < 24 && pl.host[0].g >= 0 && pl.host[0].g < 64 && P.G <= 64 && P.GH <= 24)
     pl.dyn = 2u | ((u32)pl.host[0].hslot << 8) | ((u32)pl.host[0].g << 16);
   plans[c] = pl;
@@ -1874,6 +1874,10 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         // pod of each in `pod_of`) is deferred to ONE vector pass (flush) before the general path next needs it.
         //   mc_min: lower bound of the pod counts of the NEW nodes the round has moved (every move event's count; counts only grow)
         u64 pend = 0; u32 mc_min = 0xFFFFFFFFu, pod_of = 0;
+        // rdyn: groups of dyn_groups into which the round has recorded EXACTLY (counted in rc.dd, kept out of `rall`).  Only a pod whose class the
+        // resolver follows against rc.dd (ClsBrief::dyn tag 1) may go on reading such a group; any other reader -- a class with a second topology
+        // item, or a requirement of its own on the key -- has a snapshot evaluation the counts have left behind: the round ends before it.
+        u64 rdyn = 0;
         const u64 emask = tb.E >= 64u ? ~0ull : ((1ull << tb.E) - 1ull);      // window lanes holding existing nodes (they keep their place when they take a pod)
 #ifndef KS_NO_FASTSEL
         const bool fast_on = true;
@@ -1902,7 +1906,8 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         P2T(19);
         while (k < rn) {
           P2C(15, 1);
-          if (RL64(b_tmask, k) & rall) { CUT(13); CUT(17); break; }
+          { const u64 tmk = RL64(b_tmask, k); const bool follows = dyn_on && ((RL(b_flags, k) >> 1) & 1u) != 0;
+            if (tmk & (follows ? rall : (rall | rdyn))) { CUT(13); CUT(17); break; } }
           u64 mk = RL64(mk_l, k), tfk = RL64(b_tfull, k); const u64 chgk = RL64(chg_l, k); const u32 rmk = RL(b_reqmask, k);
           u64 unk = 0;      // candidates whose answer under the counts of the moment is not known (their requirement on dyn_key is not In [v])
           const u32 hsw = hrec_on ? (RL(b_flags, k) >> 1) : 0u; const bool hsk = (hsw & 2u) != 0;      // ClsBrief::dyn tag 2: hslot = bits 8.., group = bits 16..
@@ -1942,7 +1947,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
                 const bool chgb = (chgk & ubit) != 0; const u64 rmk64 = RL64(b_rmask, k); u64 inx = rmk64;
                 if (rmk64 & dyn_groups) {      // (track_records / track_one for one pod on candidate u)
                   const u32 zb = RL(c_zone, u);
-                  if (zb != 0xFFu) { track_one(rmk64, zb); inx = rmk64 & ~dyn_groups; }
+                  if (zb != 0xFFu) { track_one(rmk64, zb); inx = rmk64 & ~dyn_groups; rdyn = UF64(rdyn | (rmk64 & dyn_groups)); }
                   else if (!chgb) inx = rmk64 & ~dyn_groups;
                 }
                 rall = UF64(rall | inx); movedmask = UF64(movedmask | ubit); pend = UF64(pend | ubit); if (chgb) closedmask = UF64(closedmask | ubit);
@@ -2020,6 +2025,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
               count_host_lanes(inS, psu, (u32)lane);
               const u64 inx = track_records(inS, prm, c_zone, (chgk >> lane) & 1ull);
               u64 orr, ors; or_masks(inS, inx, psu, orr, ors);
+              if (dyn_on) { u64 od, ou; or_masks(inS && c_zone != 0xFFu, prm & dyn_groups, 0ull, od, ou); rdyn = UF64(rdyn | od); }
               movedmask = UF64(movedmask | S); closedmask = UF64(closedmask | (S & chgk)); rall = UF64(rall | orr);
               mc_min = UF(min(mc_min, cnt_bu + 1u));
               k = UF(k + sN); n_ok = k;
@@ -2054,10 +2060,10 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
               u64 o_full, o_s; or_masks(inrun, b_rmask, b_rsure, o_full, o_s);
               if (hrec_on && o_full) { u64 o_u, o_d; or_masks(inrun, b_rmask & ~b_rsure, 0ull, o_u, o_d); uns = o_u; count_host_lanes(inrun, b_rsure, (u32)bu); }
               orr = o_full; ors = o_s; inx = o_full;
-              if (dyn_on && (o_full & dyn_groups)) { (void)track_records(inrun, b_rmask, zb, chg_bu); inx = (zb != 0xFFu || !chg_bu) ? (o_full & ~dyn_groups) : o_full; }
+              if (dyn_on && (o_full & dyn_groups)) { (void)track_records(inrun, b_rmask, zb, chg_bu); inx = (zb != 0xFFu || !chg_bu) ? (o_full & ~dyn_groups) : o_full; if (zb != 0xFFu) rdyn = UF64(rdyn | (o_full & dyn_groups)); }
             } else {
               uns = orr & ~ors; count_host_one(ors, (u32)bu);
-              if (dyn_on && (orr & dyn_groups)) { track_one(orr, zb); inx = (zb != 0xFFu || !chg_bu) ? (orr & ~dyn_groups) : orr; }
+              if (dyn_on && (orr & dyn_groups)) { track_one(orr, zb); inx = (zb != 0xFFu || !chg_bu) ? (orr & ~dyn_groups) : orr; if (zb != 0xFFu) rdyn = UF64(rdyn | (orr & dyn_groups)); }
             }
           }
           if (lane == bu) {

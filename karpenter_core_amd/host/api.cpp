@@ -68,13 +68,14 @@ int ksh_parse(const char* ksp_text, size_t len, void** out) {
 }
 void ksh_parsed_free(void* p) { delete (Parsed*)p; }
 // ms[0..5]: flatten (host) | upload | static tables + feasibility grid | pack kernel (HIP events) | whole ks_solve_dev incl. read-back | total wall
-int ksh_solve_from_pods(void* parsed, int device, uint32_t flags, void** out_handle, double* ms) {
+}  // extern "C"
+template <class ENC> static int solve_from(ENC&& make_encoded, int device, void** out_handle, double* ms) {
   if (out_handle) *out_handle = nullptr;
   try {
     using clk = std::chrono::steady_clock; auto now = [] { return clk::now(); }; auto since = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     auto t0 = now();
     auto h = std::make_unique<Handle>();
-    h->enc = ksh::encode(((Parsed*)parsed)->pr, flags);
+    h->enc = make_encoded();
     h->rb = h->enc->make_result();
     auto t1 = now();
     int rc = ks_problem_upload(&h->enc->prob, device, &h->dev); if (rc != KS_OK) return set_err(rc, ks_last_error());
@@ -87,6 +88,45 @@ int ksh_solve_from_pods(void* parsed, int device, uint32_t flags, void** out_han
     if (ms) { ms[0] = since(t0, t1); ms[1] = since(t1, t2); ms[2] = since(t2, t3); ms[3] = kms; ms[4] = since(t3, t4); ms[5] = since(t0, t4); }
     if (out_handle) *out_handle = h.release();
     return KS_OK;
+  } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());
+  } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
+}
+extern "C" {
+int ksh_solve_from_pods(void* parsed, int device, uint32_t flags, void** out_handle, double* ms) {
+  return solve_from([&] { return ksh::encode(((Parsed*)parsed)->pr, flags); }, device, out_handle, ms);
+}
+
+// ---- binary pod ingress (kshost.h): flat pod records -> the batch in compact form; then Solve for that batch against an environment ----
+struct Batch { std::shared_ptr<const ksp::PodBatch> b; };
+int ksh_pods_ingest(const ksh_pod_block* blocks, uint32_t n_blocks, void** out_batch, double* ms) {
+  if (out_batch) *out_batch = nullptr;
+  if (!out_batch || (n_blocks && !blocks)) return set_err(KS_ERR_INVALID, "null argument");
+  try {
+    auto t0 = std::chrono::steady_clock::now();
+    auto b = std::make_unique<Batch>(); b->b = ksh::ingest_pod_blocks(blocks, n_blocks);
+    if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out_batch = b.release(); return KS_OK;
+  } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
+}
+void ksh_pods_free(void* batch) { delete (Batch*)batch; }
+int ksh_pods_count(void* batch, uint32_t* n_pods, uint32_t* n_specs) {
+  if (!batch) return set_err(KS_ERR_INVALID, "null argument");
+  if (n_pods) *n_pods = (uint32_t)((Batch*)batch)->b->size();
+  if (n_specs) *n_specs = (uint32_t)((Batch*)batch)->b->specs.size();
+  return KS_OK;
+}
+int ksh_solve_from_batch(void* parsed_env, void* batch, int device, uint32_t flags, void** out_handle, double* ms) {
+  if (!parsed_env || !batch) return set_err(KS_ERR_INVALID, "null argument");
+  return solve_from([&] { return ksh::encode(((Parsed*)parsed_env)->pr, ((Batch*)batch)->b, flags); }, device, out_handle, ms);
+}
+int ksh_open_batch(void* parsed_env, void* batch, uint32_t flags, void** out) {
+  if (out) *out = nullptr;
+  if (!parsed_env || !batch || !out) return set_err(KS_ERR_INVALID, "null argument");
+  try {
+    auto h = std::make_unique<Handle>();
+    h->enc = ksh::encode(((Parsed*)parsed_env)->pr, ((Batch*)batch)->b, flags);
+    h->rb = h->enc->make_result();
+    *out = h.release(); return KS_OK;
   } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());
   } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
 }

@@ -253,7 +253,7 @@ bool same_spec(const Pod& a, const Pod& b) {
   return same_vec(a.affinity_required, b.affinity_required, same_term) && same_vec(a.affinity_preferred, b.affinity_preferred, same_w) &&
          same_vec(a.anti_required, b.anti_required, same_term) && same_vec(a.anti_preferred, b.anti_preferred, same_w);
 }
-uint64_t str_hash(const std::string& s) { Hash128 h; h.str(s); h.finish(); return h.a ^ h.b; }
+uint64_t str_hash(std::string_view s) { Hash128 h; h.bytes(s.data(), s.size()); h.finish(); return h.a ^ h.b; }
 
 struct Builder {
   Encoded& E; const ksp::Problem& pr; uint32_t flags;
@@ -280,10 +280,10 @@ struct Builder {
   std::vector<Requirement> it_cols; std::map<std::string, int> it_col_id;     // pod-side instance-type requirements (classes, topology filters; 0 = none)
   // UIDs of the batch: open-addressing table of pod indices (topology.go:66-70 excludes the batch from countDomains)
   struct UidSet {
-    const std::vector<const ksp::Pod*>* pods = nullptr; std::vector<uint32_t> tab; uint64_t mask = 0;
+    const std::vector<std::string_view>* uids = nullptr; std::vector<uint32_t> tab; uint64_t mask = 0;
     bool count(const std::string& uid) const {
       if (tab.empty()) return false;
-      for (uint64_t i = str_hash(uid) & mask;; i = (i + 1) & mask) { const uint32_t e = tab[i]; if (!e) return false; if ((*pods)[e - 1]->uid == uid) return true; }
+      for (uint64_t i = str_hash(uid) & mask;; i = (i + 1) & mask) { const uint32_t e = tab[i]; if (!e) return false; if ((*uids)[e - 1] == uid) return true; }
     }
   } batch_uids;
   std::map<std::string, const ksp::StateNode*> node_by_name;
@@ -291,7 +291,10 @@ struct Builder {
   uint32_t K = 0, R = 0, T = 0, TW = 0;
 
   // The pending batch: every pod of the problem, or -- for a what-if flattened over a shared snapshot -- the pods of its candidate nodes.
-  std::vector<const Pod*> podp;
+  std::vector<const Pod*> podp;                       // (binary ingress: pod i points at its SPEC, ksp::PodBatch::specs)
+  const ksp::PodBatch* lite = nullptr;                // binary ingress: the batch in compact form (uids / timestamps live there)
+  std::vector<std::string_view> uidv;                 // uid of pod i (a view into the pod object or the batch's uid bytes)
+  int64_t ts_of(size_t i) const { return lite ? lite->ts[i] : podp[i]->creation_ts; }
   const Builder* base = nullptr;                      // what-if mode: the finished flattening of the whole snapshot
   const std::vector<uint8_t>* removed = nullptr;      // what-if mode: nodes that leave the state-node list (helpers.go:48-61)
   bool node_in_state(size_t i) const { return removed ? !(*removed)[i] : pr.nodes[i].in_state; }
@@ -299,7 +302,7 @@ struct Builder {
   std::vector<int> base_existing_of;                  // base only: node index -> row of the base's existing-node tables (-1: not owned)
   std::vector<ksp::ResList> base_remaining;           // base only: remainingResources with every node in state
 
-  Builder(Encoded& e, uint32_t f) : E(e), pr(*e.src), flags(f) {}
+  Builder(Encoded& e, uint32_t f) : E(e), pr(*e.src), flags(f), lite(e.batch.get()) {}
   std::chrono::steady_clock::time_point tl_ = std::chrono::steady_clock::now();
   void sublap(const char* what) { if (!getenv("KSH_TIMING")) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "      . %-26s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tl_).count()); tl_ = t1; }
 
@@ -738,39 +741,54 @@ struct Builder {
   // Pods -> distinct specs (everything Solve can read of a pod except uid / creationTimestamp), in order of first occurrence.
   // Hashing and the field-by-field confirmation run on all host threads; the table is filled in pod order so that spec ids, and
   // with them the creation order of topology groups (NewTopology's Update per pod, topology.go:72-78), do not depend on threading.
+  void build_uid_table(uint32_t P, bool check_unique) {
+    uint64_t cap = 64; while (cap < 4ull * P) cap <<= 1;
+    batch_uids.uids = &uidv; batch_uids.mask = cap - 1; batch_uids.tab.assign(cap, 0);
+    for (uint32_t i = 0; i < P; ++i) {
+      uint64_t j = str_hash(uidv[i]) & batch_uids.mask;
+      for (;; j = (j + 1) & batch_uids.mask) { const uint32_t e = batch_uids.tab[j]; if (!e) break; if (check_unique && uidv[e - 1] == uidv[i]) throw ksp::Error("pod UIDs must be unique (queue.go:102-108 needs a total order)"); }
+      batch_uids.tab[j] = i + 1;
+    }
+  }
   void dedupe_specs() {
-    if (podp.empty() && !base) { podp.reserve(pr.pods.size()); for (auto& p : pr.pods) podp.push_back(&p); }
+    if (lite) {
+      if (base) throw ksp::Error("a binary pod batch cannot be a what-if over a snapshot");
+      podp.resize(lite->size()); uidv.resize(lite->size());
+      parallel_chunks(lite->size(), [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { podp[i] = &lite->specs[lite->pod_spec[i]]; uidv[i] = lite->uid(i); } });
+    } else {
+      if (podp.empty() && !base) { podp.reserve(pr.pods.size()); for (auto& p : pr.pods) podp.push_back(&p); }
+      uidv.resize(podp.size()); for (size_t i = 0; i < podp.size(); ++i) uidv[i] = podp[i]->uid;
+    }
     const uint32_t P = (uint32_t)podp.size(); collect_volumes(); sublap("(start)");
+    if (lite) {
+      // The ingest already partitioned the batch into distinct specs (records equal word for word, then field by field across blocks), in order
+      // of first occurrence; two of them may still be the same spec written differently -- that costs a spec, not correctness.
+      pod_spec.assign(lite->pod_spec.begin(), lite->pod_spec.end());
+      if (!pr.cluster_pods.empty()) build_uid_table(P, true);
+      specs.resize(lite->specs.size());
+      parallel_chunks(specs.size(), [&](size_t b, size_t e, uint32_t) { for (size_t s2 = b; s2 < e; ++s2) { StageInfo st; st.spec = lite->specs[s2]; specs[s2].stages.push_back(std::move(st)); } }, 128);
+      sublap("specs from the batch");
+      return;
+    }
     if (base) {
       // What-if over a snapshot: its pods ARE snapshot pods, and the snapshot's flattening already knows which of them share a spec (a partition
       // at least as fine as this what-if needs).  Local spec ids in order of first occurrence, as always.
       const Pod* p0 = pr.pods.data();
       std::vector<int32_t> local(base->specs.size(), -1); std::vector<uint32_t> first; pod_spec.assign(P, -1);
       for (uint32_t i = 0; i < P; ++i) { const int bs = base->pod_spec[podp[i] - p0]; if (local[bs] < 0) { local[bs] = (int32_t)first.size(); first.push_back(i); } pod_spec[i] = local[bs]; }
-      if (!pr.cluster_pods.empty()) {      // countDomains / inverse anti-affinity ask which cluster pods are in the batch
-        uint64_t cap = 64; while (cap < 4ull * P) cap <<= 1;
-        batch_uids.pods = &podp; batch_uids.mask = cap - 1; batch_uids.tab.assign(cap, 0);
-        for (uint32_t i = 0; i < P; ++i) { uint64_t j = str_hash(podp[i]->uid) & batch_uids.mask; while (batch_uids.tab[j]) j = (j + 1) & batch_uids.mask; batch_uids.tab[j] = i + 1; }
-      }
+      if (!pr.cluster_pods.empty()) build_uid_table(P, false);      // countDomains / inverse anti-affinity ask which cluster pods are in the batch
       specs.resize(first.size());
       for (size_t s2 = 0; s2 < first.size(); ++s2) { StageInfo st; st.spec = *podp[first[s2]]; st.spec.uid.clear(); specs[s2].stages.push_back(std::move(st)); }
       sublap("specs from the snapshot");
       return;
     }
-    std::vector<Hash128> hs(P); std::vector<uint64_t> uh(P);
+    std::vector<Hash128> hs(P);
     parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) {
       if (pods_have_volumes) { const std::vector<uint32_t> ve = vol_entries(*podp[i]); hs[i] = spec_hash(*podp[i], &ve); } else hs[i] = spec_hash(*podp[i]);
-      uh[i] = str_hash(podp[i]->uid); } });
+      } });
     sublap("hash"); uint64_t cap = 64; while (cap < 4ull * P) cap <<= 1;
-    if (!pr.cluster_pods.empty()) {      // countDomains / inverse anti-affinity ask which cluster pods are in the batch; without cluster pods nobody asks, and the
-                                         // uniqueness of the UIDs is checked on the sorted queue instead (encode_pods)
-      batch_uids.pods = &podp; batch_uids.mask = cap - 1; batch_uids.tab.assign(cap, 0);
-      for (uint32_t i = 0; i < P; ++i) {
-        uint64_t j = uh[i] & batch_uids.mask;
-        for (;; j = (j + 1) & batch_uids.mask) { const uint32_t e = batch_uids.tab[j]; if (!e) break; if (podp[e - 1]->uid == podp[i]->uid) throw ksp::Error("pod UIDs must be unique (queue.go:102-108 needs a total order)"); }
-        batch_uids.tab[j] = i + 1;
-      }
-    }
+    if (!pr.cluster_pods.empty()) build_uid_table(P, true);      // countDomains / inverse anti-affinity ask which cluster pods are in the batch; without cluster pods nobody asks, and the
+                                                                 // uniqueness of the UIDs is checked on the sorted queue instead (encode_pods)
     sublap("uid table"); pod_spec.assign(P, -1);
     std::vector<int32_t> tab(cap, -1); std::vector<uint32_t> first;      // table of spec ids; first[s] = first pod with spec s
     for (uint32_t i = 0; i < P; ++i) {
@@ -845,9 +863,9 @@ struct Builder {
     // and merged pairwise.  Keys are gathered first so a comparison touches one 32-byte record per side and the uid only on ties.
     sublap("chains"); struct QKey { int64_t cpu, mem, ts; uint64_t u0, u1; uint32_t pod, ulen; };     // u0,u1: the uid's first 16 bytes, big-endian (byte-wise string order)
     std::vector<QKey> keys(P);
-    auto be64 = [](const std::string& s2, size_t off) { uint64_t v = 0; for (size_t j = 0; j < 8; ++j) v = (v << 8) | (off + j < s2.size() ? (unsigned char)s2[off + j] : 0u); return v; };
-    parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t c0 = E.stage_cls[E.pod_stage_off[i]]; const std::string& u = podp[i]->uid;
-      keys[i] = QKey{E.cls_requests[(size_t)c0 * R + rc], E.cls_requests[(size_t)c0 * R + rm], podp[i]->creation_ts, be64(u, 0), be64(u, 8), (uint32_t)i, (uint32_t)u.size()}; } });
+    auto be64 = [](std::string_view s2, size_t off) { uint64_t v = 0; for (size_t j = 0; j < 8; ++j) v = (v << 8) | (off + j < s2.size() ? (unsigned char)s2[off + j] : 0u); return v; };
+    parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t c0 = E.stage_cls[E.pod_stage_off[i]]; const std::string_view u = uidv[i];
+      keys[i] = QKey{E.cls_requests[(size_t)c0 * R + rc], E.cls_requests[(size_t)c0 * R + rm], ts_of(i), be64(u, 0), be64(u, 8), (uint32_t)i, (uint32_t)u.size()}; } });
     auto less = [&](const QKey& a, const QKey& b) {
       if (a.cpu != b.cpu) return a.cpu > b.cpu;
       if (a.mem != b.mem) return a.mem > b.mem;
@@ -855,7 +873,7 @@ struct Builder {
       if (a.u0 != b.u0) return a.u0 < b.u0;
       if (a.u1 != b.u1) return a.u1 < b.u1;
       if (a.ulen <= 16 && b.ulen <= 16) return a.ulen < b.ulen;          // equal 16-byte prefixes incl. zero padding: the shorter one is a prefix (NUL bytes inside a uid fall through to the full compare)
-      return podp[a.pod]->uid < podp[b.pod]->uid;
+      return uidv[a.pod] < uidv[b.pod];
     };
     {
       uint32_t nt = 1; while (nt * 2 <= host_threads() && (size_t)nt * 2 * 4096 <= P) nt *= 2;       // power of two: pairwise merge rounds
@@ -871,7 +889,7 @@ struct Builder {
     // equal UIDs end up next to each other (everything before the UID in the order is a function of the spec and the timestamp)
     { std::atomic<bool> dup{false};
       parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = std::max<size_t>(b, 1); i < e; ++i) if (keys[i].u0 == keys[i - 1].u0 && keys[i].u1 == keys[i - 1].u1 && keys[i].ulen == keys[i - 1].ulen && keys[i].ts == keys[i - 1].ts &&
-                                                                                                                 keys[i].cpu == keys[i - 1].cpu && keys[i].mem == keys[i - 1].mem && podp[keys[i].pod]->uid == podp[keys[i - 1].pod]->uid) dup = true; });
+                                                                                                                 keys[i].cpu == keys[i - 1].cpu && keys[i].mem == keys[i - 1].mem && uidv[keys[i].pod] == uidv[keys[i - 1].pod]) dup = true; });
       if (dup) throw ksp::Error("pod UIDs must be unique (queue.go:102-108 needs a total order)"); }
     E.queue.resize(P); for (uint32_t i = 0; i < P; ++i) E.queue[i] = keys[i].pod; sublap("queue sort");
     pod_rank.resize(P); for (uint32_t i = 0; i < P; ++i) pod_rank[E.queue[i]] = i;
@@ -1082,6 +1100,102 @@ std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> pr, uint32_t
   auto e = std::make_unique<Encoded>(); e->src = std::move(pr);
   Builder b(*e, flags); b.run();
   return e;
+}
+
+std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> env, std::shared_ptr<const ksp::PodBatch> batch, uint32_t flags) {
+  if (!env->pods.empty()) throw ksp::Error("the environment of a binary pod batch must carry no pods of its own (PODS 0)");
+  auto e = std::make_unique<Encoded>(); e->src = std::move(env); e->batch = std::move(batch);
+  Builder b(*e, flags); b.run();
+  return e;
+}
+
+// Binary pod ingress (include/kshost.h, kspb.hpp).  Per block: hash every record (all host threads), partition the block's pods by
+// record equality (word for word -- the block's strings are interned), decode the DISTINCT records only, merge those across blocks
+// field by field (a second block has another string table).  Spec ids follow the first occurrence in the concatenated batch.
+std::shared_ptr<const ksp::PodBatch> ingest_pod_blocks(const ksh_pod_block* blocks, uint32_t nb) {
+  auto out = std::make_shared<ksp::PodBatch>();
+  auto tl = std::chrono::steady_clock::now(); const bool timing = getenv("KSH_TIMING") != nullptr;
+  auto lap = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "  ingest %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tl).count()); tl = t1; };
+  std::vector<size_t> pod0(nb + 1, 0);
+  for (uint32_t b = 0; b < nb; ++b) {
+    const ksh_pod_block& B = blocks[b];
+    if (B.n_pods && (!B.spec_off || !B.spec_words || !B.uid || !B.creation_ts)) throw ksp::Error("pod block: null array");
+    if (B.n_strings && (!B.str_off || !B.str_bytes)) throw ksp::Error("pod block: null string table");
+    for (uint32_t i = 0; i < B.n_strings; ++i) if (B.str_off[i] > B.str_off[i + 1]) throw ksp::Error("pod block: string offsets must ascend");
+    pod0[b + 1] = pod0[b] + B.n_pods;
+  }
+  const size_t P = pod0[nb];
+  if (P >= (1ull << 31)) throw ksp::Error("pod block: too many pods");
+  auto block_of = [&](size_t i) { uint32_t b = 0; while (i >= pod0[b + 1]) ++b; return b; };
+  // 1. hash every record
+  std::vector<Hash128> hs(P); std::atomic<int> bad{0};
+  parallel_chunks(P, [&](size_t lo, size_t hi, uint32_t) {
+    if (lo >= hi) return; uint32_t b = block_of(lo);
+    for (size_t i = lo; i < hi; ++i) {
+      while (i >= pod0[b + 1]) ++b;
+      const ksh_pod_block& B = blocks[b]; const size_t l = i - pod0[b];
+      if (B.spec_off[l] > B.spec_off[l + 1] || B.uid[l] >= B.n_strings) { bad = 1; continue; }
+      Hash128 h; h.bytes((const char*)(B.spec_words + B.spec_off[l]), 4 * (size_t)(B.spec_off[l + 1] - B.spec_off[l])); h.finish(); hs[i] = h;
+    } });
+  if (bad) throw ksp::Error("pod block: record offsets must ascend and uid ids must name a string");
+  lap("hash records");
+  // 2. per block: partition by record equality (first occurrences in pod order)
+  struct Local { std::vector<uint32_t> first; std::vector<uint32_t> of; std::vector<uint32_t> global; };
+  std::vector<Local> loc(nb); std::vector<std::exception_ptr> errs(nb);
+  run_threads(nb, [&](uint32_t b) { try {
+    const ksh_pod_block& B = blocks[b]; Local& L = loc[b]; const uint32_t n = B.n_pods; L.of.resize(n);
+    uint64_t cap = 64; while (cap < 4ull * n) cap <<= 1;
+    std::vector<int32_t> tab(cap, -1);
+    for (uint32_t i = 0; i < n; ++i) {
+      const Hash128& h = hs[pod0[b] + i]; const uint32_t len = B.spec_off[i + 1] - B.spec_off[i]; int32_t found = -1;
+      uint64_t j = h.a & (cap - 1);
+      for (;; j = (j + 1) & (cap - 1)) {
+        const int32_t sidx = tab[j]; if (sidx < 0) break;
+        const uint32_t f = L.first[sidx]; const Hash128& o = hs[pod0[b] + f];
+        if (o.a == h.a && o.b == h.b && B.spec_off[f + 1] - B.spec_off[f] == len && memcmp(B.spec_words + B.spec_off[f], B.spec_words + B.spec_off[i], 4 * (size_t)len) == 0) { found = sidx; break; }
+      }
+      if (found < 0) { found = (int32_t)L.first.size(); tab[j] = found; L.first.push_back(i); }
+      L.of[i] = (uint32_t)found;
+    } } catch (...) { errs[b] = std::current_exception(); } });
+  for (auto& e : errs) if (e) std::rethrow_exception(e);
+  lap("partition blocks");
+  // 3. decode the distinct records (all blocks, in parallel), then merge them in batch order by content
+  std::vector<size_t> d0(nb + 1, 0); for (uint32_t b = 0; b < nb; ++b) d0[b + 1] = d0[b] + loc[b].first.size();
+  const size_t D = d0[nb]; std::vector<Pod> dec(D); std::vector<Hash128> dh(D);
+  parallel_chunks(D, [&](size_t lo, size_t hi, uint32_t) {
+    for (size_t x = lo; x < hi; ++x) {
+      uint32_t b = 0; while (x >= d0[b + 1]) ++b;
+      const ksh_pod_block& B = blocks[b]; const uint32_t f = loc[b].first[x - d0[b]];
+      dec[x] = ksp::SpecReader(B, B.spec_words + B.spec_off[f], B.spec_words + B.spec_off[f + 1]).read();
+      dh[x] = spec_hash(dec[x]);
+      Hash128& h = dh[x]; h.u(dec[x].volume_error ? 1 : 0); h.u(dec[x].volumes.size()); for (auto& v : dec[x].volumes) { h.str(v.driver); h.str(v.pvc); } h.finish();
+    } }, 64);
+  lap("decode distinct");
+  auto same_volumes = [](const Pod& a, const Pod& b) { if (a.volume_error != b.volume_error || a.volumes.size() != b.volumes.size()) return false; for (size_t i = 0; i < a.volumes.size(); ++i) if (a.volumes[i].driver != b.volumes[i].driver || a.volumes[i].pvc != b.volumes[i].pvc) return false; return true; };
+  { uint64_t cap = 64; while (cap < 4ull * D) cap <<= 1; std::vector<int32_t> tab(cap, -1); std::vector<size_t> rep;      // rep[g] = index into dec of global spec g
+    for (uint32_t b = 0; b < nb; ++b) { loc[b].global.resize(loc[b].first.size());
+      for (size_t l = 0; l < loc[b].first.size(); ++l) {
+        const size_t x = d0[b] + l; int32_t found = -1; uint64_t j = dh[x].a & (cap - 1);
+        for (;; j = (j + 1) & (cap - 1)) { const int32_t g = tab[j]; if (g < 0) break; const size_t y = rep[g]; if (dh[y].a == dh[x].a && dh[y].b == dh[x].b && same_spec(dec[y], dec[x]) && same_volumes(dec[y], dec[x])) { found = g; break; } }
+        if (found < 0) { found = (int32_t)rep.size(); tab[j] = found; rep.push_back(x); }
+        loc[b].global[l] = (uint32_t)found;
+      } }
+    out->specs.reserve(rep.size()); for (size_t x : rep) out->specs.push_back(std::move(dec[x])); }
+  lap("merge across blocks");
+  // 4. per pod: spec id, timestamp, uid bytes
+  out->pod_spec.resize(P); out->ts.resize(P); out->uid_off.resize(P + 1); out->uid_off[0] = 0;
+  { size_t off = 0; for (uint32_t b = 0; b < nb; ++b) { const ksh_pod_block& B = blocks[b]; for (uint32_t i = 0; i < B.n_pods; ++i) { off += B.str_off[B.uid[i] + 1] - B.str_off[B.uid[i]]; if (off >= (1ull << 32)) throw ksp::Error("pod block: uids exceed 4 GiB"); out->uid_off[pod0[b] + i + 1] = (uint32_t)off; } }
+    out->uid_bytes.resize(off); }
+  parallel_chunks(P, [&](size_t lo, size_t hi, uint32_t) {
+    if (lo >= hi) return; uint32_t b = block_of(lo);
+    for (size_t i = lo; i < hi; ++i) {
+      while (i >= pod0[b + 1]) ++b;
+      const ksh_pod_block& B = blocks[b]; const size_t l = i - pod0[b];
+      out->pod_spec[i] = loc[b].global[loc[b].of[l]]; out->ts[i] = B.creation_ts[l];
+      memcpy(&out->uid_bytes[out->uid_off[i]], B.str_bytes + B.str_off[B.uid[l]], out->uid_off[i + 1] - out->uid_off[i]);
+    } });
+  lap("per-pod arrays");
+  return out;
 }
 
 struct SnapshotBase {

@@ -15,6 +15,7 @@
 #include "../../include/ksolve.h"
 #include "hreq.hpp"
 #include "ksp.hpp"
+#include "kspb.hpp"
 
 namespace ksh {
 
@@ -28,6 +29,7 @@ struct ReqSetsStore {
 
 struct Encoded {
   std::shared_ptr<const ksp::Problem> src;      // the semantic problem (shared with the caller: a 100k-pod problem is never copied)
+  std::shared_ptr<const ksp::PodBatch> batch;   // (binary ingress, kspb.hpp) the pending pods in compact form; `src` then only supplies the environment
   // ---- naming tables for decode ----
   std::vector<std::string> key_names;                      // narrow keys
   std::vector<std::vector<std::string>> key_values;        // universe per key (ascending)
@@ -70,6 +72,9 @@ struct Encoded {
 };
 
 std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> pr, uint32_t flags);
+std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> env, std::shared_ptr<const ksp::PodBatch> batch, uint32_t flags);
+// Binary pod ingress (include/kshost.h ksh_pods_ingest): blocks of flat pod records -> distinct specs + 16 bytes per pod.
+std::shared_ptr<const ksp::PodBatch> ingest_pod_blocks(const ksh_pod_block* blocks, uint32_t n_blocks);
 inline std::unique_ptr<Encoded> encode(ksp::Problem&& pr, uint32_t flags) { return encode(std::make_shared<const ksp::Problem>(std::move(pr)), flags); }
 uint32_t host_threads();
 

@@ -257,6 +257,138 @@ class Pod:
                 w.write(f" {_tok(v.driver)} {_tok(v.pvc_id)}")
 
 
+_OPS = {"In": 0, "NotIn": 1, "Exists": 2, "DoesNotExist": 3, "Gt": 4, "Lt": 5}
+
+
+class PodBlockWriter:
+    """Binary pod ingress (include/kshost.h `ksh_pod_block`, grammar in karpenter_core_amd/host/kspb.hpp): what a cgo shim would fill from its
+    []*v1.Pod -- a table of interned strings and, per pod, a record of u32 words (string ids, counts, int64 milli-quantities as two words), the
+    uid (a string id) and the creationTimestamp.  Maps are written in ascending key order so that equal specs are equal word for word."""
+
+    def __init__(self):
+        self._ids: Dict[str, int] = {}
+        self._strs: List[bytes] = []
+        self._words: List[int] = []
+        self._off: List[int] = [0]
+        self._uid: List[int] = []
+        self._ts: List[int] = []
+
+    def _s(self, s: str) -> int:
+        i = self._ids.get(s)
+        if i is None:
+            i = self._ids[s] = len(self._strs)
+            self._strs.append(s.encode())
+        return i
+
+    def _map(self, w, m):
+        w.append(len(m))
+        for k in sorted(m):
+            w.append(self._s(k))
+            w.append(self._s(m[k]))
+
+    def _res(self, w, rl):
+        w.append(len(rl))
+        for k in sorted(rl):
+            v = parse_quantity_milli(rl[k]) & 0xFFFFFFFFFFFFFFFF
+            w.extend((self._s(k), v & 0xFFFFFFFF, v >> 32))
+
+    def _expr(self, w, e):
+        w.extend((self._s(e.key), _OPS[e.op], len(e.values)))
+        w.extend(self._s(v) for v in e.values)
+
+    def _sel(self, w, sel):
+        if sel is None:
+            w.append(1)
+            return
+        w.append(0)
+        self._map(w, sel.match_labels)
+        w.append(len(sel.match_expressions))
+        for e in sel.match_expressions:
+            self._expr(w, e)
+
+    def _term(self, w, t):
+        w.extend((self._s(t.topology_key), len(t.namespaces)))
+        w.extend(self._s(n) for n in t.namespaces)
+        self._sel(w, t.label_selector)
+
+    def add(self, p: "Pod"):
+        w = self._words
+        w.append(self._s(p.namespace))
+        self._map(w, p.labels)
+        self._map(w, p.node_selector)
+        w.append(len(p.required_affinity))
+        for term in p.required_affinity:
+            w.append(len(term))
+            for e in term:
+                self._expr(w, e)
+        w.append(len(p.preferred_affinity))
+        for pt in p.preferred_affinity:
+            w.extend((int(pt.weight) & 0xFFFFFFFF, len(pt.exprs)))
+            for e in pt.exprs:
+                self._expr(w, e)
+        w.append(len(p.tolerations))
+        for t in p.tolerations:
+            w.extend((self._s(t.key), self._s(t.operator), self._s(t.value), self._s(t.effect)))
+        w.append(len(p.containers))
+        for c in p.containers:
+            self._res(w, c.requests)
+            self._res(w, c.limits)
+            w.append(len(c.ports))
+            for hp in c.ports:
+                w.extend((self._s(hp.host_ip), int(hp.port) & 0xFFFFFFFF, self._s(hp.protocol)))
+        w.append(len(p.init_containers))
+        for c in p.init_containers:
+            self._res(w, c.requests)
+            self._res(w, c.limits)
+        w.append(len(p.spread))
+        for sp in p.spread:
+            w.extend((int(sp.max_skew) & 0xFFFFFFFF, self._s(sp.topology_key), 1 if sp.when_unsatisfiable == SCHEDULE_ANYWAY else 0))
+            self._sel(w, sp.label_selector)
+        w.append(len(p.affinity_required))
+        for t in p.affinity_required:
+            self._term(w, t)
+        w.append(len(p.affinity_preferred))
+        for wt in p.affinity_preferred:
+            w.append(int(wt.weight) & 0xFFFFFFFF)
+            self._term(w, wt.term)
+        w.append(len(p.anti_required))
+        for t in p.anti_required:
+            self._term(w, t)
+        w.append(len(p.anti_preferred))
+        for wt in p.anti_preferred:
+            w.append(int(wt.weight) & 0xFFFFFFFF)
+            self._term(w, wt.term)
+        if p.volume_error:
+            w.append(0xFFFFFFFF)
+        else:
+            w.append(len(p.volumes))
+            for v in p.volumes:
+                w.extend((self._s(v.driver), self._s(v.pvc_id)))
+        self._off.append(len(w))
+        self._uid.append(self._s(p.uid))
+        self._ts.append(int(p.creation_ts))
+
+    def arrays(self) -> dict:
+        import numpy as np
+        so = np.zeros(len(self._strs) + 1, dtype=np.uint32)
+        np.cumsum([len(b) for b in self._strs], out=so[1:])
+        return {"n_pods": len(self._uid), "n_strings": len(self._strs), "str_off": so, "str_bytes": np.frombuffer(b"".join(self._strs) + b"\0", dtype=np.uint8).copy(),
+                "spec_off": np.asarray(self._off, dtype=np.uint32), "spec_words": np.asarray(self._words if self._words else [0], dtype=np.uint32),
+                "uid": np.asarray(self._uid if self._uid else [0], dtype=np.uint32), "creation_ts": np.asarray(self._ts if self._ts else [0], dtype=np.int64)}
+
+
+def pods_to_blocks(pods: Sequence["Pod"], n_blocks: int = 1) -> List[dict]:
+    """The pending pods as `n_blocks` binary blocks (contiguous slices, each with its own string table -- one per filling goroutine in a shim)."""
+    n_blocks = max(1, min(n_blocks, max(1, len(pods))))
+    out = []
+    for b in range(n_blocks):
+        w = PodBlockWriter()
+        for p in pods[len(pods) * b // n_blocks: len(pods) * (b + 1) // n_blocks]:
+            w.add(p)
+        out.append(w.arrays())
+    return out
+
+
 def _ksp_reslist(rl: Dict[str, str], w):
     w.write(f" {len(rl)}")
     for k in sorted(rl):

@@ -84,6 +84,11 @@ def libs():
         kh.ksh_fingerprint.argtypes = [ctypes.c_void_p]
         kh.ksh_fingerprint.restype = ctypes.c_uint64
         kh.ksh_free.argtypes = [ctypes.c_void_p]
+        kh.ksh_pods_ingest.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_double)]
+        kh.ksh_pods_free.argtypes = [ctypes.c_void_p]
+        kh.ksh_pods_count.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+        kh.ksh_solve_from_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_double)]
+        kh.ksh_open_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
         _LIBS = (ks, kh)
     return _LIBS
 
@@ -205,6 +210,67 @@ def solve_from_pods(parsed: ParsedProblem, device: int = 0, stats: bool = False,
     h = ctypes.c_void_p()
     ms = (ctypes.c_double * 6)()
     rc = kh.ksh_solve_from_pods(parsed._p, device, KS_FLAG_STATS if stats else 0, ctypes.byref(h) if keep else None, ms)
+    if rc != KS_OK:
+        raise KSolveError(rc, kh.ksh_last_error().decode())
+    fp = FlatProblem(None, _handle=h) if keep else None
+    if fp is not None:
+        fp.kernel_ms = float(ms[3])
+    return fp, dict(zip(TIMING_KEYS, [float(x) for x in ms]))
+
+
+class _PodBlock(ctypes.Structure):      # include/kshost.h ksh_pod_block
+    _fields_ = [("n_pods", ctypes.c_uint32), ("n_strings", ctypes.c_uint32), ("str_off", ctypes.c_void_p), ("str_bytes", ctypes.c_void_p),
+                ("spec_off", ctypes.c_void_p), ("spec_words", ctypes.c_void_p), ("uid", ctypes.c_void_p), ("creation_ts", ctypes.c_void_p)]
+
+
+class PodBatch:
+    """The pending pods handed over as flat arrays (`ksh_pods_ingest`; blocks from `model.pods_to_blocks`) -- the binary door a cgo shim would
+    use instead of KSP1 text.  `ingest_ms` is the library's time to take the blocks in (hash, partition, decode the distinct specs)."""
+
+    def __init__(self, blocks: Sequence[dict]):
+        kh = libs()[1]
+        arr = (_PodBlock * max(1, len(blocks)))()
+        for i, b in enumerate(blocks):
+            arr[i] = _PodBlock(b["n_pods"], b["n_strings"], b["str_off"].ctypes.data, b["str_bytes"].ctypes.data, b["spec_off"].ctypes.data,
+                               b["spec_words"].ctypes.data, b["uid"].ctypes.data, b["creation_ts"].ctypes.data)
+        self._b = ctypes.c_void_p()
+        ms = ctypes.c_double()
+        rc = kh.ksh_pods_ingest(ctypes.cast(arr, ctypes.c_void_p), len(blocks), ctypes.byref(self._b), ctypes.byref(ms))
+        if rc != KS_OK:
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+        self.ingest_ms = float(ms.value)
+        n, s = ctypes.c_uint32(), ctypes.c_uint32()
+        kh.ksh_pods_count(self._b, ctypes.byref(n), ctypes.byref(s))
+        self.n_pods, self.n_specs = int(n.value), int(s.value)
+
+    def close(self):
+        if self._b:
+            libs()[1].ksh_pods_free(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def open_batch(env: ParsedProblem, batch: PodBatch, stats: bool = False) -> FlatProblem:
+    """Flatten `batch` against the environment `env` (a ParsedProblem of a Problem WITHOUT pods): host side only, like FlatProblem(problem)."""
+    kh = libs()[1]
+    h = ctypes.c_void_p()
+    rc = kh.ksh_open_batch(env._p, batch._b, KS_FLAG_STATS if stats else 0, ctypes.byref(h))
+    if rc != KS_OK:
+        raise KSolveError(rc, kh.ksh_last_error().decode())
+    return FlatProblem(None, _handle=h)
+
+
+def solve_from_batch(env: ParsedProblem, batch: PodBatch, device: int = 0, stats: bool = False, keep: bool = True):
+    """`solve_from_pods` for a batch that came in through the binary door."""
+    kh = libs()[1]
+    h = ctypes.c_void_p()
+    ms = (ctypes.c_double * 6)()
+    rc = kh.ksh_solve_from_batch(env._p, batch._b, device, KS_FLAG_STATS if stats else 0, ctypes.byref(h) if keep else None, ms)
     if rc != KS_OK:
         raise KSolveError(rc, kh.ksh_last_error().decode())
     fp = FlatProblem(None, _handle=h) if keep else None

@@ -12,7 +12,7 @@ cp ab/x_probes.so karpenter_core_amd/libksolve.so; python tools/phase_profile.py
 cp ab/check.so karpenter_core_amd/libksolve.so
 KS_POISON=0xA5 timeout 900 python -m pytest tests/test_parity.py tests/test_fuzz.py tests/test_fuzz_mid.py tests/test_scenarios.py tests/test_consolidation.py -m gpu -x -q 2>&1 | tail -6 > $O/v1_check_poison.log
 cp /tmp/keep.so karpenter_core_amd/libksolve.so
-timeout 600 python tools/stress_cold.py --cold 60 --batches 20 > $O/v1_stress.json 2>$O/v1_stress.err
-timeout 300 python tools/stress_cold.py --cold 30 --batches 10 --poison 0xA5 > $O/v1_stress_poison.json 2>$O/v1_stress_poison.err
+timeout 600 python tools/stress_cold.py --cold 40 --batches 20 > $O/v1_stress.json 2>$O/v1_stress.err
+timeout 300 python tools/stress_cold.py --cold 15 --batches 5 --poison 0xA5 > $O/v1_stress_poison.json 2>$O/v1_stress_poison.err
 KSH_TIMING=1 python tools/time_from_pods.py 100000 3 > $O/v1_from_pods.log 2>&1
 tail -3 $O/v1_time_default.log $O/v1_parity.log $O/v1_ab.log $O/v1_check_poison.log; cat $O/v1_stress.json | head -20
