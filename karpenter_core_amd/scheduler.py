@@ -179,13 +179,17 @@ class ParsedProblem:
     """The problem as C++ objects in host memory (ksh_parse) -- the analogue of the []*v1.Pod, []*cloudprovider.InstanceType and
     []*state.Node a Go caller holds when it calls NewScheduler / Solve.  `solve_from_pods` starts from here."""
 
-    def __init__(self, problem: Problem):
+    def __init__(self, problem: Optional[Problem], _text: Optional[bytes] = None):
         kh = libs()[1]
-        text = problem.to_ksp().encode()
+        text = _text if _text is not None else problem.to_ksp().encode()
         self._p = ctypes.c_void_p()
         rc = kh.ksh_parse(text, len(text), ctypes.byref(self._p))
         if rc != KS_OK:
             raise KSolveError(rc, kh.ksh_last_error().decode())
+
+    @classmethod
+    def from_text(cls, ksp_text: bytes) -> "ParsedProblem":
+        return cls(None, _text=ksp_text)
 
     def close(self):
         if self._p:
