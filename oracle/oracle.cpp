@@ -515,9 +515,17 @@ struct Topology {
         if ((int64_t)count - (int64_t)min <= (int64_t)t.max_skew && count < minCount) { minDomain = kv.first; minCount = count; found = true; }
       }
     }
-    if (!found) return new_req_sym(podDomains.key, Op::DoesNotExist);
+    if (!found) {
+      if (&t == relax_group) {      // (model check of the kernel's round resolver only: "accepts but for the skew", see Scheduler::solve_spec_v2)
+        relax_hit = true; Req r = new_req_sym(podDomains.key, Op::In);
+        for (auto& kv : t.domains) if (req_has(nodeDomains, dom_sym(kv.first))) r.values.insert(dom_sym(kv.first));
+        return r;
+      }
+      return new_req_sym(podDomains.key, Op::DoesNotExist);
+    }
     Req r = new_req_sym(podDomains.key, Op::In); r.values.insert(dom_sym(minDomain)); return r;
   }
+  const TopologyGroup* relax_group = nullptr; bool relax_hit = false;
   // nextDomainAffinity :202-233
   Req next_affinity(TopologyGroup& t, const ksp::Pod& pod, const Req& podDomains, const Req& nodeDomains) {
     Req options = new_req_sym(podDomains.key, Op::DoesNotExist);
@@ -987,6 +995,245 @@ struct Scheduler {
     unscheduled.assign(queue.begin(), queue.end());
     for (auto& n : new_nodes) n->requirements.m.erase(hostnameKey);
   }
+
+  // ------------------------------------------------------------------------------------------------
+  // Model check of the round resolver as the kernel runs it since round 2 (ksolve.hip "P2: the leader resolves the round"): candidates that
+  // already took pods of the round stay in play (exact resources with what the round put on them, hostname-keyed items followed through the
+  // round's certain records: exact reject / slack), runs of equivalent pods (SWEEP / CLIMB), zonal spread followed exactly on pinned nodes
+  // against counts kept for the round (dynamic spread: dd / rdyn / unknown candidates), closed candidates, the window-incomplete rule.
+  // The RULES are restated on the reference-shaped state; every prediction is then committed through the real add() and compared.
+  //   flags bit 2 (mutation, tests only): leave out the rdyn rule -- the model must then report violations (it would have caught that bug).
+  //   out[] as solve_spec.
+  // ------------------------------------------------------------------------------------------------
+  struct Dry { bool ok = false, skew_failed = false, changes = false; };
+  static bool req_equal(const Req& a, const Req& b) { return a.complement == b.complement && a.values == b.values && a.has_gt == b.has_gt && a.has_lt == b.has_lt && (!a.has_gt || a.gt == b.gt) && (!a.has_lt || a.lt == b.lt); }
+  static bool reqs_equal(const Reqs& a, const Reqs& b) { if (a.m.size() != b.m.size()) return false; auto x = a.m.begin(); auto y = b.m.begin(); for (; x != a.m.end(); ++x, ++y) if (x->first != y->first || !req_equal(x->second, y->second)) return false; return true; }
+  Dry dry_v2(Node* m, ExistingNode* e, PodState& ps, const ResList& extra, const TopologyGroup* relax) {
+    Dry d; ksp::Pod& pod = ps.spec; const Stats keep = st;
+    topo.relax_group = relax; topo.relax_hit = false;
+    auto done = [&](bool ok, bool changes) { d.ok = ok; d.changes = changes; d.skew_failed = topo.relax_hit; topo.relax_group = nullptr; st = keep; return d; };
+    const std::vector<ksp::Taint>& taints = m ? m->tmpl->taints : e->taints;
+    if (!taints_tolerates(taints, pod)) return done(false, false);
+    if (!(m ? m->ports.validate(pod, nullptr) : e->ports.validate(pod, nullptr))) return done(false, false);
+    const Reqs& base = m ? m->requirements : e->requirements;
+    ResList requests = res_merge(res_merge(m ? m->requests : e->requests, extra), requests_for_pods({&pod}));
+    if (e) { if (pod.volume_error || !pod.volumes.empty()) return done(false, false); if (!res_fits(requests, e->available)) return done(false, false); }
+    Reqs nodeReqs = base; Reqs podReqs = new_pod_requirements(pod);
+    if (!reqs_compatible(cx, nodeReqs, podReqs)) return done(false, false);
+    nodeReqs.add_all(podReqs);
+    Reqs topoReqs;
+    if (!topo.add_requirements(podReqs, nodeReqs, pod, &topoReqs)) return done(false, false);
+    if (!reqs_compatible(cx, nodeReqs, topoReqs)) return done(false, false);
+    nodeReqs.add_all(topoReqs);
+    if (m && filter_types(m->options, nodeReqs, requests).empty()) return done(false, false);
+    return done(true, !reqs_equal(nodeReqs, base));
+  }
+  void solve_spec_v2(int W, long long* out, int flags = 0, int maxcls = 0) {
+    typedef const TopologyGroup* G; typedef std::set<G> GS;
+    auto meets = [](const GS& a, const GS& b) { for (G g : a) if (b.count(g)) return true; return false; };
+    auto trivial_filter = [](const TopologyGroup& t) { if (t.filter.always || t.filter.terms.empty()) return true; for (auto& term : t.filter.terms) if (term.m.empty()) return true; return false; };
+    const bool no_rdyn = (flags & 4) != 0;
+    GS initial; for (auto& tc : topo.topologies) initial.insert(tc.get());
+    // groups the resolver follows exactly: unfiltered spread groups present from the start on ONE narrow key (the one with the most of them)
+    GS dyn_groups;
+    { std::map<Sym, std::vector<G>> per; for (auto& tc : topo.topologies) if (tc->type == kSpread && !tc->is_hostname && trivial_filter(*tc) && tc->domains.size() <= 8) per[tc->key].push_back(tc.get());
+      const std::vector<G>* best = nullptr; for (auto& kv : per) if (!best || kv.second.size() > best->size()) best = &kv.second;
+      if (best) for (size_t i = 0; i < best->size() && i < 16; ++i) dyn_groups.insert((*best)[i]); }
+    const Sym dyn_key = dyn_groups.empty() ? (Sym)-1 : (*dyn_groups.begin())->key;
+    std::vector<int> q(pods.size()); for (size_t i = 0; i < pods.size(); ++i) q[i] = (int)i;
+    std::vector<ResList> rq(pods.size()); for (size_t i = 0; i < pods.size(); ++i) rq[i] = requests_for_pods({&pods[i].spec});
+    auto get = [](const ResList& r, const char* k) { auto it = r.find(k); return it == r.end() ? (int64_t)0 : it->second; };
+    std::sort(q.begin(), q.end(), [&](int a, int b) {
+      int64_t ca = get(rq[a], "cpu"), cb = get(rq[b], "cpu"); if (ca != cb) return ca > cb;
+      int64_t ma = get(rq[a], "memory"), mb = get(rq[b], "memory"); if (ma != mb) return ma > mb;
+      if (pods[a].spec.creation_ts != pods[b].spec.creation_ts) return pods[a].spec.creation_ts < pods[b].spec.creation_ts;
+      return pods[a].spec.uid < pods[b].spec.uid;
+    });
+    std::deque<int> queue(q.begin(), q.end());
+    std::unordered_map<int, size_t> lastLen;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    auto sequential_step = [&]() -> bool {
+      int pi = queue.front();
+      auto ll = lastLen.find(pi);
+      if (ll != lastLen.end() && ll->second == queue.size()) return false;
+      queue.pop_front(); st.queue_pops++;
+      PodState& ps = pods[pi];
+      if (add(ps)) return true;
+      bool relaxed = relax(ps.spec);
+      queue.push_back(pi);
+      if (relaxed) { lastLen.clear(); ps.stage++; st.relaxations++; topo.update(ps.spec); } else lastLen[pi] = queue.size();
+      return true;
+    };
+    struct Info { std::vector<TopologyGroup*> narrow, host; GS tmask, tfull, rmask, rsure, zmask; bool eligible = true; int dyn = 0; TopologyGroup* dg = nullptr; bool self = false; std::string ev; ResList req; };
+    struct Cand { Node* n = nullptr; ExistingNode* e = nullptr; size_t cnt0 = 0, cnt = 0; bool moved = false, closed = false; int np = 0, last = -1; ResList extra; GS racc, rsure, unsure; std::map<G, int> hrec; bool pinned = false; DomKey zone; uint64_t key = 0; };
+    while (!queue.empty()) {
+      std::stable_sort(new_nodes.begin(), new_nodes.end(), [](const std::unique_ptr<Node>& a, const std::unique_ptr<Node>& b) { return a->pods.size() < b->pods.size(); });
+      const size_t E = existing.size(), total = E + new_nodes.size(), nc = std::min<size_t>(64, total);
+      const bool window_complete = total <= 64;
+      std::vector<Cand> C(nc);
+      for (size_t i = 0; i < nc; ++i) {
+        Cand& c = C[i]; if (i < E) c.e = existing[i].get(); else { c.n = new_nodes[i - E].get(); c.cnt0 = c.cnt = c.n->pods.size(); }
+        c.key = i < E ? (uint64_t)i : (((uint64_t)c.cnt << 8) | (64u + (uint64_t)i));
+        if (dyn_key != (Sym)-1) { const Reqs& rq2 = c.n ? c.n->requirements : c.e->requirements; if (rq2.has(dyn_key)) { const Req& z = rq2.m.at(dyn_key); if (!z.complement && z.values.size() == 1) { c.pinned = true; c.zone = hn.of(z.values.v[0]); } } }
+      }
+      const size_t cnt_last = nc ? C[nc - 1].cnt : 0;
+      // ---- the round's pods ----
+      size_t n = 0; std::vector<Info> I;
+      { std::set<std::string> seen;
+        while (n < (size_t)W && n < queue.size() && lastLen.find(queue[n]) == lastLen.end()) {
+          PodState& ps = pods[queue[n]]; ksp::Pod& pod = ps.spec; Info in; in.ev = eval_signature(ps); in.req = requests_for_pods({&pod});
+          for (auto& c : pod.containers) if (!c.ports.empty()) in.eligible = false;
+          if (pod.volume_error || !pod.volumes.empty()) in.eligible = false;
+          if (!topo.inert) {
+            Reqs podReqs = new_pod_requirements(pod);
+            for (auto& tc : topo.topologies) if (tc->owners.count(pod.uid)) { (tc->is_hostname ? in.host : in.narrow).push_back(tc.get()); }
+            for (auto& tc : topo.inverse) if (tg_selects(*tc, pod)) { (tc->is_hostname ? in.host : in.narrow).push_back(tc.get()); }
+            for (auto* g : in.narrow) { in.tmask.insert(g); in.tfull.insert(g); }
+            for (auto* g : in.host) {
+              in.tfull.insert(g); const bool self = tg_selects(*g, pod);
+              const bool own_counter_only = g->type == kAntiAffinity || (g->type == kSpread && initial.count(g));
+              if (!own_counter_only) in.tmask.insert(g);
+              if (g->type == kAntiAffinity || (g->type == kSpread && (int64_t)g->max_skew - (self ? 1 : 0) <= 0)) in.zmask.insert(g);
+            }
+            for (auto& tc : topo.topologies) if (tg_selects(*tc, pod)) {
+              in.rmask.insert(tc.get());
+              if (tc->is_hostname) { if (initial.count(tc.get()) && trivial_filter(*tc)) in.rsure.insert(tc.get()); if (!initial.count(tc.get())) in.eligible = false; }
+            }
+            for (auto& tc : topo.inverse) if (tc->owners.count(pod.uid)) { in.rmask.insert(tc.get()); if (tc->is_hostname) in.rsure.insert(tc.get()); }
+            if (in.narrow.size() == 1 && in.host.empty() && in.narrow[0]->type == kSpread && dyn_groups.count(in.narrow[0]) && !podReqs.has(in.narrow[0]->key) && in.narrow[0]->max_skew >= 0 && in.narrow[0]->max_skew < (1 << 24)) { in.dyn = 1; in.dg = in.narrow[0]; in.self = tg_selects(*in.dg, pod); }
+            else if (in.narrow.empty() && in.host.size() == 1 && in.host[0]->type != kAffinity) { in.dyn = 2; in.dg = in.host[0]; in.self = tg_selects(*in.dg, pod); }
+          }
+          if (!in.eligible) break;
+          if (maxcls > 0 && !seen.count(in.ev)) { if ((int)seen.size() == maxcls) break; seen.insert(in.ev); }
+          I.push_back(std::move(in)); ++n;
+        } }
+      if (n < 2) { out[2]++; if (!sequential_step()) break; continue; }
+      // ---- one evaluation per evaluation class against the snapshot: strict, "but for the skew", changes-the-node ----
+      std::vector<uint64_t> m(n, 0), mo(n, 0), chg(n, 0);
+      { std::map<std::string, size_t> firstof;
+        for (size_t k = 0; k < n; ++k) {
+          auto it = firstof.find(I[k].ev); if (it != firstof.end()) { m[k] = m[it->second]; mo[k] = mo[it->second]; chg[k] = chg[it->second]; continue; }
+          firstof[I[k].ev] = k; PodState& ps = pods[queue[k]];
+          for (size_t i = 0; i < nc; ++i) {
+            Dry d = dry_v2(C[i].n, C[i].e, ps, ResList{}, I[k].dyn == 1 ? I[k].dg : nullptr);
+            if (d.ok) { mo[k] |= 1ull << i; if (!d.skew_failed) m[k] |= 1ull << i; if (d.changes) chg[k] |= 1ull << i; }
+          }
+        } }
+      // ---- the resolver ----
+      std::vector<int> win(n, -1); size_t k = 0; GS rall, rdyn; std::map<G, std::map<DomKey, int>> dd; uint64_t moved = 0, closed = 0;
+      auto hostdom = [&](const Cand& c) { const Reqs& r2 = c.n ? c.n->requirements : c.e->requirements; return hn.of(r2.m.at(hostnameKey).values.v[0]); };
+      auto scaled = [](const ResList& r, int64_t t) { ResList o; for (auto& kv : r) o[kv.first] = kv.second * t; return o; };
+      auto same_run = [&](size_t a, size_t b) { return I[a].tfull.empty() && I[b].tfull.empty() && I[a].ev == I[b].ev; };
+      // what one pod records on candidate c (track_records / track_one + count_host): returns the part of its record set that goes into rall
+      auto place_records = [&](Cand& c, const Info& in, bool chg_c) -> GS {
+        for (G g : in.rsure) if (g->is_hostname) c.hrec[g]++;
+        GS inx;
+        for (G g : in.rmask) {
+          if (!dyn_groups.count(g)) { inx.insert(g); continue; }
+          if (c.pinned) { dd[g][c.zone]++; rdyn.insert(g); }
+          else if (chg_c) inx.insert(g);
+        }
+        return inx;
+      };
+      bool cut = false;
+      while (k < n && !cut) {
+        const Info& in = I[k]; PodState& ps = pods[queue[k]];
+        const bool follows = in.dyn == 1;
+        if (meets(in.tmask, rall) || (!follows && !no_rdyn && meets(in.tmask, rdyn))) { out[4]++; break; }
+        uint64_t mk = m[k], unk = 0; GS tfk = in.tfull;
+        if (follows) {
+          TopologyGroup* g = in.dg; auto& ddg = dd[g]; bool anyd = false; for (auto& kv : ddg) if (kv.second) anyd = true;
+          int64_t mn = INT64_MAX; for (auto& kv : g->domains) { const int64_t c2 = (int64_t)kv.second + (ddg.count(kv.first) ? ddg[kv.first] : 0); if (c2 < mn) mn = c2; }
+          uint64_t pinned = 0, okz = 0;
+          for (size_t i = 0; i < nc; ++i) if (C[i].pinned) {
+            pinned |= 1ull << i; auto it = g->domains.find(C[i].zone);
+            if (it != g->domains.end()) { const int64_t c2 = (int64_t)it->second + (ddg.count(C[i].zone) ? ddg[C[i].zone] : 0) + (in.self ? 1 : 0); if (c2 - mn <= (int64_t)g->max_skew) okz |= 1ull << i; }
+          }
+          if (anyd) unk = mo[k] & ~pinned;
+          mk = (mo[k] & okz) | (anyd ? unk : (m[k] & ~pinned));
+          tfk.erase(g);
+        }
+        const bool hsk = in.dyn == 2;
+        size_t r = 1; if (tfk.empty()) while (k + r < n && same_run(k + r - 1, k + r)) ++r;
+        // candidates the round already used: exact resources with what it put on them; hostname counters
+        uint64_t A = mk & ~moved;
+        for (size_t i = 0; i < nc; ++i) if ((mk & moved) >> i & 1ull) {
+          bool ok = dry_v2(C[i].n, C[i].e, ps, C[i].extra, follows ? in.dg : nullptr).ok;
+          if (hsk) {
+            const TopologyGroup* h = in.dg; const int extra = C[i].hrec.count(h) ? C[i].hrec[h] : 0; int64_t slack = 0;
+            if (h->type == kSpread) { auto it = h->domains.find(hostdom(C[i])); const int64_t c0 = it == h->domains.end() ? 0 : it->second; slack = (int64_t)h->max_skew - (in.self ? 1 : 0) - c0; }
+            if (slack < 0) slack = 0; if (slack > 255) slack = 255;
+            if (extra > slack) ok = false;
+          } else { GS z; for (G g : tfk) if (in.zmask.count(g)) z.insert(g); if (meets(z, C[i].rsure)) ok = false; }
+          if (ok) A |= 1ull << i;
+        }
+        if (!A) { out[5]++; break; }
+        int bu = -1; for (size_t i = 0; i < nc; ++i) if ((A >> i) & 1ull) if (bu < 0 || C[i].key < C[bu].key) bu = (int)i;
+        if ((unk >> bu) & 1ull) { out[4]++; break; }
+        const bool bu_moved = (moved >> bu) & 1ull, bu_new = (size_t)bu >= E;
+        if (bu_moved) {
+          if (bu_new && !window_complete && C[bu].cnt > cnt_last) { out[5]++; break; }
+          if ((closed >> bu) & 1ull) { out[5]++; break; }
+          if (meets(tfk, hsk ? C[bu].unsure : C[bu].racc)) { out[4]++; break; }
+        }
+        if (r >= 2 && !bu_moved && bu_new) {      // SWEEP
+          std::vector<size_t> S0; for (size_t i = 0; i < nc; ++i) if (((A & ~moved) >> i) & 1ull) if (C[i].cnt == C[bu].cnt) S0.push_back(i);
+          const size_t sN = std::min(r, S0.size());
+          if (sN >= 2) {
+            for (size_t x = 0; x < sN; ++x) {
+              const size_t i = S0[x], j = k + x; Cand& c = C[i]; const Info& ij = I[j]; const bool chg_i = (chg[k] >> i) & 1ull;
+              c.extra = res_merge(c.extra, ij.req); for (G g : ij.rmask) { c.racc.insert(g); if (!ij.rsure.count(g)) c.unsure.insert(g); } for (G g : ij.rsure) c.rsure.insert(g);
+              c.np = 1; c.last = (int)j; c.cnt++; c.key = ((uint64_t)c.cnt << 8) | (uint64_t)(63 - j);
+              for (G g : place_records(c, ij, chg_i)) rall.insert(g);
+              win[j] = (int)i; moved |= 1ull << i; if (chg_i) closed |= 1ull << i;
+            }
+            k += sN; continue;
+          }
+        }
+        size_t t = 1;
+        if (r >= 2 && !((chg[k] >> bu) & 1ull)) {   // CLIMB
+          size_t t_order = r;
+          if (bu_new) {
+            uint64_t other = UINT64_MAX; for (size_t i = 0; i < nc; ++i) if (((A >> i) & 1ull) && (int)i != bu && C[i].key < other) other = C[i].key;
+            uint64_t oc = other == UINT64_MAX ? 0x00FFFFFFull : (other >> 8);
+            if (!window_complete) oc = std::min<uint64_t>(oc, cnt_last);
+            t_order = oc >= C[bu].cnt ? (size_t)(oc - C[bu].cnt + 1) : 1;
+          }
+          size_t t_res = 1; while (t_res < r && dry_v2(C[bu].n, C[bu].e, ps, res_merge(C[bu].extra, scaled(in.req, (int64_t)t_res)), nullptr).ok) ++t_res;
+          t = std::max<size_t>(1, std::min(std::min(r, t_order), t_res));
+        }
+        { Cand& c = C[bu]; const bool chg_bu = (chg[k] >> bu) & 1ull;
+          for (size_t x = 0; x < t; ++x) {
+            const Info& ij = I[k + x];
+            c.extra = res_merge(c.extra, ij.req); for (G g : ij.rmask) { c.racc.insert(g); if (!ij.rsure.count(g)) c.unsure.insert(g); } for (G g : ij.rsure) c.rsure.insert(g);
+            for (G g : place_records(c, ij, chg_bu)) rall.insert(g);
+            win[k + x] = bu;
+          }
+          c.np += (int)t; c.last = (int)(k + t - 1); if (bu_new) { c.cnt += t; c.key = ((uint64_t)c.cnt << 8) | (uint64_t)(63 - (k + t - 1)); }
+          moved |= 1ull << bu; if (chg_bu) closed |= 1ull << bu; }
+        k += t;
+      }
+      const size_t n_ok = k;
+      if (n_ok == 0) { out[2]++; if (!sequential_step()) break; continue; }
+      out[1]++; if (n_ok >= 8) out[6] += (long long)n_ok; if ((long long)n_ok > out[7]) out[7] = (long long)n_ok;
+      // ---- commit the predictions through the real algorithm and compare ----
+      bool stop = false;
+      for (size_t j = 0; j < n_ok; ++j) {
+        int pi = queue.front(); queue.pop_front(); st.queue_pops++;
+        PodState& ps = pods[pi];
+        const size_t before_nodes = new_nodes.size();
+        bool placed = add(ps);
+        bool match = placed && new_nodes.size() == before_nodes;
+        if (match) { const Cand& c = C[win[j]]; match = c.e ? (!c.e->pods.empty() && c.e->pods.back() == ps.index) : (!c.n->pods.empty() && c.n->pods.back() == ps.index); }
+        if (!match) { out[3]++; if (out[3] <= 5) fprintf(stderr, "resolver rule violated: pod %d (round position %zu of %zu) predicted candidate %d\n", pi, j, n_ok, win[j]); }
+        if (!placed) { bool relaxed = relax(ps.spec); queue.push_back(pi); if (relaxed) { lastLen.clear(); ps.stage++; st.relaxations++; topo.update(ps.spec); } else lastLen[pi] = queue.size(); stop = true; break; }
+        out[0]++;
+      }
+      (void)stop;
+    }
+    unscheduled.assign(queue.begin(), queue.end());
+    for (auto& n : new_nodes) n->requirements.m.erase(hostnameKey);
+  }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1136,7 +1383,7 @@ int ko_solve_spec2(const char* ksp_text, size_t len, int W, int flags, int maxcl
   try {
     ksp::Problem pr = ksp::Parser(ksp_text, len).parse();
     auto s = oracle::build(pr, false);
-    s->solve_spec(W, counters, flags, maxcls);
+    if (flags & 2) s->solve_spec_v2(W, counters, flags, maxcls); else s->solve_spec(W, counters, flags, maxcls);
     std::string r = oracle::result_text(*s, 0.0);
     *out_text = strdup(r.c_str()); oracle::g_in = nullptr; return 0;
   } catch (const std::exception& e) { *out_text = strdup(e.what()); oracle::g_in = nullptr; return -1; }

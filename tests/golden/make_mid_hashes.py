@@ -14,8 +14,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import oracle_py as O  # noqa: E402
 import test_fuzz_mid as T  # noqa: E402
 
-out = {}
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mid_hashes.json")
+out = json.load(open(path)) if os.path.exists(path) and "--all" not in sys.argv else {}      # (seeds already there are kept: pass --all to redo them)
 for seed in T.MID_SEEDS:
+    if str(seed) in out:
+        continue
     p = T.mid_problem(seed)
     t = time.time()
     r = O.solve(p)
@@ -23,4 +26,4 @@ for seed in T.MID_SEEDS:
                           unscheduled=len(r.unscheduled), relaxed_pods=sum(1 for s in r.final_stage if s > 0) if isinstance(r.final_stage, list) else None,
                           oracle_seconds=round(time.time() - t, 1))
     print(seed, out[str(seed)], flush=True)
-json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "mid_hashes.json"), "w"), indent=1, sort_keys=True)
+    json.dump(out, open(path, "w"), indent=1, sort_keys=True)

@@ -9,13 +9,15 @@ import pytest
 
 from karpenter_core_amd import fake, workloads as W
 from karpenter_core_amd.model import (Container, DO_NOT_SCHEDULE, Expr, LABEL_ARCH, LABEL_CAPACITY_TYPE, LABEL_HOSTNAME, LABEL_ZONE, LabelSelector,
-                                      Pod, PodAffinityTerm, PreferredTerm, Problem, SCHEDULE_ANYWAY, TopologySpreadConstraint)
+                                      Pod, PodAffinityTerm, PreferredTerm, Problem, SCHEDULE_ANYWAY, TopologySpreadConstraint, WeightedPodAffinityTerm)
 from oracle import oracle_py as O
 
-MID_SEEDS = list(range(12))
+MID_SEEDS = list(range(36))
 
 
 def mid_problem(seed: int) -> Problem:
+    if seed >= 12:
+        return mid_problem_wide(seed)
     rs = np.random.RandomState(31000 + seed)
     sizes = int(rs.randint(2, 7))                       # small types -> many nodes
     zone_sets = [[W.ZONES[0]], [W.ZONES[1]], [W.ZONES[2]], W.ZONES[:2], W.ZONES]
@@ -52,6 +54,74 @@ def mid_problem(seed: int) -> Problem:
         # k == 7: generic
         pods.append(p)
     return Problem(instance_types=its, provisioners=[fake.provisioner("default", len(its))], pods=pods, extra_well_known=fake.EXTRA_WELL_KNOWN)
+
+
+def mid_problem_wide(seed: int) -> Problem:
+    """Seeds >= 12: the same queue shapes over a wider environment -- in-flight (existing) nodes with room left, whose zone / arch / capacity-type
+    labels pin them; two provisioners (weights, one tainted, pods that tolerate it or not); and more kinds of readers of the zonal spread groups:
+    a spread over zones next to a node selector on the zone (a requirement of the pod's own on the spread key), two DoNotSchedule spreads on one
+    pod (zone + hostname), spreads that share a group with other pods' selectors at maxSkew up to 4."""
+    from karpenter_core_amd.model import (LABEL_INSTANCE_TYPE, LABEL_OS, LABEL_PROVISIONER, NO_SCHEDULE, StateNode, Taint, Toleration)
+    rs = np.random.RandomState(47000 + seed)
+    sizes = int(rs.randint(2, 6))
+    zone_sets = [[W.ZONES[0]], [W.ZONES[1]], [W.ZONES[2]], W.ZONES[:2], W.ZONES]
+    its = fake.assorted_ladder(sizes, ["amd64", "arm64"], ["linux", "windows"], zone_sets, [["spot", "on-demand"], ["on-demand"]][: 1 + seed % 2])
+    npods = int(rs.randint(2000, 6001))
+    nlab = int(rs.randint(2, 7))
+    labels = W.LABEL_VALUES[:nlab]
+    mix = rs.dirichlet(np.ones(11)) if seed % 3 else np.ones(11) / 11
+    cpus = [100, 250, 500, 1000, 1500][: int(rs.randint(2, 6))]
+    mems = [100, 256, 512, 1024][: int(rs.randint(2, 5))]
+    two_provs = seed % 2 == 0
+    provs = [fake.provisioner("default", len(its))]
+    if two_provs:
+        provs = [fake.provisioner("gold", len(its), weight=10, taints=[Taint("team", "gold", NO_SCHEDULE)]), fake.provisioner("default", len(its))]
+    nodes = []
+    for e in range(int(rs.randint(0, 40)) if seed % 4 != 1 else 0):
+        it = its[int(rs.randint(len(its)))]
+        off = it.offerings[rs.randint(len(it.offerings))]
+        arch = [r for r in it.requirements if r.key == LABEL_ARCH][0].values[0]
+        os_ = [r for r in it.requirements if r.key == LABEL_OS][0].values[0]
+        name = f"inflight-{e:03d}"
+        nodes.append(StateNode(name=name, labels={LABEL_PROVISIONER: "default", LABEL_INSTANCE_TYPE: it.name, LABEL_ZONE: off.zone, LABEL_CAPACITY_TYPE: off.capacity_type,
+                                                  LABEL_ARCH: arch, LABEL_OS: os_, LABEL_HOSTNAME: name, "karpenter.sh/initialized": "true"},
+                               available={"cpu": f"{int(rs.randint(500, 4000))}m", "memory": f"{int(rs.randint(512, 8192))}Mi", "pods": str(int(rs.randint(3, 30)))},
+                               capacity=dict(it.capacity)))
+    pods = []
+    for i in range(npods):
+        lab = {"my-label": labels[rs.randint(nlab)]}
+        c = Container(requests={"cpu": f"{cpus[rs.randint(len(cpus))]}m", "memory": f"{mems[rs.randint(len(mems))]}Mi"})
+        p = Pod(uid=f"pod-{i:06d}", labels=lab, containers=[c])
+        sel = LabelSelector({"my-label": labels[rs.randint(nlab)]})
+        k = int(rs.choice(11, p=mix))
+        if k == 0:
+            p.spread = [TopologySpreadConstraint(1 + int(rs.randint(4)), LABEL_ZONE, DO_NOT_SCHEDULE, sel)]
+        elif k == 1:
+            p.spread = [TopologySpreadConstraint(1 + int(rs.randint(3)), LABEL_HOSTNAME, DO_NOT_SCHEDULE, sel)]
+        elif k == 2:
+            p.anti_required = [PodAffinityTerm(LABEL_HOSTNAME, LabelSelector({"my-label": lab["my-label"]}) if rs.rand() < 0.7 else sel)]
+        elif k == 3:
+            p.affinity_required = [PodAffinityTerm(LABEL_ZONE, sel)]
+        elif k == 4:      # a requirement of the pod's own on the spread key
+            p.spread = [TopologySpreadConstraint(1 + int(rs.randint(3)), LABEL_ZONE, DO_NOT_SCHEDULE, sel)]
+            p.required_affinity = [[Expr(LABEL_ZONE, "In", list(rs.choice(W.ZONES, size=2, replace=False)))]]
+        elif k == 5:      # two spreads on one pod
+            p.spread = [TopologySpreadConstraint(1 + int(rs.randint(2)), LABEL_ZONE, DO_NOT_SCHEDULE, sel), TopologySpreadConstraint(1 + int(rs.randint(2)), LABEL_HOSTNAME, DO_NOT_SCHEDULE, sel)]
+        elif k == 6:
+            p.spread = [TopologySpreadConstraint(1, LABEL_ZONE, SCHEDULE_ANYWAY, sel), TopologySpreadConstraint(2, LABEL_CAPACITY_TYPE, DO_NOT_SCHEDULE, sel)]
+        elif k == 7:
+            p.preferred_affinity = [PreferredTerm(10, [Expr(LABEL_ZONE, "In", ["no-such-zone"])]), PreferredTerm(5, [Expr(LABEL_ARCH, "In", ["amd64"])])]
+        elif k == 8:
+            p.node_selector = {LABEL_ARCH: ["amd64", "arm64"][rs.randint(2)]}
+            if rs.rand() < 0.5:
+                p.node_selector[LABEL_ZONE] = W.ZONES[rs.randint(3)]
+        elif k == 9:
+            p.anti_preferred = [WeightedPodAffinityTerm(3, PodAffinityTerm(LABEL_ZONE, sel))]
+        # k == 10: generic
+        if two_provs and rs.rand() < 0.4:
+            p.tolerations = [Toleration(key="team", operator="Exists")]
+        pods.append(p)
+    return Problem(instance_types=its, provisioners=provs, pods=pods, nodes=nodes, extra_well_known=fake.EXTRA_WELL_KNOWN)
 
 
 def fingerprints(res) -> dict:
