@@ -245,6 +245,24 @@ void ks_problem_free(ks_dev_problem* d);
  * the very arrays `base` was uploaded from (instance types, offerings, prices, the instance-type-key lattice) are not copied again, and the
  * tables derived from the catalogue are shared with it.  `base` must outlive the returned problem.  Anything not shared is uploaded as usual. */
 int ks_problem_upload_shared(const ks_problem* p, const ks_dev_problem* base, ks_dev_problem** out);
+/* ---- consolidation what-ifs derived ON THE DEVICE from a resident cluster snapshot (SURVEY 8b `ks_solve_batch(shared, whatif deltas, ...)`;
+ * deprovisioning/helpers.go:48-61,81-84: a what-if = the snapshot minus its candidate nodes plus their pods).  `base` is the snapshot flattened
+ * as ONE problem -- every node an existing node, every bound pod in the batch -- resident with its tables built.  A what-if is then nothing but
+ * its candidate set: ks_whatifs_open lays out the state of all n what-ifs in one arena, uploads KBs (candidate masks, remainingResources,
+ * descriptors) and builds every batch on the device (the snapshot's queue order restricted to the candidates' pods).  ks_whatifs_problems are
+ * ordinary device problems (views owned by the batch) for ks_solve_batch_dev / ks_batch_records_dev / ks_price_filter_dev / ...; in their
+ * results pod i is the i-th pod of the what-if in the SNAPSHOT's queue order (ks_whatifs_pod_ids names the snapshot pod behind each) and
+ * existing node e is the snapshot's row e (removed nodes receive nothing).  Only for snapshots without topology groups and volume limits
+ * (KS_ERR_UNSUPPORTED otherwise: the caller flattens those what-ifs one by one). */
+typedef struct ks_whatif_batch ks_whatif_batch;
+int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, const int32_t* pod_node /* [base P] node of every snapshot pod */,
+                    const int32_t* node_row /* [n_nodes] existing-node row in base, -1 if none */, uint32_t n, const uint32_t* cand_off /* [n+1] */,
+                    const uint32_t* cand /* node indices */, const uint32_t* n_pods /* [n] pods bound to each candidate set */,
+                    const int64_t* remaining /* [n][M][R] remainingResources without the candidates */, ks_whatif_batch** out);
+ks_dev_problem* const* ks_whatifs_problems(ks_whatif_batch* b);
+uint32_t ks_whatifs_count(const ks_whatif_batch* b);
+int ks_whatifs_pod_ids(ks_whatif_batch* b, uint32_t i, uint32_t* out /* [n_pods of what-if i] snapshot pod ids, what-if pod order */);
+void ks_whatifs_free(ks_whatif_batch* b);
 int ks_problem_prepare(ks_dev_problem* d);                     /* build the static tables + feasibility grid now (otherwise the first solve does) */
 /* Solve on the uploaded problem; kernel time (ms, HIP events on the solve stream) is returned in *kernel_ms if non-NULL. */
 int ks_solve_dev(ks_dev_problem* d, ks_result* out, float* kernel_ms);

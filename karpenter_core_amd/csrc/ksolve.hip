@@ -92,6 +92,10 @@ struct DevProb {
   const u32* cls_own_off; const u32* own_list; const u32* cls_sel_off; const u32* sel_list;
   const u32* cls_isel_off; const u32* isel_list; const u32* cls_iown_off; const u32* iown_list;
   const u32* pod_stage_off; const u32* stage_cls; const u32* queue;
+  // A what-if DERIVED on the device from a resident cluster snapshot (ks_whatifs_open): the batch is a subset of the snapshot's pods.  Pod i of
+  // the what-if (its position in the snapshot's queue order: queue == nullptr reads as the identity) is the snapshot's pod pod_gid[i], whose
+  // relaxation chain lives in the snapshot's pod_stage_off / stage_cls; en_removed: bit e = existing node e left the cluster (a candidate).
+  const u32* pod_gid; const u64* en_removed;
   const u8* grp_type; const i32* grp_key; const i32* grp_max_skew; const u8* grp_active; const u32* grp_filter_off; ReqSetsD flt;
   const i32* grp_count; const i32* grp_hslot; const i32* grph_count; const i32* grph_extra_pos;
   // derived static tables (built on the device by ks_build_type_tables / ks_grid_*)
@@ -1183,13 +1187,17 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
 
   // ---------------- initialise state (global memory); wave 0 alone, it is a one-off ----------------
   if (wv == 0) {
-  for (u32 i = lane; i < P.P; i += 64) { const u32 pd = P.queue[i]; tb.q[i] = (u64)pd | ((u64)P.stage_cls[P.pod_stage_off[pd]] << 32); G_lastgen[i] = 0xFFFFFFFFu; G_lastlen[i] = 0; G_pod_stage[i] = 0; tb.pod_node[i] = -1; tb.pod_seq[i] = -1; G_pod_reason[i] = 0; }
+  for (u32 i = lane; i < P.P; i += 64) { const u32 pd = P.queue ? P.queue[i] : i; const u32 gp = P.pod_gid ? P.pod_gid[pd] : pd; tb.q[i] = (u64)pd | ((u64)P.stage_cls[P.pod_stage_off[gp]] << 32); G_lastgen[i] = 0xFFFFFFFFu; G_lastlen[i] = 0; G_pod_stage[i] = 0; tb.pod_node[i] = -1; tb.pod_seq[i] = -1; G_pod_reason[i] = 0; }
   for (u32 e = lane; e < tb.E; e += 64) {
     const Rec r = slot_rec(S, tb, e);
-    r.taints() = P.en_taints[e]; r.present() = P.en.present[e]; r.complement() = P.en.complement[e]; r.it_state() = P.en.it_state[e];
-    r.reqmask() = P.en_requests_present[e]; r.count() = 0;
+    // (derived what-if) a node that left the cluster keeps its row -- the others keep their place in the visiting order -- but takes nothing:
+    // every pod requests `pods`, and no request fits a room of INT64_MIN / 2 (existingnode.go:99-103 is the first resource test); its taints
+    // are all set besides, so that a class that tolerated everything would still be refused by the resource test
+    const bool gone = P.en_removed && ((P.en_removed[e >> 6] >> (e & 63u)) & 1ull);
+    r.taints() = gone ? ~0ull : P.en_taints[e]; r.present() = P.en.present[e]; r.complement() = P.en.complement[e]; r.it_state() = P.en.it_state[e];
+    r.reqmask() = gone ? ((1u << tb.R) - 1u) : P.en_requests_present[e]; r.count() = 0;
     for (u32 k = 0; k < tb.K; ++k) { r.mask()[k] = P.en.mask[(size_t)e * tb.K + k]; r.gt()[k] = P.en.gt[(size_t)e * tb.K + k]; r.lt()[k] = P.en.lt[(size_t)e * tb.K + k]; }
-    for (u32 rr = 0; rr < tb.R; ++rr) { r.req()[rr] = P.en_requests[(size_t)e * tb.R + rr]; r.room()[rr] = P.en_avail[(size_t)e * tb.R + rr] - P.en_requests[(size_t)e * tb.R + rr]; r.low()[rr] = INT64_MIN; }
+    for (u32 rr = 0; rr < tb.R; ++rr) { r.req()[rr] = P.en_requests[(size_t)e * tb.R + rr]; r.room()[rr] = gone ? INT64_MIN / 2 : P.en_avail[(size_t)e * tb.R + rr] - P.en_requests[(size_t)e * tb.R + rr]; r.low()[rr] = INT64_MIN; }
     i32 head = -1; for (u32 i = P.en_port_off[e]; i < P.en_port_off[e + 1]; ++i) { S.pp_entry[i] = P.ports[i]; S.pp_next[i] = head; head = (i32)i; }
     r.porthead() = head;
     for (u32 h = 0; h < tb.GH; ++h) tb.hcnt[(size_t)e * tb.GH + h] = P.grph_count[(size_t)h * tb.E + e];
@@ -1658,14 +1666,15 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
 
     // ---- failure: Preferences.Relax + Queue.Push + Topology.Update (scheduler.go:116-123) ----
     if (!placed) {
-      const u32 nst = UF(G_pod_stage_off[pod + 1] - G_pod_stage_off[pod]);
+      const u32 gpod = P.pod_gid ? UF(GC(u32, P.pod_gid)[pod]) : pod;      // (derived what-if: the chain is the snapshot pod's)
+      const u32 nst = UF(G_pod_stage_off[gpod + 1] - G_pod_stage_off[gpod]);
       const i32 stg = (i32)UF(G_pod_stage[pod]);
       const bool relaxed = (u32)stg + 1 < nst;
       u32 tail = q_head + q_len; if (tail >= nP) tail -= nP;
       q_len++; pf_ok = false;
       if (lane == 0) {
         G_pod_reason[pod] = why;
-        const u32 ncls = relaxed ? G_stage_cls[G_pod_stage_off[pod] + stg + 1] : cidx;
+        const u32 ncls = relaxed ? G_stage_cls[G_pod_stage_off[gpod] + stg + 1] : cidx;
         tb.q[tail] = (u64)pod | ((u64)ncls << 32) | (relaxed ? 0ull : (1ull << 63));
         if (relaxed) {
           G_pod_stage[pod] = stg + 1;
@@ -2560,6 +2569,7 @@ struct ks_dev_problem {
   bool any_bounds = false;       // some requirement carries Gt/Lt -> the BOUNDS kernel variant
   bool lean_ok = false;          // none of the rarely used features is present -> the LEAN kernel variant (see ks_pack)
   u32 pp_cap = 0;
+  bool view = false;             // a what-if derived from a resident snapshot (ks_whatifs_open): memory and stream belong to its ks_whatif_batch
 };
 
 static inline size_t ks_align256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -2618,6 +2628,7 @@ static int validate(const ks_problem* p) {
 
 extern "C" void ks_problem_free(ks_dev_problem* d) {
   if (!d) return;
+  if (d->view) { delete d; return; }
   hipSetDevice(d->device);
   if (d->stream) { hipStreamSynchronize(d->stream); pool().put_stream(d->device, d->stream); }
   pool().put(d->device, d->arena_bytes, false, d->arena);
@@ -2776,6 +2787,153 @@ extern "C" int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem
 extern "C" int ks_problem_upload_shared(const ks_problem* p, const ks_dev_problem* base, ks_dev_problem** out) {
   if (!base) return fail(KS_ERR_INVALID, "null shared problem");
   return upload_impl(p, base->device, base, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Consolidation what-ifs DERIVED on the device from a resident cluster snapshot (SURVEY 8b `ks_solve_batch(shared, deltas ...)`, App. D.5;
+// deprovisioning/helpers.go:48-61,81-84: a what-if is the snapshot minus its candidate nodes plus their pods).  The snapshot -- every node
+// an existing node, every bound pod in the batch, flattened and uploaded ONCE with its tables and grid built -- stays resident; a what-if is
+// its candidate set.  ks_whatifs_open lays out the mutable state of all n what-ifs in ONE arena (one allocation, one host-to-device copy
+// of the candidate masks / remaining resources / descriptors, one memset), and ks_derive_whatifs builds every what-if's batch -- the
+// snapshot's queue order restricted to the pods of its candidate nodes -- on the device.  Each what-if is then an ordinary ks_dev_problem
+// (a view: it owns nothing) and goes through ks_solve_batch_dev / ks_batch_records_dev / the price stage like any other.
+// What the derivation cannot express falls to the caller: it requires a snapshot whose what-ifs differ in nothing but the pod subset,
+// the removed nodes and remainingResources (no topology groups, no volume limits: libkshost checks, and flattens per what-if otherwise).
+// ------------------------------------------------------------------------------------------------
+struct DeriveDesc { const u64* cand_nodes; u32* pod_gid; u32 P_expected, pad; };
+// one block per what-if: the snapshot's queue in order, 256 pods per step; a pod joins iff its node is a candidate; ballots give its place
+__global__ __launch_bounds__(256) void ks_derive_whatifs(const u32* base_queue, const i32* pod_node, u32 P_base, const DeriveDesc* descs, u32* mismatch) {
+  const DeriveDesc d = descs[blockIdx.x];
+  __shared__ u32 wave_cnt[4]; __shared__ u32 base_off;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base_off = 0;
+  __syncthreads();
+  for (u32 i0 = 0; i0 < P_base; i0 += 256) {
+    const u32 i = i0 + threadIdx.x; bool in = false; u32 pod = 0;
+    if (i < P_base) { pod = base_queue[i]; const i32 nd = pod_node[pod]; in = nd >= 0 && ((d.cand_nodes[nd >> 6] >> (nd & 63)) & 1ull); }
+    const u64 b = __ballot(in);
+    if (lane == 0) wave_cnt[wv] = (u32)__builtin_popcountll(b);
+    __syncthreads();
+    u32 off = base_off; for (int w = 0; w < wv; ++w) off += wave_cnt[w];
+    if (in) d.pod_gid[off + (u32)__builtin_popcountll(b & ((1ull << lane) - 1ull))] = pod;
+    __syncthreads();
+    if (threadIdx.x == 0) base_off += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && base_off != d.P_expected) atomicAdd(mismatch, 1u);
+}
+
+struct ks_whatif_batch {
+  int device = 0; u32 n = 0; hipStream_t stream = nullptr; bool own_stream = false;
+  u8* arena = nullptr; size_t arena_bytes = 0; u8* stage = nullptr; size_t stage_bytes = 0;
+  std::vector<ks_dev_problem*> views;
+};
+extern "C" void ks_whatifs_free(ks_whatif_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  if (b->stream) { hipStreamSynchronize(b->stream); pool().put_stream(b->device, b->stream); }
+  pool().put(b->device, b->arena_bytes, false, b->arena);
+  pool().put(b->device, b->stage_bytes, true, b->stage);
+  for (auto* v : b->views) delete v;
+  delete b;
+}
+extern "C" ks_dev_problem* const* ks_whatifs_problems(ks_whatif_batch* b) { return b ? b->views.data() : nullptr; }
+extern "C" uint32_t ks_whatifs_count(const ks_whatif_batch* b) { return b ? b->n : 0; }
+
+// base: the resident snapshot (tables built).  pod_node[base P]: snapshot node index of every snapshot pod (-1: none); node_row[n_nodes]: the node's
+// existing-node row in `base`, or -1 (a node no provisioner owns).  What-if w removes nodes cand[cand_off[w] .. cand_off[w+1]); n_pods[w] = pods
+// bound to them (the caller knows; checked on the device); remaining[w][M][R] = remainingResources with those nodes gone (scheduler.go:71-75).
+extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, const int32_t* pod_node, const int32_t* node_row, uint32_t n, const uint32_t* cand_off,
+                               const uint32_t* cand, const uint32_t* n_pods, const int64_t* remaining, ks_whatif_batch** out) {
+  if (out) *out = nullptr;
+  if (!base || !out || (n && (!cand_off || !n_pods || !remaining)) || (n_nodes && (!node_row)) || (base->h.P && !pod_node)) return fail(KS_ERR_INVALID, "null argument");
+  if (!base->tables_built) return fail(KS_ERR_INVALID, "the snapshot must be resident with its tables built (ks_problem_prepare)");
+  if (base->h.G || base->h.GH || base->h.ND || base->h.pod_gid) return fail(KS_ERR_UNSUPPORTED, "what-ifs can only be derived from a snapshot without topology groups and volume limits");
+  const DevProb& bh = base->h; const u32 E = bh.E, M = bh.M, R = bh.R, K = bh.K, TW = bh.TW, C = bh.C, Pb = bh.P;
+  HIPCHK(hipSetDevice(base->device));
+  auto b = new ks_whatif_batch(); b->device = base->device; b->n = n;
+  struct Guard { ks_whatif_batch* b; bool ok = false; ~Guard() { if (!ok) ks_whatifs_free(b); } } guard{b};
+  TRY(pool().get_stream(b->device, &b->stream));
+  const size_t NW = ((size_t)n_nodes + 63) / 64, EW = ((size_t)E + 63) / 64;
+  // ---- layout: [copied | zeroed | uninitialised], 256-byte aligned pieces ----
+  size_t sz[3] = {0, 0, 0};
+  auto take = [&](int region, size_t bytes) { const size_t at = sz[region]; sz[region] += ks_align256(bytes ? bytes : 1); return at; };
+  struct Lay { size_t cand_bits, removed, remaining, q, lastlen, lastgen, pod_stage, pod_node, pod_seq, pod_reason, rec, n_tmpl, n_alive, lowi, bstart, order_g, rem_state,
+               o_present, o_complement, o_mask, o_gt, o_lt, o_it, o_req, o_reqmask, pp_entry, pp_next, wm, stats, out_counts, unscheduled, pod_gid, round_scratch; u32 P, NMAX, pp_cap; };
+  std::vector<Lay> L(n);
+  const size_t pod_node_at = take(0, (size_t)Pb * sizeof(i32));
+  const u32 rec_stride = ks_rec_stride(R, K);
+  const size_t pp_static = E ? base->src.en_port_off[E] : 0;
+  for (u32 w = 0; w < n; ++w) {
+    Lay& l = L[w]; const u32 P = n_pods[w]; l.P = P; l.NMAX = P ? P : 1; const size_t NS = (size_t)E + l.NMAX, NM = l.NMAX;
+    l.cand_bits = take(0, NW * 8); l.removed = take(0, EW * 8); l.remaining = take(0, (size_t)M * R * 8);
+    l.rec = take(1, NS * rec_stride); l.bstart = take(1, ((size_t)P + 4) * 4); l.stats = take(1, 32 * 8); l.out_counts = take(1, 4 * 4);
+    l.q = take(2, (size_t)P * 8); l.lastlen = take(2, (size_t)P * 4); l.lastgen = take(2, (size_t)P * 4); l.pod_stage = take(2, (size_t)P * 4); l.pod_node = take(2, (size_t)P * 4);
+    l.pod_seq = take(2, (size_t)P * 4); l.pod_reason = take(2, (size_t)P * 4); l.n_tmpl = take(2, NM * 4); l.n_alive = take(2, (NM + 1) * TW * 8); l.lowi = take(2, 2 * NS * 8);
+    l.order_g = take(2, NM * 4); l.rem_state = take(2, (size_t)M * R * 8);
+    l.o_present = take(2, NM * 4); l.o_complement = take(2, NM * 4); l.o_mask = take(2, NM * K * 8); l.o_gt = take(2, NM * K * 4); l.o_lt = take(2, NM * K * 4); l.o_it = take(2, NM * 4);
+    l.o_req = take(2, NM * R * 8); l.o_reqmask = take(2, NM * 4);
+    // host-port pool: the existing reservations + at most the ports of every batch pod (an upper bound: 8 per pod would be unheard of; classes with ports carry their count)
+    size_t pp = pp_static; if (C && base->src.cls_port_off[C] != pp_static) { u32 mx = 0; for (u32 c = 0; c < C; ++c) mx = std::max(mx, base->src.cls_port_off[c + 1] - base->src.cls_port_off[c]); pp += (size_t)mx * P; }
+    l.pp_entry = take(2, pp * 8); l.pp_next = take(2, pp * 4); l.wm = take(2, (size_t)C * 4); l.unscheduled = take(2, (size_t)P * 4); l.pod_gid = take(2, (size_t)P * 4);
+    l.pp_cap = (u32)pp; l.round_scratch = n == 1 ? take(2, (size_t)8 * 64 * TW * 8) : 0;      // (a batch of one runs the multi-wave kernel, whose rounds keep rows to restore)
+  }
+  const size_t desc_at = take(0, (size_t)n * sizeof(DeriveDesc)), dprob_at = take(0, (size_t)n * sizeof(DevProb)), dstate_at = take(0, (size_t)n * sizeof(DevState));
+  const size_t mismatch_at = take(1, 4);
+  b->arena_bytes = sz[0] + sz[1] + sz[2]; b->stage_bytes = sz[0];
+  { void* a = nullptr; TRY(pool().get(b->device, b->arena_bytes, false, &a)); b->arena = (u8*)a; void* st = nullptr; TRY(pool().get(b->device, b->stage_bytes, true, &st)); b->stage = (u8*)st; }
+  u8* const r0 = b->arena; u8* const r1 = r0 + sz[0]; u8* const r2 = r1 + sz[1];
+  // ---- the copied region: pod -> node, per what-if candidate / removed masks and remaining resources, then the descriptors ----
+  memset(b->stage, 0, sz[0]);
+  if (Pb) memcpy(b->stage + pod_node_at, pod_node, (size_t)Pb * sizeof(i32));
+  b->views.resize(n, nullptr);
+  DeriveDesc* hd = (DeriveDesc*)(b->stage + desc_at); DevProb* hp = (DevProb*)(b->stage + dprob_at); DevState* hsv = (DevState*)(b->stage + dstate_at);
+  for (u32 w = 0; w < n; ++w) {
+    const Lay& l = L[w];
+    u64* cb = (u64*)(b->stage + l.cand_bits); u64* rb = (u64*)(b->stage + l.removed);
+    for (u32 i = cand_off[w]; i < cand_off[w + 1]; ++i) {
+      const u32 nd = cand[i]; if (nd >= n_nodes) return fail(KS_ERR_INVALID, "candidate node out of range");
+      cb[nd >> 6] |= 1ull << (nd & 63u);
+      const i32 row = node_row[nd]; if (row >= (i32)E) return fail(KS_ERR_INVALID, "node row out of range"); if (row >= 0) rb[row >> 6] |= 1ull << (row & 63);
+    }
+    memcpy(b->stage + l.remaining, remaining + (size_t)w * M * R, (size_t)M * R * 8);
+    hd[w] = DeriveDesc{(const u64*)(r0 + l.cand_bits), (u32*)(r2 + l.pod_gid), l.P, 0};
+    auto* v = new ks_dev_problem(); b->views[w] = v;
+    v->device = b->device; v->view = true; v->stream = b->stream; v->tables_built = true; v->any_bounds = base->any_bounds; v->lean_ok = base->lean_ok; v->src = base->src;
+    DevProb& h = v->h; h = bh;
+    h.P = l.P; h.NMAX = l.NMAX; h.queue = nullptr; h.pod_gid = (const u32*)(r2 + l.pod_gid); h.en_removed = (const u64*)(r0 + l.removed); h.tmpl_remaining = (const i64*)(r0 + l.remaining);
+    h.derived_shared = 1;
+    DevState& st = v->hs; st = DevState{};
+    st.q = (u64*)(r2 + l.q); st.lastlen = (u32*)(r2 + l.lastlen); st.lastgen = (u32*)(r2 + l.lastgen); st.pod_stage = (i32*)(r2 + l.pod_stage); st.pod_node = (i32*)(r2 + l.pod_node);
+    st.pod_seq = (i32*)(r2 + l.pod_seq); st.pod_reason = (u32*)(r2 + l.pod_reason);
+    st.rec = r1 + l.rec; st.rec_stride = rec_stride; st.n_tmpl = (i32*)(r2 + l.n_tmpl); st.n_alive = (u64*)(r2 + l.n_alive); st.lowi = (u64*)(r2 + l.lowi); st.round_scratch = n == 1 ? (u64*)(r2 + l.round_scratch) : nullptr;
+    st.bstart = (u32*)(r1 + l.bstart); st.order_g = (u32*)(r2 + l.order_g);
+    st.gcnt = nullptr; st.g_reg = nullptr; st.g_pos = nullptr; st.g_active = nullptr; st.hcnt = nullptr; st.g_hpos = nullptr; st.g_hzero = nullptr;
+    st.remaining = (i64*)(r2 + l.rem_state);
+    st.pp_entry = (u64*)(r2 + l.pp_entry); st.pp_next = (i32*)(r2 + l.pp_next); st.pp_cap = l.pp_cap;
+    st.vol_pad = 0; st.vol_cnt = nullptr; st.vol_set = nullptr; st.wm = (u32*)(r2 + l.wm);
+    st.stats = (u64*)(r1 + l.stats); st.out_counts = (u32*)(r1 + l.out_counts); st.batch_meta = nullptr; st.unscheduled = (i32*)(r2 + l.unscheduled);
+    st.o_present = (u32*)(r2 + l.o_present); st.o_complement = (u32*)(r2 + l.o_complement); st.o_mask = (u64*)(r2 + l.o_mask); st.o_gt = (i32*)(r2 + l.o_gt); st.o_lt = (i32*)(r2 + l.o_lt);
+    st.o_it = (i32*)(r2 + l.o_it); st.o_req = (i64*)(r2 + l.o_req); st.o_reqmask = (u32*)(r2 + l.o_reqmask);
+    hp[w] = h; hsv[w] = st;
+    v->d_prob = (DevProb*)(r0 + dprob_at) + w; v->d_state = (DevState*)(r0 + dstate_at) + w;
+  }
+  HIPCHK(hipMemcpyAsync(r0, b->stage, sz[0], hipMemcpyHostToDevice, b->stream));
+  if (sz[1]) HIPCHK(hipMemsetAsync(r1, 0, sz[1], b->stream));
+  if (const char* pz = getenv("KS_POISON")) { if (sz[2]) HIPCHK(hipMemsetAsync(r2, (int)strtol(pz, nullptr, 0) & 0xFF, sz[2], b->stream)); }
+  if (n) hipLaunchKernelGGL(ks_derive_whatifs, dim3(n), dim3(256), 0, b->stream, bh.queue, (const i32*)(r0 + pod_node_at), Pb, (const DeriveDesc*)(r0 + desc_at), (u32*)(r1 + mismatch_at));
+  u32 mismatch = 0;
+  HIPCHK(hipMemcpyAsync(&mismatch, r1 + mismatch_at, 4, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream)); HIPCHK(hipGetLastError());
+  if (mismatch) return fail(KS_ERR_INVALID, "n_pods does not match the pods bound to the candidate nodes");
+  guard.ok = true; *out = b; return KS_OK;
+}
+// the snapshot pods behind what-if i's batch, in ITS pod order (= the snapshot's queue order): out[n_pods]
+extern "C" int ks_whatifs_pod_ids(ks_whatif_batch* b, uint32_t i, uint32_t* out) {
+  if (!b || i >= b->n || !out) return fail(KS_ERR_INVALID, "bad argument");
+  HIPCHK(hipSetDevice(b->device));
+  if (b->views[i]->h.P) HIPCHK(hipMemcpy(out, b->views[i]->h.pod_gid, (size_t)b->views[i]->h.P * 4, hipMemcpyDeviceToHost));
+  return KS_OK;
 }
 
 // Build the derived tables + the feasibility grid (idempotent).  Returns the grid kernels' time.

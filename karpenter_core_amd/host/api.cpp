@@ -13,13 +13,34 @@
 #include "encode.hpp"
 
 namespace {
+// A batch of what-ifs derived on the device (ks_whatifs_open): the arena, the resident snapshot it points into and what the candidate sets were
+struct DeltaBatch {
+  ks_whatif_batch* b = nullptr; std::shared_ptr<void> base_dev; std::shared_ptr<const ksh::SnapshotBase> sb; std::vector<uint32_t> cand_off, cand;
+  ~DeltaBatch() { if (b) ks_whatifs_free(b); }
+};
 struct Handle {
   std::unique_ptr<ksh::Encoded> enc; ks_dev_problem* dev = nullptr; std::unique_ptr<ksh::Encoded::ResultBuf> rb;
+  std::shared_ptr<DeltaBatch> delta; uint32_t delta_index = 0;      // a derived what-if: `dev` is a view the batch owns; result pod ids follow the snapshot's queue order
   std::shared_ptr<void> base_dev;      // what-ifs over a snapshot: the snapshot's own flattening, resident on the device (shared catalogue + derived tables)
   bool solved = false;                 // rb holds the result of a successful solve (the result buffers are raw memory until then)
   bool dev_result = false;             // the device holds the result of a successful solve (price filter / launch pick / records read it there)
-  ~Handle() { if (dev) ks_problem_free(dev); }
+  ~Handle() { if (dev && !delta) ks_problem_free(dev); }
 };
+// KSR1 text of the result in h->rb.  A derived what-if numbers its pods in the snapshot's queue order; callers number a what-if's pods in
+// candidate order, then pod order (ksh_open_whatifs): translate before decoding.
+static std::string decode_handle(Handle* h, double dt) {
+  if (!h->delta) return h->enc->decode(h->rb->r, dt);
+  const DeltaBatch& D = *h->delta; const ksh::DeltaInputs in = ksh::delta_inputs(*D.sb); const uint32_t w = h->delta_index;
+  std::vector<std::pair<uint32_t, uint32_t>> byrank;      // (rank in the snapshot's queue, candidate-order index)
+  for (uint32_t i = D.cand_off[w]; i < D.cand_off[w + 1]; ++i) for (uint32_t p : (*in.by_node)[D.cand[i]]) byrank.push_back({in.pod_rank[p], (uint32_t)byrank.size()});
+  std::sort(byrank.begin(), byrank.end());
+  const uint32_t P = (uint32_t)byrank.size(); const ks_result& r = h->rb->r;
+  std::vector<int32_t> pn(P + 1), ps(P + 1), pq(P + 1), un(P + 1); std::vector<uint32_t> pr(P + 1);
+  for (uint32_t k = 0; k < P; ++k) { const uint32_t c = byrank[k].second; pn[c] = r.pod_node[k]; ps[c] = r.pod_stage[k]; pq[c] = r.pod_seq[k]; pr[c] = r.pod_reason[k]; }
+  for (uint32_t i = 0; i < r.n_unscheduled; ++i) un[i] = (int32_t)byrank[(uint32_t)r.unscheduled[i]].second;
+  ks_result t = r; t.pod_node = pn.data(); t.pod_stage = ps.data(); t.pod_seq = pq.data(); t.pod_reason = pr.data(); t.unscheduled = un.data();
+  return h->enc->decode(t, dt);
+}
 thread_local std::string g_err;
 uint32_t default_threads() { return ksh::host_threads(); }
 int set_err(int code, const std::string& m) { g_err = m; return code; }
@@ -135,7 +156,7 @@ int ksh_result_text(void* hv, char** out_text) {
   Handle* h = (Handle*)hv; if (out_text) *out_text = nullptr;
   if (!h || !out_text) return set_err(KS_ERR_INVALID, "null argument");
   if (!h->solved) return set_err(KS_ERR_INVALID, "the handle holds no result: solve it first (or the last solve failed)");
-  try { std::string s = h->enc->decode(h->rb->r, 0.0); *out_text = strdup(s.c_str()); return KS_OK; }
+  try { std::string s = decode_handle(h, 0.0); *out_text = strdup(s.c_str()); return KS_OK; }
   catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
 }
 
@@ -228,6 +249,63 @@ uint64_t ksh_fingerprint(void* hv) {
   return h;
 }
 
+}  // extern "C"
+// The snapshot's own flattening resident on `device` with its tables built (once per snapshot and device; shared by every what-if over it).
+static int resident_base(const ksh::Encoded* base, int device, std::shared_ptr<void>* out) {
+  std::lock_guard<std::mutex> g(base->dev_mu);
+  auto it = base->dev_resident.find(device);
+  if (it != base->dev_resident.end()) { *out = it->second; return KS_OK; }
+  ks_dev_problem* raw = nullptr;
+  int rc = ks_problem_upload(&base->prob, device, &raw);
+  if (rc == KS_OK) rc = ks_problem_prepare(raw);
+  if (rc != KS_OK) { if (raw) ks_problem_free(raw); return set_err(rc, ks_last_error()); }
+  *out = std::shared_ptr<void>(raw, [](void* p) { ks_problem_free((ks_dev_problem*)p); });
+  base->dev_resident[device] = *out;
+  return KS_OK;
+}
+extern "C" {
+// What-ifs DERIVED on the device from the resident snapshot (include/ksolve.h ks_whatifs_open): no per-what-if flattening, an upload of KBs.
+// Same contract as ksh_open_whatifs_parsed, with the problems already resident on `device`; KS_ERR_UNSUPPORTED (nothing opened) when the
+// snapshot's what-ifs do not differ by their candidate sets alone -- the caller then uses ksh_open_whatifs_parsed.
+int ksh_open_whatifs_derived(void* parsed, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand, const int32_t* pod_node, int device, void** out_handles) {
+  for (uint32_t w = 0; w < n; ++w) out_handles[w] = nullptr;
+  try {
+    Parsed* P = (Parsed*)parsed; std::shared_ptr<const ksp::Problem> snapshot = P->pr;
+    for (uint32_t i = 0; i < cand_off[n]; ++i) if (cand[i] >= snapshot->nodes.size()) return set_err(KS_ERR_INVALID, "candidate node out of range");
+    if (flags & KS_FLAG_STATS) return set_err(KS_ERR_UNSUPPORTED, "derived what-ifs carry no reference-algorithm statistics");
+    std::shared_ptr<const ksh::SnapshotBase> sb;
+    { std::lock_guard<std::mutex> g(P->mu);
+      const size_t np = snapshot->pods.size();
+      if (P->sb && P->sb_flags == flags && P->sb_pod_node.size() == np && std::equal(pod_node, pod_node + np, P->sb_pod_node.begin())) sb = P->sb;
+      else { sb = ksh::make_snapshot_base(snapshot, pod_node, flags); P->sb = sb; P->sb_flags = flags; P->sb_pod_node.assign(pod_node, pod_node + np); } }
+    const ksh::DeltaInputs in = ksh::delta_inputs(*sb);
+    if (!in.eligible) return set_err(KS_ERR_UNSUPPORTED, "what-ifs of this snapshot cannot be derived on the device: " + in.why);
+    auto D = std::make_shared<DeltaBatch>(); D->sb = sb; D->cand_off.assign(cand_off, cand_off + n + 1); D->cand.assign(cand, cand + cand_off[n]);
+    int rc = resident_base(in.base.get(), device, &D->base_dev); if (rc != KS_OK) return rc;
+    const ks_problem& bp = in.base->prob; const uint32_t M = bp.M, R = bp.R;
+    std::vector<uint32_t> npods(n, 0); std::vector<int64_t> rem((size_t)n * M * R);
+    for (uint32_t w = 0; w < n; ++w) {
+      int64_t* rw = &rem[(size_t)w * M * R]; std::copy(bp.tmpl_remaining, bp.tmpl_remaining + (size_t)M * R, rw);
+      for (uint32_t i = cand_off[w]; i < cand_off[w + 1]; ++i) {
+        const uint32_t nd = cand[i]; npods[w] += (uint32_t)(*in.by_node)[nd].size();
+        const int32_t m = in.node_tmpl[nd]; if (m >= 0) for (uint32_t r = 0; r < R; ++r) rw[(size_t)m * R + r] += in.node_cap[(size_t)nd * R + r];      // remainingResources: the node's capacity comes back (scheduler.go:244-246)
+      }
+    }
+    rc = ks_whatifs_open((const ks_dev_problem*)D->base_dev.get(), in.n_nodes, P->sb_pod_node.data(), in.node_row, n, cand_off, cand, npods.data(), rem.data(), &D->b);
+    if (rc != KS_OK) return set_err(rc, ks_last_error());
+    ks_dev_problem* const* views = ks_whatifs_problems(D->b);
+    for (uint32_t w = 0; w < n; ++w) {
+      auto h = std::make_unique<Handle>();
+      h->enc = std::make_unique<ksh::Encoded>(); h->enc->src = snapshot; h->enc->shared = in.base; h->enc->shared_lattice = true; h->enc->view = true;
+      h->enc->prob = bp; h->enc->prob.P = npods[w]; h->enc->prob.max_new_nodes = npods[w] ? npods[w] : 1;
+      h->dev = views[w]; h->delta = D; h->delta_index = w; h->base_dev = D->base_dev;
+      out_handles[w] = h.release();
+    }
+    return KS_OK;
+  } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());
+  } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
+}
+
 // Upload the flat problem to HBM (idempotent).
 int ksh_upload(void* hv, int device) {
   Handle* h = (Handle*)hv;
@@ -287,12 +365,13 @@ int ksh_solve(void* hv, char** out_text, float* kernel_ms, double* wall_ms) {
   int rc = h->dev ? KS_OK : ksh_upload(hv, ks_current_device()); if (rc != KS_OK) return rc;      // not uploaded yet: the calling thread's current HIP device
   auto t0 = std::chrono::steady_clock::now();
   h->solved = false; h->dev_result = false;
+  if (!h->rb) h->rb = h->enc->make_result();
   rc = ks_solve_dev(h->dev, &h->rb->r, kernel_ms);
   double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (wall_ms) *wall_ms = dt * 1e3;
   if (rc != KS_OK) return set_err(rc, ks_last_error());
   h->solved = true; h->dev_result = true;
-  try { if (out_text) { std::string s = h->enc->decode(h->rb->r, dt); *out_text = strdup(s.c_str()); } }
+  try { if (out_text) { std::string s = decode_handle(h, dt); *out_text = strdup(s.c_str()); } }
   catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
   return KS_OK;
 }
@@ -301,6 +380,7 @@ int ksh_solve(void* hv, char** out_text, float* kernel_ms, double* wall_ms) {
 int ksh_solve_batch(void** hv, uint32_t n, char** out_texts, float* kernel_ms, double* wall_ms) {
   std::vector<ks_dev_problem*> ds(n); std::vector<ks_result*> rs(n);
   const int dev = ks_current_device();
+  for (uint32_t i = 0; i < n; ++i) { Handle* h = (Handle*)hv[i]; if (!h->rb) h->rb = h->enc->make_result(); }      // (derived what-ifs allocate their result buffers on first use)
   for (uint32_t i = 0; i < n; ++i) { int rc = ((Handle*)hv[i])->dev ? KS_OK : ksh_upload(hv[i], dev); if (rc != KS_OK) return rc; ds[i] = ((Handle*)hv[i])->dev; rs[i] = &((Handle*)hv[i])->rb->r; }
   auto t0 = std::chrono::steady_clock::now();
   for (uint32_t i = 0; i < n; ++i) { ((Handle*)hv[i])->solved = false; ((Handle*)hv[i])->dev_result = false; }
@@ -309,7 +389,7 @@ int ksh_solve_batch(void** hv, uint32_t n, char** out_texts, float* kernel_ms, d
   if (wall_ms) *wall_ms = dt * 1e3;
   if (rc != KS_OK) return set_err(rc, ks_last_error());
   for (uint32_t i = 0; i < n; ++i) { ((Handle*)hv[i])->solved = true; ((Handle*)hv[i])->dev_result = true; }
-  try { if (out_texts) for (uint32_t i = 0; i < n; ++i) { std::string s = ((Handle*)hv[i])->enc->decode(*rs[i], dt); out_texts[i] = strdup(s.c_str()); } }
+  try { if (out_texts) for (uint32_t i = 0; i < n; ++i) { std::string s = decode_handle((Handle*)hv[i], dt); out_texts[i] = strdup(s.c_str()); } }
   catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
   return KS_OK;
 }
@@ -365,7 +445,7 @@ int ksh_launch_pick(void** hv, uint32_t n, const uint32_t* node, int32_t* out_ty
 }
 // value `v` of the zone (which = 0) or capacity-type (which = 1) universe of the handle's problem; NULL when out of range (owned by the handle)
 const char* ksh_key_value(void* hv, int which, int32_t v) {
-  const ksh::Encoded& E = *((Handle*)hv)->enc; const int32_t k = which == 0 ? E.prob.key_zone : E.prob.key_ct;
+  const ksh::Encoded& E = ((Handle*)hv)->enc->names(); const int32_t k = which == 0 ? E.prob.key_zone : E.prob.key_ct;
   if (k < 0 || v < 0 || (size_t)v >= E.key_values[k].size()) return nullptr;
   return E.key_values[k][v].c_str();
 }

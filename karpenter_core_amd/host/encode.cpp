@@ -1201,6 +1201,7 @@ std::shared_ptr<const ksp::PodBatch> ingest_pod_blocks(const ksh_pod_block* bloc
 struct SnapshotBase {
   std::shared_ptr<const ksp::Problem> snapshot; std::shared_ptr<Encoded> enc; std::unique_ptr<Builder> builder;
   std::vector<std::vector<uint32_t>> by_node;      // pods bound to each node, in pod order
+  std::vector<int32_t> node_row, node_tmpl; std::vector<int64_t> node_cap; bool delta_ok = false; std::string delta_why;      // (delta_inputs)
 };
 std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp::Problem> snapshot, const int32_t* pod_node, uint32_t flags) {
   auto sb = std::make_shared<SnapshotBase>(); sb->snapshot = snapshot;
@@ -1208,7 +1209,27 @@ std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp
   for (size_t i = 0; i < snapshot->pods.size(); ++i) { if (pod_node[i] < 0 || (size_t)pod_node[i] >= snapshot->nodes.size()) throw ksp::Error("pod_node out of range"); sb->by_node[pod_node[i]].push_back((uint32_t)i); }
   sb->enc = std::make_shared<Encoded>(); sb->enc->src = snapshot;
   sb->builder = std::make_unique<Builder>(*sb->enc, flags); sb->builder->run();
+  {   // what deriving what-ifs on the device needs (delta_inputs)
+    const Builder& b = *sb->builder; const Encoded& E = *sb->enc; const uint32_t R = b.R, M = (uint32_t)E.templates.size(); const size_t NN = snapshot->nodes.size();
+    sb->node_row.assign(b.base_existing_of.begin(), b.base_existing_of.end()); sb->node_row.resize(NN, -1);
+    sb->node_tmpl.assign(NN, -1); sb->node_cap.assign(NN * R, 0);
+    for (size_t i = 0; i < NN; ++i) if (b.node_owned[i]) {
+      auto pl = snapshot->nodes[i].labels.find(ksp::kProvisionerName);
+      for (uint32_t m = 0; m < M; ++m) if (E.templates[m]->has_limits && E.templates[m]->name == pl->second) {
+        sb->node_tmpl[i] = (int32_t)m;
+        for (auto& kv : E.templates[m]->limits) { auto c = snapshot->nodes[i].capacity.find(kv.first); if (c != snapshot->nodes[i].capacity.end()) sb->node_cap[i * R + b.res_id.at(kv.first)] = c->second; }
+      }
+    }
+    sb->delta_ok = true;
+    if (!b.groups.empty()) { sb->delta_ok = false; sb->delta_why = "the bound pods carry topology terms (spread / affinity / anti-affinity): group counts depend on the candidate set"; }
+    else if (b.any_volume_limits || b.pods_have_volumes) { sb->delta_ok = false; sb->delta_why = "volume limits / claims: the shared-claim partition depends on the candidate set"; }
+    else for (auto& cp : snapshot->cluster_pods) if (!cp.anti_required.empty()) { sb->delta_ok = false; sb->delta_why = "a cluster pod carries required anti-affinity (inverse groups depend on the candidate set)"; break; }
+  }
   return sb;
+}
+DeltaInputs delta_inputs(const SnapshotBase& sb) {
+  DeltaInputs d; d.base = sb.enc; d.n_nodes = (uint32_t)sb.snapshot->nodes.size(); d.node_row = sb.node_row.data(); d.by_node = &sb.by_node; d.pod_rank = sb.builder->pod_rank.data();
+  d.node_cap = sb.node_cap.data(); d.node_tmpl = sb.node_tmpl.data(); d.eligible = sb.delta_ok; d.why = sb.delta_why; return d;
 }
 std::unique_ptr<Encoded> encode_whatif(const SnapshotBase& sb, const uint32_t* cand, uint32_t ncand, uint32_t flags) {
   auto e = std::make_unique<Encoded>(); e->src = sb.snapshot; e->shared = sb.enc;
@@ -1234,6 +1255,11 @@ std::unique_ptr<Encoded::ResultBuf> Encoded::make_result() const {
 static std::string tokq(const std::string& s) { return s.empty() ? "~" : s; }
 
 std::string Encoded::decode(const ks_result& r, double solve_seconds) const {
+  if (view && shared) {      // a what-if derived on the device: every naming table is the snapshot's; the dimensions are this what-if's
+    Encoded tmp; tmp.src = shared->src; tmp.key_names = shared->key_names; tmp.key_values = shared->key_values; tmp.res_names = shared->res_names; tmp.templates = shared->templates;
+    tmp.existing = shared->existing; tmp.shared = shared; tmp.shared_lattice = true; tmp.prob = prob;
+    return tmp.decode(r, solve_seconds);
+  }
   const ks_problem& p = prob; const uint32_t TW = (p.T + 63) / 64, NE = p.E;
   std::vector<std::vector<std::pair<int32_t, int32_t>>> pods_of(NE + r.n_new);   // (seq, pod)
   for (uint32_t i = 0; i < p.P; ++i) if (r.pod_node[i] >= 0) pods_of[r.pod_node[i]].push_back({r.pod_seq[i], (int32_t)i});

@@ -56,6 +56,10 @@ struct Encoded {
   std::shared_ptr<const Encoded> shared; bool shared_lattice = false;
   // (snapshot flattenings only) the same problem resident on a device, per device: what-ifs upload against it (ks_problem_upload_shared)
   mutable std::mutex dev_mu; mutable std::map<int, std::shared_ptr<void>> dev_resident;
+  // A what-if DERIVED on the device from the resident snapshot (ks_whatifs_open) has no flattening of its own at all: `view` marks an Encoded that
+  // only carries dimensions (prob.P / max_new_nodes / ...) and reads every naming table through `shared`.
+  bool view = false;
+  const Encoded& names() const { return view && shared ? *shared : *this; }
   const Encoded& catalogue() const { return shared ? *shared : *this; }
   const Encoded& lattice() const { return shared && shared_lattice ? *shared : *this; }
 
@@ -84,5 +88,14 @@ uint32_t host_threads();
 struct SnapshotBase;
 std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp::Problem> snapshot, const int32_t* pod_node, uint32_t flags);
 std::unique_ptr<Encoded> encode_whatif(const SnapshotBase& sb, const uint32_t* cand, uint32_t ncand, uint32_t flags);
+// What deriving what-ifs on the device (include/ksolve.h ks_whatifs_open) needs of a snapshot's flattening.  `eligible`: its what-ifs differ in
+// nothing but the pod subset, the removed nodes and remainingResources (no topology groups among the bound pods, no cluster pod with required
+// anti-affinity, no volume limits / claims); otherwise `why` says what stands in the way and the what-ifs are flattened one by one.
+struct DeltaInputs {
+  std::shared_ptr<const Encoded> base; uint32_t n_nodes = 0; const int32_t* node_row = nullptr; const std::vector<std::vector<uint32_t>>* by_node = nullptr;
+  const uint32_t* pod_rank = nullptr; const int64_t* node_cap = nullptr /* [n_nodes][R] capacity of a node whose provisioner has limits, masked to the limited resources */;
+  const int32_t* node_tmpl = nullptr /* template with limits the node counts against, or -1 */; bool eligible = false; std::string why;
+};
+DeltaInputs delta_inputs(const SnapshotBase& sb);
 
 }  // namespace ksh

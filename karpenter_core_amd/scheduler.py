@@ -84,6 +84,8 @@ def libs():
         kh.ksh_fingerprint.argtypes = [ctypes.c_void_p]
         kh.ksh_fingerprint.restype = ctypes.c_uint64
         kh.ksh_free.argtypes = [ctypes.c_void_p]
+        kh.ksh_open_whatifs_derived.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
+                                                ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         kh.ksh_pods_ingest.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_double)]
         kh.ksh_pods_free.argtypes = [ctypes.c_void_p]
         kh.ksh_pods_count.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
@@ -283,7 +285,7 @@ def solve_from_batch(env: ParsedProblem, batch: PodBatch, device: int = 0, stats
     return fp, dict(zip(TIMING_KEYS, [float(x) for x in ms]))
 
 
-def open_whatifs(snapshot, pod_node: Sequence[int], candidate_sets: Sequence[Sequence[int]], threads: int = 0, stats: bool = False) -> List[FlatProblem]:
+def open_whatifs(snapshot, pod_node: Sequence[int], candidate_sets: Sequence[Sequence[int]], threads: int = 0, stats: bool = False, derive=None, device: int = 0) -> List[FlatProblem]:
     """Flatten N consolidation what-ifs over one cluster snapshot natively (simulateScheduling, deprovisioning/helpers.go:42-115):
     `snapshot` (a `Problem`, or a `ParsedProblem` already held as objects) lists every state node and, as its pod batch, every bound pod
     (full spec); pod_node[i] = node index of pod i.  What-if w removes candidate_sets[w] from the state nodes and makes their pods
@@ -303,6 +305,18 @@ def open_whatifs(snapshot, pod_node: Sequence[int], candidate_sets: Sequence[Seq
     c_cand = flat.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
     c_pn = pn.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
     hs = (ctypes.c_void_p * max(1, n))()
+    # derive: None = derive the what-ifs on the device when the snapshot allows it (a ParsedProblem without topology terms / volume limits), else flatten
+    # them one by one on the host; True = derive or raise; False = always flatten on the host.  Derived what-ifs are resident on `device` at once.
+    if derive is not False and not stats and n:
+        if not isinstance(snapshot, ParsedProblem):
+            snapshot = ParsedProblem(snapshot)       # (the handles keep what they need of it alive)
+        rc = kh.ksh_open_whatifs_derived(snapshot._p, 0, n, c_off, c_cand, c_pn, device, hs)
+        if rc == KS_OK:
+            return [FlatProblem(None, _handle=ctypes.c_void_p(hs[i])) for i in range(n)]
+        if derive is True or rc not in (KS_ERR_UNSUPPORTED, KS_ERR_DEVICE):
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+    elif derive is True:
+        raise KSolveError(KS_ERR_UNSUPPORTED, "derived what-ifs carry no reference-algorithm statistics")
     if isinstance(snapshot, ParsedProblem):
         rc = kh.ksh_open_whatifs_parsed(snapshot._p, KS_FLAG_STATS if stats else 0, n, c_off, c_cand, c_pn, threads, hs)
     else:

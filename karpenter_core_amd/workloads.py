@@ -190,9 +190,11 @@ def config5(pods: int = 1_000_000, sizes: int = 50, seed: int = 46) -> Problem:
 
 
 # ---- config #4: consolidation what-ifs over one cluster snapshot ----
-def cluster_snapshot(existing: int = 2048, sizes: int = 50, seed: int = 45):
+def cluster_snapshot(existing: int = 2048, sizes: int = 50, seed: int = 45, spare_pod_slots: int = -1):
     """E existing (owned, initialised) nodes running 8-40 pods each at 30-70 % utilisation; returns
-    (instance_types, provisioner, nodes, per-node bound pods as `Pod` objects)."""
+    (instance_types, provisioner, nodes, per-node bound pods as `Pod` objects).
+    spare_pod_slots >= 0: a cluster that is full by pod COUNT (max-pods): only that many nodes, picked at random, keep 1-3 free pod slots, every
+    other node has none -- the pods of a removed node then mostly need a NEW node (consolidation's "replace" outcome, consolidation.go:230-274)."""
     rs = np.random.RandomState(seed)
     zone_sets = [[ZONES[0]], [ZONES[1]], [ZONES[2]], ZONES[:2], ZONES]
     its = _taint_catalogue(sizes, zone_sets, [["spot", "on-demand"], ["on-demand"]])
@@ -230,6 +232,11 @@ def cluster_snapshot(existing: int = 2048, sizes: int = 50, seed: int = 45):
                                           "pods": str(alloc_pods - len(pods_here))},
                                capacity=dict(it.capacity)))
         bound.append(pods_here)
+    if spare_pod_slots >= 0:
+        rs2 = np.random.RandomState(seed + 1000)
+        keep = set(int(x) for x in rs2.choice(existing, size=min(spare_pod_slots, existing), replace=False))
+        for e, n in enumerate(nodes):
+            n.available = dict(n.available, pods=str(int(rs2.randint(1, 4))) if e in keep else "0")
     return its, prov, nodes, bound
 
 
@@ -269,6 +276,11 @@ def config4_sets(whatifs: int = 512, existing: int = 2048, seed: int = 45) -> Li
     half = whatifs // 2
     rs = np.random.RandomState(seed + 1)
     return [list(range(0, i + 1)) for i in range(half)] + [[int(rs.randint(existing))] for _ in range(whatifs - half)]
+
+
+def config4b_snapshot(existing: int = 2048, sizes: int = 50, seed: int = 47):
+    """BASELINE configs[3]'s shape over a cluster that is full by pod count: the what-ifs REPLACE (open one node) or fail, instead of all deleting."""
+    return cluster_snapshot(existing, sizes, seed, spare_pod_slots=12)
 
 
 def config4(whatifs: int = 512, existing: int = 2048, sizes: int = 50, seed: int = 45, with_cluster_pods: bool = False) -> List[Problem]:

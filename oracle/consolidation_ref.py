@@ -91,8 +91,8 @@ def canon_reqs(reqs):
     return {k: (r.complement, tuple(sorted(r.values)), r.greater_than, r.less_than) for k, r in reqs.items()}
 
 
-def compute_consolidation(snapshot, cand_idx):
-    """-> (action, nodes_to_remove, options, requirements dict of requirement-like objects)"""
+def compute_consolidation(snapshot, cand_idx, result_sink=None):
+    """-> (action, nodes_to_remove, options, requirements dict of requirement-like objects); result_sink (a list) receives the simulation's SolveResult"""
     types = {it.name: it for it in snapshot.instance_types}
     cands = [Cand(snapshot, i) for i in cand_idx]
     # simulateScheduling, helpers.go:42-99: nodes marked for deletion are no state nodes; a candidate that is itself deleting is an error; the batch
@@ -103,6 +103,8 @@ def compute_consolidation(snapshot, cand_idx):
     problem = workloads.whatif(snapshot.instance_types, snapshot.provisioner, snapshot.nodes, snapshot.bound, list(cand_idx) + deleting)
     problem.pods = list(getattr(snapshot, "pending", [])) + problem.pods
     res = oracle_py.solve(problem)
+    if result_sink is not None:
+        result_sink.append(res)
     # helpers.go:102-111: `for _, n := range ifn { if n.Node.Labels[LabelNodeInitialized] != "true" { return nil, false, nil } }` -- ifn is every
     # in-state (owned) existing node Solve was given, whether or not it received a pod
     for j, n in enumerate(snapshot.nodes):

@@ -45,6 +45,30 @@ def config4_entry():
             "instance_types": len(probs[0].instance_types), "pods": pods, "new_nodes": new_nodes, "unscheduled": unsched, "oracle_seconds": round(time.time() - t, 1)}
 
 
+def config4b_entry():
+    """The replace variant of configs[3] (workloads.config4b_snapshot: a cluster full by pod count): per what-if the fingerprint of the simulation
+    AND of the consolidation command the reference's computeConsolidation derives from it (price filter, spot rules; oracle/consolidation_ref.py),
+    plus the launch-time pick for the what-ifs that open exactly one node."""
+    from karpenter_core_amd import consolidation as C
+    from oracle import consolidation_ref as R
+    t = time.time()
+    its, prov, nodes, bound = W.config4b_snapshot()
+    snap = C.Snapshot(its, prov, nodes, bound)
+    sets = W.config4_sets(512, 2048, 47)
+    fps, cmds, picks, actions, new_nodes, unsched, pods = [], [], [], {}, 0, 0, 0
+    for cs in sets:
+        sink = []
+        cmd = R.canonical(R.compute_consolidation(snap, cs, sink))
+        r = sink[0]
+        fps.append(fingerprint(r)); cmds.append(hashlib.sha256(json.dumps(cmd, sort_keys=True, default=str).encode()).hexdigest())
+        actions[cmd[0]] = actions.get(cmd[0], 0) + 1
+        new_nodes += len(r.new_nodes); unsched += len(r.unscheduled); pods += sum(len(bound[i]) for i in cs)
+        pk = R.launch_pick(its, r.new_nodes[0]) if len(r.new_nodes) == 1 else None
+        picks.append([pk[0], pk[1]] if pk else None)
+    return {"whatif_sha256": fps, "command_sha256": cmds, "launch_pick": picks, "actions": actions, "whatifs": len(sets), "existing_nodes": 2048, "instance_types": len(its),
+            "pods": pods, "new_nodes": new_nodes, "unscheduled": unsched, "one_new_node": sum(1 for p in picks if p is not None), "oracle_seconds": round(time.time() - t, 1)}
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config_hashes.json")
@@ -52,6 +76,9 @@ if __name__ == "__main__":
     if not only or "config4_512x2048" in only:
         out["config4_512x2048"] = config4_entry()
         print("config4_512x2048", {k: v for k, v in out["config4_512x2048"].items() if k != "whatif_sha256"}, flush=True)
+    if not only or "config4b_512x2048_replace" in only:
+        out["config4b_512x2048_replace"] = config4b_entry()
+        print("config4b_512x2048_replace", {k: v for k, v in out["config4b_512x2048_replace"].items() if k not in ("whatif_sha256", "command_sha256", "launch_pick")}, flush=True)
     CASES = {k: v for k, v in CASES.items() if not only or k in only}
     for name, mk in CASES.items():
         pr = mk()

@@ -280,3 +280,37 @@ def test_config5_at_5000_instance_types_matches_oracle_fingerprint():
     res = S.solve_problem(pr)
     assert len(res.new_nodes) == gold["new_nodes"] and len(res.unscheduled) == gold["unscheduled"]
     assert _fingerprint(res) == gold["sha256"]
+
+
+def test_full_size_config4b_replacing_whatifs_match_reference_decisions():
+    """BASELINE configs[3]'s shape over a cluster that is full by pod count (workloads.config4b_snapshot): the what-ifs open nodes -- about half
+    REPLACE, the long prefixes fail on "more than one node".  All 512 through `consolidation.compute_consolidations` (one batched launch, price
+    stage on the device): every simulation's fingerprint, every command (action, nodes to remove, price-filtered options in order, requirements
+    incl. the spot pin) and every launch-time pick equal what the CPU restatement of computeConsolidation (consolidation.go:190-274,
+    helpers.go:148-157,292-315; oracle/consolidation_ref.py) produced offline."""
+    import hashlib
+    import json
+    from karpenter_core_amd import consolidation as C
+    gold = _golden("config4b_512x2048_replace")
+    its, prov, nodes, bound = W.config4b_snapshot()
+    sets = W.config4_sets(512, 2048, 47)
+    cmds, flats, results = C.compute_consolidations(C.Snapshot(its, prov, nodes, bound), sets)
+    try:
+        assert gold["actions"].get("replace", 0) >= 0.3 * 512 and gold["one_new_node"] >= 0.3 * 512
+        bad = [i for i, r in enumerate(results) if _fingerprint(r) != gold["whatif_sha256"][i]]
+        assert not bad, f"simulations differing from the oracle: {bad[:10]}"
+        got = [hashlib.sha256(json.dumps(c.canonical(), sort_keys=True, default=str).encode()).hexdigest() for c in cmds]
+        bad = [i for i, (a, b) in enumerate(zip(got, gold["command_sha256"])) if a != b]
+        assert not bad, f"commands differing from the reference's: {bad[:10]} e.g. {cmds[bad[0]].canonical()[:2] if bad else None}"
+        acts = {}
+        for c in cmds:
+            acts[c.action] = acts.get(c.action, 0) + 1
+        assert acts == gold["actions"]
+        one = [i for i, r in enumerate(results) if len(r.new_nodes) == 1]
+        picks = S.launch_pick([flats[i] for i in one], [0] * len(one))
+        for i, pk in zip(one, picks):
+            want = gold["launch_pick"][i]
+            assert want is not None and pk is not None and its[pk[0]].name == want[0] and pk[3] == want[1], (i, pk, want)
+    finally:
+        for f in flats:
+            f.close()

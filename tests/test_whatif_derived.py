@@ -1,0 +1,92 @@
+"""What-ifs DERIVED on the device from the resident snapshot (include/ksolve.h `ks_whatifs_open`, kshost.h `ksh_open_whatifs_derived`; SURVEY 8b
+`ks_solve_batch(shared, whatif deltas, ...)`): a what-if is its candidate set, nothing is flattened per what-if.  They must solve exactly like the
+what-ifs flattened one by one on the host (and like the oracle), and a snapshot whose what-ifs differ by more than the candidate set must be
+refused, not approximated."""
+import numpy as np
+import pytest
+
+from karpenter_core_amd import scheduler as S, workloads as W
+from karpenter_core_amd.model import DO_NOT_SCHEDULE, LABEL_ZONE, LabelSelector, TopologySpreadConstraint
+
+
+def _snapshot(existing, sizes, seed, spare=-1, limits=None):
+    its, prov, nodes, bound = W.cluster_snapshot(existing, sizes, seed, spare_pod_slots=spare)
+    if limits:
+        prov.limits = limits
+    return its, prov, nodes, bound
+
+
+def test_ineligible_snapshots_are_refused_on_the_host():
+    """(CPU) bound pods with topology terms: the group counts depend on the candidate set -- refused before anything touches a device."""
+    its, prov, nodes, bound = _snapshot(24, 5, 8)
+    for pods in bound:
+        for p in pods[:1]:
+            p.spread = [TopologySpreadConstraint(1, LABEL_ZONE, DO_NOT_SCHEDULE, LabelSelector({"my-label": p.labels["my-label"]}))]
+    snap, pod_node = W.snapshot_problem(its, prov, nodes, bound, True)
+    with pytest.raises(S.KSolveError) as e:
+        S.open_whatifs(S.ParsedProblem(snap), pod_node, [[0], [1, 2]], derive=True)
+    assert e.value.code == S.KS_ERR_UNSUPPORTED and "topology" in str(e.value)
+    flats = S.open_whatifs(S.ParsedProblem(snap), pod_node, [[0], [1, 2]])          # derive=None: flattened on the host instead
+    assert [f.dims["P"] for f in flats] == [len(bound[0]), len(bound[1]) + len(bound[2])]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["plain", "full-by-pod-count", "limits"])
+def test_derived_whatifs_solve_like_flattened_ones(case):
+    its, prov, nodes, bound = {"plain": lambda: _snapshot(96, 8, 5), "full-by-pod-count": lambda: _snapshot(96, 8, 6, spare=3),
+                               "limits": lambda: _snapshot(64, 6, 7, spare=2, limits={"cpu": "3000", "memory": "9000Gi"})}[case]()
+    snap, pod_node = W.snapshot_problem(its, prov, nodes, bound, False)
+    rs = np.random.RandomState(1)
+    sets = [list(range(0, i + 1)) for i in range(0, 24, 3)] + [[int(x)] for x in rs.randint(len(nodes), size=8)] + [[5, 2, 40], [63, 0, 31, 7]]
+    parsed = S.ParsedProblem(snap)
+    derived = S.open_whatifs(parsed, pod_node, sets, derive=True)
+    flat = S.open_whatifs(parsed, pod_node, sets, derive=False)
+    try:
+        assert [f.dims["P"] for f in derived] == [f.dims["P"] for f in flat]
+        got, _, _ = S.solve_batch(derived)
+        want, _, _ = S.solve_batch(flat)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a.canonical() == b.canonical(), (case, i, sets[i])
+            assert a.reasons == b.reasons
+        if case != "plain":
+            assert any(len(r.new_nodes) >= 1 for r in want)
+        # the records consolidation reads, built on the device, agree as well
+        words = (len(its) + 63) // 64
+        S.solve_batch_resident(derived)
+        import torch
+        rec = torch.zeros((len(sets), 3 + words), dtype=torch.int64, device="cuda:0")
+        S.result_records_dev(derived, list(range(len(sets))), words, rec)
+        assert (rec.cpu().numpy() == S.result_records(flat, list(range(len(sets))), words)).all()
+    finally:
+        for f in derived + flat:
+            f.close()
+
+
+@pytest.mark.gpu
+def test_a_batch_of_one_and_the_oracle():
+    from oracle import oracle_py as O
+    its, prov, nodes, bound = _snapshot(40, 6, 9, spare=2)
+    snap, pod_node = W.snapshot_problem(its, prov, nodes, bound, False)
+    (f,) = S.open_whatifs(S.ParsedProblem(snap), pod_node, [[3, 9, 11, 20]], derive=True)      # one what-if: the multi-wave kernel
+    got = f.solve()
+    want = O.solve(W.whatif(its, prov, nodes, bound, [3, 9, 11, 20], False))
+    assert got.canonical() == want.canonical()
+    f.close()
+
+
+@pytest.mark.gpu
+def test_full_size_config4_derived_matches_oracle_fingerprints():
+    """BASELINE configs[3] at its stated size through the derived route: all 512 fingerprints the oracle produced offline."""
+    import hashlib
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config_hashes.json")))["config4_512x2048"]
+    its, prov, nodes, bound = W.cluster_snapshot(2048, 50, 45)
+    snap, pod_node = W.snapshot_problem(its, prov, nodes, bound, False)
+    flats = S.open_whatifs(S.ParsedProblem(snap), pod_node, W.config4_sets(512, 2048, 45), derive=True)
+    res, _, _ = S.solve_batch(flats)
+    for f in flats:
+        f.close()
+    got = [hashlib.sha256(json.dumps(r.canonical(), sort_keys=True).encode()).hexdigest() for r in res]
+    bad = [i for i, (a, b) in enumerate(zip(got, gold["whatif_sha256"])) if a != b]
+    assert not bad, f"what-ifs differing from the oracle: {bad[:10]}"
