@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-only", action="store_true", help="time the CPU oracle on the bounded sample only (skip the full-size run, about two minutes of one host core)")
     ap.add_argument("--whatifs", type=int, default=512, help="consolidation what-ifs (BASELINE configs[3]); 0 skips the N=1 what-if leg")
+    ap.add_argument("--config5", type=int, default=0, metavar="PODS", help="BASELINE configs[4] instead of configs[2]: PODS pods (1000000 = the stated size), 5 000 instance types, full "
+                    "constraint set, one Solve on one GPU through the general 4-wave kernel; prints the contract line for THAT workload (generation takes minutes)")
     ap.add_argument("--whatifs-only", action="store_true", help="diagnostic: only the N=1 what-if leg (prints its object alone, not the contract line)")
     args = ap.parse_args()
 
@@ -107,6 +109,9 @@ def main():
         return whatif_fanout(args, rank, world, local_rank, torch, dist, S, W)
     if args.whatifs_only:
         print(json.dumps(whatif_leg(args, 0, 1, local_rank, torch, None, S, W), indent=1))
+        return
+    if args.config5:
+        print(json.dumps(config5_leg(args, local_rank, torch, S, W)))
         return
 
     # ---- the pod list and the cluster objects in host memory (untimed: the caller holds them) ----
@@ -232,6 +237,55 @@ def main():
     print(json.dumps(out))
 
 
+def config5_leg(args, device, torch, S, W):
+    """BASELINE configs[4]: 1 M pods / 5 000 instance types / the full constraint set (taints, Gt selectors on an integer label, zonal + hostname +
+    capacity-type spread, pod affinity and anti-affinity, host ports, two weighted provisioners, one with a cpu limit).  A single Solve does not
+    shard, so this is one GPU; host ports and limits route it through the general (non-LEAN, BOUNDS) 4-wave kernel."""
+    t0 = time.time()
+    problem = W.config5(pods=args.config5, sizes=50, seed=46)
+    parsed = S.ParsedProblem(problem)
+    prep_s = time.time() - t0
+    steps = max(1, min(args.steps, 3))
+    for _ in range(min(args.warmup, 1)):
+        fp, _ = S.solve_from_pods(parsed, device); fp.close()
+    torch.cuda.synchronize()
+    rows, lat = [], []
+    t_start = time.perf_counter()
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        fp, ms = S.solve_from_pods(parsed, device)
+        lat.append((time.perf_counter() - t1) * 1e3); rows.append(ms)
+        if len(rows) < steps:
+            fp.close()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    dims, res = fp.dims, fp.result()
+    fp.close()
+    fps, _ = S.solve_from_pods(parsed, device, stats=True)
+    st = fps.result().stats
+    fps.close()
+    abytes = algorithmic_bytes(dims["T"], st, dims["P"])
+    kms = statistics.mean(r["pack_kernel_ms"] for r in rows)
+    gold = None
+    try:
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", "config_hashes.json")))
+        for name in ("config5_250k_5k_types", "config5_5k_types"):
+            if g.get(name, {}).get("pods") == dims["P"]:
+                gold = {"entry": name, "matches_oracle_fingerprint": hashlib.sha256(json.dumps(res.canonical(), sort_keys=True).encode()).hexdigest() == g[name]["sha256"]}
+    except Exception:
+        pass
+    return {"metric": "pod-placement decisions/sec (Solve())", "value": dims["P"] * steps / elapsed, "unit": "decisions/s", "n_gpus": 1, "steps": steps, "warmup": min(args.warmup, 1),
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4]: {dims['P']} pods, {dims['T']} instance types, full constraint set (workloads.config5 seed 46)", "pods": dims["P"],
+                       "instance_types": dims["T"], "pod_classes": dims["C"], "topology_groups": dims["G"], "new_nodes": len(res.new_nodes), "unschedulable": len(res.unscheduled),
+                       "parallelism": "1 Solve on 1 GPU (a single Solve is replicas-only)", "timed_window": "Solve() from the pod list in host memory (scheduler.solve_from_pods)"},
+            "p50_solve_latency_ms": statistics.median(lat), "phases_ms_mean": {k: statistics.mean(r[k] for r in rows) for k in S.TIMING_KEYS}, "prep_seconds_untimed": prep_s,
+            "oracle_fingerprint": gold,
+            "roofline": {"kernel": "ks_pack<general, 4 waves>", "bound": "hbm", "achieved": abytes / (kms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": abytes / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": abytes, "kernel_ms_mean": kms,
+                         "ref_attempts": st["attempts"], "ref_types_scanned": st["types_scanned"], "formula": f"SURVEY 8d with R={ROOFLINE_R}, K={ROOFLINE_K}"}}
+
+
 def ingress_leg(args, problem, device, S):
     """How the caller's pods get INTO the library, and what Solve() costs when that is counted: the binary door (`ksh_pods_ingest`: flat u32
     records + string tables, what a cgo shim fills from its []*v1.Pod) against the KSP1 text door (`ksh_parse`).  Filling the blocks / printing the
@@ -315,16 +369,22 @@ def whatif_leg(args, rank, world, local_rank, torch, dist, S, W):
     mine = list(range(rank, len(sets), world))
     words = (T + 63) // 64
 
+    rec_e2e = torch.full((len(mine), 3 + words), -1, dtype=torch.int64, device=f"cuda:{local_rank}")
+
     def end_to_end():
+        """What a consolidation pass pays per batch of candidate sets over a snapshot it already holds (multinodeconsolidation.go:74-114): open the
+        what-ifs (derived on the device from the resident snapshot: candidate masks up, batches built there), one batched launch, the fixed-size
+        decision records built on the device and brought to the host."""
         t0 = time.perf_counter()
         flats = S.open_whatifs(parsed, pod_node, [sets[i] for i in mine], device=local_rank)
         t1 = time.perf_counter()
-        S.upload_batch(flats, local_rank)
+        S.upload_batch(flats, local_rank)                      # (derived what-ifs are resident already: a no-op; the host-flattened fallback uploads here)
         t2 = time.perf_counter()
-        _, kms, _ = S.solve_batch(flats, decode=False)
-        rec = S.result_records(flats, mine, words)
+        kms, _ = S.solve_batch_resident(flats)
+        S.result_records_dev(flats, mine, words, rec_e2e)
+        rec = rec_e2e.cpu().numpy()
         t3 = time.perf_counter()
-        return flats, rec, {"flatten_ms": (t1 - t0) * 1e3, "upload_ms": (t2 - t1) * 1e3, "solve_records_ms": (t3 - t2) * 1e3, "kernel_ms": kms, "total_ms": (t3 - t0) * 1e3}
+        return flats, rec, {"open_ms": (t1 - t0) * 1e3, "upload_ms": (t2 - t1) * 1e3, "solve_records_ms": (t3 - t2) * 1e3, "kernel_ms": kms, "total_ms": (t3 - t0) * 1e3}
 
     flats, rec, first = end_to_end()       # first batch over this snapshot: also flattens the snapshot itself (once per snapshot, cached in the
                                            # parsed object), puts that flattening on the device (shared catalogue + derived tables), warms the pools
@@ -348,7 +408,8 @@ def whatif_leg(args, rank, world, local_rank, torch, dist, S, W):
         S.result_records_dev(flats, mine, words, rec_dev)
         res.append(((time.perf_counter() - t1) * 1e3, kms))
     wms, kms = sorted(res)[2]
-    assert (rec_dev.cpu().numpy() == rec).all(), "device-built records differ from the host-built ones"
+    S.solve_batch(flats, decode=False)                       # the same batch read back in full (every pod's node): the host-built records must agree
+    assert (S.result_records(flats, mine, words) == rec).all() and (rec_dev.cpu().numpy() == rec).all(), "device-built records differ from the host-built ones"
     pods_mine = sum(f.dims["P"] for f in flats)
     # roofline of the batch kernel: the REFERENCE algorithm's bytes for these what-ifs (untimed KS_FLAG_STATS batch) over the launch's HIP-event time
     sflats = S.open_whatifs(parsed, pod_node, [sets[i] for i in mine], stats=True)
@@ -360,7 +421,7 @@ def whatif_leg(args, rank, world, local_rank, torch, dist, S, W):
     out = {"workload": f"{len(flats)} consolidation what-ifs over 2048 existing nodes / {T} instance types (BASELINE configs[3])",
            "whatifs": len(flats), "decisions": pods_mine, "records": int(rec.shape[0]),
            "first_batch_over_the_snapshot": dict(first, what="cold: + the snapshot's own flattening and its upload (once per snapshot), buffer pools, code objects"),
-           "end_to_end": dict(ms, what="a batch of candidate sets over a snapshot already seen (a consolidation pass probes many): flatten the what-ifs over the shared snapshot base + upload + one batched launch + result records",
+           "end_to_end": dict(ms, what="a batch of candidate sets over a snapshot already seen (a consolidation pass probes many): what-ifs derived on the device from the resident snapshot + one batched launch + decision records to the host",
                               decisions_per_s=pods_mine / (ms["total_ms"] / 1e3), whatifs_per_s=len(flats) / (ms["total_ms"] / 1e3)),
            "resident": {"what": "the N>1 fan-out's step at world size 1: batched launch, results left on the device, records built there",
                         "kernel_ms": kms, "wall_ms": wms, "decisions_per_s_kernel": pods_mine / (kms / 1e3), "decisions_per_s_wall": pods_mine / (wms / 1e3),

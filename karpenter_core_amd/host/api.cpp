@@ -277,11 +277,15 @@ int ksh_open_whatifs_derived(void* parsed, uint32_t flags, uint32_t n, const uin
     { std::lock_guard<std::mutex> g(P->mu);
       const size_t np = snapshot->pods.size();
       if (P->sb && P->sb_flags == flags && P->sb_pod_node.size() == np && std::equal(pod_node, pod_node + np, P->sb_pod_node.begin())) sb = P->sb;
-      else { sb = ksh::make_snapshot_base(snapshot, pod_node, flags); P->sb = sb; P->sb_flags = flags; P->sb_pod_node.assign(pod_node, pod_node + np); } }
+      else { auto ts = std::chrono::steady_clock::now(); sb = ksh::make_snapshot_base(snapshot, pod_node, flags); P->sb = sb; P->sb_flags = flags; P->sb_pod_node.assign(pod_node, pod_node + np);
+             if (getenv("KSH_TIMING")) fprintf(stderr, "  derived what-ifs: %-28s %8.2f ms\n", "snapshot flattened (once)", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count()); } }
+    const bool timing = getenv("KSH_TIMING") != nullptr; auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "  derived what-ifs: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; };
     const ksh::DeltaInputs in = ksh::delta_inputs(*sb);
     if (!in.eligible) return set_err(KS_ERR_UNSUPPORTED, "what-ifs of this snapshot cannot be derived on the device: " + in.why);
     auto D = std::make_shared<DeltaBatch>(); D->sb = sb; D->cand_off.assign(cand_off, cand_off + n + 1); D->cand.assign(cand, cand + cand_off[n]);
     int rc = resident_base(in.base.get(), device, &D->base_dev); if (rc != KS_OK) return rc;
+    lap("snapshot resident");
     const ks_problem& bp = in.base->prob; const uint32_t M = bp.M, R = bp.R;
     std::vector<uint32_t> npods(n, 0); std::vector<int64_t> rem((size_t)n * M * R);
     for (uint32_t w = 0; w < n; ++w) {
@@ -291,8 +295,10 @@ int ksh_open_whatifs_derived(void* parsed, uint32_t flags, uint32_t n, const uin
         const int32_t m = in.node_tmpl[nd]; if (m >= 0) for (uint32_t r = 0; r < R; ++r) rw[(size_t)m * R + r] += in.node_cap[(size_t)nd * R + r];      // remainingResources: the node's capacity comes back (scheduler.go:244-246)
       }
     }
+    lap("masks / remaining (host)");
     rc = ks_whatifs_open((const ks_dev_problem*)D->base_dev.get(), in.n_nodes, P->sb_pod_node.data(), in.node_row, n, cand_off, cand, npods.data(), rem.data(), &D->b);
     if (rc != KS_OK) return set_err(rc, ks_last_error());
+    lap("ks_whatifs_open (device)");
     ks_dev_problem* const* views = ks_whatifs_problems(D->b);
     for (uint32_t w = 0; w < n; ++w) {
       auto h = std::make_unique<Handle>();
@@ -301,6 +307,7 @@ int ksh_open_whatifs_derived(void* parsed, uint32_t flags, uint32_t n, const uin
       h->dev = views[w]; h->delta = D; h->delta_index = w; h->base_dev = D->base_dev;
       out_handles[w] = h.release();
     }
+    lap("handles");
     return KS_OK;
   } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());
   } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }

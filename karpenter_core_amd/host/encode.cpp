@@ -259,6 +259,7 @@ struct Builder {
   Encoded& E; const ksp::Problem& pr; uint32_t flags;
   std::set<std::string> wellKnown;
   std::map<std::string, int> key_id; std::vector<std::set<std::string>> key_vals;   // pre-pass universes
+  std::vector<std::set<std::string>> key_named; std::vector<std::set<long long>> key_bounds; std::set<std::string> topo_keys; bool passive_values = false;   // (value classes, see Encoded::key_members)
   std::map<std::string, int> res_id;
   std::map<std::string, int> taint_id;
   std::map<std::string, uint32_t> ip_id, proto_id;
@@ -310,15 +311,17 @@ struct Builder {
   int key_of(const std::string& k, bool create) {
     auto it = key_id.find(k); if (it != key_id.end()) return it->second;
     if (!create) return -1;
-    int id = (int)key_vals.size(); key_id[k] = id; key_vals.emplace_back(); return id;
+    int id = (int)key_vals.size(); key_id[k] = id; key_vals.emplace_back(); key_named.emplace_back(); key_bounds.emplace_back(); return id;
   }
+  void note_value(int id, const std::string& v) { key_vals[id].insert(v); if (!passive_values) key_named[id].insert(v); }
   static bool special_key(const std::string& k) { return k == ksp::kHostname || k == ksp::kInstanceType; }
   void note_expr(const Expr& e) {
     std::string k = ksp::normalize_key(e.key); if (special_key(k)) return;
     int id = key_of(k, true);
-    if (e.op == Op::In || e.op == Op::NotIn) for (auto& v : e.values) key_vals[id].insert(v);
+    if (e.op == Op::In || e.op == Op::NotIn) for (auto& v : e.values) note_value(id, v);
+    if ((e.op == Op::Gt || e.op == Op::Lt) && !e.values.empty()) { long long x; if (Atoi(e.values[0], &x)) key_bounds[id].insert(x); }
   }
-  void note_label(const std::string& key, const std::string& v) { std::string k = ksp::normalize_key(key); if (special_key(k)) return; key_vals[key_of(k, true)].insert(v); }
+  void note_label(const std::string& key, const std::string& v) { std::string k = ksp::normalize_key(key); if (special_key(k)) return; note_value(key_of(k, true), v); }
   int res_of(const std::string& r) { auto it = res_id.find(r); if (it != res_id.end()) return it->second; int id = (int)res_id.size(); res_id[r] = id; return id; }
   void note_res(const ksp::ResList& l) { for (auto& kv : l) res_of(kv.first); }
   void note_pod(const Pod& p) {
@@ -327,7 +330,7 @@ struct Builder {
     for (auto& t : p.preferred_affinity) for (auto& e : t.exprs) note_expr(e);
     for (auto& c : p.containers) { note_res(c.requests); note_res(c.limits); }
     for (auto& c : p.init_containers) { note_res(c.requests); note_res(c.limits); }
-    auto topo_key = [&](const std::string& k) { if (k == ksp::kInstanceType) throw Unsupported("topology key node.kubernetes.io/instance-type"); if (k != ksp::kHostname) key_of(k, true); };
+    auto topo_key = [&](const std::string& k) { if (k == ksp::kInstanceType) throw Unsupported("topology key node.kubernetes.io/instance-type"); if (k != ksp::kHostname) { key_of(k, true); topo_keys.insert(k); } };
     for (auto& s : p.spread) topo_key(s.key);
     for (auto& t : p.affinity_required) topo_key(t.topology_key);
     for (auto& t : p.affinity_preferred) topo_key(t.term.topology_key);
@@ -349,7 +352,8 @@ struct Builder {
     }
     for (auto& si : specs) note_pod(si.stages[0].spec);      // every pod is one of the distinct specs (dedupe_specs), first occurrences in pod order
     for (auto& p : pr.daemons) note_pod(p);
-    for (auto& cp : pr.cluster_pods) for (auto& t : cp.anti_required) { if (t.topology_key != ksp::kHostname) key_of(t.topology_key, true); }
+    for (auto& cp : pr.cluster_pods) for (auto& t : cp.anti_required) { if (t.topology_key != ksp::kHostname) { key_of(t.topology_key, true); topo_keys.insert(t.topology_key); } }
+    passive_values = true;      // from here on values join a universe without being named by anything that could tell them apart
     // Instance types last: a label key that ONLY instance types carry (real catalogues have many, often with hundreds of
     // values -- the fake provider's `integer` has one per type) can never meet a node requirement: node requirements come from
     // provisioners, pods, topology keys and existing-node labels, and Intersects / Compatible only look at keys both sides
@@ -360,30 +364,51 @@ struct Builder {
         const std::string k = ksp::normalize_key(e.key);
         if (special_key(k) || key_id.count(k)) note_expr(e);
       }
-      for (auto& o : it.offerings) { key_vals[key_of(ksp::kZone, true)].insert(o.zone); key_vals[key_of(ksp::kCapacityType, true)].insert(o.capacity_type); }
+      for (auto& o : it.offerings) { note_value(key_of(ksp::kZone, true), o.zone); note_value(key_of(ksp::kCapacityType, true), o.capacity_type); }
       note_res(it.capacity); note_res(it.overhead);
     }
     // node labels: only keys something else references matter (existing-node requirements are never
     // returned); values of referenced keys join the universe (they become topology domains / In sets)
     for (auto& n : pr.nodes) {
-      for (auto& kv : n.labels) { std::string k = ksp::normalize_key(kv.first); auto it = key_id.find(k); if (it != key_id.end()) key_vals[it->second].insert(kv.second);
-        auto raw = key_id.find(kv.first); if (raw != key_id.end() && raw->first != k) key_vals[raw->second].insert(kv.second); }
+      for (auto& kv : n.labels) { std::string k = ksp::normalize_key(kv.first); auto it = key_id.find(k); if (it != key_id.end()) note_value(it->second, kv.second);
+        auto raw = key_id.find(kv.first); if (raw != key_id.end() && raw->first != k) note_value(raw->second, kv.second); }
       note_res(n.available); note_res(n.capacity); note_res(n.daemonset_requests);
     }
     K = (uint32_t)key_vals.size(); R = (uint32_t)res_id.size(); T = (uint32_t)pr.instance_types.size(); TW = (T + 63) / 64;
     if (K > KS_MAX_KEYS) throw Unsupported("more than 32 distinct label keys on the path");
     if (R > KS_MAX_RES) throw Unsupported("more than 8 distinct resource names");
     E.key_names.assign(K, ""); for (auto& kv : key_id) E.key_names[kv.second] = kv.first;
-    E.key_values.resize(K); E.key_nvalues.assign(K, 0); E.value_int.assign((size_t)K * 64, INT32_MIN);
+    E.key_values.resize(K); E.key_nvalues.assign(K, 0); E.value_int.assign((size_t)K * 64, INT32_MIN); E.key_members.assign(K, {}); E.key_class.assign(K, {});
     for (uint32_t k = 0; k < K; ++k) {
-      if (key_vals[k].size() > 64) throw Unsupported("label key " + E.key_names[k] + " has more than 64 distinct values");
-      E.key_values[k].assign(key_vals[k].begin(), key_vals[k].end()); E.key_nvalues[k] = (uint32_t)E.key_values[k].size();
+      if (key_vals[k].size() > 64) {
+        // Value classes.  Only for keys whose values are never told apart one by one: not a topology key (domains are counted per value, and a
+        // requirement with exactly one value is a domain choice), not the zone / capacity type (offerings are looked up per value).
+        const std::string& kn = E.key_names[k];
+        if (topo_keys.count(kn) || kn == ksp::kZone || kn == ksp::kCapacityType) throw Unsupported("label key " + kn + " has more than 64 distinct values and is a topology / offering key");
+        const std::vector<long long> bounds(key_bounds[k].begin(), key_bounds[k].end());
+        std::map<std::string, std::vector<std::string>> cls;      // class id (sortable) -> members
+        for (auto& v : key_vals[k]) {
+          std::string id;
+          if (key_named[k].count(v)) id = "n:" + v;
+          else { long long x; if (!Atoi(v, &x)) id = "p:~"; else { const size_t lo = std::lower_bound(bounds.begin(), bounds.end(), x) - bounds.begin(); char buf[48]; snprintf(buf, sizeof buf, "p:%08zu%c", lo, (lo < bounds.size() && bounds[lo] == x) ? '=' : '<'); id = buf; } }
+          cls[id].push_back(v);
+        }
+        if (cls.size() > 64) throw Unsupported("label key " + kn + " has more than 64 values that pods / provisioners name or bound apart");
+        // class order = ascending representative (the smallest member), like any other universe
+        std::vector<std::pair<std::string, std::vector<std::string>>> ordered;
+        for (auto& kv : cls) { auto mem = kv.second; std::sort(mem.begin(), mem.end()); ordered.emplace_back(mem.front(), std::move(mem)); }
+        std::sort(ordered.begin(), ordered.end());
+        E.key_members[k].resize(ordered.size());
+        for (size_t c = 0; c < ordered.size(); ++c) { E.key_values[k].push_back(ordered[c].first); E.key_members[k][c] = ordered[c].second; for (auto& m : ordered[c].second) E.key_class[k][m] = (int)c; }
+        E.key_nvalues[k] = (uint32_t)E.key_values[k].size();
+      } else { E.key_values[k].assign(key_vals[k].begin(), key_vals[k].end()); E.key_nvalues[k] = (uint32_t)E.key_values[k].size(); }
       for (size_t v = 0; v < E.key_values[k].size(); ++v) { long long x; if (Atoi(E.key_values[k][v], &x)) { if (x <= INT32_MIN + 1 || x >= INT32_MAX - 1) throw Unsupported("integer label value outside int32"); E.value_int[k * 64 + v] = (int32_t)x; } }
     }
     E.res_names.assign(R, ""); for (auto& kv : res_id) E.res_names[kv.second] = kv.first;
   }
 
   int value_id(int k, const std::string& v) const {
+    if ((size_t)k < E.key_class.size() && !E.key_class[k].empty()) { auto c = E.key_class[k].find(v); return c == E.key_class[k].end() ? -1 : c->second; }
     auto& vs = E.key_values[k]; auto it = std::lower_bound(vs.begin(), vs.end(), v);
     if (it == vs.end() || *it != v) return -1; return (int)(it - vs.begin());
   }
@@ -636,7 +661,7 @@ struct Builder {
     const Builder& b = *base; const Encoded& B = b.E;
     wellKnown = b.wellKnown; key_id = b.key_id; res_id = b.res_id; taint_id = b.taint_id; taints = b.taints; ip_id = b.ip_id; proto_id = b.proto_id;      // (domains: read in place)
     blocked_taint = b.blocked_taint; toleratePreferNoSchedule = b.toleratePreferNoSchedule; K = b.K; R = b.R; T = b.T; TW = b.TW;
-    E.key_names = B.key_names; E.key_values = B.key_values; E.res_names = B.res_names; E.key_nvalues = B.key_nvalues; E.value_int = B.value_int;
+    E.key_names = B.key_names; E.key_values = B.key_values; E.key_members = B.key_members; E.key_class = B.key_class; E.res_names = B.res_names; E.key_nvalues = B.key_nvalues; E.value_int = B.value_int;
     // the catalogue arrays (it_*) stay the snapshot's: Encoded::shared keeps them alive, finish() points ks_problem at them
     E.templates = B.templates; E.tmpl = B.tmpl; E.tmpl_taints = B.tmpl_taints; E.tmpl_types = B.tmpl_types; E.tmpl_daemon = B.tmpl_daemon; E.tmpl_daemon_present = B.tmpl_daemon_present;
     E.tmpl_limit_present = B.tmpl_limit_present;
@@ -1256,7 +1281,7 @@ static std::string tokq(const std::string& s) { return s.empty() ? "~" : s; }
 
 std::string Encoded::decode(const ks_result& r, double solve_seconds) const {
   if (view && shared) {      // a what-if derived on the device: every naming table is the snapshot's; the dimensions are this what-if's
-    Encoded tmp; tmp.src = shared->src; tmp.key_names = shared->key_names; tmp.key_values = shared->key_values; tmp.res_names = shared->res_names; tmp.templates = shared->templates;
+    Encoded tmp; tmp.src = shared->src; tmp.key_names = shared->key_names; tmp.key_values = shared->key_values; tmp.key_members = shared->key_members; tmp.res_names = shared->res_names; tmp.templates = shared->templates;
     tmp.existing = shared->existing; tmp.shared = shared; tmp.shared_lattice = true; tmp.prob = prob;
     return tmp.decode(r, solve_seconds);
   }
@@ -1279,7 +1304,10 @@ std::string Encoded::decode(const ks_result& r, double solve_seconds) const {
     std::map<std::string, Out> reqs;
     for (uint32_t k = 0; k < p.K; ++k) if ((r.node_present[j] >> k) & 1u) {
       Out x; x.c = (r.node_complement[j] >> k) & 1u; const uint64_t m = r.node_mask[(size_t)j * p.K + k];
-      for (size_t v = 0; v < key_values[k].size(); ++v) if ((m >> v) & 1ull) x.vals.push_back(key_values[k][v]);
+      for (size_t v = 0; v < key_values[k].size(); ++v) if ((m >> v) & 1ull) {
+        if (k < key_members.size() && !key_members[k].empty()) x.vals.insert(x.vals.end(), key_members[k][v].begin(), key_members[k][v].end());      // a value class: every member
+        else x.vals.push_back(key_values[k][v]);
+      }
       const int32_t gt = r.node_gt[(size_t)j * p.K + k], lt = r.node_lt[(size_t)j * p.K + k];
       x.gt = gt == KS_NO_BOUND_GT ? "-" : std::to_string(gt); x.lt = lt == KS_NO_BOUND_LT ? "-" : std::to_string(lt);
       reqs[key_names[k]] = std::move(x);

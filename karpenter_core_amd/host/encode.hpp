@@ -33,6 +33,11 @@ struct Encoded {
   // ---- naming tables for decode ----
   std::vector<std::string> key_names;                      // narrow keys
   std::vector<std::vector<std::string>> key_values;        // universe per key (ascending)
+  // A key with more than 64 values that nothing tells apart one by one (only instance types / existing nodes carry them; pods reach the key through
+  // Gt / Lt, Exists or a few named values) is encoded over value CLASSES: every named value a class of its own, the others grouped by where they
+  // stand relative to every Gt / Lt bound of the problem (and "not an integer").  key_values[k][c] is then the class's representative,
+  // key_members[k][c] its values, key_class[k] the value -> class map; for every other key both are empty.
+  std::vector<std::vector<std::vector<std::string>>> key_members; std::vector<std::map<std::string, int>> key_class;
   std::vector<std::string> res_names;
   std::vector<const ksp::Provisioner*> templates;          // weight order
   std::vector<int> existing;                                // indices into src.nodes

@@ -29,6 +29,7 @@ CASES = {
     "config2_10k_500": lambda: W.config2(),
     "config3_100k_2k": lambda: W.config3(),
     "config5_5k_types": lambda: W.config5(pods=CONFIG5_PODS, sizes=50, seed=46),     # 5 000 instance types, full constraint set
+    "config5_250k_5k_types": lambda: W.config5(pods=250_000, sizes=50, seed=46),     # the largest size the oracle finishes within the hour (1 M needs most of a day)
 }
 CONFIG5_PODS = 100_000
 
@@ -88,4 +89,6 @@ if __name__ == "__main__":
                      "new_nodes": len(r.new_nodes), "unscheduled": len(r.unscheduled), "attempts": r.stats["attempts"],
                      "types_scanned": r.stats["types_scanned"], "oracle_seconds": round(time.time() - t, 1)}
         print(name, out[name], flush=True)
+    if only and os.path.exists(path):      # (another refresh may have finished meanwhile: merge into the file as it is NOW)
+        cur = json.load(open(path)); cur.update({k: out[k] for k in only if k in out}); out = cur
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
