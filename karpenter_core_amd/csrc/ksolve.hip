@@ -155,7 +155,11 @@ __device__ __forceinline__ KReq load_req(const u32 present, const u32 complement
 __device__ __forceinline__ KReq type_req(const DevProb& P, u32 t, int k) {   // instance types never carry bounds (encoder enforces)
   KReq r; r.present = (P.it_present[t] >> k) & 1u; r.complement = (P.it_complement[t] >> k) & 1u; r.mask = P.it_mask[(size_t)k * P.T + t]; r.gt = KS_NOGT; r.lt = KS_NOLT; return r;
 }
-__device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }      // (__builtin_amdgcn_ballot_w64 on the bool itself saves two VALU ops per ballot but miscompiled this kernel: memory faults)
+#ifdef KS_BALLOT_BUILTIN   /* experiment builds only (tools/mkvariant.sh t_ballot -DKS_BALLOT_BUILTIN): see DESIGN.md "open items" */
+__device__ __forceinline__ u64 ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+#else
+__device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }      // (__builtin_amdgcn_ballot_w64 on the bool itself saves two VALU ops per ballot; in round 2 a build with it faulted -- re-examined in round 3)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // ks_build_type_tables: one wave per table row

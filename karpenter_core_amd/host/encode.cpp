@@ -378,7 +378,7 @@ struct Builder {
     if (K > KS_MAX_KEYS) throw Unsupported("more than 32 distinct label keys on the path");
     if (R > KS_MAX_RES) throw Unsupported("more than 8 distinct resource names");
     E.key_names.assign(K, ""); for (auto& kv : key_id) E.key_names[kv.second] = kv.first;
-    E.key_values.resize(K); E.key_nvalues.assign(K, 0); E.value_int.assign((size_t)K * 64, INT32_MIN); E.key_members.assign(K, {}); E.key_class.assign(K, {});
+    E.key_values.resize(K); E.key_nvalues.assign(K, 0); E.value_int.assign((size_t)K * 64, INT32_MIN); E.key_members.assign(K, {}); E.key_class.assign(K, {}); E.key_ints.assign(K, {});
     for (uint32_t k = 0; k < K; ++k) {
       if (key_vals[k].size() > 64) {
         // Value classes.  Only for keys whose values are never told apart one by one: not a topology key (domains are counted per value, and a
@@ -402,11 +402,23 @@ struct Builder {
         for (size_t c = 0; c < ordered.size(); ++c) { E.key_values[k].push_back(ordered[c].first); E.key_members[k][c] = ordered[c].second; for (auto& m : ordered[c].second) E.key_class[k][m] = (int)c; }
         E.key_nvalues[k] = (uint32_t)E.key_values[k].size();
       } else { E.key_values[k].assign(key_vals[k].begin(), key_vals[k].end()); E.key_nvalues[k] = (uint32_t)E.key_values[k].size(); }
-      for (size_t v = 0; v < E.key_values[k].size(); ++v) { long long x; if (Atoi(E.key_values[k][v], &x)) { if (x <= INT32_MIN + 1 || x >= INT32_MAX - 1) throw Unsupported("integer label value outside int32"); E.value_int[k * 64 + v] = (int32_t)x; } }
+      // integers of the key: label values that parse (a value class: its representative stands for every member) and every Gt / Lt bound
+      std::set<long long> ints(key_bounds[k].begin(), key_bounds[k].end()); bool wide = false;
+      for (auto& v : E.key_values[k]) { long long x; if (Atoi(v, &x)) ints.insert(x); }
+      for (long long x : ints) if (x <= INT32_MIN + 1 || x >= INT32_MAX - 1) wide = true;
+      if (wide) E.key_ints[k].assign(ints.begin(), ints.end());
+      for (size_t v = 0; v < E.key_values[k].size(); ++v) { long long x; if (Atoi(E.key_values[k][v], &x)) E.value_int[k * 64 + v] = int_code((int)k, x); }
     }
     E.res_names.assign(R, ""); for (auto& kv : res_id) E.res_names[kv.second] = kv.first;
   }
 
+  // the kernel-side code of integer x on key k: x itself, or its rank among the key's integers (Encoded::key_ints)
+  int32_t int_code(int k, long long x) const {
+    if ((size_t)k >= E.key_ints.size() || E.key_ints[k].empty()) { if (x <= INT32_MIN + 1 || x >= INT32_MAX - 1) throw Unsupported("integer outside int32 on a key whose universe was closed without it"); return (int32_t)x; }
+    auto& v = E.key_ints[k]; auto it = std::lower_bound(v.begin(), v.end(), x);
+    if (it == v.end() || *it != x) throw std::logic_error("integer missing from the key's universe");
+    return (int32_t)(it - v.begin());
+  }
   int value_id(int k, const std::string& v) const {
     if ((size_t)k < E.key_class.size() && !E.key_class[k].empty()) { auto c = E.key_class[k].find(v); return c == E.key_class[k].end() ? -1 : c->second; }
     auto& vs = E.key_values[k]; auto it = std::lower_bound(vs.begin(), vs.end(), v);
@@ -444,8 +456,8 @@ struct Builder {
       st.present[idx] |= 1u << k; if (r.complement) st.complement[idx] |= 1u << k;
       uint64_t m = 0; for (auto& v : r.values) { int vid = value_id(k, v); if (vid < 0) throw std::logic_error("value missing from universe: " + v); m |= 1ull << vid; }
       st.mask[(size_t)idx * K + k] = m;
-      if (r.greaterThan) { if (*r.greaterThan <= INT32_MIN + 1 || *r.greaterThan >= INT32_MAX - 1) throw Unsupported("Gt bound outside int32"); st.gt[(size_t)idx * K + k] = (int32_t)*r.greaterThan; }
-      if (r.lessThan) { if (*r.lessThan <= INT32_MIN + 1 || *r.lessThan >= INT32_MAX - 1) throw Unsupported("Lt bound outside int32"); st.lt[(size_t)idx * K + k] = (int32_t)*r.lessThan; }
+      if (r.greaterThan) st.gt[(size_t)idx * K + k] = int_code(k, *r.greaterThan);
+      if (r.lessThan) st.lt[(size_t)idx * K + k] = int_code(k, *r.lessThan);
     }
     return idx;
   }
@@ -661,7 +673,7 @@ struct Builder {
     const Builder& b = *base; const Encoded& B = b.E;
     wellKnown = b.wellKnown; key_id = b.key_id; res_id = b.res_id; taint_id = b.taint_id; taints = b.taints; ip_id = b.ip_id; proto_id = b.proto_id;      // (domains: read in place)
     blocked_taint = b.blocked_taint; toleratePreferNoSchedule = b.toleratePreferNoSchedule; K = b.K; R = b.R; T = b.T; TW = b.TW;
-    E.key_names = B.key_names; E.key_values = B.key_values; E.key_members = B.key_members; E.key_class = B.key_class; E.res_names = B.res_names; E.key_nvalues = B.key_nvalues; E.value_int = B.value_int;
+    E.key_names = B.key_names; E.key_values = B.key_values; E.key_members = B.key_members; E.key_class = B.key_class; E.key_ints = B.key_ints; E.res_names = B.res_names; E.key_nvalues = B.key_nvalues; E.value_int = B.value_int;
     // the catalogue arrays (it_*) stay the snapshot's: Encoded::shared keeps them alive, finish() points ks_problem at them
     E.templates = B.templates; E.tmpl = B.tmpl; E.tmpl_taints = B.tmpl_taints; E.tmpl_types = B.tmpl_types; E.tmpl_daemon = B.tmpl_daemon; E.tmpl_daemon_present = B.tmpl_daemon_present;
     E.tmpl_limit_present = B.tmpl_limit_present;
@@ -1281,7 +1293,7 @@ static std::string tokq(const std::string& s) { return s.empty() ? "~" : s; }
 
 std::string Encoded::decode(const ks_result& r, double solve_seconds) const {
   if (view && shared) {      // a what-if derived on the device: every naming table is the snapshot's; the dimensions are this what-if's
-    Encoded tmp; tmp.src = shared->src; tmp.key_names = shared->key_names; tmp.key_values = shared->key_values; tmp.key_members = shared->key_members; tmp.res_names = shared->res_names; tmp.templates = shared->templates;
+    Encoded tmp; tmp.src = shared->src; tmp.key_names = shared->key_names; tmp.key_values = shared->key_values; tmp.key_members = shared->key_members; tmp.key_ints = shared->key_ints; tmp.res_names = shared->res_names; tmp.templates = shared->templates;
     tmp.existing = shared->existing; tmp.shared = shared; tmp.shared_lattice = true; tmp.prob = prob;
     return tmp.decode(r, solve_seconds);
   }
@@ -1309,7 +1321,8 @@ std::string Encoded::decode(const ks_result& r, double solve_seconds) const {
         else x.vals.push_back(key_values[k][v]);
       }
       const int32_t gt = r.node_gt[(size_t)j * p.K + k], lt = r.node_lt[(size_t)j * p.K + k];
-      x.gt = gt == KS_NO_BOUND_GT ? "-" : std::to_string(gt); x.lt = lt == KS_NO_BOUND_LT ? "-" : std::to_string(lt);
+      const bool ranks = k < key_ints.size() && !key_ints[k].empty();      // (bounds carried as ranks: back to the integers)
+      x.gt = gt == KS_NO_BOUND_GT ? "-" : std::to_string(ranks ? key_ints[k].at((size_t)gt) : (long long)gt); x.lt = lt == KS_NO_BOUND_LT ? "-" : std::to_string(ranks ? key_ints[k].at((size_t)lt) : (long long)lt);
       reqs[key_names[k]] = std::move(x);
     }
     if (r.node_it_state[j] > 0) {

@@ -38,6 +38,10 @@ struct Encoded {
   // stand relative to every Gt / Lt bound of the problem (and "not an integer").  key_values[k][c] is then the class's representative,
   // key_members[k][c] its values, key_class[k] the value -> class map; for every other key both are empty.
   std::vector<std::vector<std::vector<std::string>>> key_members; std::vector<std::map<std::string, int>> key_class;
+  // Integers on a key (label values that parse, Gt / Lt bounds) are compared, never added: when one of them does not fit the kernel's int32 fields the
+  // key is encoded over RANKS -- key_ints[k] lists, ascending, every integer the key can meet; value_int and the bounds carry positions in it (Go's int
+  // is 64 bits wide: requirement.go:227-269).  Empty for a key whose integers all fit (the encoding is then the integers themselves).
+  std::vector<std::vector<long long>> key_ints;
   std::vector<std::string> res_names;
   std::vector<const ksp::Provisioner*> templates;          // weight order
   std::vector<int> existing;                                // indices into src.nodes

@@ -99,7 +99,10 @@ def test_unsupported_is_loud():
     pr = W.reference_benchmark(50, instance_count=100)   # `integer` label with 100 distinct values ...
     S.FlatProblem(pr).close()                             # ... is fine while only instance types carry it (the key is left out)
     from karpenter_core_amd.model import Expr
-    pr.pods[0].required_affinity = [[Expr(fake.LABEL_INTEGER, "Gt", ["50"])]]   # a pod references it: 100 values do not fit a 64-bit mask
+    pr.pods[0].required_affinity = [[Expr(fake.LABEL_INTEGER, "Gt", ["50"])]]   # a pod bounds it: the 100 values fall into classes by that bound (tests/test_value_classes.py)
+    S.FlatProblem(pr).close()
+    from karpenter_core_amd.model import DO_NOT_SCHEDULE, LabelSelector, TopologySpreadConstraint
+    pr.pods[1].spread = [TopologySpreadConstraint(1, fake.LABEL_INTEGER, DO_NOT_SCHEDULE, LabelSelector({"app": "x"}))]   # a topology key needs every value as a domain of its own
     with pytest.raises(S.KSolveError) as ei:
         S.FlatProblem(pr)
     assert ei.value.code == S.KS_ERR_UNSUPPORTED

@@ -57,3 +57,41 @@ def test_gpu_matches_oracle_on_the_reference_fixture(seed):
     want = O.solve(p)
     assert got.canonical() == want.canonical() and got.reasons == want.reasons
     assert any(fake.LABEL_INTEGER in n.requirements for n in want.new_nodes)
+
+
+def wide_integer_problem(seed=1):
+    """Go's int is 64 bits wide (requirement.go:227-269): label values and Gt / Lt bounds beyond int32 on a custom key."""
+    from karpenter_core_amd.model import LABEL_ZONE
+    rs = np.random.RandomState(seed)
+    its = fake.assorted_ladder(4, ["amd64"], ["linux"], [W.ZONES], [["spot", "on-demand"]])
+    big = [5_000_000_000, 7_000_000_000, -9_000_000_000, 12, 2_147_483_647]
+    provs = [fake.provisioner(f"p{i}", len(its), weight=10 - i, labels={"example.com/serial": str(v)}) for i, v in enumerate(big)]
+    pods = W.diverse_pods(rs, 300)
+    for i in range(0, 300, 3):
+        k = int(rs.randint(4))
+        if k == 0:
+            ra = [[Expr("example.com/serial", "Gt", ["6000000000"])]]
+        elif k == 1:
+            ra = [[Expr("example.com/serial", "Lt", ["-1"])]]
+        elif k == 2:
+            ra = [[Expr("example.com/serial", "Gt", ["11"]), Expr("example.com/serial", "Lt", ["5000000001"])]]
+        else:
+            ra = [[Expr("example.com/serial", "Gt", ["9223372036854775000"])]]      # nothing qualifies: the pod stays pending
+        pods[i] = Pod(uid=pods[i].uid, labels=pods[i].labels, containers=pods[i].containers, required_affinity=ra)
+    del LABEL_ZONE
+    return Problem(instance_types=its, provisioners=provs, pods=pods, extra_well_known=fake.EXTRA_WELL_KNOWN)
+
+
+def test_integers_beyond_int32_flatten():
+    f = S.FlatProblem(wide_integer_problem())
+    assert f.dims["M"] == 5
+    f.close()
+
+
+@pytest.mark.gpu
+def test_gpu_matches_oracle_with_64_bit_integers():
+    from oracle import oracle_py as O
+    p = wide_integer_problem()
+    got, want = S.solve_problem(p), O.solve(p)
+    assert got.canonical() == want.canonical() and got.reasons == want.reasons
+    assert want.unscheduled and any(n.requirements.get("example.com/serial") is not None for n in want.new_nodes)
