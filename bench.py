@@ -160,10 +160,11 @@ def main():
     grid_bytes = dims["C"] * (8 * dims["R"] + 16 * dims["K"] + 16) + dims["T"] * (8 * dims["R"] + 16 * dims["K"] + 8) + dims["M"] * dims["C"] * TW * 8
     traffic, traffic_src, issue = None, None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_pmc.json")))
+        pmc_name = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_pmc.json"))[-1]      # the latest round's counter passes
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
         if pmc.get("kernel_source_sha16") == kernel_source_sha16() and pmc.get("pods") == dims["P"] and pmc.get("instance_types") == dims["T"]:
             traffic = pmc["ks_pack_per_launch"]["hbm_bytes_fetch_x2_plus_write"]
-            traffic_src = "profiles/r02_bench_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, same kernel source)"
+            traffic_src = f"profiles/{pmc_name} (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, same kernel source)"
             ipl = pmc["ks_pack_per_launch"].get("instructions")
             if ipl:
                 clk = pmc["ks_pack_per_launch"].get("shader_clock_ghz", 2.4)

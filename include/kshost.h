@@ -71,6 +71,7 @@ void ksh_pods_free(void* batch);
 int ksh_pods_count(void* batch, uint32_t* n_pods, uint32_t* n_specs);
 int ksh_solve_from_batch(void* parsed_env, void* batch, int device, uint32_t flags, void** out_handle, double* ms /* as ksh_solve_from_pods */);
 int ksh_open_batch(void* parsed_env, void* batch, uint32_t flags, void** out_handle);   /* flatten only (no GPU needed) */
+int ksh_open_parsed(void* parsed, uint32_t flags, void** out_handle);                   /* ksh_open for objects already held (ksh_parse) */
 
 /* ---- the same in steps ---- */
 int ksh_open(const char* ksp_text, size_t len, uint32_t flags, void** out_handle);      /* parse + flatten (no GPU needed) */

@@ -1418,7 +1418,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         const PlanTopo& th = c.host[i]; const u32 f = UF(*(const u32*)&th.type); const u32 ty = f & 0xFF, self = (f >> 8) & 0xFF;
         if ((ty == 2 || (ty == 0 && (i64)UF(th.maxskew) - (i64)self <= 0)) && (i32)UF(sh.host_zero[i]) <= 0) dead = true;
       }
-      if (dead) { pos_base = tb.E + nnew; reuse = false; r_valid = false; }
+      if (dead) { pos_base = tb.E + nnew; reuse = false; r_valid = false; CUT(26); }
     }
     if (NW == 1 && cr.eq != 0) CTR(8, 1);
     r_valid = reuse;               // any other path re-evaluates (or moves nodes in ways the window does not track)
@@ -1647,6 +1647,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           nnew = jw + 1;
         }
         pp_used += cr.port_cnt; ++seq; placed = true;
+        if (NW > 1) { if (fresh) CUT(29); else if (pos_base == wm0) CUT(12); else CUT(20); }      // (experiment builds) sequential pods: opened a node / first window / deeper
         if constexpr (NW > 1) { if (lane == 0) { const u32 hb = 1u << (cidx & 31u); if (fresh || (!reuse && pos_base != 0)) ls.hard[(cidx >> 5) & 7u] |= hb; else ls.hard[(cidx >> 5) & 7u] &= ~hb; } }
         LSYNC();
         PROBE(18);
@@ -1670,6 +1671,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
 
     // ---- failure: Preferences.Relax + Queue.Push + Topology.Update (scheduler.go:116-123) ----
     if (!placed) {
+      CUT(31);
       const u32 gpod = P.pod_gid ? UF(GC(u32, P.pod_gid)[pod]) : pod;      // (derived what-if: the chain is the snapshot pod's)
       const u32 nst = UF(G_pod_stage_off[gpod + 1] - G_pod_stage_off[gpod]);
       const i32 stg = (i32)UF(G_pod_stage[pod]);

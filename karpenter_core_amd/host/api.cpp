@@ -81,6 +81,7 @@ const ks_problem* ksh_problem(void* h) { return &((Handle*)h)->enc->prob; }
 struct Parsed {
   std::shared_ptr<const ksp::Problem> pr;
   std::mutex mu; std::shared_ptr<const ksh::SnapshotBase> sb; std::vector<int32_t> sb_pod_node; uint32_t sb_flags = 0;
+  ksh::EnvCache env;      // the flattening of everything but the pods, reused by the next batch with the same universe signature
 };
 int ksh_parse(const char* ksp_text, size_t len, void** out) {
   *out = nullptr;
@@ -114,7 +115,7 @@ template <class ENC> static int solve_from(ENC&& make_encoded, int device, void*
 }
 extern "C" {
 int ksh_solve_from_pods(void* parsed, int device, uint32_t flags, void** out_handle, double* ms) {
-  return solve_from([&] { return ksh::encode(((Parsed*)parsed)->pr, flags); }, device, out_handle, ms);
+  return solve_from([&] { return ksh::encode(((Parsed*)parsed)->pr, flags, &((Parsed*)parsed)->env); }, device, out_handle, ms);
 }
 
 // ---- binary pod ingress (kshost.h): flat pod records -> the batch in compact form; then Solve for that batch against an environment ----
@@ -138,14 +139,26 @@ int ksh_pods_count(void* batch, uint32_t* n_pods, uint32_t* n_specs) {
 }
 int ksh_solve_from_batch(void* parsed_env, void* batch, int device, uint32_t flags, void** out_handle, double* ms) {
   if (!parsed_env || !batch) return set_err(KS_ERR_INVALID, "null argument");
-  return solve_from([&] { return ksh::encode(((Parsed*)parsed_env)->pr, ((Batch*)batch)->b, flags); }, device, out_handle, ms);
+  return solve_from([&] { return ksh::encode(((Parsed*)parsed_env)->pr, ((Batch*)batch)->b, flags, &((Parsed*)parsed_env)->env); }, device, out_handle, ms);
+}
+// flatten only (no GPU needed) the problem a ksh_parse holds: ksh_open without the text
+int ksh_open_parsed(void* parsed, uint32_t flags, void** out) {
+  if (out) *out = nullptr;
+  if (!parsed || !out) return set_err(KS_ERR_INVALID, "null argument");
+  try {
+    auto h = std::make_unique<Handle>();
+    h->enc = ksh::encode(((Parsed*)parsed)->pr, flags, &((Parsed*)parsed)->env);
+    h->rb = h->enc->make_result();
+    *out = h.release(); return KS_OK;
+  } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());
+  } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
 }
 int ksh_open_batch(void* parsed_env, void* batch, uint32_t flags, void** out) {
   if (out) *out = nullptr;
   if (!parsed_env || !batch || !out) return set_err(KS_ERR_INVALID, "null argument");
   try {
     auto h = std::make_unique<Handle>();
-    h->enc = ksh::encode(((Parsed*)parsed_env)->pr, ((Batch*)batch)->b, flags);
+    h->enc = ksh::encode(((Parsed*)parsed_env)->pr, ((Batch*)batch)->b, flags, &((Parsed*)parsed_env)->env);
     h->rb = h->enc->make_result();
     *out = h.release(); return KS_OK;
   } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());

@@ -297,6 +297,8 @@ struct Builder {
   std::vector<std::string_view> uidv;                 // uid of pod i (a view into the pod object or the batch's uid bytes)
   int64_t ts_of(size_t i) const { return lite ? lite->ts[i] : podp[i]->creation_ts; }
   const Builder* base = nullptr;                      // what-if mode: the finished flattening of the whole snapshot
+  bool env_mode = false;                              // `base` is a cached flattening of the SAME environment for another batch (EnvCache): nothing leaves, the pods are new
+  std::vector<uint8_t> env_removed;                   // env mode: the nodes that are not in state, in the role of `removed'
   const std::vector<uint8_t>* removed = nullptr;      // what-if mode: nodes that leave the state-node list (helpers.go:48-61)
   bool node_in_state(size_t i) const { return removed ? !(*removed)[i] : pr.nodes[i].in_state; }
   std::vector<uint32_t> pod_rank;                     // base only: a pod's position in the snapshot-wide queue order
@@ -338,7 +340,7 @@ struct Builder {
     for (auto& t : p.anti_preferred) topo_key(t.term.topology_key);
   }
 
-  void collect_universes() {
+  void collect_active() {
     for (auto k : kBuiltinWellKnown) wellKnown.insert(k);
     for (auto& k : pr.extra_well_known) wellKnown.insert(k);
     res_of("cpu"); res_of("memory"); res_of("pods");
@@ -354,6 +356,17 @@ struct Builder {
     for (auto& p : pr.daemons) note_pod(p);
     for (auto& cp : pr.cluster_pods) for (auto& t : cp.anti_required) { if (t.topology_key != ksp::kHostname) { key_of(t.topology_key, true); topo_keys.insert(t.topology_key); } }
     passive_values = true;      // from here on values join a universe without being named by anything that could tell them apart
+  }
+  // What the batch, the provisioners and the daemonsets contribute to the universes, in canonical form: two batches with equal signatures flatten
+  // against the SAME catalogue encoding (EnvCache, encode()).
+  std::string active_signature() const {
+    std::string s; std::vector<std::pair<std::string, int>> ks(key_id.begin(), key_id.end());      // (std::map: ascending key names)
+    for (auto& kv : ks) { s += kv.first; s += '\1'; for (auto& v : key_named[kv.second]) { s += v; s += '\2'; } s += '\3'; for (long long b : key_bounds[kv.second]) { s += std::to_string(b); s += ','; } s += '\4'; }
+    s += '\5'; for (auto& k : topo_keys) { s += k; s += '\1'; } s += '\5'; for (auto& kv : res_id) { s += kv.first; s += '\1'; } s += toleratePreferNoSchedule ? "T" : "F";
+    return s;
+  }
+  void collect_universes() { collect_active(); collect_passive(); }
+  void collect_passive() {
     // Instance types last: a label key that ONLY instance types carry (real catalogues have many, often with hundreds of
     // values -- the fake provider's `integer` has one per type) can never meet a node requirement: node requirements come from
     // provisioners, pods, topology keys and existing-node labels, and Intersects / Compatible only look at keys both sides
@@ -562,7 +575,9 @@ struct Builder {
     if (base && !base->any_volume_limits) { for (auto* p : podp) if (p->volume_error) { pods_have_volumes = true; break; } return; }      // no node limits a volume: only a failed lookup matters
     for (size_t i = 0; i < pr.nodes.size(); ++i) if (node_in_state(i) && pr.nodes[i].owned()) for (auto& kv : pr.nodes[i].volume_limits) if (!vol_driver_id.count(kv.first)) { const int id = (int)vol_driver_id.size(); vol_driver_id[kv.first] = id; }
     if (vol_driver_id.size() > 64) throw Unsupported("more than 64 CSI drivers with volume limits");
-    for (auto* p : podp) if (p->volume_error || !p->volumes.empty()) { pods_have_volumes = true; break; }
+    { std::atomic<bool> any{false};      // (a scan over every pod object: on the worker threads)
+      parallel_chunks(podp.size(), [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e && !any.load(std::memory_order_relaxed); ++i) if (podp[i]->volume_error || !podp[i]->volumes.empty()) any = true; }, 16384);
+      pods_have_volumes = any; }
     if (!pods_have_volumes || vol_driver_id.empty()) return;
     std::unordered_set<std::string> on_node;
     for (size_t i = 0; i < pr.nodes.size(); ++i) if (node_in_state(i) && pr.nodes[i].owned()) for (auto& v : pr.nodes[i].volumes) if (vol_driver_id.count(v.driver)) on_node.insert(vol_pair(v));
@@ -663,7 +678,7 @@ struct Builder {
       std::copy_n(&B.en_avail[(size_t)b * R], R, &E.en_avail[(size_t)e * R]); std::copy_n(&B.en_requests[(size_t)b * R], R, &E.en_requests[(size_t)e * R]);
     }
     std::vector<ksp::ResList> remaining = base->base_remaining;
-    for (size_t i = 0; i < pr.nodes.size(); ++i) if ((*removed)[i] && base->node_owned[i]) {
+    if (!env_mode) for (size_t i = 0; i < pr.nodes.size(); ++i) if ((*removed)[i] && base->node_owned[i]) {      // (env mode: the same nodes are in state as in the cached flattening)
       auto pl = pr.nodes[i].labels.find(ksp::kProvisionerName);
       for (uint32_t m = 0; m < M; ++m) if (E.templates[m]->has_limits && E.templates[m]->name == pl->second) for (auto& kv : remaining[m]) { auto c = pr.nodes[i].capacity.find(kv.first); if (c != pr.nodes[i].capacity.end()) kv.second += c->second; }
     }
@@ -789,12 +804,12 @@ struct Builder {
   }
   void dedupe_specs() {
     if (lite) {
-      if (base) throw ksp::Error("a binary pod batch cannot be a what-if over a snapshot");
+      if (base && !env_mode) throw ksp::Error("a binary pod batch cannot be a what-if over a snapshot");
       podp.resize(lite->size()); uidv.resize(lite->size());
       parallel_chunks(lite->size(), [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { podp[i] = &lite->specs[lite->pod_spec[i]]; uidv[i] = lite->uid(i); } });
     } else {
-      if (podp.empty() && !base) { podp.reserve(pr.pods.size()); for (auto& p : pr.pods) podp.push_back(&p); }
-      uidv.resize(podp.size()); for (size_t i = 0; i < podp.size(); ++i) uidv[i] = podp[i]->uid;
+      if (podp.empty() && !base) { podp.resize(pr.pods.size()); const Pod* p0 = pr.pods.data(); parallel_chunks(podp.size(), [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) podp[i] = p0 + i; }, 16384); }
+      uidv.resize(podp.size()); parallel_chunks(podp.size(), [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) uidv[i] = podp[i]->uid; }, 16384);
     }
     const uint32_t P = (uint32_t)podp.size(); collect_volumes(); sublap("(start)");
     if (lite) {
@@ -807,7 +822,7 @@ struct Builder {
       sublap("specs from the batch");
       return;
     }
-    if (base) {
+    if (base && !env_mode) {
       // What-if over a snapshot: its pods ARE snapshot pods, and the snapshot's flattening already knows which of them share a spec (a partition
       // at least as fine as this what-if needs).  Local spec ids in order of first occurrence, as always.
       const Pod* p0 = pr.pods.data();
@@ -888,7 +903,7 @@ struct Builder {
     E.stage_cls.resize(E.pod_stage_off[P]);
     parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const auto& cl = specs[pod_spec[i]].cls; std::copy(cl.begin(), cl.end(), E.stage_cls.begin() + E.pod_stage_off[i]); } });
     // NewQueue: byCPUAndMemoryDescending, queue.go:74-110
-    if (base) {      // the order is a total order on pods: a what-if's queue is its pods in the snapshot's order
+    if (base && !env_mode) {      // the order is a total order on pods: a what-if's queue is its pods in the snapshot's order
       const Pod* p0 = pr.pods.data(); std::vector<std::pair<uint32_t, uint32_t>> k(P);
       for (uint32_t i = 0; i < P; ++i) k[i] = {base->pod_rank[podp[i] - p0], i};
       std::sort(k.begin(), k.end());
@@ -912,7 +927,37 @@ struct Builder {
       if (a.ulen <= 16 && b.ulen <= 16) return a.ulen < b.ulen;          // equal 16-byte prefixes incl. zero padding: the shorter one is a prefix (NUL bytes inside a uid fall through to the full compare)
       return uidv[a.pod] < uidv[b.pod];
     };
-    {
+    // cpu and memory are a function of the spec, so the queue falls into a few (cpu, memory) buckets -- 30 for BASELINE configs[2] -- whose order is
+    // known at once; inside a bucket only (timestamp, uid) decide.  Buckets are counted, filled and sorted independently on the worker threads; a
+    // batch that is mostly ONE bucket takes the chunked merge sort below instead.
+    bool bucketed = false;
+    if (P >= 8192) {
+      std::vector<std::pair<int64_t, int64_t>> cm(specs.size());
+      for (size_t s2 = 0; s2 < specs.size(); ++s2) { const uint32_t c0 = specs[s2].cls[0]; cm[s2] = {E.cls_requests[(size_t)c0 * R + rc], E.cls_requests[(size_t)c0 * R + rm]}; }
+      std::vector<std::pair<int64_t, int64_t>> dist(cm); std::sort(dist.begin(), dist.end(), [](auto& a, auto& b) { return a.first != b.first ? a.first > b.first : a.second > b.second; });
+      dist.erase(std::unique(dist.begin(), dist.end()), dist.end());
+      const size_t NB = dist.size();
+      if (NB >= 2 && NB <= 4096) {
+        std::vector<uint32_t> bucket_of(specs.size());
+        for (size_t s2 = 0; s2 < specs.size(); ++s2) bucket_of[s2] = (uint32_t)(std::lower_bound(dist.begin(), dist.end(), cm[s2], [](auto& a, auto& b) { return a.first != b.first ? a.first > b.first : a.second > b.second; }) - dist.begin());
+        std::vector<size_t> off(NB + 1, 0); for (uint32_t i = 0; i < P; ++i) ++off[bucket_of[pod_spec[i]] + 1];
+        size_t biggest = 0; for (size_t b = 0; b < NB; ++b) { biggest = std::max(biggest, off[b + 1]); off[b + 1] += off[b]; }
+        if (biggest <= P / 3) {
+          std::vector<QKey> sorted(P); { std::vector<size_t> at(off.begin(), off.end() - 1); for (uint32_t i = 0; i < P; ++i) sorted[at[bucket_of[pod_spec[i]]]++] = keys[i]; }
+          std::atomic<size_t> next{0};
+          auto lessb = [&](const QKey& a, const QKey& b) {
+            if (a.ts != b.ts) return a.ts < b.ts;
+            if (a.u0 != b.u0) return a.u0 < b.u0;
+            if (a.u1 != b.u1) return a.u1 < b.u1;
+            if (a.ulen <= 16 && b.ulen <= 16) return a.ulen < b.ulen;
+            return uidv[a.pod] < uidv[b.pod];
+          };
+          run_threads((uint32_t)std::min<size_t>(host_threads(), NB), [&](uint32_t) { for (;;) { const size_t b = next.fetch_add(1); if (b >= NB) return; std::sort(sorted.begin() + off[b], sorted.begin() + off[b + 1], lessb); } });
+          keys.swap(sorted); bucketed = true;
+        }
+      }
+    }
+    if (!bucketed) {
       uint32_t nt = 1; while (nt * 2 <= host_threads() && (size_t)nt * 2 * 4096 <= P) nt *= 2;       // power of two: pairwise merge rounds
       std::vector<size_t> cut(nt + 1); for (uint32_t t = 0; t <= nt; ++t) cut[t] = (size_t)P * t / nt;
       auto run = [&](uint32_t n, auto&& body) { run_threads(n, body); };
@@ -1088,7 +1133,7 @@ struct Builder {
   void finish() {
     ks_problem& p = E.prob;
     p.P = (uint32_t)podp.size(); p.C = E.cls.n; p.T = T; p.M = (uint32_t)E.templates.size(); p.E = (uint32_t)E.existing.size(); p.K = K; p.R = R;
-    p.max_new_nodes = p.P ? p.P : 1; p.flags = flags | ((pr.simulation_mode || base) ? KS_FLAG_SIMULATION : 0);
+    p.max_new_nodes = p.P ? p.P : 1; p.flags = flags | ((pr.simulation_mode || (base && !env_mode)) ? KS_FLAG_SIMULATION : 0);
     p.wellknown_mask = 0; for (uint32_t k = 0; k < K; ++k) if (wellKnown.count(E.key_names[k])) p.wellknown_mask |= 1u << k;
     p.key_nvalues = E.key_nvalues.data(); p.value_int = E.value_int.data(); p.key_zone = key_id.at(ksp::kZone); p.key_ct = key_id.at(ksp::kCapacityType); p.n_ct = E.key_nvalues[p.key_ct];
     const Encoded& CAT = E.catalogue(); const Encoded& LAT = E.lattice();
@@ -1107,6 +1152,13 @@ struct Builder {
     p.grp_count = E.grp_count.data(); p.grp_hslot = E.grp_hslot.data(); p.grph_count = E.grph_count.data(); p.grph_extra_pos = E.grph_extra_pos.data();
   }
 
+  bool specs_done = false, active_done = false;      // encode() with an EnvCache runs these two first (it needs the signature)
+  // env mode: the batch against the cached flattening of its environment -- everything that does not depend on the pods is adopted
+  void run_env() {
+    const bool timing = getenv("KSH_TIMING") != nullptr; auto t0 = std::chrono::steady_clock::now();
+    adopt_base(); encode_existing(); encode_pods(); encode_existing_rest_from_base(); encode_groups(); encode_it_states(); encode_volumes(); finish();
+    if (timing) fprintf(stderr, "  encode %-24s %8.2f ms\n", "batch over cached env", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
   void run() {
     const bool timing = getenv("KSH_TIMING") != nullptr;
     auto t0 = std::chrono::steady_clock::now();
@@ -1115,8 +1167,9 @@ struct Builder {
       adopt_base(); dedupe_specs(); encode_existing(); encode_pods(); encode_existing_rest_from_base(); encode_groups(); encode_it_states(); encode_volumes(); finish(); lap("what-if over shared snapshot");
       return;
     }
-    dedupe_specs(); lap("dedupe_specs");
-    collect_universes(); lap("collect_universes");
+    if (!specs_done) { dedupe_specs(); lap("dedupe_specs"); }
+    if (!active_done) collect_active();
+    collect_passive(); lap("collect_universes");
     encode_instance_types(); lap("encode_instance_types");
     it_reqs.push_back(Requirement()); it_cols.push_back(Requirement());   // state / column 0 == key absent
     encode_templates(); lap("encode_templates");
@@ -1133,17 +1186,43 @@ struct Builder {
 
 }  // namespace
 
-std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> pr, uint32_t flags) {
-  auto e = std::make_unique<Encoded>(); e->src = std::move(pr);
-  Builder b(*e, flags); b.run();
+// The flattening of an environment (catalogue, universes, templates, state-node rows, instance-type lattice) for ONE universe signature, kept
+// with the caller's objects: the next batch with the same signature adopts it instead of encoding 2 000 instance types again.
+struct EnvBase { std::string sig; uint32_t flags = 0; std::shared_ptr<Encoded> enc; std::unique_ptr<Builder> builder; };
+EnvCache::EnvCache() {}
+EnvCache::~EnvCache() {}
+static std::unique_ptr<Encoded> encode_cached(std::unique_ptr<Encoded> e, uint32_t flags, EnvCache* cache) {
+  static const bool off = getenv("KSH_NO_ENV_CACHE") != nullptr;
+  Builder b(*e, flags);
+  if (!cache || off) { b.run(); return e; }
+  const bool timing = getenv("KSH_TIMING") != nullptr; auto t0 = std::chrono::steady_clock::now();
+  b.dedupe_specs(); b.specs_done = true; b.collect_active(); b.active_done = true;
+  const std::string sig = b.active_signature();
+  if (timing) fprintf(stderr, "  encode %-24s %8.2f ms\n", "dedupe + signature", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  std::shared_ptr<const EnvBase> eb;
+  { std::lock_guard<std::mutex> g(cache->mu); if (cache->base && cache->base->sig == sig && cache->base->flags == flags) eb = cache->base; }
+  if (!eb) {
+    // first batch with this signature: flatten completely (this batch is as good as any to close the universes over) and keep the result;
+    // the batch itself then takes the same road every later one takes, so that a hit and a miss produce the same flat problem
+    auto nb = std::make_shared<EnvBase>(); nb->sig = sig; nb->flags = flags; nb->enc = std::make_shared<Encoded>(); nb->enc->src = e->src; nb->enc->batch = e->batch;
+    nb->builder = std::make_unique<Builder>(*nb->enc, flags); nb->builder->run();
+    eb = nb; std::lock_guard<std::mutex> g(cache->mu); cache->base = nb;
+  }
+  b.base = eb->builder.get(); b.env_mode = true; e->shared = eb->enc;
+  b.env_removed.assign(e->src->nodes.size(), 0); for (size_t i = 0; i < e->src->nodes.size(); ++i) b.env_removed[i] = e->src->nodes[i].in_state ? 0 : 1;
+  b.removed = &b.env_removed;
+  b.run_env();
   return e;
 }
+std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> pr, uint32_t flags, EnvCache* cache) {
+  auto e = std::make_unique<Encoded>(); e->src = std::move(pr);
+  return encode_cached(std::move(e), flags, cache);
+}
 
-std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> env, std::shared_ptr<const ksp::PodBatch> batch, uint32_t flags) {
+std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> env, std::shared_ptr<const ksp::PodBatch> batch, uint32_t flags, EnvCache* cache) {
   if (!env->pods.empty()) throw ksp::Error("the environment of a binary pod batch must carry no pods of its own (PODS 0)");
   auto e = std::make_unique<Encoded>(); e->src = std::move(env); e->batch = std::move(batch);
-  Builder b(*e, flags); b.run();
-  return e;
+  return encode_cached(std::move(e), flags, cache);
 }
 
 // Binary pod ingress (include/kshost.h, kspb.hpp).  Per block: hash every record (all host threads), partition the block's pods by

@@ -84,8 +84,13 @@ struct Encoded {
   std::string decode(const ks_result& r, double solve_seconds) const;   // KSR1 text (see model.py parse_result)
 };
 
-std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> pr, uint32_t flags);
-std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> env, std::shared_ptr<const ksp::PodBatch> batch, uint32_t flags);
+// What a caller keeps next to the objects it holds (ksh_parse): the flattening of their ENVIRONMENT -- instance types, provisioners, state nodes,
+// daemonsets: provisioner.go:237-296 rebuilds all of that per Solve -- for the universe signature of the last batch.  A batch that names the same label
+// keys / values / bounds / resources (the steady state of a provisioning loop) adopts it and only flattens its pods.  Thread-safe.
+struct EnvBase;
+struct EnvCache { std::mutex mu; std::shared_ptr<const EnvBase> base; EnvCache(); ~EnvCache(); };
+std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> pr, uint32_t flags, EnvCache* cache = nullptr);
+std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> env, std::shared_ptr<const ksp::PodBatch> batch, uint32_t flags, EnvCache* cache = nullptr);
 // Binary pod ingress (include/kshost.h ksh_pods_ingest): blocks of flat pod records -> distinct specs + 16 bytes per pod.
 std::shared_ptr<const ksp::PodBatch> ingest_pod_blocks(const ksh_pod_block* blocks, uint32_t n_blocks);
 inline std::unique_ptr<Encoded> encode(ksp::Problem&& pr, uint32_t flags) { return encode(std::make_shared<const ksp::Problem>(std::move(pr)), flags); }

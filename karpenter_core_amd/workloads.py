@@ -280,7 +280,7 @@ def config4_sets(whatifs: int = 512, existing: int = 2048, seed: int = 45) -> Li
 
 def config4b_snapshot(existing: int = 2048, sizes: int = 50, seed: int = 47):
     """BASELINE configs[3]'s shape over a cluster that is full by pod count: the what-ifs REPLACE (open one node) or fail, instead of all deleting."""
-    return cluster_snapshot(existing, sizes, seed, spare_pod_slots=12)
+    return cluster_snapshot(existing, sizes, seed, spare_pod_slots=3)      # (a handful of free pod slots in the whole cluster: nearly every what-if opens a node)
 
 
 def config4(whatifs: int = 512, existing: int = 2048, sizes: int = 50, seed: int = 45, with_cluster_pods: bool = False) -> List[Problem]:
