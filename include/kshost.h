@@ -40,7 +40,11 @@ extern "C" {
 const char* ksh_last_error(void);
 void ksh_free(char* p);
 
-/* ---- objects in memory ---- */
+/* ---- objects in memory ----
+ * A parsed object also keeps, behind a mutex, what later calls derive from it once: the flattening of its ENVIRONMENT (instance types, provisioners,
+ * state nodes, daemonsets -- everything but the pods) for the universe signature of the last batch, which the next batch with the same label keys /
+ * values / bounds / resources adopts instead of encoding the catalogue again (KSH_NO_ENV_CACHE=1 turns that off); and, for a cluster snapshot, its
+ * own flattening, shared by the what-ifs over it.  It is otherwise immutable: any number of threads may use it at once. */
 int ksh_parse(const char* ksp_text, size_t len, void** out_parsed);
 void ksh_parsed_free(void* parsed);
 

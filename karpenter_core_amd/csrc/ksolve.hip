@@ -38,6 +38,7 @@
 #include "../../include/ksolve.h"
 #include "ks_algebra.h"
 
+#define KS_FLAG_NOFOLD 0x10000u   /* internal (KS_NO_FOLD=1 at upload): the rounds do not fold node-opening pods in (A/B and parity of both ways) */
 #define KS_MAX_TOPO 24       // topology groups evaluated per pod class
 #define KS_MAX_TOUCH 12      // distinct narrow keys a class may touch (own requirements + topology + recorded keys)
 
@@ -625,6 +626,7 @@ template <int RM> struct RoundCtlT {   // speculation-round hand-off between the
   // hostname-keyed items that tolerate more than zero pods (ClsBrief::dyn tag 2): the round's certain records per candidate and group
   u32 hrec32[64][6];                             // [candidate][hslot / 4]: 8-bit counters, hslot < 24
   u8 hslack[KS_MAX_WAVES][64];                   // per worker: how many more pods of its group candidate i takes (maxSkew - self - count at the snapshot)
+  u64 hz0[KS_MAX_WAVES];                         // per worker (ClsBrief::dyn tag 2): candidates whose own counter of the item's group was 0 at the snapshot
 };
 
 // ---- slot record (AoS).  Offsets in bytes; stride = ks_rec_stride(R,K) ----
@@ -1797,6 +1799,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           i32 slack = 0;
           if (slot != 0xFFFFFFFFu && ty == 0) slack = h0max - (i32)self - hc_pre;
           rc.hslack[kw][lane] = (u8)(slack < 0 ? 0 : (slack > 255 ? 255 : slack));
+          const u64 hz = ballot64(slot != 0xFFFFFFFFu && hc_pre == 0); if (lane == 0) rc.hz0[kw] = hz;
         }
         if (kw == 0) {
           rc.cnt[lane] = ev.count; rc.rmsk[lane] = ev.reqmask;
@@ -1811,7 +1814,8 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
 #endif
       // ---- P2: the leader resolves the round.  Lane i plays two parts: round pod i (b_*) and window candidate i (c_*). ----
       u32 c_cnt = 0, c_cnt0 = 0, c_rm = 0, c_np = 0, c_last = 0, c_first = 0, c_key = 0xFFFFFFFFu; u64 c_racc = 0, c_rsure = 0; i64 c_room[RM];
-      u64 movedmask = 0; u32 n_ok = 0, nocand_cls = 0xFFFFFFFFu;
+      u64 movedmask = 0; u32 n_ok = 0, nocand_cls = 0xFFFFFFFFu, fold_k = 0xFFFFFFFFu;
+      const bool getenv_nofold = (UF(P.flags) & KS_FLAG_NOFOLD) != 0;      // (test hook: KS_NO_FOLD=1 at upload time)
       // Workers: what the filter phase and the commit read from global memory is requested NOW and arrives while the leader resolves --
       // lane l as window candidate l: its slot and the ladder indices of its filter thresholds (DevState::lowi);
       // lane l as round pod l (if this wave evaluated its class): the first groups Topology.Record will visit.
@@ -2002,6 +2006,15 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             // nothing in the window takes this pod (and a window only loses acceptors as the round goes on): it needs a deeper scan or a new
             // node -- remember its class so that the next plan hands it to the sequential path instead of opening a round that ends at once
             nocand_cls = RL((u32)(b_e >> 32), k) & 0x7FFFFFFFu;
+            // Fold (LEAN kernel): the pod needs a node whose own counter of ONE hostname-keyed group is 0 (anti-affinity, spread with maxSkew - self == 0),
+            // every registered hostname that still counts 0 for that group stands in this window (census == the snapshot's zero-count candidates), and
+            // none of them takes the pod with what the round did to them: no node anywhere takes it -- scheduler.add goes to the templates
+            // (scheduler.go:193-213).  The leader prepares that node while the workers filter and commits it after the round's order moves: the step that
+            // would have opened it, its plan and its barriers fall away.
+            if constexpr (LEAN) if (k >= 1 && hsk && !getenv_nofold) {
+              const u32 hsl = (hsw >> 8) & 31u, gk = (hsw >> 16) & 63u;
+              if (((RL64(b_zmask, k) >> gk) & 1ull) && (u32)__builtin_popcountll(UF64(rc.hz0[RL(b_w, k) & (KS_MAX_WAVES - 1)])) == (u32)UF((u32)tb.g_hzero[hsl])) fold_k = k;
+            }
             CUT(14); break;
           }
           const u64 un = A & ~movedmask;
@@ -2255,6 +2268,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
 #endif
       }
       u32 sp_head = q_head, sp_len = q_len, sp_seq = seq;
+      bool fold_ok = false; Pub f_pb; u32 f_pod = 0, f_cidx = 0, f_mt = 0; f_pb.slot = 0; f_pb.present = 0; f_pb.complement = 0; f_pb.changed = 0; f_pb.narrowed = 0; f_pb.valid = 0; f_pb.rm = 0; f_pb.count = 0; f_pb.it_state = 0; f_pb.it_before = 0; f_pb.need = false;
+#pragma unroll
+      for (int i = 0; i < RM; ++i) { f_pb.req_new[i] = 0; f_pb.room_new[i] = 0; }
       if (wv == 0) {
         // While the workers filter, plan the step after this round as if the round commits (a filter comes back empty a handful of times
         // per Solve; the plan is then redone): queue entries and class briefs of the next pods are requested a whole phase early.
@@ -2263,7 +2279,63 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         sp_head = q_head + n_ok; if (sp_head >= nP) sp_head -= nP; sp_len = q_len - n_ok; sp_seq = seq + n_ok;
         { u32 idx = sp_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; pq_e = tb.q[idx]; pq_ok = true; }
         if (n_ok == 0) seq_credit = 1;                 // the head pod needs more than the window offers: take it sequentially
-        plan(sp_head, sp_len, sp_seq);
+        if (fold_k == 0xFFFFFFFFu) plan(sp_head, sp_len, sp_seq);
+        else if constexpr (LEAN) {
+          // ---- fold, first half (while the workers filter): NewNode + Node.Add up to and including the instance-type filter for round pod fold_k on
+          // a fresh node -- everything that only WRITES the node's own slot (record, hostname counters, alive row).  Nothing of it is visible before
+          // the second half commits it; a round that is cancelled, or a template that does not work out at once, simply drops it. ----
+          if (lane == 0) rc.mode2[stepc & 1u] = 0xFFu;      // (no plan yet: the workers must not stage a class for the next step)
+          spec_mode = 0; pq_ok = false;
+          const u64 fe = RL64(b_e, fold_k); f_pod = (u32)fe; f_cidx = (u32)(fe >> 32) & 0x7FFFFFFFu;
+          { const GA u32x4* src = (const GA u32x4*)(plans + f_cidx); u32x4* dst = (u32x4*)&sh.cls; dst[lane] = src[lane]; if ((u32)lane + 64 < KS_PLAN_V) dst[lane + 64] = src[lane + 64]; }
+          stage_class(tb, sh, lane);
+          const ClsPlan& c = sh.cls;
+          ClsR fcr; fcr.tol = UF64(c.tol); fcr.reqmask = UF(c.reqmask); fcr.ntouch = UF(c.ntouch); fcr.nhost = UF(c.nhost); fcr.hn_mode = 0; fcr.port_cnt = 0; fcr.vol_cnt = 0; fcr.it_state = 0; fcr.tkeys = UF64(c.tkeys); fcr.eq = UF(c.eq);
+#pragma unroll
+          for (int i = 0; i < RM; ++i) fcr.req[i] = (i64)UF64(c.req[i]);
+          const u32 fnn = UF(nnew);
+          if (!UF(c.overflow) && fnn < nMAX) {
+            // the first template that survives the pre-checks (scheduler.go:193-213; LEAN: no provisioner has limits)
+            bool have = false; u32 m_t = 0; size_t mc = 0;
+            for (u32 tmf = 0; tmf < nM && !have; ++tmf) {
+              m_t = tmf; mc = (size_t)m_t * nC + f_cidx; bool lany = false;
+              for (u32 wbase = 0; wbase < tb.TW; wbase += 64) {
+                const u32 w = wbase + lane; u64 a = 0;
+                if (w < tb.TW) { a = GC(u64, P.tmpl_types)[(size_t)m_t * tb.TW + w]; scratch[w] = a & G_grid[mc * tb.TW + w]; }
+                if (ballot64(a != 0)) lany = true;
+              }
+              if (!lany) continue;
+              if (!UF(GC(u8, P.mc_ok)[mc])) continue;
+              have = true;
+            }
+            if (have) {
+              const u32 fs = tb.E + fnn; const Rec fr = slot_rec(S, tb, fs);
+              if ((u32)lane < tb.K) { fr.mask()[lane] = GC(u64, P.mc_mask)[mc * tb.K + lane]; fr.gt()[lane] = GC(i32, P.mc_gt)[mc * tb.K + lane]; fr.lt()[lane] = GC(i32, P.mc_lt)[mc * tb.K + lane]; }
+              if (lane >= 32 && (u32)lane < 32 + tb.R) { fr.req()[lane - 32] = GC(i64, P.tmpl_daemon)[(size_t)m_t * tb.R + lane - 32]; fr.room()[lane - 32] = INT64_MAX / 2; fr.low()[lane - 32] = INT64_MIN; }
+              if (lane == 63) { fr.taints() = GC(u64, P.tmpl_taints)[m_t]; fr.present() = GC(u32, P.mc_present)[mc]; fr.complement() = GC(u32, P.mc_complement)[mc]; fr.it_state() = GC(i32, P.mc_it)[mc]; fr.reqmask() = GC(u32, P.tmpl_daemon_present)[m_t]; fr.porthead() = -1; fr.count() = 0; }
+              for (u32 g = lane; g < nG; g += 64) { const i32 hs = GC(i32, P.grp_hslot)[g]; if (hs >= 0) tb.hcnt[(size_t)fs * tb.GH + hs] = tb.g_active[g] ? 0 : -1; }   // Topology.Register(hostname), node.go:47
+              __threadfence_block();
+              GSYNC();
+              u32 fslot = 0xFFFFFFFFu; if (lane == 0) fslot = fs;
+              Ev fev; fev.rc = 0; fev.count = 0; fev.reqmask = 0; fev.tchg = 0; fev.tnar = 0; fev.tpres = 0; fev.tcomp = 0; fev.present = 0; fev.complement = 0; fev.it_state = 0; fev.it0 = 0;
+#pragma unroll
+              for (int i = 0; i < RM; ++i) { fev.room[i] = 0; fev.req[i] = 0; fev.low[i] = INT64_MIN; }
+              if (fslot != 0xFFFFFFFFu) eval_node<BOUNDS, LEAN, RM>(P, S, tb, sh, wb, fslot, false, true, fev, lane, tprobe, fcr);
+              if (ballot64(fev.rc == 2) & 1ull) {
+                publish_eval<BOUNDS, RM>(tb, sh, wb, fev, fslot, true, lane, 0, fcr, f_pb);
+                GA u64* const alive = tb.n_alive + (size_t)fnn * tb.TW;
+                const u32 keys = f_pb.narrowed;
+                const bool zc = (tb.key_zone >= 0 && ((keys >> tb.key_zone) & 1u)) || (tb.key_ct >= 0 && ((keys >> tb.key_ct) & 1u));
+                u64 aw[2];
+                if (filter_types(P, tb, f_pb, sh, fr, scratch, alive, f_pb.rm, keys, zc, false, lane, tprobe, aw)) {
+                  if ((u32)lane < tb.R && ((f_pb.rm >> lane) & 1u)) fr.low()[lane] = sh.low_new[lane];
+                  if (lane < 2 && 4 * lane < RM) { u64 li2 = 0; for (int i = 0; i < 4; ++i) li2 |= (u64)((u32)(4 * lane + i) < tb.R ? (sh.low_idx[4 * lane + i] & 0xFFFFu) : 0xFFFFu) << (16 * i); ((GA u64*)S.lowi)[2 * (size_t)fs + lane] = li2; }
+                  fold_ok = true; f_mt = m_t;
+                }
+              }
+            }
+          }
+        }
 #ifdef KS_P2PROBES
         { const u64 now_ = __builtin_readcyclecounter(); if (lane == 0) ls.ctr[14] += now_ - t_ph; }      // the leader's own share of the filter phase
 #endif
@@ -2460,6 +2532,44 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
           CTR(KS_STAT_FULLCHECKS, (u32)__builtin_popcountll(M_moved));
         }
         const u32 n_commit = cancelled ? 0u : n_ok;
+        if constexpr (LEAN) if (!cancelled && fold_k != 0xFFFFFFFFu) {
+          if (fold_ok) {
+            // ---- fold, second half (the workers write their nodes' records meanwhile; counters, order array and bucket starts are the leader's):
+            // node.go:100-105 + scheduler.go:214-216 for the node prepared during the filter phase; the pod comes right after the round's pods ----
+            nnew = UF(nnew); seq = UF(seq); q_head = UF(q_head); q_len = UF(q_len); maxc = UF(maxc);
+            const u32 jw = nnew, fs = tb.E + jw; const Rec r = slot_rec(S, tb, fs);
+            for (u32 g = lane; g < nG; g += 64) { const i32 hs = GC(i32, P.grp_hslot)[g]; if (hs >= 0 && tb.g_active[g]) atomicAdd(&tb.g_hzero[hs], 1); }      // its registered hostnames join the zero-count census
+            LSYNC();
+            topology_record<true>(P, S, tb, f_pb, sh, r, fs, lane);
+            LSYNC();
+            write_record<BOUNDS, RM>(tb, r, f_pb, sh, f_pb.rm, lane);
+            if (lane == 0) { r.count() = 1; G_n_tmpl[jw] = (i32)f_mt; tb.pod_node[f_pod] = (i32)fs; tb.pod_seq[f_pod] = (i32)seq; G_pod_reason[f_pod] = 0; }
+            // visiting order: appended -> BACK of the count-1 bucket, i.e. position bstart[2]; everything after shifts right
+            if (ord_in_lds && nnew + 1 > ord_cap) { for (u32 i = lane; i < nnew; i += 64) ord_g[i] = ord_l[i]; GSYNC(); ord_in_lds = false; }
+            if (maxc == 0) { if (lane == 0) { bst_wr(1, 0); bst_wr(2, 1); ORD_WR(0, jw); } maxc = 1; }
+            else {
+              const u32 ins = UF(bst_rd(2));
+              for (u32 hi = nnew; hi > ins; ) {
+                const u32 lo = hi > ins + 256 ? hi - 256 : ins; u32 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const u32 ii = lo + 64u * (u32)u + (u32)lane; v[u] = 0; if (ii < hi) v[u] = ORD_RD(ii); }
+                if (ord_in_lds) LSYNC(); else GSYNC();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const u32 ii = lo + 64u * (u32)u + (u32)lane; if (ii < hi) ORD_WR(ii + 1, v[u]); }
+                if (ord_in_lds) LSYNC(); else GSYNC();
+                hi = lo;
+              }
+              if (lane == 0) ORD_WR(ins, jw);
+              for (u32 cc = 2 + lane; cc <= maxc + 1; cc += 64) bst_wr(cc, bst_rd(cc) + 1u);
+            }
+            nnew = jw + 1; ++seq; q_head = (q_head + 1 == nP) ? 0 : q_head + 1; q_len--;
+            CTR(KS_STAT_POPS, 1); CTR(KS_STAT_FULLCHECKS, 1); CUT(31);
+            if (lane == 0) ls.hard[(f_cidx >> 5) & 7u] |= 1u << (f_cidx & 31u);
+            __threadfence_block();
+            GSYNC();
+          }
+          pq_ok = false; plan(q_head, q_len, seq);      // (none was made during the filter phase)
+        }
 #ifdef KS_PROBES
         CTR(8, rn); CTR(9, 1); CTR(10, n_commit); CTR(11, n_ok); CTR(27, __builtin_readcyclecounter() - t_round); CTR(25, __builtin_readcyclecounter() - t_ph);
 #endif
@@ -2661,7 +2771,7 @@ static int upload_impl(const ks_problem* p, int device, const ks_dev_problem* ba
   auto layout = [&]() -> int {
   DevProb& h = d->h;
   h.P = p->P; h.C = p->C; h.T = p->T; h.TW = (p->T + 63) / 64; h.M = p->M; h.E = p->E; h.K = p->K; h.R = p->R; h.G = p->G; h.GH = p->GH; h.S = p->S; h.SC = p->SC;
-  h.NMAX = p->max_new_nodes ? p->max_new_nodes : 1; h.flags = p->flags; h.n_topologies = p->n_topologies;
+  h.NMAX = p->max_new_nodes ? p->max_new_nodes : 1; h.flags = p->flags | (getenv("KS_NO_FOLD") ? KS_FLAG_NOFOLD : 0u); h.n_topologies = p->n_topologies;
   h.wellknown_mask = p->wellknown_mask; h.key_zone = p->key_zone; h.key_ct = p->key_ct; h.n_ct = p->n_ct;
   {   // groups the round resolver may follow exactly (DevProb::dyn_groups)
     h.dyn_groups = 0; h.dyn_key = -1; h.dyn_nz = 0;
