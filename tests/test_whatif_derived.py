@@ -30,11 +30,31 @@ def test_ineligible_snapshots_are_refused_on_the_host():
     assert [f.dims["P"] for f in flats] == [len(bound[0]), len(bound[1]) + len(bound[2])]
 
 
+def _with_ports():
+    """some bound pods hold host ports (their nodes list them, hostportusage.go:122-144): a pod that leaves its node must not land where its port is taken"""
+    from karpenter_core_amd.model import HostPort
+    its, prov, nodes, bound = _snapshot(64, 6, 12, spare=30)
+    rs = np.random.RandomState(3)
+    for i, pods in enumerate(bound):
+        for p in pods:
+            if rs.rand() < 0.25:
+                p.containers[0].ports = [HostPort(port=9000 + int(rs.randint(3)))]
+        seen, hps = set(), []
+        for p in pods:
+            for hp in p.containers[0].ports:
+                if hp.port not in seen:
+                    seen.add(hp.port); hps.append(hp)
+                else:
+                    p.containers[0].ports = []          # (a node holds a port once)
+        nodes[i].host_ports = hps
+    return its, prov, nodes, bound
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["plain", "full-by-pod-count", "limits"])
+@pytest.mark.parametrize("case", ["plain", "full-by-pod-count", "limits", "host-ports"])
 def test_derived_whatifs_solve_like_flattened_ones(case):
     its, prov, nodes, bound = {"plain": lambda: _snapshot(96, 8, 5), "full-by-pod-count": lambda: _snapshot(96, 8, 6, spare=3),
-                               "limits": lambda: _snapshot(64, 6, 7, spare=2, limits={"cpu": "3000", "memory": "9000Gi"})}[case]()
+                               "limits": lambda: _snapshot(64, 6, 7, spare=2, limits={"cpu": "3000", "memory": "9000Gi"}), "host-ports": _with_ports}[case]()
     snap, pod_node = W.snapshot_problem(its, prov, nodes, bound, False)
     rs = np.random.RandomState(1)
     sets = [list(range(0, i + 1)) for i in range(0, 24, 3)] + [[int(x)] for x in rs.randint(len(nodes), size=8)] + [[5, 2, 40], [63, 0, 31, 7]]
