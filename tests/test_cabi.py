@@ -187,3 +187,24 @@ def test_flattening_fingerprints_are_pinned():
     want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "flat_fingerprints.json")))
     got = M.compute()
     assert got == want, sorted(k for k in want if got.get(k) != want[k])
+
+
+def test_headers_are_plain_c(tmp_path):
+    """include/*.h must be usable from C (what cgo compiles): tests/cabi_usage.c -- parse an environment, hand one pod over through the binary door,
+    flatten, ask for a Solve -- is compiled as C99 with -Wall -Werror -pedantic, linked against both libraries and run.  Without a GPU the Solve
+    must be refused with KS_ERR_DEVICE (no CPU path); with one it solves."""
+    import dataclasses
+    import subprocess
+    pkg = os.path.join(ROOT, "karpenter_core_amd")
+    exe = str(tmp_path / "cabi_usage")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cabi_usage.c"),
+                           "-o", exe, "-L", pkg, "-lkshost", "-lksolve", "-Wl,-rpath," + pkg])
+    env_file = tmp_path / "env.ksp"
+    env_file.write_text(dataclasses.replace(W.config1(pods=1, types=5), pods=[]).to_ksp())
+    out = subprocess.run([exe, str(env_file)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "pods 1 specs 1 flat P=1 C=1 T=5" in out.stdout
+    if S.device_count() == 0:
+        assert "solve refused: -3" in out.stdout
+    else:
+        assert "solved in" in out.stdout

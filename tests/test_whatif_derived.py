@@ -110,3 +110,45 @@ def test_full_size_config4_derived_matches_oracle_fingerprints():
     got = [hashlib.sha256(json.dumps(r.canonical(), sort_keys=True).encode()).hexdigest() for r in res]
     bad = [i for i, (a, b) in enumerate(zip(got, gold["whatif_sha256"])) if a != b]
     assert not bad, f"what-ifs differing from the oracle: {bad[:10]}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_derived_against_flattened_and_oracle(seed):
+    """Random snapshots (size, spare pod slots, provisioner limits, host ports, an unowned node whose pods are pending-like) and random candidate
+    sets: derived == flattened on every what-if, and == the oracle on a few of them."""
+    from karpenter_core_amd.model import StateNode
+    from oracle import oracle_py as O
+    rs = np.random.RandomState(7000 + seed)
+    n = int(rs.randint(24, 160))
+    if seed % 3 == 2:
+        its, prov, nodes, bound = _with_ports()
+    else:
+        its, prov, nodes, bound = _snapshot(n, int(rs.randint(4, 9)), 100 + seed, spare=int(rs.choice([-1, 0, 2, 9])),
+                                            limits={"cpu": str(int(rs.randint(200, 4000)))} if seed % 2 else None)
+    if seed % 4 == 1:      # a node no provisioner owns: it is no existing node, its pods can still be asked to move (consolidation's pending-pod device)
+        nodes.append(StateNode(name="unowned")); bound.append([dataclasses_replace_uid(p, f"extra-{i}") for i, p in enumerate(bound[0][:5])])
+    snap, pod_node = W.snapshot_problem(its, prov, nodes, bound, False)
+    sets = []
+    for _ in range(24):
+        k = int(rs.choice([1, 1, 2, 3, 6, 15]))
+        sets.append([int(x) for x in rs.choice(len(nodes), size=min(k, len(nodes)), replace=False)])
+    parsed = S.ParsedProblem(snap)
+    derived = S.open_whatifs(parsed, pod_node, sets, derive=True)
+    flat = S.open_whatifs(parsed, pod_node, sets, derive=False)
+    try:
+        got, _, _ = S.solve_batch(derived)
+        want, _, _ = S.solve_batch(flat)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a.canonical() == b.canonical() and a.reasons == b.reasons, (seed, i, sets[i])
+        for i in (0, 7, 23):
+            ref = O.solve(W.whatif(its, prov, nodes, bound, sets[i], False))
+            assert got[i].canonical() == ref.canonical(), (seed, i)
+    finally:
+        for f in derived + flat:
+            f.close()
+
+
+def dataclasses_replace_uid(p, uid):
+    import dataclasses
+    return dataclasses.replace(p, uid=uid)
