@@ -114,8 +114,10 @@ const char* ksh_key_value(void* handle, int which /* 0 zone, 1 capacity-type */,
 int ksh_types_subset(void** handles, uint32_t n, const uint32_t* node, const uint64_t* lhs, uint32_t stride_words, uint32_t* out);
 /* What-ifs DERIVED on the device from the resident snapshot (ksolve.h ks_whatifs_open; SURVEY 8b `ks_solve_batch(shared, whatif deltas, ...)`): no
  * per-what-if flattening on the host, an upload of KBs (candidate masks, remainingResources, descriptors); the handles come back already resident on
- * `device`.  Results read exactly like those of ksh_open_whatifs_parsed.  KS_ERR_UNSUPPORTED -- nothing opened -- when the snapshot's what-ifs do
- * not differ by their candidate sets alone (bound pods with topology terms, volume limits): use ksh_open_whatifs_parsed then. */
+ * `device`.  Results read exactly like those of ksh_open_whatifs_parsed.  Bound pods may carry spread / affinity / preferred terms: which groups a
+ * what-if starts with and what countDomains finds for it follow from per-node tables of the snapshot (ks_whatif_topo).  KS_ERR_UNSUPPORTED -- nothing
+ * opened -- where a what-if depends on its candidate set in other ways: required anti-affinity among bound or cluster pods (inverse groups), more than 64
+ * groups, one spread group shared by pods whose node filters differ, volume limits / claims.  Use ksh_open_whatifs_parsed then. */
 int ksh_open_whatifs_derived(void* parsed_snapshot, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand, const int32_t* pod_node, int device, void** out_handles);
 int ksh_open_whatifs_parsed(void* parsed_snapshot, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand, const int32_t* pod_node, uint32_t nthreads, void** out_handles);
 

@@ -252,13 +252,27 @@ int ks_problem_upload_shared(const ks_problem* p, const ks_dev_problem* base, ks
  * descriptors) and builds every batch on the device (the snapshot's queue order restricted to the candidates' pods).  ks_whatifs_problems are
  * ordinary device problems (views owned by the batch) for ks_solve_batch_dev / ks_batch_records_dev / ks_price_filter_dev / ...; in their
  * results pod i is the i-th pod of the what-if in the SNAPSHOT's queue order (ks_whatifs_pod_ids names the snapshot pod behind each) and
- * existing node e is the snapshot's row e (removed nodes receive nothing).  Only for snapshots without topology groups and volume limits
- * (KS_ERR_UNSUPPORTED otherwise: the caller flattens those what-ifs one by one). */
+ * existing node e is the snapshot's row e (removed nodes receive nothing).  Not for snapshots with volume limits, inverse anti-affinity groups or more
+ * than 64 topology groups (KS_ERR_UNSUPPORTED: the caller flattens those what-ifs one by one). */
 typedef struct ks_whatif_batch ks_whatif_batch;
+/* Snapshots whose bound pods carry spread / affinity terms (base G > 0; no inverse anti-affinity groups, G <= 64): what a what-if's topology takes from its
+ * candidate set is derived on the device too -- which groups exist from the start (owned by a pod of the batch: topology.go:72-78) and countDomains over
+ * the cluster pods that stay (topology.go:231-276) -- from per-node tables of the snapshot: */
+typedef struct ks_whatif_topo {
+  const int32_t* node_cnt;    /* [G][n_nodes] pods on the node that group g counts when they are NOT in the batch (selector, namespace, node filter, key present) */
+  const int32_t* node_dom;    /* [G][n_nodes] the node's domain for group g: value id of its label on the group's key, -1 if none; hostname-keyed groups: the
+                                              pods on the node the group counts that are in NO batch (they count under its hostname even when the node is a candidate) */
+  const uint64_t* node_own;   /* [n_nodes]    groups (bit g) some pod bound to the node owns at its first relaxation stage */
+  const int32_t* tot;         /* [G][64]      node_cnt summed per domain over every node */
+  const int32_t* extra_tot;   /* [GH]         hostname-keyed groups: nodes that are no existing row and count > 0 */
+  const int32_t* grph_base;   /* [GH][E]      hostname-keyed groups: what every existing row counts while its node stays; 0 = registered without pods,
+                                              -2 = registered only in a group a pod of the batch owns from the start (existingnode.go:73), else unknown (-1) */
+} ks_whatif_topo;
 int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, const int32_t* pod_node /* [base P] node of every snapshot pod */,
                     const int32_t* node_row /* [n_nodes] existing-node row in base, -1 if none */, uint32_t n, const uint32_t* cand_off /* [n+1] */,
                     const uint32_t* cand /* node indices */, const uint32_t* n_pods /* [n] pods bound to each candidate set */,
-                    const int64_t* remaining /* [n][M][R] remainingResources without the candidates */, ks_whatif_batch** out);
+                    const int64_t* remaining /* [n][M][R] remainingResources without the candidates */,
+                    const ks_whatif_topo* topo /* NULL for a snapshot without topology groups */, ks_whatif_batch** out);
 ks_dev_problem* const* ks_whatifs_problems(ks_whatif_batch* b);
 uint32_t ks_whatifs_count(const ks_whatif_batch* b);
 int ks_whatifs_pod_ids(ks_whatif_batch* b, uint32_t i, uint32_t* out /* [n_pods of what-if i] snapshot pod ids, what-if pod order */);

@@ -97,6 +97,7 @@ struct DevProb {
   // the what-if (its position in the snapshot's queue order: queue == nullptr reads as the identity) is the snapshot's pod pod_gid[i], whose
   // relaxation chain lives in the snapshot's pod_stage_off / stage_cls; en_removed: bit e = existing node e left the cluster (a candidate).
   const u32* pod_gid; const u64* en_removed;
+  const i32* hgrp_of;      // derived what-if over a snapshot WITH topology groups: hostname row h -> its group (grp_active is then this what-if's: a group no pod of the batch owns yet)
   const u8* grp_type; const i32* grp_key; const i32* grp_max_skew; const u8* grp_active; const u32* grp_filter_off; ReqSetsD flt;
   const i32* grp_count; const i32* grp_hslot; const i32* grph_count; const i32* grph_extra_pos;
   // derived static tables (built on the device by ks_build_type_tables / ks_grid_*)
@@ -161,6 +162,17 @@ __device__ __forceinline__ u64 ballot64(bool p) { return __builtin_amdgcn_ballot
 #else
 __device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }      // (__builtin_amdgcn_ballot_w64 on the bool itself saves two VALU ops per ballot; in round 2 a build with it faulted -- re-examined in round 3)
 #endif
+
+// The count existing node e starts with in hostname-keyed group (row) h.  A derived what-if (DevProb::en_removed / hgrp_of) reads the SNAPSHOT's table --
+// the pods of the cluster that match the group on that node, as countDomains would find them were none of them in the batch (topology.go:231-276) --
+// and adjusts it to its candidate set: a node that left registers nowhere, and in a group no pod of the batch owns yet (created later by a relaxation,
+// topology.go:86-117) a hostname is registered only where pods were counted (NewTopologyGroup registers the universe, which holds no hostnames).
+__device__ __forceinline__ i32 ks_host_count0(const DevProb& P, u32 h, u32 e) {
+  i32 c = P.grph_count[(size_t)h * P.E + e];
+  if (P.en_removed && ((P.en_removed[e >> 6] >> (e & 63u)) & 1ull)) return -1;
+  if (c == -2) c = (P.hgrp_of && P.grp_active[P.hgrp_of[h]]) ? 0 : -1;      // (ks_whatif_topo::grph_base: a hostname only NewExistingNode would register)
+  return c;
+}
 
 // ------------------------------------------------------------------------------------------------
 // ks_build_type_tables: one wave per table row
@@ -1206,7 +1218,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     for (u32 rr = 0; rr < tb.R; ++rr) { r.req()[rr] = P.en_requests[(size_t)e * tb.R + rr]; r.room()[rr] = gone ? INT64_MIN / 2 : P.en_avail[(size_t)e * tb.R + rr] - P.en_requests[(size_t)e * tb.R + rr]; r.low()[rr] = INT64_MIN; }
     i32 head = -1; for (u32 i = P.en_port_off[e]; i < P.en_port_off[e + 1]; ++i) { S.pp_entry[i] = P.ports[i]; S.pp_next[i] = head; head = (i32)i; }
     r.porthead() = head;
-    for (u32 h = 0; h < tb.GH; ++h) tb.hcnt[(size_t)e * tb.GH + h] = P.grph_count[(size_t)h * tb.E + e];
+    for (u32 h = 0; h < tb.GH; ++h) tb.hcnt[(size_t)e * tb.GH + h] = ks_host_count0(P, h, e);
   }
   for (u32 i = lane; i < P.C; i += 64) G_wm[i] = 0;
   for (u32 i = lane; i < tb.E * P.ND; i += 64) S.vol_cnt[i] = P.en_vol_count[i];
@@ -1234,7 +1246,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       u64 reg = 0, pos = 0; for (int d = 0; d < 64; ++d) { const i32 c = P.grp_count[(size_t)g * 64 + d]; if (c >= 0) reg |= 1ull << d; if (c > 0) pos |= 1ull << d; }
       sm_g_reg[g] = reg; sm_g_pos[g] = pos; sm_g_active[g] = P.grp_active[g];
     }
-    for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h], nz = 0; for (u32 e = 0; e < tb.E; ++e) { const i32 c = P.grph_count[(size_t)h * tb.E + e]; if (c > 0) ++np; if (c == 0) ++nz; } sm_g_hpos[h] = np; sm_g_hzero[h] = nz; }
+    for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h], nz = 0; for (u32 e = 0; e < tb.E; ++e) { const i32 c = ks_host_count0(P, h, e); if (c > 0) ++np; if (c == 0) ++nz; } sm_g_hpos[h] = np; sm_g_hzero[h] = nz; }
     for (u32 i = lane; i < tb.R; i += 64) sm_ge_cnt[i] = P.ge_cnt[i];
     for (u32 r = 0; r < tb.R; ++r) for (u32 i = lane; i < gs; i += 64) ge[(size_t)r * gs + i] = i < P.ge_cnt[r] ? P.ge_vals[(size_t)r * tb.T + i] : INT64_MAX;
     }
@@ -1247,7 +1259,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       u64 reg = 0, pos = 0; for (int d = 0; d < 64; ++d) { const i32 c = P.grp_count[(size_t)g * 64 + d]; if (c >= 0) reg |= 1ull << d; if (c > 0) pos |= 1ull << d; }
       S.g_reg[g] = reg; S.g_pos[g] = pos; S.g_active[g] = P.grp_active[g];
     }
-    for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h], nz = 0; for (u32 e = 0; e < tb.E; ++e) { const i32 c = P.grph_count[(size_t)h * tb.E + e]; if (c > 0) ++np; if (c == 0) ++nz; } S.g_hpos[h] = np; S.g_hzero[h] = nz; }
+    for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h], nz = 0; for (u32 e = 0; e < tb.E; ++e) { const i32 c = ks_host_count0(P, h, e); if (c > 0) ++np; if (c == 0) ++nz; } S.g_hpos[h] = np; S.g_hzero[h] = nz; }
   }
   if (wv == 0) ls.hslot_of[lane] = ((u32)lane < P.G && P.grp_hslot[lane] >= 0 && P.grp_hslot[lane] < 255) ? (u8)P.grp_hslot[lane] : (u8)0xFF;
   if (wv == 0 && lane < 32) ls.ctr[lane] = 0;
@@ -2686,6 +2698,7 @@ struct ks_dev_problem {
   bool lean_ok = false;          // none of the rarely used features is present -> the LEAN kernel variant (see ks_pack)
   u32 pp_cap = 0;
   bool view = false;             // a what-if derived from a resident snapshot (ks_whatifs_open): memory and stream belong to its ks_whatif_batch
+  bool no_multi = false;         // ... over a snapshot with topology groups: the class briefs (round eligibility, certain records) were built for the snapshot's group activity, not this what-if's -- single-wave kernel only
 };
 
 static inline size_t ks_align256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -2939,6 +2952,34 @@ __global__ __launch_bounds__(256) void ks_derive_whatifs(const u32* base_queue, 
   if (threadIdx.x == 0 && base_off != d.P_expected) atomicAdd(mismatch, 1u);
 }
 
+// Topology of a derived what-if (snapshots whose bound pods carry spread / affinity terms): lane g = group g (G <= 64).
+//   active: some pod of the batch owns the group at its first relaxation stage (NewTopology's Update per pod, topology.go:72-78)
+//   counts: NewTopologyGroup's registered domains + countDomains over the cluster pods that are NOT in the batch (topology.go:231-276) =
+//           the snapshot-wide totals minus what the candidate nodes' pods contribute
+struct TopoDesc { const u32* cand; u32 ncand, pad; u8* active; i32* count; i32* extra; };
+__global__ __launch_bounds__(64) void ks_derive_topology(const TopoDesc* descs, u32 G, u32 GH, u32 n_nodes, const i32* node_cnt, const i32* node_dom, const u64* node_own,
+                                                        const i32* tot, const i32* reg, const i32* extra_tot, const i32* grp_hslot, const i32* node_row) {
+  const TopoDesc d = descs[blockIdx.x]; const u32 g = threadIdx.x;
+  u64 own = 0; for (u32 i = 0; i < d.ncand; ++i) own |= node_own[d.cand[i]];
+  if (g >= G) return;
+  d.active[g] = (u8)((own >> g) & 1ull);
+  const i32 hs = grp_hslot[g];
+  if (hs >= 0) {      // hostname key: the rows are the snapshot's (ks_host_count0); what moves is the number of positive domains that are no existing node
+    i32 ex = extra_tot[hs];
+    for (u32 i = 0; i < d.ncand; ++i) {      // (node_dom of a hostname-keyed group: the pods that are never in a batch -- they keep counting under a hostname that is no row any more)
+      const u32 nd = d.cand[i]; const i32 stay = node_dom[(size_t)g * n_nodes + nd], all = stay + node_cnt[(size_t)g * n_nodes + nd];
+      if (node_row[nd] < 0) ex -= (all > 0) - (stay > 0); else ex += stay > 0;
+    }
+    d.extra[hs] = ex;
+    for (u32 v = 0; v < 64; ++v) d.count[(size_t)g * 64 + v] = reg[(size_t)g * 64 + v];
+    return;
+  }
+  i32 c[64];
+  for (u32 v = 0; v < 64; ++v) c[v] = tot[(size_t)g * 64 + v];
+  for (u32 i = 0; i < d.ncand; ++i) { const u32 nd = d.cand[i]; const i32 dm = node_dom[(size_t)g * n_nodes + nd]; if (dm >= 0) c[dm] -= node_cnt[(size_t)g * n_nodes + nd]; }
+  for (u32 v = 0; v < 64; ++v) { const i32 r = reg[(size_t)g * 64 + v]; d.count[(size_t)g * 64 + v] = (r >= 0 || c[v] > 0) ? (r > 0 ? r : 0) + c[v] : -1; }
+}
+
 struct ks_whatif_batch {
   int device = 0; u32 n = 0; hipStream_t stream = nullptr; bool own_stream = false;
   u8* arena = nullptr; size_t arena_bytes = 0; u8* stage = nullptr; size_t stage_bytes = 0;
@@ -2960,11 +3001,14 @@ extern "C" uint32_t ks_whatifs_count(const ks_whatif_batch* b) { return b ? b->n
 // existing-node row in `base`, or -1 (a node no provisioner owns).  What-if w removes nodes cand[cand_off[w] .. cand_off[w+1]); n_pods[w] = pods
 // bound to them (the caller knows; checked on the device); remaining[w][M][R] = remainingResources with those nodes gone (scheduler.go:71-75).
 extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, const int32_t* pod_node, const int32_t* node_row, uint32_t n, const uint32_t* cand_off,
-                               const uint32_t* cand, const uint32_t* n_pods, const int64_t* remaining, ks_whatif_batch** out) {
+                               const uint32_t* cand, const uint32_t* n_pods, const int64_t* remaining, const ks_whatif_topo* topo, ks_whatif_batch** out) {
   if (out) *out = nullptr;
   if (!base || !out || (n && (!cand_off || !n_pods || !remaining)) || (n_nodes && (!node_row)) || (base->h.P && !pod_node)) return fail(KS_ERR_INVALID, "null argument");
   if (!base->tables_built) return fail(KS_ERR_INVALID, "the snapshot must be resident with its tables built (ks_problem_prepare)");
-  if (base->h.G || base->h.GH || base->h.ND || base->h.pod_gid) return fail(KS_ERR_UNSUPPORTED, "what-ifs can only be derived from a snapshot without topology groups and volume limits");
+  if (base->h.ND || base->h.pod_gid) return fail(KS_ERR_UNSUPPORTED, "what-ifs cannot be derived from a snapshot with volume limits");
+  const bool with_topo = base->h.G != 0;
+  if (with_topo && (!topo || !topo->node_cnt || !topo->node_dom || !topo->node_own || !topo->tot || !topo->extra_tot || !topo->grph_base)) return fail(KS_ERR_UNSUPPORTED, "the snapshot has topology groups: their per-node tables (ks_whatif_topo) are needed to derive what-ifs from it");
+  if (with_topo && (base->h.G > 64 || base->h.n_topologies != base->h.G)) return fail(KS_ERR_UNSUPPORTED, "derived what-ifs: at most 64 topology groups, none of them an inverse anti-affinity group");
   const DevProb& bh = base->h; const u32 E = bh.E, M = bh.M, R = bh.R, K = bh.K, TW = bh.TW, C = bh.C, Pb = bh.P;
   HIPCHK(hipSetDevice(base->device));
   auto b = new ks_whatif_batch(); b->device = base->device; b->n = n;
@@ -2975,9 +3019,16 @@ extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, con
   size_t sz[3] = {0, 0, 0};
   auto take = [&](int region, size_t bytes) { const size_t at = sz[region]; sz[region] += ks_align256(bytes ? bytes : 1); return at; };
   struct Lay { size_t cand_bits, removed, remaining, q, lastlen, lastgen, pod_stage, pod_node, pod_seq, pod_reason, rec, n_tmpl, n_alive, lowi, bstart, order_g, rem_state,
-               o_present, o_complement, o_mask, o_gt, o_lt, o_it, o_req, o_reqmask, pp_entry, pp_next, wm, stats, out_counts, unscheduled, pod_gid, round_scratch; u32 P, NMAX, pp_cap; };
+               o_present, o_complement, o_mask, o_gt, o_lt, o_it, o_req, o_reqmask, pp_entry, pp_next, wm, stats, out_counts, unscheduled, pod_gid, round_scratch,
+               t_active, t_count, t_extra, gcnt, g_reg, g_pos, g_active, hcnt, g_hpos, g_hzero; u32 P, NMAX, pp_cap; };
   std::vector<Lay> L(n);
   const size_t pod_node_at = take(0, (size_t)Pb * sizeof(i32));
+  const u32 G = bh.G, GH = bh.GH; const size_t GN = (size_t)G * n_nodes;
+  size_t t_cnt_at = 0, t_dom_at = 0, t_own_at = 0, t_tot_at = 0, t_ext_at = 0, t_hbase_at = 0, t_row_at = 0, t_hg_at = 0, t_cand_at = 0, t_desc_at = 0;
+  if (with_topo) {
+    t_cnt_at = take(0, GN * 4); t_dom_at = take(0, GN * 4); t_own_at = take(0, (size_t)n_nodes * 8); t_tot_at = take(0, (size_t)G * 64 * 4); t_ext_at = take(0, (size_t)GH * 4);
+    t_hbase_at = take(0, (size_t)GH * E * 4); t_row_at = take(0, (size_t)n_nodes * 4); t_hg_at = take(0, (size_t)GH * 4); t_cand_at = take(0, (size_t)cand_off[n] * 4); t_desc_at = take(0, (size_t)n * sizeof(TopoDesc));
+  }
   const u32 rec_stride = ks_rec_stride(R, K);
   const size_t pp_static = E ? base->src.en_port_off[E] : 0;
   for (u32 w = 0; w < n; ++w) {
@@ -2993,6 +3044,11 @@ extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, con
     size_t pp = pp_static; if (C && base->src.cls_port_off[C] != pp_static) { u32 mx = 0; for (u32 c = 0; c < C; ++c) mx = std::max(mx, base->src.cls_port_off[c + 1] - base->src.cls_port_off[c]); pp += (size_t)mx * P; }
     l.pp_entry = take(2, pp * 8); l.pp_next = take(2, pp * 4); l.wm = take(2, (size_t)C * 4); l.unscheduled = take(2, (size_t)P * 4); l.pod_gid = take(2, (size_t)P * 4);
     l.pp_cap = (u32)pp; l.round_scratch = n == 1 ? take(2, (size_t)8 * 64 * TW * 8) : 0;      // (a batch of one runs the multi-wave kernel, whose rounds keep rows to restore)
+    if (with_topo) {
+      l.t_active = take(2, G); l.t_count = take(2, (size_t)G * 64 * 4); l.t_extra = take(2, (size_t)GH * 4);
+      l.gcnt = take(2, (size_t)G * 64 * 4); l.g_reg = take(2, (size_t)G * 8); l.g_pos = take(2, (size_t)G * 8); l.g_active = take(2, G);
+      l.hcnt = take(2, (size_t)GH * NS * 4); l.g_hpos = take(2, (size_t)GH * 4); l.g_hzero = take(2, (size_t)GH * 4);
+    }
   }
   const size_t desc_at = take(0, (size_t)n * sizeof(DeriveDesc)), dprob_at = take(0, (size_t)n * sizeof(DevProb)), dstate_at = take(0, (size_t)n * sizeof(DevState));
   const size_t mismatch_at = take(1, 4);
@@ -3004,6 +3060,13 @@ extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, con
   if (Pb) memcpy(b->stage + pod_node_at, pod_node, (size_t)Pb * sizeof(i32));
   b->views.resize(n, nullptr);
   DeriveDesc* hd = (DeriveDesc*)(b->stage + desc_at); DevProb* hp = (DevProb*)(b->stage + dprob_at); DevState* hsv = (DevState*)(b->stage + dstate_at);
+  TopoDesc* htd = with_topo ? (TopoDesc*)(b->stage + t_desc_at) : nullptr;
+  if (with_topo) {
+    memcpy(b->stage + t_cnt_at, topo->node_cnt, GN * 4); memcpy(b->stage + t_dom_at, topo->node_dom, GN * 4); memcpy(b->stage + t_own_at, topo->node_own, (size_t)n_nodes * 8);
+    memcpy(b->stage + t_tot_at, topo->tot, (size_t)G * 64 * 4); if (GH) { memcpy(b->stage + t_ext_at, topo->extra_tot, (size_t)GH * 4); memcpy(b->stage + t_hbase_at, topo->grph_base, (size_t)GH * E * 4); }
+    memcpy(b->stage + t_row_at, node_row, (size_t)n_nodes * 4); if (cand_off[n]) memcpy(b->stage + t_cand_at, cand, (size_t)cand_off[n] * 4);
+    i32* hg = (i32*)(b->stage + t_hg_at); for (u32 g = 0; g < G; ++g) { const i32 hs = base->src.grp_hslot[g]; if (hs >= 0 && (u32)hs < GH) hg[hs] = (i32)g; }
+  }
   for (u32 w = 0; w < n; ++w) {
     const Lay& l = L[w];
     u64* cb = (u64*)(b->stage + l.cand_bits); u64* rb = (u64*)(b->stage + l.removed);
@@ -3019,12 +3082,19 @@ extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, con
     DevProb& h = v->h; h = bh;
     h.P = l.P; h.NMAX = l.NMAX; h.queue = nullptr; h.pod_gid = (const u32*)(r2 + l.pod_gid); h.en_removed = (const u64*)(r0 + l.removed); h.tmpl_remaining = (const i64*)(r0 + l.remaining);
     h.derived_shared = 1;
+    if (with_topo) {
+      h.grp_active = (const u8*)(r2 + l.t_active); h.grp_count = (const i32*)(r2 + l.t_count); h.grph_count = (const i32*)(r0 + t_hbase_at); h.grph_extra_pos = (const i32*)(r2 + l.t_extra);
+      h.hgrp_of = (const i32*)(r0 + t_hg_at); v->no_multi = true;
+      htd[w] = TopoDesc{(const u32*)(r0 + t_cand_at) + cand_off[w], cand_off[w + 1] - cand_off[w], 0, (u8*)(r2 + l.t_active), (i32*)(r2 + l.t_count), (i32*)(r2 + l.t_extra)};
+    }
     DevState& st = v->hs; st = DevState{};
     st.q = (u64*)(r2 + l.q); st.lastlen = (u32*)(r2 + l.lastlen); st.lastgen = (u32*)(r2 + l.lastgen); st.pod_stage = (i32*)(r2 + l.pod_stage); st.pod_node = (i32*)(r2 + l.pod_node);
     st.pod_seq = (i32*)(r2 + l.pod_seq); st.pod_reason = (u32*)(r2 + l.pod_reason);
     st.rec = r1 + l.rec; st.rec_stride = rec_stride; st.n_tmpl = (i32*)(r2 + l.n_tmpl); st.n_alive = (u64*)(r2 + l.n_alive); st.lowi = (u64*)(r2 + l.lowi); st.round_scratch = n == 1 ? (u64*)(r2 + l.round_scratch) : nullptr;
     st.bstart = (u32*)(r1 + l.bstart); st.order_g = (u32*)(r2 + l.order_g);
     st.gcnt = nullptr; st.g_reg = nullptr; st.g_pos = nullptr; st.g_active = nullptr; st.hcnt = nullptr; st.g_hpos = nullptr; st.g_hzero = nullptr;
+    if (with_topo) { st.gcnt = (i32*)(r2 + l.gcnt); st.g_reg = (u64*)(r2 + l.g_reg); st.g_pos = (u64*)(r2 + l.g_pos); st.g_active = (u8*)(r2 + l.g_active); st.hcnt = (i32*)(r2 + l.hcnt);
+                     st.g_hpos = (i32*)(r2 + l.g_hpos); st.g_hzero = (i32*)(r2 + l.g_hzero); }
     st.remaining = (i64*)(r2 + l.rem_state);
     st.pp_entry = (u64*)(r2 + l.pp_entry); st.pp_next = (i32*)(r2 + l.pp_next); st.pp_cap = l.pp_cap;
     st.vol_pad = 0; st.vol_cnt = nullptr; st.vol_set = nullptr; st.wm = (u32*)(r2 + l.wm);
@@ -3038,6 +3108,8 @@ extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, con
   if (sz[1]) HIPCHK(hipMemsetAsync(r1, 0, sz[1], b->stream));
   if (const char* pz = getenv("KS_POISON")) { if (sz[2]) HIPCHK(hipMemsetAsync(r2, (int)strtol(pz, nullptr, 0) & 0xFF, sz[2], b->stream)); }
   if (n) hipLaunchKernelGGL(ks_derive_whatifs, dim3(n), dim3(256), 0, b->stream, bh.queue, (const i32*)(r0 + pod_node_at), Pb, (const DeriveDesc*)(r0 + desc_at), (u32*)(r1 + mismatch_at));
+  if (n && with_topo) hipLaunchKernelGGL(ks_derive_topology, dim3(n), dim3(64), 0, b->stream, (const TopoDesc*)(r0 + t_desc_at), G, GH, n_nodes, (const i32*)(r0 + t_cnt_at), (const i32*)(r0 + t_dom_at),
+                                         (const u64*)(r0 + t_own_at), (const i32*)(r0 + t_tot_at), bh.grp_count, (const i32*)(r0 + t_ext_at), bh.grp_hslot, (const i32*)(r0 + t_row_at));
   u32 mismatch = 0;
   HIPCHK(hipMemcpyAsync(&mismatch, r1 + mismatch_at, 4, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream)); HIPCHK(hipGetLastError());
@@ -3245,7 +3317,7 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   }
   // A single Solve whose problem takes the LEAN, FAST, no-bounds kernel gets 8 waves: waves 1..7 join wave 0 for the
   // speculation rounds (see ks_pack).  T <= 8192 keeps a node's surviving-type mask in two registers per lane.
-  bool multi = n == 1 && fast && ds[0]->h.TW <= 128 && !(ds[0]->h.flags & KS_FLAG_STATS) && !getenv("KS_ONE_WAVE");
+  bool multi = n == 1 && fast && ds[0]->h.TW <= 128 && !(ds[0]->h.flags & KS_FLAG_STATS) && !getenv("KS_ONE_WAVE") && !ds[0]->no_multi;
   if (multi) {
     const u32 lds_mw = 44u * 1024u;
     if ((size_t)ds[0]->h.R * ds[0]->h.ge_max * 8 + 8192 > lds_mw) multi = false;

@@ -309,7 +309,7 @@ int ksh_open_whatifs_derived(void* parsed, uint32_t flags, uint32_t n, const uin
       }
     }
     lap("masks / remaining (host)");
-    rc = ks_whatifs_open((const ks_dev_problem*)D->base_dev.get(), in.n_nodes, P->sb_pod_node.data(), in.node_row, n, cand_off, cand, npods.data(), rem.data(), &D->b);
+    rc = ks_whatifs_open((const ks_dev_problem*)D->base_dev.get(), in.n_nodes, P->sb_pod_node.data(), in.node_row, n, cand_off, cand, npods.data(), rem.data(), in.topo, &D->b);
     if (rc != KS_OK) return set_err(rc, ks_last_error());
     lap("ks_whatifs_open (device)");
     ks_dev_problem* const* views = ks_whatifs_problems(D->b);

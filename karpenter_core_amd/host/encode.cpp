@@ -277,6 +277,7 @@ struct Builder {
     const auto& m = base ? base->node_by_name : node_by_name; auto it = m.find(n); return it == m.end() ? nullptr : it->second;
   }
   std::vector<std::unique_ptr<Group>> groups; std::map<std::string, int> topo_by_id, inverse_by_id;   // creation order; inverse flagged
+  bool shared_filter_differs = false;                 // two pods share a spread group while their node filters differ in content (the first one's counts)
   std::vector<Requirement> it_reqs; std::map<std::string, int> it_state_id;   // node-side instance-type states (index 0 = absent)
   std::vector<Requirement> it_cols; std::map<std::string, int> it_col_id;     // pod-side instance-type requirements (classes, topology filters; 0 = none)
   // UIDs of the batch: open-addressing table of pod indices (topology.go:66-70 excludes the batch from countDomains)
@@ -285,6 +286,10 @@ struct Builder {
     bool count(const std::string& uid) const {
       if (tab.empty()) return false;
       for (uint64_t i = str_hash(uid) & mask;; i = (i + 1) & mask) { const uint32_t e = tab[i]; if (!e) return false; if ((*uids)[e - 1] == uid) return true; }
+    }
+    int64_t find(const std::string& uid) const {      // the batch pod with that uid, -1 if none
+      if (tab.empty()) return -1;
+      for (uint64_t i = str_hash(uid) & mask;; i = (i + 1) & mask) { const uint32_t e = tab[i]; if (!e) return -1; if ((*uids)[e - 1] == uid) return (int64_t)e - 1; }
     }
   } batch_uids;
   std::map<std::string, const ksp::StateNode*> node_by_name;
@@ -755,6 +760,7 @@ struct Builder {
     if (it != index.end()) {
       Group& g = *groups[it->second];
       if (!g.active && !active_now && g.filter_sig != filter_content(f)) throw Unsupported("late-created topology group whose node filter depends on which pod relaxes first");
+      if (g.filter_sig != filter_content(f)) shared_filter_differs = true;      // the group keeps its creator's filter (the identity hashes the filter's KEYS only): which pod came first matters
       return it->second;
     }
     auto g = std::make_unique<Group>(); g->type = type; g->key = key; g->namespaces = nss; g->selector = sel; g->max_skew = max_skew; g->filter = f; g->inverse = inverse; g->active = active_now;
@@ -1318,7 +1324,70 @@ struct SnapshotBase {
   std::shared_ptr<const ksp::Problem> snapshot; std::shared_ptr<Encoded> enc; std::unique_ptr<Builder> builder;
   std::vector<std::vector<uint32_t>> by_node;      // pods bound to each node, in pod order
   std::vector<int32_t> node_row, node_tmpl; std::vector<int64_t> node_cap; bool delta_ok = false; std::string delta_why;      // (delta_inputs)
+  // snapshots with topology groups: what a what-if's NewTopology takes from its candidate set (ksolve.h ks_whatif_topo)
+  std::vector<int32_t> t_node_cnt, t_node_dom, t_tot, t_extra_tot, t_grph_base; std::vector<uint64_t> t_node_own; ks_whatif_topo topo{}; bool has_topo = false;
 };
+// The per-node tables behind ks_whatif_topo.  A what-if's groups are the snapshot's (its pods' specs are a subset); what depends on the candidate set is
+// which groups a pod of the batch owns from the start, and which cluster pods countDomains still sees: a bound pod's cluster-pod record counts exactly
+// while its node stays.  Returns "" or what stands in the way.
+static std::string build_topo_tables(SnapshotBase& sb, const int32_t* pod_node) {
+  const Builder& b = *sb.builder; const Encoded& E = *sb.enc; const ksp::Problem& pr = *sb.snapshot;
+  const uint32_t G = E.prob.G, GH = E.prob.GH, NE = E.prob.E; const size_t NN = pr.nodes.size();
+  if (E.prob.n_topologies != G) return "a bound pod carries required anti-affinity (inverse groups exist for some candidate sets only)";
+  if (G > 64) return "more than 64 topology groups";
+  if (b.shared_filter_differs) return "two pods share a spread group while their node filters differ: the group's filter is that of the first pod of each batch";
+  sb.t_node_cnt.assign((size_t)G * NN, 0); sb.t_node_dom.assign((size_t)G * NN, -1); sb.t_node_own.assign(NN, 0); sb.t_tot.assign((size_t)G * 64, 0);
+  sb.t_extra_tot.assign(GH, 0); sb.t_grph_base.assign((size_t)GH * NE, 0);
+  for (size_t i = 0; i < pr.pods.size(); ++i) for (int g : b.specs[b.pod_spec[i]].stages[0].sg.own) sb.t_node_own[pod_node[i]] |= 1ull << g;      // (no inverse groups: creation order IS the encoded order)
+  // does group g count pods on node n at all (key present, node filter), and under which domain
+  std::vector<uint8_t> counts_on((size_t)G * NN, 0); std::vector<int32_t> key_of(G, -1);
+  for (uint32_t g = 0; g < G; ++g) if (b.groups[g]->key != ksp::kHostname) key_of[g] = b.key_id.at(b.groups[g]->key);
+  for (size_t n = 0; n < NN; ++n) {
+    const Requirements nr = Requirements::FromLabels(pr.nodes[n].labels);
+    for (uint32_t g = 0; g < G; ++g) {
+      const Group& gr = *b.groups[g]; const bool host = gr.key == ksp::kHostname;
+      auto lt = pr.nodes[n].labels.find(gr.key);
+      if (!host && lt == pr.nodes[n].labels.end()) continue;
+      if (!FilterMatches(gr.filter, nr, b.wellKnown)) continue;
+      counts_on[g * NN + n] = 1;
+      if (!host) sb.t_node_dom[g * NN + n] = b.value_id(key_of[g], lt->second); else sb.t_node_dom[g * NN + n] = 0;      // (hostname-keyed: the count of the pods that are never in a batch)
+    }
+  }
+  std::map<std::string, size_t> node_index; for (size_t n = 0; n < NN; ++n) node_index.emplace(pr.nodes[n].name, n);
+  std::unordered_map<std::string, uint64_t> selects;      // (namespace, labels) -> groups that list such a pod (TopologyListOptions: a nil selector lists everything)
+  for (auto& cp : pr.cluster_pods) {
+    const int64_t pi = b.batch_uids.find(cp.uid);
+    auto ni = node_index.find(cp.node_name); if (ni == node_index.end()) continue;      // countDomains skips pods whose node it cannot find
+    const size_t n = ni->second;
+    if (pi >= 0 && (size_t)pod_node[pi] != n) return "a cluster pod record names another node than the one its pod is bound to";
+    std::string sig = cp.ns; sig += '\3'; sig_map(sig, cp.labels);
+    auto it = selects.find(sig);
+    if (it == selects.end()) {
+      uint64_t m = 0;
+      for (uint32_t g = 0; g < G; ++g) { const Group& gr = *b.groups[g]; if (gr.namespaces.count(cp.ns) && (gr.selector.nil || SelectorMatches(gr.selector, cp.labels))) m |= 1ull << g; }
+      it = selects.emplace(std::move(sig), m).first;
+    }
+    for (uint64_t m = it->second; m; m &= m - 1) {
+      const uint32_t g = (uint32_t)__builtin_ctzll(m); if (!counts_on[g * NN + n]) continue;
+      const bool host = key_of[g] < 0;
+      if (pi >= 0) { sb.t_node_cnt[g * NN + n]++; if (!host) { const int32_t d = sb.t_node_dom[g * NN + n]; if (d < 0 || d >= 64) return "a counted topology domain is missing from the universe"; sb.t_tot[(size_t)g * 64 + d]++; } }
+      else if (host) sb.t_node_dom[g * NN + n]++;      // (value-keyed groups: the snapshot's own grp_count already holds the pods that are never in a batch)
+    }
+  }
+  for (uint32_t g = 0; g < G; ++g) {
+    const int32_t hs = E.grp_hslot[g]; if (hs < 0) continue;
+    const Group& gr = *b.groups[g];
+    for (size_t n = 0; n < NN; ++n) {
+      const int32_t c = sb.t_node_cnt[g * NN + n] + sb.t_node_dom[g * NN + n], e = sb.node_row[n];
+      if (e < 0) { if (c > 0) sb.t_extra_tot[hs]++; continue; }
+      auto hl = pr.nodes[n].labels.find(ksp::kHostname); const std::string& hostname = (hl == pr.nodes[n].labels.end() || hl->second.empty()) ? pr.nodes[n].name : hl->second;
+      sb.t_grph_base[(size_t)hs * NE + e] = c > 0 ? c : (gr.counts.count(hostname) ? 0 : -2);      // -2: registered only if a pod of the batch owns the group (existingnode.go:73)
+    }
+  }
+  sb.topo.node_cnt = sb.t_node_cnt.data(); sb.topo.node_dom = sb.t_node_dom.data(); sb.topo.node_own = sb.t_node_own.data(); sb.topo.tot = sb.t_tot.data();
+  sb.topo.extra_tot = sb.t_extra_tot.data(); sb.topo.grph_base = sb.t_grph_base.data(); sb.has_topo = true;
+  return "";
+}
 std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp::Problem> snapshot, const int32_t* pod_node, uint32_t flags) {
   auto sb = std::make_shared<SnapshotBase>(); sb->snapshot = snapshot;
   sb->by_node.resize(snapshot->nodes.size());
@@ -1337,15 +1406,15 @@ std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp
       }
     }
     sb->delta_ok = true;
-    if (!b.groups.empty()) { sb->delta_ok = false; sb->delta_why = "the bound pods carry topology terms (spread / affinity / anti-affinity): group counts depend on the candidate set"; }
-    else if (b.any_volume_limits || b.pods_have_volumes) { sb->delta_ok = false; sb->delta_why = "volume limits / claims: the shared-claim partition depends on the candidate set"; }
+    if (b.any_volume_limits || b.pods_have_volumes) { sb->delta_ok = false; sb->delta_why = "volume limits / claims: the shared-claim partition depends on the candidate set"; }
     else for (auto& cp : snapshot->cluster_pods) if (!cp.anti_required.empty()) { sb->delta_ok = false; sb->delta_why = "a cluster pod carries required anti-affinity (inverse groups depend on the candidate set)"; break; }
+    if (sb->delta_ok && !b.groups.empty()) { const std::string why = build_topo_tables(*sb, pod_node); if (!why.empty()) { sb->delta_ok = false; sb->delta_why = why; } }
   }
   return sb;
 }
 DeltaInputs delta_inputs(const SnapshotBase& sb) {
   DeltaInputs d; d.base = sb.enc; d.n_nodes = (uint32_t)sb.snapshot->nodes.size(); d.node_row = sb.node_row.data(); d.by_node = &sb.by_node; d.pod_rank = sb.builder->pod_rank.data();
-  d.node_cap = sb.node_cap.data(); d.node_tmpl = sb.node_tmpl.data(); d.eligible = sb.delta_ok; d.why = sb.delta_why; return d;
+  d.node_cap = sb.node_cap.data(); d.node_tmpl = sb.node_tmpl.data(); d.eligible = sb.delta_ok; d.why = sb.delta_why; d.topo = sb.has_topo ? &sb.topo : nullptr; return d;
 }
 std::unique_ptr<Encoded> encode_whatif(const SnapshotBase& sb, const uint32_t* cand, uint32_t ncand, uint32_t flags) {
   auto e = std::make_unique<Encoded>(); e->src = sb.snapshot; e->shared = sb.enc;

@@ -103,12 +103,13 @@ struct SnapshotBase;
 std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp::Problem> snapshot, const int32_t* pod_node, uint32_t flags);
 std::unique_ptr<Encoded> encode_whatif(const SnapshotBase& sb, const uint32_t* cand, uint32_t ncand, uint32_t flags);
 // What deriving what-ifs on the device (include/ksolve.h ks_whatifs_open) needs of a snapshot's flattening.  `eligible`: its what-ifs differ in
-// nothing but the pod subset, the removed nodes and remainingResources (no topology groups among the bound pods, no cluster pod with required
-// anti-affinity, no volume limits / claims); otherwise `why` says what stands in the way and the what-ifs are flattened one by one.
+// nothing but the pod subset, the removed nodes, remainingResources and -- derived on the device from per-node tables -- which topology groups exist from
+// the start and what countDomains finds (no required anti-affinity among bound or cluster pods, at most 64 groups, no volume limits / claims); otherwise `why` says what stands in the way and the what-ifs are flattened one by one.
 struct DeltaInputs {
   std::shared_ptr<const Encoded> base; uint32_t n_nodes = 0; const int32_t* node_row = nullptr; const std::vector<std::vector<uint32_t>>* by_node = nullptr;
   const uint32_t* pod_rank = nullptr; const int64_t* node_cap = nullptr /* [n_nodes][R] capacity of a node whose provisioner has limits, masked to the limited resources */;
   const int32_t* node_tmpl = nullptr /* template with limits the node counts against, or -1 */; bool eligible = false; std::string why;
+  const ks_whatif_topo* topo = nullptr;      // snapshots with topology groups: the per-node tables a what-if's groups are derived from
 };
 DeltaInputs delta_inputs(const SnapshotBase& sb);
 

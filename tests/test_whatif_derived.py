@@ -17,17 +17,133 @@ def _snapshot(existing, sizes, seed, spare=-1, limits=None):
 
 
 def test_ineligible_snapshots_are_refused_on_the_host():
-    """(CPU) bound pods with topology terms: the group counts depend on the candidate set -- refused before anything touches a device."""
+    """(CPU) bound pods with REQUIRED anti-affinity: inverse groups exist for some candidate sets only -- refused before anything touches a device."""
+    from karpenter_core_amd.model import PodAffinityTerm
     its, prov, nodes, bound = _snapshot(24, 5, 8)
     for pods in bound:
         for p in pods[:1]:
-            p.spread = [TopologySpreadConstraint(1, LABEL_ZONE, DO_NOT_SCHEDULE, LabelSelector({"my-label": p.labels["my-label"]}))]
+            p.anti_required = [PodAffinityTerm(LABEL_ZONE, LabelSelector({"my-label": "nobody"}))]
     snap, pod_node = W.snapshot_problem(its, prov, nodes, bound, True)
     with pytest.raises(S.KSolveError) as e:
         S.open_whatifs(S.ParsedProblem(snap), pod_node, [[0], [1, 2]], derive=True)
-    assert e.value.code == S.KS_ERR_UNSUPPORTED and "topology" in str(e.value)
+    assert e.value.code == S.KS_ERR_UNSUPPORTED and "anti-affinity" in str(e.value)
     flats = S.open_whatifs(S.ParsedProblem(snap), pod_node, [[0], [1, 2]])          # derive=None: flattened on the host instead
     assert [f.dims["P"] for f in flats] == [len(bound[0]), len(bound[1]) + len(bound[2])]
+
+
+def _topology_snapshot(existing, sizes, seed, spare=-1, extras=True, kinds=None):
+    """A cluster whose bound pods carry spread / affinity / preferred terms (no required anti-affinity), listed as cluster pods the way
+    countDomains finds them -- plus pods that are in no batch (daemon-like, on candidate nodes too), one on a node nobody knows, and a node no
+    provisioner owns."""
+    from karpenter_core_amd.model import (ClusterPod, Expr, LABEL_HOSTNAME, PodAffinityTerm, PreferredTerm, SCHEDULE_ANYWAY, StateNode,
+                                          WeightedPodAffinityTerm)
+    its, prov, nodes, bound = _snapshot(existing, sizes, seed, spare=spare)
+    rs = np.random.RandomState(900 + seed)
+    zones = sorted({n.labels[LABEL_ZONE] for n in nodes})
+    for pods in bound:
+        for p in pods:
+            own, r = LabelSelector({"my-label": p.labels["my-label"]}), rs.rand()
+            if p.labels["my-label"] not in "abc":      # (the derived route holds a snapshot's groups in one 64-bit word: a handful of constrained workloads, many plain ones)
+                continue
+            if kinds is not None and sum(r >= t for t in (0.22, 0.34, 0.42, 0.50, 0.56, 0.62, 0.68, 0.74)) not in kinds:      # (debugging: some kinds of terms only)
+                continue
+            if r < 0.22:
+                p.spread = [TopologySpreadConstraint(1, LABEL_ZONE, DO_NOT_SCHEDULE, own)]
+            elif r < 0.34:
+                p.spread = [TopologySpreadConstraint(4, LABEL_HOSTNAME, DO_NOT_SCHEDULE, own)]
+            elif r < 0.42:
+                p.spread = [TopologySpreadConstraint(1, LABEL_ZONE, SCHEDULE_ANYWAY, own), TopologySpreadConstraint(3, LABEL_HOSTNAME, DO_NOT_SCHEDULE, own)]
+            elif r < 0.50:
+                p.affinity_required = [PodAffinityTerm(LABEL_ZONE, LabelSelector({"my-label": "abc"[int(rs.randint(3))]}))]
+            elif r < 0.56:
+                p.affinity_preferred = [WeightedPodAffinityTerm(int(rs.randint(1, 50)), PodAffinityTerm(LABEL_HOSTNAME, own))]
+            elif r < 0.62:
+                p.anti_preferred = [WeightedPodAffinityTerm(int(rs.randint(1, 50)), PodAffinityTerm(LABEL_HOSTNAME if rs.rand() < 0.5 else LABEL_ZONE, own))]
+            elif r < 0.68:      # a node selector narrows the spread's node filter: another group; two affinity terms: the relaxed pod owns a group created late
+                p.node_selector = {LABEL_ZONE: zones[ord(p.labels["my-label"]) % len(zones)]}      # (one zone per workload: see test_a_spread_group_shared_across_node_filters_is_refused)
+                p.spread = [TopologySpreadConstraint(2, LABEL_HOSTNAME, DO_NOT_SCHEDULE, own)]
+            elif r < 0.74:
+                p.required_affinity = [[Expr(LABEL_ZONE, "In", [zones[0]])], [Expr(LABEL_ZONE, "In", zones[1:] or zones)]]
+                p.spread = [TopologySpreadConstraint(1, LABEL_ZONE, DO_NOT_SCHEDULE, own)]
+            elif r < 0.78:
+                p.preferred_affinity = [PreferredTerm(5, [Expr(LABEL_ZONE, "In", [zones[-1]])])]
+                p.spread = [TopologySpreadConstraint(2, LABEL_ZONE, DO_NOT_SCHEDULE, own)]
+    if extras:
+        nodes.append(StateNode(name="unowned", labels={LABEL_ZONE: zones[0], LABEL_HOSTNAME: "unowned"}))
+        bound.append([dataclasses_replace_uid(p, f"extra-{i}") for i, p in enumerate(bound[0][:6])])
+    snap, pod_node = W.snapshot_problem(its, prov, nodes, bound, True)
+    if extras:
+        for i in range(existing // 2):
+            snap.cluster_pods.append(ClusterPod(uid=f"ds-{i}", namespace="default", node_name=nodes[int(rs.randint(len(nodes)))].name, labels={"my-label": "abcdefg"[int(rs.randint(7))]}))
+        snap.cluster_pods.append(ClusterPod(uid="lost", namespace="default", node_name="no-such-node", labels={"my-label": "a"}))
+        snap.cluster_pods.append(ClusterPod(uid="elsewhere", namespace="other", node_name=nodes[0].name, labels={"my-label": "a"}))
+    return its, prov, nodes, bound, snap, pod_node
+
+
+def _whatif_problem(snap, pod_node, cand):
+    """simulateScheduling's problem for one candidate set, from the snapshot problem (cluster pods kept as they are)."""
+    import dataclasses
+    cs = set(cand)
+    by_node = {}
+    for p, n in zip(snap.pods, pod_node):
+        by_node.setdefault(n, []).append(p)
+    return dataclasses.replace(snap, pods=[p for n in cand for p in by_node.get(n, [])],      # (pod indices of a what-if run in candidate order)
+                               nodes=[dataclasses.replace(n, in_state=(i not in cs)) for i, n in enumerate(snap.nodes)])
+
+
+def test_a_spread_group_shared_across_node_filters_is_refused():
+    """(CPU) The reference hashes a spread group's node filter by its KEYS only (topologygroup.go:76-88: hashstructure skips the unexported value sets), so
+    two pods whose selectors differ only in the zone they name share ONE group -- with the filter of whichever came first in the batch.  That depends on
+    the candidate set in a way the per-node tables do not capture: flattened one by one instead."""
+    its, prov, nodes, bound = _snapshot(24, 5, 8)
+    zones = sorted({n.labels[LABEL_ZONE] for n in nodes})
+    from karpenter_core_amd.model import LABEL_HOSTNAME
+    for i, pods in enumerate([b for b in bound if b][:6]):
+        pods[0].labels = {"my-label": "a"}
+        pods[0].node_selector = {LABEL_ZONE: zones[i % len(zones)]}
+        pods[0].spread = [TopologySpreadConstraint(2, LABEL_HOSTNAME, DO_NOT_SCHEDULE, LabelSelector({"my-label": "a"}))]
+    snap, pod_node = W.snapshot_problem(its, prov, nodes, bound, True)
+    with pytest.raises(S.KSolveError) as e:
+        S.open_whatifs(S.ParsedProblem(snap), pod_node, [[0], [1, 2]], derive=True)
+    assert e.value.code == S.KS_ERR_UNSUPPORTED and "node filters differ" in str(e.value), str(e.value)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_topology_snapshots_are_eligible(seed):
+    """(CPU) the tables behind ks_whatif_topo are built; the flattened what-ifs (the comparison side of the GPU tests) flatten."""
+    its, prov, nodes, bound, snap, pod_node = _topology_snapshot(32, 5, seed, spare=2)
+    parsed = S.ParsedProblem(snap)
+    flats = S.open_whatifs(parsed, pod_node, [[0], [1, 2, 32]], derive=False)
+    assert flats[1].dims["G"] > 0 and flats[1].dims["P"] == len(bound[1]) + len(bound[2]) + len(bound[32])
+    if S.device_count() == 0:
+        with pytest.raises(S.KSolveError) as e:      # eligible: the refusal is the missing device, not the snapshot
+            S.open_whatifs(parsed, pod_node, [[0]], derive=True)
+        assert e.value.code == S.KS_ERR_DEVICE
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_derived_whatifs_with_topology_groups(seed):
+    """Bound pods with spread / affinity / preferred terms: which groups exist from the start and what countDomains finds are derived on the device
+    from per-node tables.  derived == flattened one by one on every what-if (placements, requirements, relaxation stages, reasons), == the oracle on some."""
+    from oracle import oracle_py as O
+    rs = np.random.RandomState(seed)
+    its, prov, nodes, bound, snap, pod_node = _topology_snapshot(int(rs.randint(24, 120)), int(rs.randint(4, 8)), 50 + seed, spare=int(rs.choice([-1, 0, 3])), extras=seed != 0)
+    sets = [[int(x) for x in rs.choice(len(nodes), size=int(rs.choice([1, 1, 2, 4, 9])), replace=False)] for _ in range(20)] + [[len(nodes) - 1], [0, len(nodes) - 1]]
+    parsed = S.ParsedProblem(snap)
+    derived = S.open_whatifs(parsed, pod_node, sets, derive=True)
+    flat = S.open_whatifs(parsed, pod_node, sets, derive=False)
+    try:
+        got, _, _ = S.solve_batch(derived)
+        want, _, _ = S.solve_batch(flat)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a.canonical() == b.canonical() and a.reasons == b.reasons, (seed, i, sets[i])
+        for i in (0, 5, 21):
+            ref = O.solve(_whatif_problem(snap, pod_node, sets[i]))
+            assert got[i].canonical() == ref.canonical(), (seed, i)
+    finally:
+        for f in derived + flat:
+            f.close()
 
 
 def _with_ports():
