@@ -662,7 +662,7 @@ def test_inflight_taints(backend):
     assert a == b
 
 
-# ---------------- E24: topology counted across provisioners (topology_test.go:2174-2207) ----------------
+# ---------------- E24: topology counted across provisioners (topology_test.go:2174-2207; T:2174) ----------------
 def test_zonal_spread_across_provisioners(backend):
     its = fake.default_instance_types()
     provs = [fake.provisioner("a", len(its), requirements=[Expr(LABEL_ZONE, "In", ["test-zone-1"])], discovery_label=True),

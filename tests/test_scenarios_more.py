@@ -459,3 +459,221 @@ def test_tolerations_generate_no_taints(backend):
     res = sim.provision([p])
     assert sim.scheduled(p) is not None and sim.scheduled(p).taints == []      # (the reference's one taint is the not-ready taint of a fresh Machine)
     assert len(res.new_nodes) == 1
+
+
+# ---------------- suite_test.go: well-known labels, node selectors + requirements + preferences ----------------
+ZONES3 = ["test-zone-1", "test-zone-2", "test-zone-3"]
+
+
+def _alone(backend, pod, **kw):
+    sim = ClusterSim(backend, **kw)
+    sim.provision([pod])
+    return sim.scheduled(pod)
+
+
+def test_zone_requirements_and_preferences(backend):
+    z = LABEL_ZONE
+    assert _alone(backend, mkpod(required_affinity=[[Expr(z, "In", ["test-zone-3"])]])).labels[z] == "test-zone-3"                               # S:203
+    assert _alone(backend, mkpod(required_affinity=[[Expr(z, "In", ["unknown"])]])) is None                                                       # S:231
+    assert _alone(backend, mkpod(required_affinity=[[Expr(z, "NotIn", ["test-zone-1", "test-zone-2", "unknown"])]])).labels[z] == "test-zone-3"   # S:240
+    assert _alone(backend, mkpod(required_affinity=[[Expr(z, "NotIn", ZONES3 + ["unknown"])]])) is None                                           # S:250
+    wide = [[Expr(z, "In", ZONES3 + ["unknown"])]]
+    assert _alone(backend, mkpod(required_affinity=wide, preferred_affinity=[PreferredTerm(1, [Expr(z, "In", ["test-zone-2", "unknown"])])])).labels[z] == "test-zone-2"       # S:260
+    assert _alone(backend, mkpod(required_affinity=wide, preferred_affinity=[PreferredTerm(1, [Expr(z, "In", ["unknown"])])])) is not None                                      # S:273 (relaxed away)
+    assert _alone(backend, mkpod(required_affinity=wide, preferred_affinity=[PreferredTerm(1, [Expr(z, "NotIn", ["test-zone-1", "test-zone-3"])])])).labels[z] == "test-zone-2"  # S:285
+    assert _alone(backend, mkpod(required_affinity=wide, preferred_affinity=[PreferredTerm(1, [Expr(z, "NotIn", ZONES3)])])) is not None                                        # S:298
+    n = _alone(backend, mkpod(node_selector={z: "test-zone-3"}, required_affinity=[[Expr(z, "In", ZONES3)]], preferred_affinity=[PreferredTerm(1, [Expr(z, "In", ZONES3)])]))  # S:310
+    assert n.labels[z] == "test-zone-3"
+    n = _alone(backend, mkpod(node_selector={z: "test-zone-3", LABEL_INSTANCE_TYPE: "arm-instance-type"},                                                                       # S:324
+                              required_affinity=[[Expr(z, "In", ["test-zone-1", "test-zone-3"]), Expr(LABEL_INSTANCE_TYPE, "In", ["default-instance-type", "arm-instance-type"])]],
+                              preferred_affinity=[PreferredTerm(1, [Expr(z, "NotIn", ["unknown"]), Expr(LABEL_INSTANCE_TYPE, "NotIn", ["unknown"])])]))
+    assert n.labels[z] == "test-zone-3" and n.labels[LABEL_INSTANCE_TYPE] == "arm-instance-type"
+
+
+def test_restricted_labels_never_schedule(backend):
+    for key in ("karpenter.sh/emptiness-timestamp", LABEL_HOSTNAME,                      # S:348 v1alpha5.RestrictedLabels
+                "kubernetes.io/test", "k8s.io/test", "karpenter.sh/test"):              # S:358 RestrictedLabelDomains
+        # (the reference turns these pods away while validating the batch, provisioner.go:185-215; Solve would refuse them as well: nothing defines the label)
+        assert _alone(backend, mkpod(required_affinity=[[Expr(key, "In", ["test"])]])) is None, key
+
+
+def test_labels_of_excepted_domains_come_from_the_provisioner(backend):
+    keys = [d + "/test" for d in ("kops.k8s.io", "node.kubernetes.io", "testing.karpenter.sh")]                                    # S:368 LabelDomainExceptions
+    prov = default_prov(requirements=[Expr(k, "In", ["test-value"]) for k in keys])
+    n = _alone(backend, mkpod(), provisioners=[prov])
+    assert all(n.labels[k] == "test-value" for k in keys)
+
+
+# ---------------- suite_test.go: instance type compatibility ----------------
+def arch_prov(*archs):
+    return default_prov(requirements=[Expr(LABEL_ARCH, "In", list(archs))])
+
+
+def test_instance_types_the_provisioner_excludes(backend):
+    amd = lambda: [arch_prov("amd64")]                                                                                             # noqa: E731
+    assert _alone(backend, mkpod(required_affinity=[[Expr(LABEL_INSTANCE_TYPE, "In", ["arm-instance-type"])]]), provisioners=amd()) is None      # S:708
+    assert _alone(backend, mkpod(required_affinity=[[Expr(LABEL_OS, "In", ["ios"])]]), provisioners=amd()) is None                               # S:725 (only the arm type runs ios)
+    assert _alone(backend, mkpod(limits={"cpu": "14"}), provisioners=amd()) is None                                                              # S:747 (only the arm type has 14 cpu; limits stand in for requests)
+
+
+def test_different_selectors_need_different_nodes(backend):
+    for a, b in (({LABEL_OS: "linux"}, {LABEL_OS: "windows"}),                                                                     # S:760
+                 ({"beta.kubernetes.io/instance-type": "small-instance-type"}, {LABEL_INSTANCE_TYPE: "default-instance-type"}),    # S:780 (the beta label is normalised)
+                 ({LABEL_ZONE: "test-zone-1"}, {LABEL_ZONE: "test-zone-2"})):                                                      # S:800
+        sim = ClusterSim(backend, provisioners=[arch_prov("arm64", "amd64")])
+        pa, pb = mkpod(node_selector=a), mkpod(node_selector=b)
+        sim.provision([pa, pb])
+        assert sim.scheduled(pa).name != sim.scheduled(pb).name
+
+
+def test_provider_specific_labels(backend):
+    def sim5():
+        return ClusterSim(backend, instance_types=fake.instance_types(5))
+    sim = sim5()                                                                                                                   # S:865
+    large, small = mkpod(node_selector={fake.LABEL_INSTANCE_SIZE: "large"}), mkpod(node_selector={fake.LABEL_INSTANCE_SIZE: "small"})
+    sim.provision([large, small])
+    assert sim.node_types[sim.scheduled(large).name] == "fake-it-4" and sim.node_types[sim.scheduled(small).name] == "fake-it-0"
+    sim = sim5()                                                                                                                   # S:877
+    pods = [mkpod(node_selector={fake.LABEL_INSTANCE_SIZE: "large", LABEL_INSTANCE_TYPE: "fake-it-0"}), mkpod(node_selector={fake.LABEL_INSTANCE_SIZE: "small", LABEL_INSTANCE_TYPE: "fake-it-4"})]
+    sim.provision(pods)
+    assert all(sim.scheduled(p) is None for p in pods)
+    sim = sim5()                                                                                                                   # S:893: only some types carry the key
+    p = mkpod(required_affinity=[[Expr(fake.LABEL_EXOTIC, "Exists")]])
+    sim.provision([p])
+    assert fake.LABEL_EXOTIC in sim.scheduled(p).labels and sim.node_types[sim.scheduled(p).name] == "fake-it-4"
+    sim = ClusterSim(backend, instance_types=fake.instance_types(5), provisioners=[fake.provisioner("default", 5, discovery_label=True)])        # S:906
+    p = mkpod(required_affinity=[[Expr(fake.LABEL_EXOTIC, "DoesNotExist")]])
+    sim.provision([p])
+    assert sim.scheduled(p) is not None and fake.LABEL_EXOTIC not in sim.scheduled(p).labels
+
+
+# ---------------- suite_test.go: bin packing, in-flight nodes ----------------
+from helpers import format_milli, parse_quantity_milli      # noqa: E402
+
+
+def test_small_pod_takes_the_smallest_type(backend):
+    sim = ClusterSim(backend)                                                                                                      # S:1090
+    p = mkpod(requests={"memory": "2000M"})
+    sim.provision([p])
+    assert sim.node_types[sim.scheduled(p).name] == "small-instance-type"
+
+
+def test_inflight_node_reuse_by_zone_intersection(backend):
+    sim = ClusterSim(backend)                                                                                                      # S:1359
+    a = mkpod(limits={"cpu": "10m"}, required_affinity=zone_in("test-zone-2"))
+    sim.provision([a])
+    b = mkpod(limits={"cpu": "10m"}, required_affinity=zone_in("test-zone-1", "test-zone-2"))
+    sim.provision([b])
+    assert sim.scheduled(a).name == sim.scheduled(b).name      # zone-2 is in the intersection and the node has room
+    c = mkpod(limits={"cpu": "10m"}, required_affinity=zone_in("test-zone-1", "test-zone-3"))
+    sim.provision([c])
+    assert sim.scheduled(c).name != sim.scheduled(a).name
+
+
+def test_a_terminating_inflight_node_is_not_reused(backend):
+    sim = ClusterSim(backend)                                                                                                      # S:1438
+    a = mkpod(limits={"cpu": "10m"})
+    sim.provision([a])
+    first = sim.scheduled(a)
+    first.in_state = False      # deleted: cluster state marks it for deletion and Solve never sees it (scheduler.go:260-264 via provisioner.go:249-254)
+    b = mkpod(limits={"cpu": "10m"})
+    sim.provision([b])
+    assert sim.scheduled(b).name != first.name
+
+
+def test_hostname_spread_prefers_new_nodes_over_inflight_ones(backend):
+    lab = {"foo": "bar"}                                                                                                           # S:1498
+    topo = spread(LABEL_HOSTNAME, labels=lab)
+    sim = ClusterSim(backend)
+    sim.provision(mkpods(4, labels=lab, spread=topo))
+    assert sim.skew(LABEL_HOSTNAME, topo[0].label_selector) == [1, 1, 1, 1]
+    sim.provision(mkpods(5, labels=lab, spread=topo))
+    assert sim.skew(LABEL_HOSTNAME, topo[0].label_selector) == [1] * 9
+
+
+def _emptied_node_with_bound_daemon(sim, first, ds_cpu, ds_mem):
+    """the first pod is deleted again and a daemonset pod of (ds_cpu, ds_mem) is bound by hand: state.Node then reports it under DaemonSetRequests() and
+    takes it off Available() (state/node.go:172-190; S:1697-1722 asserts 15.9 -> 14.9 cpu)"""
+    node = sim.scheduled(first)
+    sim.delete_pod(first)
+    avail = dict(node._alloc)
+    avail["cpu"] -= parse_quantity_milli(ds_cpu); avail["memory"] -= parse_quantity_milli(ds_mem); avail["pods"] -= 1000
+    node.available = {k: format_milli(v) for k, v in avail.items()}
+    node.daemonset_requests = {"cpu": ds_cpu, "memory": ds_mem, "pods": "1"}
+    return node
+
+
+def test_bound_daemonset_pods_are_not_reserved_twice(backend):
+    ds = mkpod(requests={"cpu": "1", "memory": "1Gi"})                                                                             # S:1660
+    sim = ClusterSim(backend, daemonsets=[ds])
+    first = mkpod(limits={"cpu": "8"})
+    sim.provision([first])
+    node = _emptied_node_with_bound_daemon(sim, first, "1", "2Gi")
+    assert node.available["cpu"] == "14900m"
+    second = mkpod(limits={"cpu": "14.9"})
+    sim.provision([second])
+    assert sim.scheduled(second).name == node.name      # the daemonset pod has bound: nothing of it remains to be reserved, 14.9 cpu are free
+
+
+def test_unexpected_daemonset_pods_do_not_free_capacity(backend):
+    ds1 = mkpod(requests={"cpu": "1", "memory": "1Gi"}, node_selector={"my-node-label": "value"})                                  # S:1732
+    ds2 = mkpod(requests={"cpu": "1m"})
+    sim = ClusterSim(backend, daemonsets=[ds1, ds2])
+    first = mkpod(limits={"cpu": "8"})
+    sim.provision([first])
+    node = _emptied_node_with_bound_daemon(sim, first, "1", "2Gi")
+    node.labels["my-node-label"] = "value"      # "this label appears on the node for some reason that Karpenter can't track"
+    second = mkpod(limits={"cpu": "15.5"})
+    sim.provision([second])
+    assert sim.scheduled(second) is not None and sim.scheduled(second).name != node.name      # a NEGATIVE remainder of daemonset resources would have made room for it
+
+
+def test_inflight_nodes_are_packed_before_new_ones_open(backend):
+    import numpy as np
+    its = [fake.new_instance_type("medium", {"cpu": "4.25", "pods": "4"})]                                                         # S:1824 (rand.Intn(10) batches: seeded here)
+    rs = np.random.RandomState(4)
+    sim = ClusterSim(backend, instance_types=its)
+    for _ in range(10):
+        pods = mkpods(int(rs.randint(10)), limits={"cpu": "1"})
+        sim.provision(pods)
+        assert all(sim.scheduled(p) is not None for p in pods)
+    free = sum(parse_quantity_milli(n.available["cpu"]) >= 1000 for n in sim.nodes)
+    assert free <= 1      # only the final node may have room for another pod
+
+
+def _provision_no_binding(sim, pods):
+    """ExpectProvisionedNoBinding (expectations.go:234-262): the nodes are launched, the pods stay pending"""
+    res = sim.provision(pods, bind=False)
+    provs = {p.name: p for p in sim.provisioners}
+    for nn in res.new_nodes:
+        sim.nodes.append(sim._launch(nn, provs[nn.provisioner]))
+    return res
+
+
+def test_no_pre_binding(backend):
+    sim = ClusterSim(backend)                                                                                                      # S:1895 (and S:1864, issue #2011: the same flow through a ProviderRef)
+    a = mkpod(limits={"cpu": "10m"})
+    _provision_no_binding(sim, [a])
+    assert len(sim.nodes) == 1 and sim.scheduled(a) is None
+    res = _provision_no_binding(sim, [mkpod(limits={"cpu": "10m"})])
+    assert len(sim.nodes) == 1 and not res.new_nodes      # the in-flight node takes it: no second node
+
+
+def test_self_affinity_prefers_the_inflight_nodes_zone(backend):
+    lab = {"security": "s2"}                                                                                                       # S:1963 (issue #1975)
+    pods = mkpods(2, labels=lab, affinity_required=aff(LABEL_ZONE, lab))
+    sim = ClusterSim(backend)
+    _provision_no_binding(sim, [pods[0]])
+    _provision_no_binding(sim, [pods[1]])
+    assert len(sim.nodes) == 1      # nothing is counted anywhere yet: the existing node's zone must win over "any viable domain"
+
+
+def test_extended_resources_zeroed_by_the_kubelet_at_startup(backend):
+    sim = ClusterSim(backend)                                                                                                      # S:1923 (issue #1459)
+    a = mkpod(limits={"cpu": "10m", fake.RES_GPU_A: "1"})
+    _provision_no_binding(sim, [a])
+    assert len(sim.nodes) == 1
+    # the kubelet reports the extended resource as 0 until the device plugin registers; state.Node.Available() of a node that is not initialised yet
+    # keeps the instance type's figures (state/node.go:131-146) -- the input Solve sees is unchanged, and the second pod must still fit the in-flight node
+    res = _provision_no_binding(sim, [mkpod(limits={"cpu": "10m", fake.RES_GPU_A: "1"})])
+    assert len(sim.nodes) == 1 and not res.new_nodes
