@@ -2958,11 +2958,11 @@ __global__ __launch_bounds__(256) void ks_derive_whatifs(const u32* base_queue, 
 //           the snapshot-wide totals minus what the candidate nodes' pods contribute
 struct TopoDesc { const u32* cand; u32 ncand, pad; u8* active; i32* count; i32* extra; };
 __global__ __launch_bounds__(64) void ks_derive_topology(const TopoDesc* descs, u32 G, u32 GH, u32 n_nodes, const i32* node_cnt, const i32* node_dom, const u64* node_own,
-                                                        const i32* tot, const i32* reg, const i32* extra_tot, const i32* grp_hslot, const i32* node_row) {
+                                                        const i32* tot, const i32* reg, const i32* extra_tot, const i32* grp_hslot, const i32* node_row, u32 n_topologies) {
   const TopoDesc d = descs[blockIdx.x]; const u32 g = threadIdx.x;
   u64 own = 0; for (u32 i = 0; i < d.ncand; ++i) own |= node_own[d.cand[i]];
   if (g >= G) return;
-  d.active[g] = (u8)((own >> g) & 1ull);
+  d.active[g] = g >= n_topologies ? (u8)1 : (u8)((own >> g) & 1ull);      // (a hostname-keyed inverse group with zero counts constrains nothing: it may exist in every what-if)
   const i32 hs = grp_hslot[g];
   if (hs >= 0) {      // hostname key: the rows are the snapshot's (ks_host_count0); what moves is the number of positive domains that are no existing node
     i32 ex = extra_tot[hs];
@@ -3008,7 +3008,8 @@ extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, con
   if (base->h.ND || base->h.pod_gid) return fail(KS_ERR_UNSUPPORTED, "what-ifs cannot be derived from a snapshot with volume limits");
   const bool with_topo = base->h.G != 0;
   if (with_topo && (!topo || !topo->node_cnt || !topo->node_dom || !topo->node_own || !topo->tot || !topo->extra_tot || !topo->grph_base)) return fail(KS_ERR_UNSUPPORTED, "the snapshot has topology groups: their per-node tables (ks_whatif_topo) are needed to derive what-ifs from it");
-  if (with_topo && (base->h.G > 64 || base->h.n_topologies != base->h.G)) return fail(KS_ERR_UNSUPPORTED, "derived what-ifs: at most 64 topology groups, none of them an inverse anti-affinity group");
+  if (with_topo && base->h.G > 64) return fail(KS_ERR_UNSUPPORTED, "derived what-ifs: at most 64 topology groups");
+  if (with_topo) for (u32 g = base->h.n_topologies; g < base->h.G; ++g) if (base->src.grp_hslot[g] < 0) return fail(KS_ERR_UNSUPPORTED, "derived what-ifs: an inverse anti-affinity group on a key other than the hostname");
   const DevProb& bh = base->h; const u32 E = bh.E, M = bh.M, R = bh.R, K = bh.K, TW = bh.TW, C = bh.C, Pb = bh.P;
   HIPCHK(hipSetDevice(base->device));
   auto b = new ks_whatif_batch(); b->device = base->device; b->n = n;
@@ -3109,7 +3110,7 @@ extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, con
   if (const char* pz = getenv("KS_POISON")) { if (sz[2]) HIPCHK(hipMemsetAsync(r2, (int)strtol(pz, nullptr, 0) & 0xFF, sz[2], b->stream)); }
   if (n) hipLaunchKernelGGL(ks_derive_whatifs, dim3(n), dim3(256), 0, b->stream, bh.queue, (const i32*)(r0 + pod_node_at), Pb, (const DeriveDesc*)(r0 + desc_at), (u32*)(r1 + mismatch_at));
   if (n && with_topo) hipLaunchKernelGGL(ks_derive_topology, dim3(n), dim3(64), 0, b->stream, (const TopoDesc*)(r0 + t_desc_at), G, GH, n_nodes, (const i32*)(r0 + t_cnt_at), (const i32*)(r0 + t_dom_at),
-                                         (const u64*)(r0 + t_own_at), (const i32*)(r0 + t_tot_at), bh.grp_count, (const i32*)(r0 + t_ext_at), bh.grp_hslot, (const i32*)(r0 + t_row_at));
+                                         (const u64*)(r0 + t_own_at), (const i32*)(r0 + t_tot_at), bh.grp_count, (const i32*)(r0 + t_ext_at), bh.grp_hslot, (const i32*)(r0 + t_row_at), bh.n_topologies);
   u32 mismatch = 0;
   HIPCHK(hipMemcpyAsync(&mismatch, r1 + mismatch_at, 4, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream)); HIPCHK(hipGetLastError());

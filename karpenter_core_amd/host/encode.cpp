@@ -277,6 +277,7 @@ struct Builder {
     const auto& m = base ? base->node_by_name : node_by_name; auto it = m.find(n); return it == m.end() ? nullptr : it->second;
   }
   std::vector<std::unique_ptr<Group>> groups; std::map<std::string, int> topo_by_id, inverse_by_id;   // creation order; inverse flagged
+  std::vector<int> group_order, group_remap;          // encoded group index -> creation index, and back (encode_groups: topologies first, then inverse groups)
   bool shared_filter_differs = false;                 // two pods share a spread group while their node filters differ in content (the first one's counts)
   std::vector<Requirement> it_reqs; std::map<std::string, int> it_state_id;   // node-side instance-type states (index 0 = absent)
   std::vector<Requirement> it_cols; std::map<std::string, int> it_col_id;     // pod-side instance-type requirements (classes, topology filters; 0 = none)
@@ -752,9 +753,13 @@ struct Builder {
       g.counts[domain]++;
     }
   }
+  static std::string group_id(int type, const std::string& key, const std::set<std::string>& nss, const ksp::Selector& sel, int32_t max_skew, const Filter& f) {
+    std::string id = key + "|" + std::to_string(type) + "|"; for (auto& n : nss) id += n + ","; id += "|" + selector_identity(sel) + "|" + std::to_string(max_skew) + "|" + filter_identity(f);
+    return id;
+  }
   int get_group(bool inverse, int type, const std::string& key, const std::set<std::string>& nss, const ksp::Selector& sel, int32_t max_skew, const Pod& owner, bool active_now) {
     Filter f; if (type == 0) f = MakeTopologyNodeFilter(owner);
-    std::string id = key + "|" + std::to_string(type) + "|"; for (auto& n : nss) id += n + ","; id += "|" + selector_identity(sel) + "|" + std::to_string(max_skew) + "|" + filter_identity(f);
+    const std::string id = group_id(type, key, nss, sel, max_skew, f);
     auto& index = inverse ? inverse_by_id : topo_by_id;
     auto it = index.find(id);
     if (it != index.end()) {
@@ -1035,6 +1040,7 @@ struct Builder {
     const uint32_t ntopo = (uint32_t)order.size();
     for (size_t g = 0; g < groups.size(); ++g) if (groups[g]->inverse) order.push_back((int)g);
     for (size_t i = 0; i < order.size(); ++i) remap[order[i]] = (int)i;
+    group_order = order; group_remap = remap;
     const uint32_t G = (uint32_t)order.size(); const uint32_t NE = (uint32_t)E.existing.size();
     E.grp_count.assign((size_t)G * 64, -1); E.grp_filter_off.assign(1, 0);
     uint32_t GH = 0;
@@ -1332,29 +1338,41 @@ struct SnapshotBase {
 // while its node stays.  Returns "" or what stands in the way.
 static std::string build_topo_tables(SnapshotBase& sb, const int32_t* pod_node) {
   const Builder& b = *sb.builder; const Encoded& E = *sb.enc; const ksp::Problem& pr = *sb.snapshot;
-  const uint32_t G = E.prob.G, GH = E.prob.GH, NE = E.prob.E; const size_t NN = pr.nodes.size();
-  if (E.prob.n_topologies != G) return "a bound pod carries required anti-affinity (inverse groups exist for some candidate sets only)";
+  const uint32_t G = E.prob.G, GH = E.prob.GH, NE = E.prob.E, NT = E.prob.n_topologies; const size_t NN = pr.nodes.size();
   if (G > 64) return "more than 64 topology groups";
   if (b.shared_filter_differs) return "two pods share a spread group while their node filters differ: the group's filter is that of the first pod of each batch";
+  auto grp = [&](uint32_t gi) -> const Group& { return *b.groups[b.group_order[gi]]; };
+  // Inverse groups (required anti-affinity, topology.go:181-199,202-229) EXIST only while an owner is in the batch or stays bound outside it.  A hostname-keyed
+  // one whose counts are all zero constrains nothing (every hostname is registered with 0, nothing is narrowed), so it may simply exist in every what-if;
+  // a value-keyed one narrows the node's requirement to its registered domains by existing -- that depends on the candidate set: refused.
+  for (uint32_t gi = NT; gi < G; ++gi) if (grp(gi).key != ksp::kHostname) return "required anti-affinity on a key other than the hostname (such an inverse group narrows requirements by merely existing, and it exists for some candidate sets only)";
+  if (NT < G) for (auto& n : pr.nodes) { auto hl = n.labels.find(ksp::kHostname); if (hl != n.labels.end() && hl->second.empty()) return "a node with an empty hostname label under hostname-keyed anti-affinity"; }
   sb.t_node_cnt.assign((size_t)G * NN, 0); sb.t_node_dom.assign((size_t)G * NN, -1); sb.t_node_own.assign(NN, 0); sb.t_tot.assign((size_t)G * 64, 0);
   sb.t_extra_tot.assign(GH, 0); sb.t_grph_base.assign((size_t)GH * NE, 0);
-  for (size_t i = 0; i < pr.pods.size(); ++i) for (int g : b.specs[b.pod_spec[i]].stages[0].sg.own) sb.t_node_own[pod_node[i]] |= 1ull << g;      // (no inverse groups: creation order IS the encoded order)
+  for (size_t i = 0; i < pr.pods.size(); ++i) for (int g : b.specs[b.pod_spec[i]].stages[0].sg.own) sb.t_node_own[pod_node[i]] |= 1ull << b.group_remap[g];
   // does group g count pods on node n at all (key present, node filter), and under which domain
   std::vector<uint8_t> counts_on((size_t)G * NN, 0); std::vector<int32_t> key_of(G, -1);
-  for (uint32_t g = 0; g < G; ++g) if (b.groups[g]->key != ksp::kHostname) key_of[g] = b.key_id.at(b.groups[g]->key);
+  for (uint32_t g = 0; g < G; ++g) if (grp(g).key != ksp::kHostname) key_of[g] = b.key_id.at(grp(g).key);
   for (size_t n = 0; n < NN; ++n) {
     const Requirements nr = Requirements::FromLabels(pr.nodes[n].labels);
     for (uint32_t g = 0; g < G; ++g) {
-      const Group& gr = *b.groups[g]; const bool host = gr.key == ksp::kHostname;
+      const Group& gr = grp(g); const bool host = gr.key == ksp::kHostname;
       auto lt = pr.nodes[n].labels.find(gr.key);
-      if (!host && lt == pr.nodes[n].labels.end()) continue;
-      if (!FilterMatches(gr.filter, nr, b.wellKnown)) continue;
+      if (g >= NT) { if (lt == pr.nodes[n].labels.end()) continue; }      // updateInverseAntiAffinity reads the node's label, nothing else
+      else { if (!host && lt == pr.nodes[n].labels.end()) continue; if (!FilterMatches(gr.filter, nr, b.wellKnown)) continue; }
       counts_on[g * NN + n] = 1;
       if (!host) sb.t_node_dom[g * NN + n] = b.value_id(key_of[g], lt->second); else sb.t_node_dom[g * NN + n] = 0;      // (hostname-keyed: the count of the pods that are never in a batch)
     }
   }
   std::map<std::string, size_t> node_index; for (size_t n = 0; n < NN; ++n) node_index.emplace(pr.nodes[n].name, n);
   std::unordered_map<std::string, uint64_t> selects;      // (namespace, labels) -> groups that list such a pod (TopologyListOptions: a nil selector lists everything)
+  auto count_one = [&](uint32_t g, size_t n, bool in_a_batch) -> const char* {
+    if (!counts_on[g * NN + n]) return nullptr;
+    const bool host = key_of[g] < 0;
+    if (in_a_batch) { sb.t_node_cnt[g * NN + n]++; if (!host) { const int32_t d = sb.t_node_dom[g * NN + n]; if (d < 0 || d >= 64) return "a counted topology domain is missing from the universe"; sb.t_tot[(size_t)g * 64 + d]++; } }
+    else if (host) sb.t_node_dom[g * NN + n]++;      // (value-keyed groups: the snapshot's own grp_count already holds the pods that are never in a batch)
+    return nullptr;
+  };
   for (auto& cp : pr.cluster_pods) {
     const int64_t pi = b.batch_uids.find(cp.uid);
     auto ni = node_index.find(cp.node_name); if (ni == node_index.end()) continue;      // countDomains skips pods whose node it cannot find
@@ -1364,24 +1382,24 @@ static std::string build_topo_tables(SnapshotBase& sb, const int32_t* pod_node) 
     auto it = selects.find(sig);
     if (it == selects.end()) {
       uint64_t m = 0;
-      for (uint32_t g = 0; g < G; ++g) { const Group& gr = *b.groups[g]; if (gr.namespaces.count(cp.ns) && (gr.selector.nil || SelectorMatches(gr.selector, cp.labels))) m |= 1ull << g; }
+      for (uint32_t g = 0; g < NT; ++g) { const Group& gr = grp(g); if (gr.namespaces.count(cp.ns) && (gr.selector.nil || SelectorMatches(gr.selector, cp.labels))) m |= 1ull << g; }
       it = selects.emplace(std::move(sig), m).first;
     }
-    for (uint64_t m = it->second; m; m &= m - 1) {
-      const uint32_t g = (uint32_t)__builtin_ctzll(m); if (!counts_on[g * NN + n]) continue;
-      const bool host = key_of[g] < 0;
-      if (pi >= 0) { sb.t_node_cnt[g * NN + n]++; if (!host) { const int32_t d = sb.t_node_dom[g * NN + n]; if (d < 0 || d >= 64) return "a counted topology domain is missing from the universe"; sb.t_tot[(size_t)g * 64 + d]++; } }
-      else if (host) sb.t_node_dom[g * NN + n]++;      // (value-keyed groups: the snapshot's own grp_count already holds the pods that are never in a batch)
+    for (uint64_t m = it->second; m; m &= m - 1) if (const char* why = count_one((uint32_t)__builtin_ctzll(m), n, pi >= 0)) return why;
+    for (auto& t : cp.anti_required) {      // the inverse group its required anti-affinity owns while the pod stays bound (topology.go:181-199)
+      auto gi = b.inverse_by_id.find(Builder::group_id(2, t.topology_key, Builder::ns_list(cp.ns, t.namespaces), t.selector, INT32_MAX, Filter{}));
+      if (gi == b.inverse_by_id.end()) return "a cluster pod's required anti-affinity names a group none of the bound pods owns";
+      if (const char* why = count_one((uint32_t)b.group_remap[gi->second], n, pi >= 0)) return why;
     }
   }
   for (uint32_t g = 0; g < G; ++g) {
     const int32_t hs = E.grp_hslot[g]; if (hs < 0) continue;
-    const Group& gr = *b.groups[g];
+    const Group& gr = grp(g);
     for (size_t n = 0; n < NN; ++n) {
       const int32_t c = sb.t_node_cnt[g * NN + n] + sb.t_node_dom[g * NN + n], e = sb.node_row[n];
       if (e < 0) { if (c > 0) sb.t_extra_tot[hs]++; continue; }
       auto hl = pr.nodes[n].labels.find(ksp::kHostname); const std::string& hostname = (hl == pr.nodes[n].labels.end() || hl->second.empty()) ? pr.nodes[n].name : hl->second;
-      sb.t_grph_base[(size_t)hs * NE + e] = c > 0 ? c : (gr.counts.count(hostname) ? 0 : -2);      // -2: registered only if a pod of the batch owns the group (existingnode.go:73)
+      sb.t_grph_base[(size_t)hs * NE + e] = c > 0 ? c : ((g >= NT || gr.counts.count(hostname)) ? 0 : -2);      // -2: registered only if a pod of the batch owns the group (existingnode.go:73)
     }
   }
   sb.topo.node_cnt = sb.t_node_cnt.data(); sb.topo.node_dom = sb.t_node_dom.data(); sb.topo.node_own = sb.t_node_own.data(); sb.topo.tot = sb.t_tot.data();
@@ -1407,7 +1425,6 @@ std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp
     }
     sb->delta_ok = true;
     if (b.any_volume_limits || b.pods_have_volumes) { sb->delta_ok = false; sb->delta_why = "volume limits / claims: the shared-claim partition depends on the candidate set"; }
-    else for (auto& cp : snapshot->cluster_pods) if (!cp.anti_required.empty()) { sb->delta_ok = false; sb->delta_why = "a cluster pod carries required anti-affinity (inverse groups depend on the candidate set)"; break; }
     if (sb->delta_ok && !b.groups.empty()) { const std::string why = build_topo_tables(*sb, pod_node); if (!why.empty()) { sb->delta_ok = false; sb->delta_why = why; } }
   }
   return sb;

@@ -249,7 +249,7 @@ def whatif(its, prov, nodes, bound, candidates: List[int], with_cluster_pods: bo
     pods = [p for i in candidates for p in bound[i]]
     # the bound pods only matter to countDomains / inverse anti-affinity; a snapshot whose pods carry no
     # topology terms can skip listing them (nothing would be counted)
-    cps = [ClusterPod(uid=p.uid, namespace=p.namespace, node_name=nodes[i].name, labels=p.labels)
+    cps = [ClusterPod(uid=p.uid, namespace=p.namespace, node_name=nodes[i].name, labels=p.labels, anti_required=list(p.anti_required))
            for i in range(len(nodes)) for p in bound[i]] if with_cluster_pods else []
     return Problem(instance_types=its, provisioners=[prov], pods=pods, nodes=ns, cluster_pods=cps,
                    extra_well_known=fake.EXTRA_WELL_KNOWN, simulation_mode=True)
@@ -264,7 +264,7 @@ def snapshot_problem(its, prov, nodes, bound, with_cluster_pods: bool = True):
             pods.append(p)
             pod_node.append(i)
     ns = [dataclasses.replace(n, in_state=True) for n in nodes]
-    cps = [ClusterPod(uid=p.uid, namespace=p.namespace, node_name=nodes[i].name, labels=p.labels)
+    cps = [ClusterPod(uid=p.uid, namespace=p.namespace, node_name=nodes[i].name, labels=p.labels, anti_required=list(p.anti_required))
            for i in range(len(nodes)) for p in bound[i]] if with_cluster_pods else []
     return Problem(instance_types=its, provisioners=[prov], pods=pods, nodes=ns, cluster_pods=cps,
                    extra_well_known=fake.EXTRA_WELL_KNOWN, simulation_mode=True), pod_node

@@ -17,7 +17,8 @@ def _snapshot(existing, sizes, seed, spare=-1, limits=None):
 
 
 def test_ineligible_snapshots_are_refused_on_the_host():
-    """(CPU) bound pods with REQUIRED anti-affinity: inverse groups exist for some candidate sets only -- refused before anything touches a device."""
+    """(CPU) bound pods with REQUIRED anti-affinity on a key other than the hostname: such an inverse group narrows requirements by merely existing, and it
+    exists for some candidate sets only -- refused before anything touches a device."""
     from karpenter_core_amd.model import PodAffinityTerm
     its, prov, nodes, bound = _snapshot(24, 5, 8)
     for pods in bound:
@@ -31,7 +32,7 @@ def test_ineligible_snapshots_are_refused_on_the_host():
     assert [f.dims["P"] for f in flats] == [len(bound[0]), len(bound[1]) + len(bound[2])]
 
 
-def _topology_snapshot(existing, sizes, seed, spare=-1, extras=True, kinds=None):
+def _topology_snapshot(existing, sizes, seed, spare=-1, extras=True, kinds=None, anti=False):
     """A cluster whose bound pods carry spread / affinity / preferred terms (no required anti-affinity), listed as cluster pods the way
     countDomains finds them -- plus pods that are in no batch (daemon-like, on candidate nodes too), one on a node nobody knows, and a node no
     provisioner owns."""
@@ -68,6 +69,9 @@ def _topology_snapshot(existing, sizes, seed, spare=-1, extras=True, kinds=None)
             elif r < 0.78:
                 p.preferred_affinity = [PreferredTerm(5, [Expr(LABEL_ZONE, "In", [zones[-1]])])]
                 p.spread = [TopologySpreadConstraint(2, LABEL_ZONE, DO_NOT_SCHEDULE, own)]
+            elif r < 0.86 and anti:      # required anti-affinity per hostname: against a workload of its own label ("z-*", at most one per node), or against another
+                p.labels = {"my-label": "z-" + p.labels["my-label"]}
+                p.anti_required = [PodAffinityTerm(LABEL_HOSTNAME, LabelSelector({"my-label": p.labels["my-label"] if rs.rand() < 0.7 else "abc"[int(rs.randint(3))]}))]
     if extras:
         nodes.append(StateNode(name="unowned", labels={LABEL_ZONE: zones[0], LABEL_HOSTNAME: "unowned"}))
         bound.append([dataclasses_replace_uid(p, f"extra-{i}") for i, p in enumerate(bound[0][:6])])
@@ -75,6 +79,9 @@ def _topology_snapshot(existing, sizes, seed, spare=-1, extras=True, kinds=None)
     if extras:
         for i in range(existing // 2):
             snap.cluster_pods.append(ClusterPod(uid=f"ds-{i}", namespace="default", node_name=nodes[int(rs.randint(len(nodes)))].name, labels={"my-label": "abcdefg"[int(rs.randint(7))]}))
+        if anti:      # a pod that is in no batch and refuses the company of workload "a" on its node
+            snap.cluster_pods.append(ClusterPod(uid="loner", namespace="default", node_name=nodes[1].name, labels={"my-label": "q"},
+                                                anti_required=[PodAffinityTerm(LABEL_HOSTNAME, LabelSelector({"my-label": "a"}))]))
         snap.cluster_pods.append(ClusterPod(uid="lost", namespace="default", node_name="no-such-node", labels={"my-label": "a"}))
         snap.cluster_pods.append(ClusterPod(uid="elsewhere", namespace="other", node_name=nodes[0].name, labels={"my-label": "a"}))
     return its, prov, nodes, bound, snap, pod_node
@@ -119,6 +126,33 @@ def test_topology_snapshots_are_eligible(seed):
         with pytest.raises(S.KSolveError) as e:      # eligible: the refusal is the missing device, not the snapshot
             S.open_whatifs(parsed, pod_node, [[0]], derive=True)
         assert e.value.code == S.KS_ERR_DEVICE
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_derived_whatifs_with_hostname_anti_affinity(seed):
+    """... and REQUIRED anti-affinity per hostname among the bound pods (the usual "one replica per node"): its inverse group exists only while an owner
+    is in the batch or stays bound, but a hostname-keyed inverse group without counts constrains nothing, so the snapshot's serves every what-if.  The
+    staying owners' counts come from the per-node tables like any other count."""
+    from oracle import oracle_py as O
+    rs = np.random.RandomState(100 + seed)
+    its, prov, nodes, bound, snap, pod_node = _topology_snapshot(int(rs.randint(24, 100)), int(rs.randint(4, 8)), 150 + seed, spare=int(rs.choice([-1, 0, 3])), extras=seed != 0, anti=True)
+    assert any(cp.anti_required for cp in snap.cluster_pods)
+    sets = [[int(x) for x in rs.choice(len(nodes), size=int(rs.choice([1, 1, 2, 4, 9])), replace=False)] for _ in range(20)] + [[1], [0, 1, 2]]
+    parsed = S.ParsedProblem(snap)
+    derived = S.open_whatifs(parsed, pod_node, sets, derive=True)
+    flat = S.open_whatifs(parsed, pod_node, sets, derive=False)
+    try:
+        got, _, _ = S.solve_batch(derived)
+        want, _, _ = S.solve_batch(flat)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a.canonical() == b.canonical() and a.reasons == b.reasons, (seed, i, sets[i])
+        for i in (0, 5, 21):
+            ref = O.solve(_whatif_problem(snap, pod_node, sets[i]))
+            assert got[i].canonical() == ref.canonical(), (seed, i)
+    finally:
+        for f in derived + flat:
+            f.close()
 
 
 @pytest.mark.gpu

@@ -7,9 +7,10 @@ from karpenter_core_amd import scheduler as S
 from oracle import oracle_py as O
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 kinds = set(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 and sys.argv[2] != "all" else None
-noextras = len(sys.argv) > 3
+noextras = len(sys.argv) > 3 and sys.argv[3] == "x"
+anti = len(sys.argv) > 4
 rs = np.random.RandomState(seed)
-its, prov, nodes, bound, snap, pod_node = _topology_snapshot(int(rs.randint(24, 120)), int(rs.randint(4, 8)), 50 + seed, spare=int(rs.choice([-1, 0, 3])), extras=(seed != 0 and not noextras), kinds=kinds)
+its, prov, nodes, bound, snap, pod_node = _topology_snapshot(int(rs.randint(24, 120)), int(rs.randint(4, 8)), 50 + seed, spare=int(rs.choice([-1, 0, 3])), extras=(seed != 0 and not noextras), kinds=kinds, anti=anti)
 sets = [[int(x) for x in rs.choice(len(nodes), size=int(rs.choice([1, 1, 2, 4, 9])), replace=False)] for _ in range(20)] + [[len(nodes) - 1], [0, len(nodes) - 1]]
 parsed = S.ParsedProblem(snap)
 derived = S.open_whatifs(parsed, pod_node, sets, derive=True)
