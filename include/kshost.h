@@ -118,7 +118,7 @@ int ksh_types_subset(void** handles, uint32_t n, const uint32_t* node, const uin
  * what-if starts with and what countDomains finds for it follow from per-node tables of the snapshot (ks_whatif_topo).  Required anti-affinity per HOSTNAME is covered as well
  * (a hostname-keyed inverse group without counts constrains nothing, so the snapshot's serves every what-if; the staying owners are counted per node).
  * KS_ERR_UNSUPPORTED -- nothing opened -- where a what-if depends on its candidate set in other ways: required anti-affinity on another key (such an inverse
- * group narrows requirements by merely existing), more than 64 groups, one spread group shared by pods whose node filters differ, volume limits / claims.
+ * group narrows requirements by merely existing), more than 1024 groups, one spread group shared by pods whose node filters differ, volume limits / claims.
  * Use ksh_open_whatifs_parsed then. */
 int ksh_open_whatifs_derived(void* parsed_snapshot, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand, const int32_t* pod_node, int device, void** out_handles);
 int ksh_open_whatifs_parsed(void* parsed_snapshot, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand, const int32_t* pod_node, uint32_t nthreads, void** out_handles);

@@ -253,16 +253,16 @@ int ks_problem_upload_shared(const ks_problem* p, const ks_dev_problem* base, ks
  * ordinary device problems (views owned by the batch) for ks_solve_batch_dev / ks_batch_records_dev / ks_price_filter_dev / ...; in their
  * results pod i is the i-th pod of the what-if in the SNAPSHOT's queue order (ks_whatifs_pod_ids names the snapshot pod behind each) and
  * existing node e is the snapshot's row e (removed nodes receive nothing).  Not for snapshots with volume limits, inverse anti-affinity groups on a key
- * other than the hostname, or more than 64 topology groups (KS_ERR_UNSUPPORTED: the caller flattens those what-ifs one by one). */
+ * other than the hostname, or more than 1024 topology groups (KS_ERR_UNSUPPORTED: the caller flattens those what-ifs one by one). */
 typedef struct ks_whatif_batch ks_whatif_batch;
-/* Snapshots whose bound pods carry spread / affinity / anti-affinity terms (base G > 0, G <= 64; inverse groups hostname-keyed): what a what-if's topology takes from its
+/* Snapshots whose bound pods carry spread / affinity / anti-affinity terms (base G > 0, G <= 1024; inverse groups hostname-keyed): what a what-if's topology takes from its
  * candidate set is derived on the device too -- which groups exist from the start (owned by a pod of the batch: topology.go:72-78) and countDomains over
  * the cluster pods that stay (topology.go:231-276) -- from per-node tables of the snapshot: */
 typedef struct ks_whatif_topo {
   const int32_t* node_cnt;    /* [G][n_nodes] pods on the node that group g counts when they are NOT in the batch (selector, namespace, node filter, key present) */
   const int32_t* node_dom;    /* [G][n_nodes] the node's domain for group g: value id of its label on the group's key, -1 if none; hostname-keyed groups: the
                                               pods on the node the group counts that are in NO batch (they count under its hostname even when the node is a candidate) */
-  const uint64_t* node_own;   /* [n_nodes]    groups (bit g) some pod bound to the node owns at its first relaxation stage */
+  const uint64_t* node_own;   /* [n_nodes][ceil(G/64)] groups (bit g) some pod bound to the node owns at its first relaxation stage */
   const int32_t* tot;         /* [G][64]      node_cnt summed per domain over every node */
   const int32_t* extra_tot;   /* [GH]         hostname-keyed groups: nodes that are no existing row and count > 0 */
   const int32_t* grph_base;   /* [GH][E]      hostname-keyed groups: what every existing row counts while its node stays; 0 = registered without pods,

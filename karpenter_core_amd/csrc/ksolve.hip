@@ -2952,17 +2952,17 @@ __global__ __launch_bounds__(256) void ks_derive_whatifs(const u32* base_queue, 
   if (threadIdx.x == 0 && base_off != d.P_expected) atomicAdd(mismatch, 1u);
 }
 
-// Topology of a derived what-if (snapshots whose bound pods carry spread / affinity terms): lane g = group g (G <= 64).
+// Topology of a derived what-if (snapshots whose bound pods carry spread / affinity terms): thread g = group g (G <= 1024).
 //   active: some pod of the batch owns the group at its first relaxation stage (NewTopology's Update per pod, topology.go:72-78)
 //   counts: NewTopologyGroup's registered domains + countDomains over the cluster pods that are NOT in the batch (topology.go:231-276) =
 //           the snapshot-wide totals minus what the candidate nodes' pods contribute
 struct TopoDesc { const u32* cand; u32 ncand, pad; u8* active; i32* count; i32* extra; };
-__global__ __launch_bounds__(64) void ks_derive_topology(const TopoDesc* descs, u32 G, u32 GH, u32 n_nodes, const i32* node_cnt, const i32* node_dom, const u64* node_own,
+__global__ __launch_bounds__(1024) void ks_derive_topology(const TopoDesc* descs, u32 G, u32 GH, u32 n_nodes, const i32* node_cnt, const i32* node_dom, const u64* node_own,
                                                         const i32* tot, const i32* reg, const i32* extra_tot, const i32* grp_hslot, const i32* node_row, u32 n_topologies) {
-  const TopoDesc d = descs[blockIdx.x]; const u32 g = threadIdx.x;
-  u64 own = 0; for (u32 i = 0; i < d.ncand; ++i) own |= node_own[d.cand[i]];
+  const TopoDesc d = descs[blockIdx.x]; const u32 g = threadIdx.x, GW = (G + 63) / 64;      // (blockDim = 64 * GW: node_own holds GW words per node)
   if (g >= G) return;
-  d.active[g] = g >= n_topologies ? (u8)1 : (u8)((own >> g) & 1ull);      // (a hostname-keyed inverse group with zero counts constrains nothing: it may exist in every what-if)
+  u64 own = 0; for (u32 i = 0; i < d.ncand; ++i) own |= node_own[(size_t)d.cand[i] * GW + (g >> 6)];
+  d.active[g] = g >= n_topologies ? (u8)1 : (u8)((own >> (g & 63u)) & 1ull);      // (a hostname-keyed inverse group with zero counts constrains nothing: it may exist in every what-if)
   const i32 hs = grp_hslot[g];
   if (hs >= 0) {      // hostname key: the rows are the snapshot's (ks_host_count0); what moves is the number of positive domains that are no existing node
     i32 ex = extra_tot[hs];
@@ -3008,7 +3008,7 @@ extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, con
   if (base->h.ND || base->h.pod_gid) return fail(KS_ERR_UNSUPPORTED, "what-ifs cannot be derived from a snapshot with volume limits");
   const bool with_topo = base->h.G != 0;
   if (with_topo && (!topo || !topo->node_cnt || !topo->node_dom || !topo->node_own || !topo->tot || !topo->extra_tot || !topo->grph_base)) return fail(KS_ERR_UNSUPPORTED, "the snapshot has topology groups: their per-node tables (ks_whatif_topo) are needed to derive what-ifs from it");
-  if (with_topo && base->h.G > 64) return fail(KS_ERR_UNSUPPORTED, "derived what-ifs: at most 64 topology groups");
+  if (with_topo && base->h.G > 1024) return fail(KS_ERR_UNSUPPORTED, "derived what-ifs: at most 1024 topology groups");
   if (with_topo) for (u32 g = base->h.n_topologies; g < base->h.G; ++g) if (base->src.grp_hslot[g] < 0) return fail(KS_ERR_UNSUPPORTED, "derived what-ifs: an inverse anti-affinity group on a key other than the hostname");
   const DevProb& bh = base->h; const u32 E = bh.E, M = bh.M, R = bh.R, K = bh.K, TW = bh.TW, C = bh.C, Pb = bh.P;
   HIPCHK(hipSetDevice(base->device));
@@ -3027,7 +3027,7 @@ extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, con
   const u32 G = bh.G, GH = bh.GH; const size_t GN = (size_t)G * n_nodes;
   size_t t_cnt_at = 0, t_dom_at = 0, t_own_at = 0, t_tot_at = 0, t_ext_at = 0, t_hbase_at = 0, t_row_at = 0, t_hg_at = 0, t_cand_at = 0, t_desc_at = 0;
   if (with_topo) {
-    t_cnt_at = take(0, GN * 4); t_dom_at = take(0, GN * 4); t_own_at = take(0, (size_t)n_nodes * 8); t_tot_at = take(0, (size_t)G * 64 * 4); t_ext_at = take(0, (size_t)GH * 4);
+    t_cnt_at = take(0, GN * 4); t_dom_at = take(0, GN * 4); t_own_at = take(0, (size_t)n_nodes * ((G + 63) / 64) * 8); t_tot_at = take(0, (size_t)G * 64 * 4); t_ext_at = take(0, (size_t)GH * 4);
     t_hbase_at = take(0, (size_t)GH * E * 4); t_row_at = take(0, (size_t)n_nodes * 4); t_hg_at = take(0, (size_t)GH * 4); t_cand_at = take(0, (size_t)cand_off[n] * 4); t_desc_at = take(0, (size_t)n * sizeof(TopoDesc));
   }
   const u32 rec_stride = ks_rec_stride(R, K);
@@ -3063,7 +3063,7 @@ extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, con
   DeriveDesc* hd = (DeriveDesc*)(b->stage + desc_at); DevProb* hp = (DevProb*)(b->stage + dprob_at); DevState* hsv = (DevState*)(b->stage + dstate_at);
   TopoDesc* htd = with_topo ? (TopoDesc*)(b->stage + t_desc_at) : nullptr;
   if (with_topo) {
-    memcpy(b->stage + t_cnt_at, topo->node_cnt, GN * 4); memcpy(b->stage + t_dom_at, topo->node_dom, GN * 4); memcpy(b->stage + t_own_at, topo->node_own, (size_t)n_nodes * 8);
+    memcpy(b->stage + t_cnt_at, topo->node_cnt, GN * 4); memcpy(b->stage + t_dom_at, topo->node_dom, GN * 4); memcpy(b->stage + t_own_at, topo->node_own, (size_t)n_nodes * ((G + 63) / 64) * 8);
     memcpy(b->stage + t_tot_at, topo->tot, (size_t)G * 64 * 4); if (GH) { memcpy(b->stage + t_ext_at, topo->extra_tot, (size_t)GH * 4); memcpy(b->stage + t_hbase_at, topo->grph_base, (size_t)GH * E * 4); }
     memcpy(b->stage + t_row_at, node_row, (size_t)n_nodes * 4); if (cand_off[n]) memcpy(b->stage + t_cand_at, cand, (size_t)cand_off[n] * 4);
     i32* hg = (i32*)(b->stage + t_hg_at); for (u32 g = 0; g < G; ++g) { const i32 hs = base->src.grp_hslot[g]; if (hs >= 0 && (u32)hs < GH) hg[hs] = (i32)g; }
@@ -3109,7 +3109,7 @@ extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, con
   if (sz[1]) HIPCHK(hipMemsetAsync(r1, 0, sz[1], b->stream));
   if (const char* pz = getenv("KS_POISON")) { if (sz[2]) HIPCHK(hipMemsetAsync(r2, (int)strtol(pz, nullptr, 0) & 0xFF, sz[2], b->stream)); }
   if (n) hipLaunchKernelGGL(ks_derive_whatifs, dim3(n), dim3(256), 0, b->stream, bh.queue, (const i32*)(r0 + pod_node_at), Pb, (const DeriveDesc*)(r0 + desc_at), (u32*)(r1 + mismatch_at));
-  if (n && with_topo) hipLaunchKernelGGL(ks_derive_topology, dim3(n), dim3(64), 0, b->stream, (const TopoDesc*)(r0 + t_desc_at), G, GH, n_nodes, (const i32*)(r0 + t_cnt_at), (const i32*)(r0 + t_dom_at),
+  if (n && with_topo) hipLaunchKernelGGL(ks_derive_topology, dim3(n), dim3(64 * ((G + 63) / 64)), 0, b->stream, (const TopoDesc*)(r0 + t_desc_at), G, GH, n_nodes, (const i32*)(r0 + t_cnt_at), (const i32*)(r0 + t_dom_at),
                                          (const u64*)(r0 + t_own_at), (const i32*)(r0 + t_tot_at), bh.grp_count, (const i32*)(r0 + t_ext_at), bh.grp_hslot, (const i32*)(r0 + t_row_at), bh.n_topologies);
   u32 mismatch = 0;
   HIPCHK(hipMemcpyAsync(&mismatch, r1 + mismatch_at, 4, hipMemcpyDeviceToHost, b->stream));

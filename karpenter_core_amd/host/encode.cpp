@@ -1339,7 +1339,8 @@ struct SnapshotBase {
 static std::string build_topo_tables(SnapshotBase& sb, const int32_t* pod_node) {
   const Builder& b = *sb.builder; const Encoded& E = *sb.enc; const ksp::Problem& pr = *sb.snapshot;
   const uint32_t G = E.prob.G, GH = E.prob.GH, NE = E.prob.E, NT = E.prob.n_topologies; const size_t NN = pr.nodes.size();
-  if (G > 64) return "more than 64 topology groups";
+  if (G > 1024) return "more than 1024 topology groups";
+  const uint32_t GW = (G + 63) / 64;
   if (b.shared_filter_differs) return "two pods share a spread group while their node filters differ: the group's filter is that of the first pod of each batch";
   auto grp = [&](uint32_t gi) -> const Group& { return *b.groups[b.group_order[gi]]; };
   // Inverse groups (required anti-affinity, topology.go:181-199,202-229) EXIST only while an owner is in the batch or stays bound outside it.  A hostname-keyed
@@ -1347,9 +1348,9 @@ static std::string build_topo_tables(SnapshotBase& sb, const int32_t* pod_node) 
   // a value-keyed one narrows the node's requirement to its registered domains by existing -- that depends on the candidate set: refused.
   for (uint32_t gi = NT; gi < G; ++gi) if (grp(gi).key != ksp::kHostname) return "required anti-affinity on a key other than the hostname (such an inverse group narrows requirements by merely existing, and it exists for some candidate sets only)";
   if (NT < G) for (auto& n : pr.nodes) { auto hl = n.labels.find(ksp::kHostname); if (hl != n.labels.end() && hl->second.empty()) return "a node with an empty hostname label under hostname-keyed anti-affinity"; }
-  sb.t_node_cnt.assign((size_t)G * NN, 0); sb.t_node_dom.assign((size_t)G * NN, -1); sb.t_node_own.assign(NN, 0); sb.t_tot.assign((size_t)G * 64, 0);
+  sb.t_node_cnt.assign((size_t)G * NN, 0); sb.t_node_dom.assign((size_t)G * NN, -1); sb.t_node_own.assign(NN * GW, 0); sb.t_tot.assign((size_t)G * 64, 0);
   sb.t_extra_tot.assign(GH, 0); sb.t_grph_base.assign((size_t)GH * NE, 0);
-  for (size_t i = 0; i < pr.pods.size(); ++i) for (int g : b.specs[b.pod_spec[i]].stages[0].sg.own) sb.t_node_own[pod_node[i]] |= 1ull << b.group_remap[g];
+  for (size_t i = 0; i < pr.pods.size(); ++i) for (int g : b.specs[b.pod_spec[i]].stages[0].sg.own) { const uint32_t gi = (uint32_t)b.group_remap[g]; sb.t_node_own[(size_t)pod_node[i] * GW + (gi >> 6)] |= 1ull << (gi & 63u); }
   // does group g count pods on node n at all (key present, node filter), and under which domain
   std::vector<uint8_t> counts_on((size_t)G * NN, 0); std::vector<int32_t> key_of(G, -1);
   for (uint32_t g = 0; g < G; ++g) if (grp(g).key != ksp::kHostname) key_of[g] = b.key_id.at(grp(g).key);
@@ -1365,7 +1366,7 @@ static std::string build_topo_tables(SnapshotBase& sb, const int32_t* pod_node) 
     }
   }
   std::map<std::string, size_t> node_index; for (size_t n = 0; n < NN; ++n) node_index.emplace(pr.nodes[n].name, n);
-  std::unordered_map<std::string, uint64_t> selects;      // (namespace, labels) -> groups that list such a pod (TopologyListOptions: a nil selector lists everything)
+  std::unordered_map<std::string, std::vector<uint32_t>> selects;      // (namespace, labels) -> groups that list such a pod (TopologyListOptions: a nil selector lists everything)
   auto count_one = [&](uint32_t g, size_t n, bool in_a_batch) -> const char* {
     if (!counts_on[g * NN + n]) return nullptr;
     const bool host = key_of[g] < 0;
@@ -1381,11 +1382,11 @@ static std::string build_topo_tables(SnapshotBase& sb, const int32_t* pod_node) 
     std::string sig = cp.ns; sig += '\3'; sig_map(sig, cp.labels);
     auto it = selects.find(sig);
     if (it == selects.end()) {
-      uint64_t m = 0;
-      for (uint32_t g = 0; g < NT; ++g) { const Group& gr = grp(g); if (gr.namespaces.count(cp.ns) && (gr.selector.nil || SelectorMatches(gr.selector, cp.labels))) m |= 1ull << g; }
-      it = selects.emplace(std::move(sig), m).first;
+      std::vector<uint32_t> m;
+      for (uint32_t g = 0; g < NT; ++g) { const Group& gr = grp(g); if (gr.namespaces.count(cp.ns) && (gr.selector.nil || SelectorMatches(gr.selector, cp.labels))) m.push_back(g); }
+      it = selects.emplace(std::move(sig), std::move(m)).first;
     }
-    for (uint64_t m = it->second; m; m &= m - 1) if (const char* why = count_one((uint32_t)__builtin_ctzll(m), n, pi >= 0)) return why;
+    for (uint32_t g : it->second) if (const char* why = count_one(g, n, pi >= 0)) return why;
     for (auto& t : cp.anti_required) {      // the inverse group its required anti-affinity owns while the pod stays bound (topology.go:181-199)
       auto gi = b.inverse_by_id.find(Builder::group_id(2, t.topology_key, Builder::ns_list(cp.ns, t.namespaces), t.selector, INT32_MAX, Filter{}));
       if (gi == b.inverse_by_id.end()) return "a cluster pod's required anti-affinity names a group none of the bound pods owns";

@@ -32,7 +32,7 @@ def test_ineligible_snapshots_are_refused_on_the_host():
     assert [f.dims["P"] for f in flats] == [len(bound[0]), len(bound[1]) + len(bound[2])]
 
 
-def _topology_snapshot(existing, sizes, seed, spare=-1, extras=True, kinds=None, anti=False):
+def _topology_snapshot(existing, sizes, seed, spare=-1, extras=True, kinds=None, anti=False, wide=False):
     """A cluster whose bound pods carry spread / affinity / preferred terms (no required anti-affinity), listed as cluster pods the way
     countDomains finds them -- plus pods that are in no batch (daemon-like, on candidate nodes too), one on a node nobody knows, and a node no
     provisioner owns."""
@@ -44,14 +44,14 @@ def _topology_snapshot(existing, sizes, seed, spare=-1, extras=True, kinds=None,
     for pods in bound:
         for p in pods:
             own, r = LabelSelector({"my-label": p.labels["my-label"]}), rs.rand()
-            if p.labels["my-label"] not in "abc":      # (the derived route holds a snapshot's groups in one 64-bit word: a handful of constrained workloads, many plain ones)
+            if p.labels["my-label"] not in "abc" and not wide:      # (a handful of constrained workloads, many plain ones: <= 64 groups, the kernels' fast variants; `wide`: every workload)
                 continue
             if kinds is not None and sum(r >= t for t in (0.22, 0.34, 0.42, 0.50, 0.56, 0.62, 0.68, 0.74)) not in kinds:      # (debugging: some kinds of terms only)
                 continue
             if r < 0.22:
-                p.spread = [TopologySpreadConstraint(1, LABEL_ZONE, DO_NOT_SCHEDULE, own)]
+                p.spread = [TopologySpreadConstraint(int(rs.randint(1, 4)) if wide else 1, LABEL_ZONE, DO_NOT_SCHEDULE, own)]
             elif r < 0.34:
-                p.spread = [TopologySpreadConstraint(4, LABEL_HOSTNAME, DO_NOT_SCHEDULE, own)]
+                p.spread = [TopologySpreadConstraint(int(rs.randint(2, 6)) if wide else 4, LABEL_HOSTNAME, DO_NOT_SCHEDULE, own)]
             elif r < 0.42:
                 p.spread = [TopologySpreadConstraint(1, LABEL_ZONE, SCHEDULE_ANYWAY, own), TopologySpreadConstraint(3, LABEL_HOSTNAME, DO_NOT_SCHEDULE, own)]
             elif r < 0.50:
@@ -126,6 +126,27 @@ def test_topology_snapshots_are_eligible(seed):
         with pytest.raises(S.KSolveError) as e:      # eligible: the refusal is the missing device, not the snapshot
             S.open_whatifs(parsed, pod_node, [[0]], derive=True)
         assert e.value.code == S.KS_ERR_DEVICE
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(3))
+def test_derived_whatifs_with_more_than_64_groups(seed):
+    """Every workload constrained: 80-130 groups per snapshot (node_own spans several words, the what-ifs take the kernels' general variants)."""
+    rs = np.random.RandomState(200 + seed)
+    its, prov, nodes, bound, snap, pod_node = _topology_snapshot(int(rs.randint(60, 120)), int(rs.randint(4, 8)), 250 + seed, spare=int(rs.choice([-1, 3])), anti=seed == 2, wide=True)
+    sets = [[int(x) for x in rs.choice(len(nodes), size=int(rs.choice([1, 2, 4, 9])), replace=False)] for _ in range(16)]
+    parsed = S.ParsedProblem(snap)
+    derived = S.open_whatifs(parsed, pod_node, sets, derive=True)
+    flat = S.open_whatifs(parsed, pod_node, sets, derive=False)
+    try:
+        assert S.FlatProblem(snap).dims["G"] > 64
+        got, _, _ = S.solve_batch(derived)
+        want, _, _ = S.solve_batch(flat)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a.canonical() == b.canonical() and a.reasons == b.reasons, (seed, i, sets[i])
+    finally:
+        for f in derived + flat:
+            f.close()
 
 
 @pytest.mark.gpu
