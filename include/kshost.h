@@ -115,11 +115,10 @@ int ksh_types_subset(void** handles, uint32_t n, const uint32_t* node, const uin
 /* What-ifs DERIVED on the device from the resident snapshot (ksolve.h ks_whatifs_open; SURVEY 8b `ks_solve_batch(shared, whatif deltas, ...)`): no
  * per-what-if flattening on the host, an upload of KBs (candidate masks, remainingResources, descriptors); the handles come back already resident on
  * `device`.  Results read exactly like those of ksh_open_whatifs_parsed.  Bound pods may carry spread / affinity / preferred terms: which groups a
- * what-if starts with and what countDomains finds for it follow from per-node tables of the snapshot (ks_whatif_topo).  Required anti-affinity per HOSTNAME is covered as well
- * (a hostname-keyed inverse group without counts constrains nothing, so the snapshot's serves every what-if; the staying owners are counted per node).
- * KS_ERR_UNSUPPORTED -- nothing opened -- where a what-if depends on its candidate set in other ways: required anti-affinity on another key (such an inverse
- * group narrows requirements by merely existing), more than 1024 groups, one spread group shared by pods whose node filters differ, volume limits / claims.
- * Use ksh_open_whatifs_parsed then. */
+ * what-if starts with and what countDomains finds for it follow from per-node tables of the snapshot (ks_whatif_topo).  Required anti-affinity is covered as well: an inverse group
+ * exists only while an owner is in the batch or stays bound (decided per what-if on the device; the evaluation skips a group that does not exist), and the
+ * staying owners are counted per node.  KS_ERR_UNSUPPORTED -- nothing opened -- where a what-if depends on its candidate set in other ways: more than 1024
+ * groups, one spread group shared by pods whose node filters differ, volume limits / claims.  Use ksh_open_whatifs_parsed then. */
 int ksh_open_whatifs_derived(void* parsed_snapshot, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand, const int32_t* pod_node, int device, void** out_handles);
 int ksh_open_whatifs_parsed(void* parsed_snapshot, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand, const int32_t* pod_node, uint32_t nthreads, void** out_handles);
 

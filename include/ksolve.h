@@ -252,10 +252,10 @@ int ks_problem_upload_shared(const ks_problem* p, const ks_dev_problem* base, ks
  * descriptors) and builds every batch on the device (the snapshot's queue order restricted to the candidates' pods).  ks_whatifs_problems are
  * ordinary device problems (views owned by the batch) for ks_solve_batch_dev / ks_batch_records_dev / ks_price_filter_dev / ...; in their
  * results pod i is the i-th pod of the what-if in the SNAPSHOT's queue order (ks_whatifs_pod_ids names the snapshot pod behind each) and
- * existing node e is the snapshot's row e (removed nodes receive nothing).  Not for snapshots with volume limits, inverse anti-affinity groups on a key
- * other than the hostname, or more than 1024 topology groups (KS_ERR_UNSUPPORTED: the caller flattens those what-ifs one by one). */
+ * existing node e is the snapshot's row e (removed nodes receive nothing).  Not for snapshots with volume limits or more than 1024 topology groups
+ * (KS_ERR_UNSUPPORTED: the caller flattens those what-ifs one by one). */
 typedef struct ks_whatif_batch ks_whatif_batch;
-/* Snapshots whose bound pods carry spread / affinity / anti-affinity terms (base G > 0, G <= 1024; inverse groups hostname-keyed): what a what-if's topology takes from its
+/* Snapshots whose bound pods carry spread / affinity / anti-affinity terms (base G > 0, G <= 1024): what a what-if's topology takes from its
  * candidate set is derived on the device too -- which groups exist from the start (owned by a pod of the batch: topology.go:72-78) and countDomains over
  * the cluster pods that stay (topology.go:231-276) -- from per-node tables of the snapshot: */
 typedef struct ks_whatif_topo {

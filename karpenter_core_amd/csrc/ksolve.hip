@@ -817,9 +817,11 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
       const KReq before = a;
       const KReq nd = before.present ? before : kreq_exists();
       const u64 ND = kreq_has_mask(nd, vi, nv);
-      u64 dom = ~0ull;
+      u64 dom = ~0ull; bool constrained = false;
       for (u32 j = t.topo_begin; j < t.topo_end; ++j) {
         const PlanTopo& tg = c.topo[j]; const TopoDyn& d = sh.dyn[j]; u64 options = 0;
+        if (d.reg == 0 && d.pos == ~0ull) continue;               // (derived what-if) an inverse anti-affinity group none of whose owners is around: it does not exist
+        constrained = true;
         struct { u64 PD; i32 g, maxskew; u32 type, self, pod_has; } tt;
         { const u32 f = UF(*(const u32*)&tg.type); tt.type = f & 0xFF; tt.self = (f >> 8) & 0xFF; tt.pod_has = (f >> 16) & 0xFF; tt.g = (i32)UF(tg.g); tt.maxskew = (i32)UF(tg.maxskew); tt.PD = tg.PD; }
         if (tt.type == 0) {                                       // spread: nextDomainTopologySpread :155-182
@@ -847,10 +849,12 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
       }
       // nodeRequirements.Compatible(topologyRequirements) on this key: the topology requirement is
       // node ∩ In[dom]; see DESIGN.md "topology compatibility" for the reduction used here.
+      if (constrained) {
       const KReq in = kreq_in(dom);
       if (!before.present) { if (!((tb.wellknown >> k) & 1u)) { ev.rc = -KS_WHY_TOPOLOGY_REQS; return; } a = in; }
       else { const KReq mg = kreq_intersect(in, before, vi, nv); if (kreq_len0(mg) && !kreq_nidne(before)) { ev.rc = -KS_WHY_TOPOLOGY_REQS; return; } a = mg; }
       if (kreq_differs(a, before)) ev.tnar |= 1u << i;
+      }
     }
     if (a.present) ev.tpres |= 1u << i;
     if (a.complement) ev.tcomp |= 1u << i;
@@ -1244,6 +1248,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     for (u32 i = lane; i < P.G * 64; i += 64) sm_gcnt[i] = P.grp_count[i];
     for (u32 g = lane; g < P.G; g += 64) {
       u64 reg = 0, pos = 0; for (int d = 0; d < 64; ++d) { const i32 c = P.grp_count[(size_t)g * 64 + d]; if (c >= 0) reg |= 1ull << d; if (c > 0) pos |= 1ull << d; }
+      if (P.grp_count[(size_t)g * 64] == INT32_MIN) { reg = 0; pos = ~0ull; }      // (ks_derive_topology) the group does not exist in this what-if: eval_node skips it
       sm_g_reg[g] = reg; sm_g_pos[g] = pos; sm_g_active[g] = P.grp_active[g];
     }
     for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h], nz = 0; for (u32 e = 0; e < tb.E; ++e) { const i32 c = ks_host_count0(P, h, e); if (c > 0) ++np; if (c == 0) ++nz; } sm_g_hpos[h] = np; sm_g_hzero[h] = nz; }
@@ -1257,6 +1262,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     for (u32 i = lane; i < P.G * 64; i += 64) S.gcnt[i] = P.grp_count[i];
     for (u32 g = lane; g < P.G; g += 64) {
       u64 reg = 0, pos = 0; for (int d = 0; d < 64; ++d) { const i32 c = P.grp_count[(size_t)g * 64 + d]; if (c >= 0) reg |= 1ull << d; if (c > 0) pos |= 1ull << d; }
+      if (P.grp_count[(size_t)g * 64] == INT32_MIN) { reg = 0; pos = ~0ull; }
       S.g_reg[g] = reg; S.g_pos[g] = pos; S.g_active[g] = P.grp_active[g];
     }
     for (u32 h = lane; h < tb.GH; h += 64) { i32 np = P.grph_extra_pos[h], nz = 0; for (u32 e = 0; e < tb.E; ++e) { const i32 c = ks_host_count0(P, h, e); if (c > 0) ++np; if (c == 0) ++nz; } S.g_hpos[h] = np; S.g_hzero[h] = nz; }
@@ -2977,7 +2983,9 @@ __global__ __launch_bounds__(1024) void ks_derive_topology(const TopoDesc* descs
   i32 c[64];
   for (u32 v = 0; v < 64; ++v) c[v] = tot[(size_t)g * 64 + v];
   for (u32 i = 0; i < d.ncand; ++i) { const u32 nd = d.cand[i]; const i32 dm = node_dom[(size_t)g * n_nodes + nd]; if (dm >= 0) c[dm] -= node_cnt[(size_t)g * n_nodes + nd]; }
-  for (u32 v = 0; v < 64; ++v) { const i32 r = reg[(size_t)g * 64 + v]; d.count[(size_t)g * 64 + v] = (r >= 0 || c[v] > 0) ? (r > 0 ? r : 0) + c[v] : -1; }
+  bool owners = (own >> (g & 63u)) & 1ull;      // an inverse group exists while an owner is in the batch, stays bound outside it, or is in no batch at all (topology.go:181-229)
+  for (u32 v = 0; v < 64; ++v) { const i32 r = reg[(size_t)g * 64 + v]; const i32 x = (r >= 0 || c[v] > 0) ? (r > 0 ? r : 0) + c[v] : -1; d.count[(size_t)g * 64 + v] = x; if (x > 0) owners = true; }
+  if (g >= n_topologies && !owners) d.count[(size_t)g * 64] = INT32_MIN;      // it does not exist in this what-if: the pack kernel's evaluation skips it (see its init)
 }
 
 struct ks_whatif_batch {
@@ -3007,9 +3015,8 @@ extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, con
   if (!base->tables_built) return fail(KS_ERR_INVALID, "the snapshot must be resident with its tables built (ks_problem_prepare)");
   if (base->h.ND || base->h.pod_gid) return fail(KS_ERR_UNSUPPORTED, "what-ifs cannot be derived from a snapshot with volume limits");
   const bool with_topo = base->h.G != 0;
-  if (with_topo && (!topo || !topo->node_cnt || !topo->node_dom || !topo->node_own || !topo->tot || !topo->extra_tot || !topo->grph_base)) return fail(KS_ERR_UNSUPPORTED, "the snapshot has topology groups: their per-node tables (ks_whatif_topo) are needed to derive what-ifs from it");
+  if (with_topo && (!topo || !topo->node_cnt || !topo->node_dom || !topo->node_own || !topo->tot || (base->h.GH && (!topo->extra_tot || (base->h.E && !topo->grph_base))))) return fail(KS_ERR_UNSUPPORTED, "the snapshot has topology groups: their per-node tables (ks_whatif_topo) are needed to derive what-ifs from it");
   if (with_topo && base->h.G > 1024) return fail(KS_ERR_UNSUPPORTED, "derived what-ifs: at most 1024 topology groups");
-  if (with_topo) for (u32 g = base->h.n_topologies; g < base->h.G; ++g) if (base->src.grp_hslot[g] < 0) return fail(KS_ERR_UNSUPPORTED, "derived what-ifs: an inverse anti-affinity group on a key other than the hostname");
   const DevProb& bh = base->h; const u32 E = bh.E, M = bh.M, R = bh.R, K = bh.K, TW = bh.TW, C = bh.C, Pb = bh.P;
   HIPCHK(hipSetDevice(base->device));
   auto b = new ks_whatif_batch(); b->device = base->device; b->n = n;
@@ -3064,7 +3071,7 @@ extern "C" int ks_whatifs_open(const ks_dev_problem* base, uint32_t n_nodes, con
   TopoDesc* htd = with_topo ? (TopoDesc*)(b->stage + t_desc_at) : nullptr;
   if (with_topo) {
     memcpy(b->stage + t_cnt_at, topo->node_cnt, GN * 4); memcpy(b->stage + t_dom_at, topo->node_dom, GN * 4); memcpy(b->stage + t_own_at, topo->node_own, (size_t)n_nodes * ((G + 63) / 64) * 8);
-    memcpy(b->stage + t_tot_at, topo->tot, (size_t)G * 64 * 4); if (GH) { memcpy(b->stage + t_ext_at, topo->extra_tot, (size_t)GH * 4); memcpy(b->stage + t_hbase_at, topo->grph_base, (size_t)GH * E * 4); }
+    memcpy(b->stage + t_tot_at, topo->tot, (size_t)G * 64 * 4); if (GH) { memcpy(b->stage + t_ext_at, topo->extra_tot, (size_t)GH * 4); if (E) memcpy(b->stage + t_hbase_at, topo->grph_base, (size_t)GH * E * 4); }
     memcpy(b->stage + t_row_at, node_row, (size_t)n_nodes * 4); if (cand_off[n]) memcpy(b->stage + t_cand_at, cand, (size_t)cand_off[n] * 4);
     i32* hg = (i32*)(b->stage + t_hg_at); for (u32 g = 0; g < G; ++g) { const i32 hs = base->src.grp_hslot[g]; if (hs >= 0 && (u32)hs < GH) hg[hs] = (i32)g; }
   }

@@ -1345,12 +1345,15 @@ static std::string build_topo_tables(SnapshotBase& sb, const int32_t* pod_node) 
   auto grp = [&](uint32_t gi) -> const Group& { return *b.groups[b.group_order[gi]]; };
   // Inverse groups (required anti-affinity, topology.go:181-199,202-229) EXIST only while an owner is in the batch or stays bound outside it.  A hostname-keyed
   // one whose counts are all zero constrains nothing (every hostname is registered with 0, nothing is narrowed), so it may simply exist in every what-if;
-  // a value-keyed one narrows the node's requirement to its registered domains by existing -- that depends on the candidate set: refused.
-  for (uint32_t gi = NT; gi < G; ++gi) if (grp(gi).key != ksp::kHostname) return "required anti-affinity on a key other than the hostname (such an inverse group narrows requirements by merely existing, and it exists for some candidate sets only)";
+  // a value-keyed one narrows the node's requirement to its registered domains by existing: ks_derive_topology decides per what-if whether it does
+  // (an owner in the batch: node_own; an owner that stays: the counts) and the evaluation skips a group that does not.
   if (NT < G) for (auto& n : pr.nodes) { auto hl = n.labels.find(ksp::kHostname); if (hl != n.labels.end() && hl->second.empty()) return "a node with an empty hostname label under hostname-keyed anti-affinity"; }
   sb.t_node_cnt.assign((size_t)G * NN, 0); sb.t_node_dom.assign((size_t)G * NN, -1); sb.t_node_own.assign(NN * GW, 0); sb.t_tot.assign((size_t)G * 64, 0);
   sb.t_extra_tot.assign(GH, 0); sb.t_grph_base.assign((size_t)GH * NE, 0);
-  for (size_t i = 0; i < pr.pods.size(); ++i) for (int g : b.specs[b.pod_spec[i]].stages[0].sg.own) { const uint32_t gi = (uint32_t)b.group_remap[g]; sb.t_node_own[(size_t)pod_node[i] * GW + (gi >> 6)] |= 1ull << (gi & 63u); }
+  for (size_t i = 0; i < pr.pods.size(); ++i) {
+    const auto& sg = b.specs[b.pod_spec[i]].stages[0].sg;      // (required anti-affinity terms survive every relaxation: the first stage owns what all stages own)
+    for (const auto* l : {&sg.own, &sg.iown}) for (int g : *l) { const uint32_t gi = (uint32_t)b.group_remap[g]; sb.t_node_own[(size_t)pod_node[i] * GW + (gi >> 6)] |= 1ull << (gi & 63u); }
+  }
   // does group g count pods on node n at all (key present, node filter), and under which domain
   std::vector<uint8_t> counts_on((size_t)G * NN, 0); std::vector<int32_t> key_of(G, -1);
   for (uint32_t g = 0; g < G; ++g) if (grp(g).key != ksp::kHostname) key_of[g] = b.key_id.at(grp(g).key);

@@ -17,17 +17,18 @@ def _snapshot(existing, sizes, seed, spare=-1, limits=None):
 
 
 def test_ineligible_snapshots_are_refused_on_the_host():
-    """(CPU) bound pods with REQUIRED anti-affinity on a key other than the hostname: such an inverse group narrows requirements by merely existing, and it
-    exists for some candidate sets only -- refused before anything touches a device."""
-    from karpenter_core_amd.model import PodAffinityTerm
+    """(CPU) volume limits: the partition of the claims into shared and private ones depends on the candidate set -- refused before anything touches a device."""
+    from karpenter_core_amd.model import Volume
     its, prov, nodes, bound = _snapshot(24, 5, 8)
-    for pods in bound:
+    for i, pods in enumerate(bound):
         for p in pods[:1]:
-            p.anti_required = [PodAffinityTerm(LABEL_ZONE, LabelSelector({"my-label": "nobody"}))]
+            p.volumes = [Volume("ebs.csi", f"default/claim-{i}")]
+        nodes[i].volumes = [v for p in pods for v in p.volumes]
+        nodes[i].volume_limits = {"ebs.csi": 5}
     snap, pod_node = W.snapshot_problem(its, prov, nodes, bound, True)
     with pytest.raises(S.KSolveError) as e:
         S.open_whatifs(S.ParsedProblem(snap), pod_node, [[0], [1, 2]], derive=True)
-    assert e.value.code == S.KS_ERR_UNSUPPORTED and "anti-affinity" in str(e.value)
+    assert e.value.code == S.KS_ERR_UNSUPPORTED and "volume" in str(e.value)
     flats = S.open_whatifs(S.ParsedProblem(snap), pod_node, [[0], [1, 2]])          # derive=None: flattened on the host instead
     assert [f.dims["P"] for f in flats] == [len(bound[0]), len(bound[1]) + len(bound[2])]
 
@@ -72,6 +73,9 @@ def _topology_snapshot(existing, sizes, seed, spare=-1, extras=True, kinds=None,
             elif r < 0.86 and anti:      # required anti-affinity per hostname: against a workload of its own label ("z-*", at most one per node), or against another
                 p.labels = {"my-label": "z-" + p.labels["my-label"]}
                 p.anti_required = [PodAffinityTerm(LABEL_HOSTNAME, LabelSelector({"my-label": p.labels["my-label"] if rs.rand() < 0.7 else "abc"[int(rs.randint(3))]}))]
+            elif r < 0.90 and anti:      # ... and per ZONE against another workload: its inverse group narrows a node's zones by merely existing, and exists only while an owner is around
+                p.labels = {"my-label": "y-" + p.labels["my-label"]}
+                p.anti_required = [PodAffinityTerm(LABEL_ZONE, LabelSelector({"my-label": "def"[int(rs.randint(3))]}))]
     if extras:
         nodes.append(StateNode(name="unowned", labels={LABEL_ZONE: zones[0], LABEL_HOSTNAME: "unowned"}))
         bound.append([dataclasses_replace_uid(p, f"extra-{i}") for i, p in enumerate(bound[0][:6])])
@@ -129,6 +133,41 @@ def test_topology_snapshots_are_eligible(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("listed", [False, True])
+def test_an_inverse_group_exists_only_while_an_owner_is_around(listed):
+    """One bound pod refuses the company of workload X in its ZONE.  Where its node stays and the cluster lists it (`listed`), its inverse group exists and
+    keeps X's pods out of that zone; where nobody lists it, the group exists only in the what-ifs that move the pod itself -- in the others X's pods open
+    nodes whose zone requirement nothing narrows (a group that merely existed would narrow it to the registered zones, topologygroup.go:235-243)."""
+    from karpenter_core_amd.model import PodAffinityTerm
+    its, prov, nodes, bound = _snapshot(48, 6, 21, spare=0)      # full by pod count: whoever moves opens a node
+    a = next(i for i, pods in enumerate(bound) if pods)
+    owner = bound[a][0]
+    b = next(i for i, pods in enumerate(bound) if i != a and pods and nodes[i].labels[LABEL_ZONE] == nodes[a].labels[LABEL_ZONE])
+    x = bound[b][0].labels["my-label"]
+    owner.labels = {"my-label": "loner"}
+    owner.anti_required = [PodAffinityTerm(LABEL_ZONE, LabelSelector({"my-label": x}))]
+    snap, pod_node = W.snapshot_problem(its, prov, nodes, bound, listed)
+    sets = [[b], [a], [a, b], [b, (b + 1) % len(nodes)], [i for i in range(len(nodes)) if i != a][:12]]
+    parsed = S.ParsedProblem(snap)
+    derived = S.open_whatifs(parsed, pod_node, sets, derive=True)
+    flat = S.open_whatifs(parsed, pod_node, sets, derive=False)
+    try:
+        got, _, _ = S.solve_batch(derived)
+        want, _, _ = S.solve_batch(flat)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g.canonical() == w.canonical() and g.reasons == w.reasons, (listed, i, sets[i])
+        assert want[0].new_nodes, "the moved pods were meant to open nodes"
+        zones = [n.requirements.get(LABEL_ZONE) for n in got[0].new_nodes]      # what-if 0 moves X's pods while the owner stays
+        if listed:
+            assert all(z is not None and nodes[a].labels[LABEL_ZONE] not in z.values for z in zones)      # the owner's zone is closed to them
+        else:
+            assert all(z is None for z in zones)                                                            # no such group: nothing narrows the zone
+    finally:
+        for f in derived + flat:
+            f.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(3))
 def test_derived_whatifs_with_more_than_64_groups(seed):
     """Every workload constrained: 80-130 groups per snapshot (node_own spans several words, the what-ifs take the kernels' general variants)."""
@@ -152,9 +191,10 @@ def test_derived_whatifs_with_more_than_64_groups(seed):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(6))
 def test_derived_whatifs_with_hostname_anti_affinity(seed):
-    """... and REQUIRED anti-affinity per hostname among the bound pods (the usual "one replica per node"): its inverse group exists only while an owner
-    is in the batch or stays bound, but a hostname-keyed inverse group without counts constrains nothing, so the snapshot's serves every what-if.  The
-    staying owners' counts come from the per-node tables like any other count."""
+    """... and REQUIRED anti-affinity among the bound pods -- per hostname (the usual "one replica per node") and, rarer, per zone.  An inverse group exists
+    only while an owner is in the batch or stays bound.  A hostname-keyed one without counts constrains nothing, so the snapshot's serves every what-if;
+    a zone-keyed one narrows a node's zones by merely existing: the device decides per what-if whether it does, and the evaluation skips one that does
+    not.  The staying owners' counts come from the per-node tables like any other count."""
     from oracle import oracle_py as O
     rs = np.random.RandomState(100 + seed)
     its, prov, nodes, bound, snap, pod_node = _topology_snapshot(int(rs.randint(24, 100)), int(rs.randint(4, 8)), 150 + seed, spare=int(rs.choice([-1, 0, 3])), extras=seed != 0, anti=True)
