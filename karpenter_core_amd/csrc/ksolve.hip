@@ -489,7 +489,13 @@ __global__ __launch_bounds__(64) void ks_build_plans(const DevProb* probs) {
   // Rejections by an EXISTING node are monotone for a class that consults no topology group and whose own requirements are all on
   // well-known keys: taints are static, host ports / volumes / requests only accumulate, requirement sets only narrow.  (A custom
   // label the node does not define is the exception -- "label does not have known values" until another pod's NotIn defines it.)
-  pl.mono = (!pl.overflow && pl.ntopo == 0 && pl.nhost == 0 && (pl.present & ~P.wellknown_mask) == 0) ? 1u : 0u;
+  // Anti-affinity items (own or inverse) keep it monotone: they need a count of 0, counts only grow within a Solve, and every domain such a group will ever
+  // know of an existing node is registered before the first pod (topology.go:56-84, existingnode.go:73).  Spread (the minimum moves) and affinity (a domain
+  // becomes eligible once it counts) do not.
+  bool only_anti = true;
+  for (u32 j = 0; j < pl.ntopo; ++j) if (pl.topo[j].type != 2) only_anti = false;
+  for (u32 j = 0; j < pl.nhost; ++j) if (pl.host[j].type != 2) only_anti = false;
+  pl.mono = (!pl.overflow && only_anti && (pl.present & ~P.wellknown_mask) == 0) ? 1u : 0u;
   pl.dyn = 0;
   if (!pl.overflow && pl.ntopo == 1 && pl.nhost == 0 && pl.topo[0].type == 0 && !pl.topo[0].pod_has && pl.topo[0].g < 64 && ((P.dyn_groups >> pl.topo[0].g) & 1ull) &&
       pl.topo[0].maxskew >= 0 && pl.topo[0].maxskew < (1 << 24) /* RoundCtl::dynq packs it into 24 bits */) pl.dyn = 1u | ((u32)pl.topo[0].g << 8) | ((u32)pl.topo[0].self << 16);
