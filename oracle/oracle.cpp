@@ -997,6 +997,62 @@ struct Scheduler {
   }
 
   // ------------------------------------------------------------------------------------------------
+  // Model check of the kernel's WATERMARK over the existing nodes (ksolve.hip ClsPlan::mono, tests only).  The kernel starts a pod's scan where the last
+  // pod of its class stopped, on the claim that an existing node which refused the class once refuses it for the rest of the Solve -- for classes whose
+  // own requirements are on well-known keys and whose topology items, if any, are all anti-affinity (own or inverse).  Here every pod of such a class is
+  // dry-run against EVERY existing node right before the sequential algorithm places it: a node on record as having refused the class must refuse again.
+  //   out[0] violations (must be 0), out[1] dry runs compared, out[2] pods of watermark classes, out[3] of them with anti-affinity items
+  //   mutate: also treat classes with spread / affinity items as watermark classes (the claim is false for them: the check must be able to tell)
+  // ------------------------------------------------------------------------------------------------
+  void solve_watermark_check(long long* out, bool mutate) {
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    std::vector<int> q(pods.size()); for (size_t i = 0; i < pods.size(); ++i) q[i] = (int)i;
+    std::vector<ResList> rq(pods.size()); for (size_t i = 0; i < pods.size(); ++i) rq[i] = requests_for_pods({&pods[i].spec});
+    auto get = [](const ResList& r, const char* k) { auto it = r.find(k); return it == r.end() ? (int64_t)0 : it->second; };
+    std::sort(q.begin(), q.end(), [&](int a, int b) {
+      int64_t ca = get(rq[a], "cpu"), cb = get(rq[b], "cpu"); if (ca != cb) return ca > cb;
+      int64_t ma = get(rq[a], "memory"), mb = get(rq[b], "memory"); if (ma != mb) return ma > mb;
+      if (pods[a].spec.creation_ts != pods[b].spec.creation_ts) return pods[a].spec.creation_ts < pods[b].spec.creation_ts;
+      return pods[a].spec.uid < pods[b].spec.uid;
+    });
+    std::deque<int> queue(q.begin(), q.end());
+    std::unordered_map<int, size_t> lastLen;
+    std::map<std::string, std::vector<uint8_t>> refused;      // class signature -> per existing node: refused it before
+    for (;;) {
+      if (queue.empty()) break;
+      int pi = queue.front();
+      auto ll = lastLen.find(pi);
+      if (ll != lastLen.end() && ll->second == queue.size()) break;
+      queue.pop_front(); st.queue_pops++;
+      PodState& ps = pods[pi];
+      {
+        bool eligible = true, anti = false;
+        Reqs pr = new_pod_requirements(ps.spec);
+        for (auto& kv : pr.m) if (!cx.well_known.count(kv.first)) eligible = false;
+        for (auto& tc : topo.topologies) if (tc->owners.count(ps.spec.uid)) { if (tc->type == kAntiAffinity) anti = true; else if (!mutate) eligible = false; }
+        for (auto& tc : topo.inverse) if (tg_selects(*tc, ps.spec)) anti = true;
+        if (eligible && !existing.empty()) {
+          out[2]++; if (anti) out[3]++;
+          auto& rf = refused[eval_signature(ps)]; rf.resize(existing.size(), 0);
+          Stats keep = st;
+          for (size_t i = 0; i < existing.size(); ++i) {
+            const bool ok = dry_existing(*existing[i], ps); out[1]++;
+            if (ok && rf[i]) { out[0]++; if (out[0] <= 5) fprintf(stderr, "watermark rule violated: pod %d accepted by existing node %zu that refused its class before\n", pi, i); }
+            if (!ok) rf[i] = 1;
+          }
+          st = keep;
+        }
+      }
+      if (add(ps)) continue;
+      bool relaxed = relax(ps.spec);
+      queue.push_back(pi);
+      if (relaxed) { lastLen.clear(); ps.stage++; st.relaxations++; topo.update(ps.spec); } else lastLen[pi] = queue.size();
+    }
+    unscheduled.assign(queue.begin(), queue.end());
+    for (auto& n : new_nodes) n->requirements.m.erase(hostnameKey);
+  }
+
+  // ------------------------------------------------------------------------------------------------
   // Model check of the round resolver as the kernel runs it since round 2 (ksolve.hip "P2: the leader resolves the round"): candidates that
   // already took pods of the round stay in play (exact resources with what the round put on them, hostname-keyed items followed through the
   // round's certain records: exact reject / slack), runs of equivalent pods (SWEEP / CLIMB), zonal spread followed exactly on pinned nodes
@@ -1383,7 +1439,8 @@ int ko_solve_spec2(const char* ksp_text, size_t len, int W, int flags, int maxcl
   try {
     ksp::Problem pr = ksp::Parser(ksp_text, len).parse();
     auto s = oracle::build(pr, false);
-    if (flags & 2) s->solve_spec_v2(W, counters, flags, maxcls); else s->solve_spec(W, counters, flags, maxcls);
+    if (flags & 8) s->solve_watermark_check(counters, (flags & 16) != 0);
+    else if (flags & 2) s->solve_spec_v2(W, counters, flags, maxcls); else s->solve_spec(W, counters, flags, maxcls);
     std::string r = oracle::result_text(*s, 0.0);
     *out_text = strdup(r.c_str()); oracle::g_in = nullptr; return 0;
   } catch (const std::exception& e) { *out_text = strdup(e.what()); oracle::g_in = nullptr; return -1; }

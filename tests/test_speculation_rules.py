@@ -85,3 +85,35 @@ def test_the_model_catches_a_missing_rdyn_rule():
     out the model reports it on the CPU."""
     assert _check_v2(_mid(0), flags=V2 | 4)["violations"] > 0
     assert _check_v2(_mid(0))["violations"] == 0
+
+
+# ---------------- the watermark over the existing nodes (ksolve.hip ClsPlan::mono) ----------------
+def _topology_whatif(seed, cand, spare=-1):
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_whatif_derived import _topology_snapshot, _whatif_problem
+    its, prov, nodes, bound, snap, pod_node = _topology_snapshot(40, 6, seed, spare=spare, anti=True)
+    return _whatif_problem(snap, pod_node, cand)
+
+
+@pytest.mark.parametrize("maker", [lambda s=s: _topology_whatif(s, list(range(0, 14))) for s in range(8)] +          # roomy clusters: anti-affinity per hostname and per zone,
+                                  [lambda s=s: _topology_whatif(s, [1, 4, 7, 9, 20, 21, 22, 30], spare=2) for s in (3, 5)] +      # spreads, affinities; clusters full by pod count
+                                  [lambda: W.whatif(*W.cluster_snapshot(existing=48, sizes=6, seed=5), list(range(0, 9)))])
+def test_existing_nodes_that_refused_a_watermark_class_keep_refusing(maker):
+    """The kernel starts a pod's scan of the existing nodes where the last pod of its class stopped.  Since round 3 that includes
+    classes whose only topology items are anti-affinity ones: a count of 0 is needed and counts only grow.  The CPU model dry-runs every such pod
+    against EVERY existing node just before it is placed: a node on record as having refused the class must refuse again."""
+    pr = maker()
+    res, ctr = O.watermark_check(pr)
+    assert res.canonical() == O.solve(pr).canonical()
+    assert ctr["violations"] == 0, ctr
+    assert ctr["watermark_pods"] > 0 and ctr["dry_runs"] > 0
+
+
+def test_the_watermark_model_covers_anti_affinity_and_rejects_spread():
+    """... the anti-affinity classes are really among the checked ones, and the check can tell: with spread / affinity classes ALSO treated as
+    watermark classes (a mutation) it reports nodes that refused a class and accept it later (the minimum moved, a domain began to count)."""
+    checked = [O.watermark_check(_topology_whatif(s, list(range(0, 14))))[1] for s in (0, 3)]
+    assert all(c["violations"] == 0 for c in checked) and all(c["with_anti_affinity"] > 0 for c in checked)
+    assert O.watermark_check(_topology_whatif(0, list(range(0, 14))), mutate=True)[1]["violations"] > 0
