@@ -121,6 +121,10 @@ int ksh_types_subset(void** handles, uint32_t n, const uint32_t* node, const uin
  * groups, one spread group shared by pods whose node filters differ, volume limits / claims.  Use ksh_open_whatifs_parsed then. */
 int ksh_open_whatifs_derived(void* parsed_snapshot, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand, const int32_t* pod_node, int device, void** out_handles);
 int ksh_open_whatifs_parsed(void* parsed_snapshot, uint32_t flags, uint32_t n, const uint32_t* cand_off, const uint32_t* cand, const int32_t* pod_node, uint32_t nthreads, void** out_handles);
+/* Diagnostic (no GPU needed, not on any solving path): what the device would derive for ONE candidate set -- group activity, domain counts, hostname rows --
+ * restated in plain loops over the per-node tables and compared with that what-if flattened by itself.  KS_OK, or KS_ERR_INVALID with the first difference
+ * in ksh_last_error(); KS_ERR_UNSUPPORTED for a snapshot ksh_open_whatifs_derived refuses. */
+int ksh_check_whatif_derivation(void* parsed_snapshot, uint32_t flags, const uint32_t* cand, uint32_t ncand, const int32_t* pod_node);
 
 #ifdef __cplusplus
 }

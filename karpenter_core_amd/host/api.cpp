@@ -326,6 +326,21 @@ int ksh_open_whatifs_derived(void* parsed, uint32_t flags, uint32_t n, const uin
   } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
 }
 
+// CPU self-check of what ksh_open_whatifs_derived would derive on the device for ONE candidate set (kshost.h).
+int ksh_check_whatif_derivation(void* parsed, uint32_t flags, const uint32_t* cand, uint32_t ncand, const int32_t* pod_node) {
+  try {
+    Parsed* P = (Parsed*)parsed; std::shared_ptr<const ksp::Problem> snapshot = P->pr;
+    std::shared_ptr<const ksh::SnapshotBase> sb;
+    { std::lock_guard<std::mutex> g(P->mu);
+      const size_t np = snapshot->pods.size();
+      if (P->sb && P->sb_flags == flags && P->sb_pod_node.size() == np && std::equal(pod_node, pod_node + np, P->sb_pod_node.begin())) sb = P->sb;
+      else { sb = ksh::make_snapshot_base(snapshot, pod_node, flags); P->sb = sb; P->sb_flags = flags; P->sb_pod_node.assign(pod_node, pod_node + np); } }
+    const std::string why = ksh::check_derived_topology(*sb, cand, ncand, flags);
+    return why.empty() ? KS_OK : set_err(why.rfind("not derivable", 0) == 0 ? KS_ERR_UNSUPPORTED : KS_ERR_INVALID, why);
+  } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());
+  } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
+}
+
 // Upload the flat problem to HBM (idempotent).
 int ksh_upload(void* hv, int device) {
   Handle* h = (Handle*)hv;

@@ -1446,6 +1446,63 @@ std::unique_ptr<Encoded> encode_whatif(const SnapshotBase& sb, const uint32_t* c
   return e;
 }
 
+// CPU self-check of the device derivation (tests): what ks_derive_topology computes from the per-node tables for ONE candidate set -- restated here in
+// plain loops -- against the what-if flattened by itself (encode_whatif), group by group (matched by identity), domain by domain, row by row.  "" or the
+// first difference.  Not on any solving path.
+std::string check_derived_topology(const SnapshotBase& sb, const uint32_t* cand, uint32_t ncand, uint32_t flags) {
+  if (!sb.delta_ok) return "not derivable: " + sb.delta_why;
+  const Builder& bb = *sb.builder; const Encoded& EB = *sb.enc; const uint32_t G = EB.prob.G, GH = EB.prob.GH, NE = EB.prob.E, NT = EB.prob.n_topologies, GW = (G + 63) / 64;
+  const size_t NN = sb.snapshot->nodes.size();
+  auto e = std::make_unique<Encoded>(); e->src = sb.snapshot; e->shared = sb.enc;
+  std::vector<uint8_t> removed(NN, 0);
+  Builder wb(*e, flags); wb.base = sb.builder.get(); wb.removed = &removed;
+  for (uint32_t i = 0; i < ncand; ++i) { if (cand[i] >= NN) throw ksp::Error("candidate node out of range"); removed[cand[i]] = 1; for (uint32_t p : sb.by_node[cand[i]]) wb.podp.push_back(&sb.snapshot->pods[p]); }
+  wb.run();
+  const Encoded& EW = *e;
+  if (!G) return EW.prob.G ? "the what-if has groups the snapshot lacks" : "";
+  // ---- the derivation (ksolve.hip ks_derive_topology + ks_host_count0) ----
+  std::vector<uint8_t> active(G, 0); std::vector<int32_t> count((size_t)G * 64, -1), extra(GH, 0); std::vector<uint8_t> exists(G, 1);
+  std::vector<uint64_t> own(GW, 0); for (uint32_t i = 0; i < ncand; ++i) for (uint32_t w = 0; w < GW; ++w) own[w] |= sb.t_node_own[(size_t)cand[i] * GW + w];
+  for (uint32_t g = 0; g < G; ++g) {
+    const bool ownbit = (own[g >> 6] >> (g & 63u)) & 1ull;
+    active[g] = g >= NT ? 1 : (ownbit ? 1 : 0);
+    const int32_t hs = EB.grp_hslot[g];
+    if (hs >= 0) {
+      int32_t ex = sb.t_extra_tot[hs];
+      for (uint32_t i = 0; i < ncand; ++i) { const uint32_t nd = cand[i]; const int32_t stay = sb.t_node_dom[g * NN + nd], all = stay + sb.t_node_cnt[g * NN + nd]; if (sb.node_row[nd] < 0) ex -= (all > 0) - (stay > 0); else ex += stay > 0; }
+      extra[hs] = ex; continue;
+    }
+    int32_t c[64]; for (int v = 0; v < 64; ++v) c[v] = sb.t_tot[(size_t)g * 64 + v];
+    for (uint32_t i = 0; i < ncand; ++i) { const int32_t dm = sb.t_node_dom[g * NN + cand[i]]; if (dm >= 0) c[dm] -= sb.t_node_cnt[g * NN + cand[i]]; }
+    bool owners = ownbit;
+    for (int v = 0; v < 64; ++v) { const int32_t r = EB.grp_count[(size_t)g * 64 + v]; const int32_t x = (r >= 0 || c[v] > 0) ? (r > 0 ? r : 0) + c[v] : -1; count[(size_t)g * 64 + v] = x; if (x > 0) owners = true; }
+    if (g >= NT && !owners) exists[g] = 0;
+  }
+  auto row = [&](uint32_t hs, uint32_t g, uint32_t eb) -> int32_t { int32_t c = sb.t_grph_base[(size_t)hs * NE + eb]; if (c == -2) c = active[g] ? 0 : -1; return c; };
+  // ---- against the what-if's own flattening ----
+  std::vector<uint8_t> seen(G, 0);
+  auto where = [&](uint32_t gb) { return " (snapshot group " + std::to_string(gb) + ", key " + bb.groups[bb.group_order[gb]]->key + ")"; };
+  for (int inv = 0; inv < 2; ++inv) for (auto& kv : (inv ? wb.inverse_by_id : wb.topo_by_id)) {
+    const auto& idx = inv ? bb.inverse_by_id : bb.topo_by_id; auto it = idx.find(kv.first);
+    if (it == idx.end()) return "the what-if owns a group the snapshot does not have: " + kv.first;
+    const uint32_t gw = (uint32_t)wb.group_remap[kv.second], gb = (uint32_t)bb.group_remap[it->second]; seen[gb] = 1;
+    if (!exists[gb]) return "a group the what-if has does not exist in the derivation" + where(gb);
+    if ((EW.grp_active[gw] != 0) != (active[gb] != 0)) return "group activity differs" + where(gb);
+    const int32_t hw = EW.grp_hslot[gw], hb = EB.grp_hslot[gb];
+    if ((hw >= 0) != (hb >= 0)) return "hostname slot kind differs" + where(gb);
+    if (hb < 0) { for (int v = 0; v < 64; ++v) if (EW.grp_count[(size_t)gw * 64 + v] != count[(size_t)gb * 64 + v]) return "count of domain " + std::to_string(v) + " differs: " + std::to_string(EW.grp_count[(size_t)gw * 64 + v]) + " flattened, " + std::to_string(count[(size_t)gb * 64 + v]) + " derived" + where(gb); continue; }
+    if (EW.grph_extra_pos[hw] != extra[hb]) return "count of positive hostnames that are no existing node differs: " + std::to_string(EW.grph_extra_pos[hw]) + " flattened, " + std::to_string(extra[hb]) + " derived" + where(gb);
+    for (uint32_t ew = 0; ew < EW.prob.E; ++ew) { const int32_t eb = sb.node_row[EW.existing[ew]]; const int32_t a = EW.grph_count[(size_t)hw * EW.prob.E + ew], d = row((uint32_t)hb, gb, (uint32_t)eb); if (a != d) return "hostname row of node " + std::to_string(EW.existing[ew]) + " differs: " + std::to_string(a) + " flattened, " + std::to_string(d) + " derived" + where(gb); }
+  }
+  for (uint32_t gb = 0; gb < G; ++gb) if (!seen[gb]) {      // groups of the snapshot this what-if does not have: they must be inert in it
+    if (gb < NT) { if (active[gb]) return "a group no pod of the batch owns is active" + where(gb); continue; }
+    const int32_t hb = EB.grp_hslot[gb];
+    if (hb < 0) { if (exists[gb]) return "an inverse group without owners exists" + where(gb); continue; }
+    for (uint32_t ew = 0; ew < EW.prob.E; ++ew) if (row((uint32_t)hb, gb, (uint32_t)sb.node_row[EW.existing[ew]]) != 0) return "an inverse group without owners counts on node " + std::to_string(EW.existing[ew]) + where(gb);
+  }
+  return "";
+}
+
 std::unique_ptr<Encoded::ResultBuf> Encoded::make_result() const {
   auto rb = std::make_unique<ResultBuf>(); const ks_problem& p = prob; const size_t N = p.max_new_nodes, TW = (p.T + 63) / 64;
   rb->pod_node.resize(p.P + 1); rb->pod_stage.resize(p.P + 1); rb->pod_seq.resize(p.P + 1); rb->unscheduled.resize(p.P + 1); rb->pod_reason.resize(p.P + 1);

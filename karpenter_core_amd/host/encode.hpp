@@ -112,5 +112,7 @@ struct DeltaInputs {
   const ks_whatif_topo* topo = nullptr;      // snapshots with topology groups: the per-node tables a what-if's groups are derived from
 };
 DeltaInputs delta_inputs(const SnapshotBase& sb);
+// CPU self-check (tests): the device derivation of one what-if's topology, restated in plain loops, against that what-if flattened by itself.  "" or the first difference.
+std::string check_derived_topology(const SnapshotBase& sb, const uint32_t* cand, uint32_t ncand, uint32_t flags);
 
 }  // namespace ksh

@@ -327,6 +327,19 @@ def open_whatifs(snapshot, pod_node: Sequence[int], candidate_sets: Sequence[Seq
     return [FlatProblem(None, _handle=ctypes.c_void_p(hs[i])) for i in range(n)]
 
 
+def check_whatif_derivation(snapshot: "ParsedProblem", pod_node: Sequence[int], candidates: Sequence[int]) -> None:
+    """Diagnostic, no GPU needed (kshost.h `ksh_check_whatif_derivation`): what the device would derive for this candidate set -- group activity, domain
+    counts, hostname rows -- restated on the host and compared with the what-if flattened by itself.  Raises KSolveError with the first difference."""
+    import numpy as np
+    kh = libs()[1]
+    cand = np.ascontiguousarray(np.asarray(list(candidates) or [0], dtype=np.uint32))
+    pn = np.ascontiguousarray(np.asarray(pod_node, dtype=np.int32)) if len(pod_node) else np.zeros(1, dtype=np.int32)
+    kh.ksh_check_whatif_derivation.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.POINTER(ctypes.c_int32)]
+    rc = kh.ksh_check_whatif_derivation(snapshot._p, 0, cand.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), len(candidates), pn.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    if rc != KS_OK:
+        raise KSolveError(rc, kh.ksh_last_error().decode())
+
+
 def solve_batch(flats: Sequence[FlatProblem], decode: bool = True):
     """N independent Solve() calls in one launch (consolidation what-ifs)."""
     kh = libs()[1]

@@ -119,6 +119,36 @@ def test_a_spread_group_shared_across_node_filters_is_refused():
     assert e.value.code == S.KS_ERR_UNSUPPORTED and "node filters differ" in str(e.value), str(e.value)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_the_derivation_matches_each_whatif_flattened_by_itself(seed):
+    """(CPU) `ksh_check_whatif_derivation`: the arithmetic of `ks_derive_topology` / `ks_host_count0` restated on the host over the per-node tables, against
+    each what-if flattened by itself -- group by group (matched by identity), domain by domain, hostname row by hostname row, and the groups of the snapshot
+    a what-if does not have must be inert in it.  Random clusters with every kind of term the derivation accepts, with and without cluster-pod records."""
+    rs = np.random.RandomState(500 + seed)
+    its, prov, nodes, bound, snap, pod_node = _topology_snapshot(int(rs.randint(24, 90)), int(rs.randint(4, 8)), 300 + seed, spare=int(rs.choice([-1, 0, 3])),
+                                                                  extras=seed % 4 != 0, anti=seed % 3 != 0, wide=seed % 5 == 4)
+    if seed % 4 == 3:      # some owners of anti-affinity are not listed by the cluster: their inverse groups exist in some what-ifs only
+        snap.cluster_pods = [cp for cp in snap.cluster_pods if not (cp.anti_required and rs.rand() < 0.6)]
+    parsed = S.ParsedProblem(snap)
+    sets = [[int(x) for x in rs.choice(len(nodes), size=int(rs.choice([1, 1, 2, 4, 9, 20])), replace=False)] for _ in range(40)] + [[len(nodes) - 1], list(range(len(nodes)))[:30]]
+    for cs in sets:
+        S.check_whatif_derivation(parsed, pod_node, cs)
+
+
+def test_the_derivation_check_can_fail():
+    """... and the check is not vacuous: against tables built for ANOTHER binding of the pods it reports a difference."""
+    its, prov, nodes, bound, snap, pod_node = _topology_snapshot(40, 6, 7, spare=-1, anti=True)
+    parsed = S.ParsedProblem(snap)
+    S.check_whatif_derivation(parsed, pod_node, [0, 1, 2])
+    import dataclasses
+    moved = dataclasses.replace(snap, cluster_pods=[dataclasses.replace(cp, labels={"my-label": "a"}) for cp in snap.cluster_pods])      # the records lie about the labels:
+    lying = S.ParsedProblem(moved)                                                                                                      # consistent on both routes -> still equal
+    S.check_whatif_derivation(lying, pod_node, [0, 1, 2])
+    wrong = list(pod_node); i, j = 0, next(k for k, n in enumerate(pod_node) if n != pod_node[0]); wrong[i], wrong[j] = wrong[j], wrong[i]
+    with pytest.raises(S.KSolveError):      # a pod said to be bound elsewhere than its cluster-pod record says: refused (KS_ERR_UNSUPPORTED), not derived wrongly
+        S.check_whatif_derivation(S.ParsedProblem(snap), wrong, [0, 1, 2])
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 def test_topology_snapshots_are_eligible(seed):
     """(CPU) the tables behind ks_whatif_topo are built; the flattened what-ifs (the comparison side of the GPU tests) flatten."""
