@@ -70,6 +70,42 @@ def config4b_entry():
             "pods": pods, "new_nodes": new_nodes, "unscheduled": unsched, "one_new_node": sum(1 for p in picks if p is not None), "oracle_seconds": round(time.time() - t, 1)}
 
 
+def _config4t_one(args):
+    spare, i = args
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_whatif_derived import _whatif_problem
+    snap, pod_node, sets = _config4t_inputs(spare)
+    r = parse_result(O.solve_text(_whatif_problem(snap, pod_node, sets[i]).to_ksp()))
+    return i, fingerprint(r), len(r.new_nodes), len(r.unscheduled), sum(1 for st in r.final_stage if st)
+
+
+_C4T = {}
+
+
+def _config4t_inputs(spare):
+    if spare not in _C4T:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_whatif_derived import _topology_snapshot
+        its, prov, nodes, bound, snap, pod_node = _topology_snapshot(2048, 50, 45, spare=spare, extras=True, anti=True, zone_anti=False)
+        _C4T[spare] = (snap, pod_node, W.config4_sets(512, 2048, 45))
+    return _C4T[spare]
+
+
+def config4t_entry(spare):
+    """BASELINE configs[3]'s shape over a cluster whose bound pods carry topology terms (tests/test_whatif_derived.py `_topology_snapshot`: zonal / hostname
+    spreads, affinities, preferred terms, required anti-affinity per hostname; cluster-pod records, daemon-like pods, a node no provisioner owns): one
+    fingerprint per what-if.  spare = -1: a roomy cluster (the pods move to other nodes); 3: full by pod count (they open nodes)."""
+    import multiprocessing as mp
+    t = time.time()
+    snap, pod_node, sets = _config4t_inputs(spare)
+    with mp.get_context("fork").Pool(min(8, os.cpu_count() or 1)) as pool:
+        rows = sorted(pool.map(_config4t_one, [(spare, i) for i in range(len(sets))], chunksize=1))
+    fps = [r[1] for r in rows]
+    return {"sha256_of_sha256s": hashlib.sha256("".join(fps).encode()).hexdigest(), "whatif_sha256": fps, "whatifs": len(sets), "nodes": len(snap.nodes), "bound_pods": len(snap.pods),
+            "cluster_pod_records": len(snap.cluster_pods), "spare_pod_slots": spare,
+            "new_nodes": sum(r[2] for r in rows), "unscheduled": sum(r[3] for r in rows), "relaxed_pods": sum(r[4] for r in rows), "oracle_seconds_8_procs": round(time.time() - t, 1)}
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config_hashes.json")
@@ -80,6 +116,10 @@ if __name__ == "__main__":
     if not only or "config4b_512x2048_replace" in only:
         out["config4b_512x2048_replace"] = config4b_entry()
         print("config4b_512x2048_replace", {k: v for k, v in out["config4b_512x2048_replace"].items() if k not in ("whatif_sha256", "command_sha256", "launch_pick")}, flush=True)
+    for name, spare in (("config4t_512x2048_topology", -1), ("config4t_512x2048_topology_replace", 3)):
+        if not only or name in only:
+            out[name] = config4t_entry(spare)
+            print(name, {k: v for k, v in out[name].items() if k != "whatif_sha256"}, flush=True)
     CASES = {k: v for k, v in CASES.items() if not only or k in only}
     for name, mk in CASES.items():
         pr = mk()

@@ -33,7 +33,7 @@ def test_ineligible_snapshots_are_refused_on_the_host():
     assert [f.dims["P"] for f in flats] == [len(bound[0]), len(bound[1]) + len(bound[2])]
 
 
-def _topology_snapshot(existing, sizes, seed, spare=-1, extras=True, kinds=None, anti=False, wide=False):
+def _topology_snapshot(existing, sizes, seed, spare=-1, extras=True, kinds=None, anti=False, wide=False, zone_anti=True):
     """A cluster whose bound pods carry spread / affinity / preferred terms (no required anti-affinity), listed as cluster pods the way
     countDomains finds them -- plus pods that are in no batch (daemon-like, on candidate nodes too), one on a node nobody knows, and a node no
     provisioner owns."""
@@ -73,7 +73,7 @@ def _topology_snapshot(existing, sizes, seed, spare=-1, extras=True, kinds=None,
             elif r < 0.86 and anti:      # required anti-affinity per hostname: against a workload of its own label ("z-*", at most one per node), or against another
                 p.labels = {"my-label": "z-" + p.labels["my-label"]}
                 p.anti_required = [PodAffinityTerm(LABEL_HOSTNAME, LabelSelector({"my-label": p.labels["my-label"] if rs.rand() < 0.7 else "abc"[int(rs.randint(3))]}))]
-            elif r < 0.90 and anti:      # ... and per ZONE against another workload: its inverse group narrows a node's zones by merely existing, and exists only while an owner is around
+            elif r < 0.90 and anti and zone_anti:      # ... and per ZONE against another workload: its inverse group narrows a node's zones by merely existing, and exists only while an owner is around
                 p.labels = {"my-label": "y-" + p.labels["my-label"]}
                 p.anti_required = [PodAffinityTerm(LABEL_ZONE, LabelSelector({"my-label": "def"[int(rs.randint(3))]}))]
     if extras:
@@ -351,6 +351,30 @@ def test_full_size_config4_derived_matches_oracle_fingerprints():
     got = [hashlib.sha256(json.dumps(r.canonical(), sort_keys=True).encode()).hexdigest() for r in res]
     bad = [i for i, (a, b) in enumerate(zip(got, gold["whatif_sha256"])) if a != b]
     assert not bad, f"what-ifs differing from the oracle: {bad[:10]}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry,spare", [("config4t_512x2048_topology", -1), ("config4t_512x2048_topology_replace", 3)])
+def test_full_size_topology_whatifs_derived_match_oracle_fingerprints(entry, spare):
+    """BASELINE configs[3]'s shape -- 512 what-ifs over 2 048 nodes -- on a cluster whose bound pods carry topology terms (spreads, affinities, preferred
+    terms, required anti-affinity per hostname; 40 k cluster-pod records): every what-if derived on the device solves to the fingerprint the oracle
+    produced offline for that what-if built by hand (tests/golden/make_config_hashes.py `config4t_entry`)."""
+    import hashlib
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config_hashes.json"))).get(entry)
+    if gold is None:
+        pytest.skip(f"no golden entry {entry}")
+    its, prov, nodes, bound, snap, pod_node = _topology_snapshot(2048, 50, 45, spare=spare, extras=True, anti=True, zone_anti=False)
+    flats = S.open_whatifs(S.ParsedProblem(snap), pod_node, W.config4_sets(512, 2048, 45), derive=True)
+    res, _, _ = S.solve_batch(flats)
+    for f in flats:
+        f.close()
+    got = [hashlib.sha256(json.dumps(r.canonical(), sort_keys=True).encode()).hexdigest() for r in res]
+    bad = [i for i, (a, b) in enumerate(zip(got, gold["whatif_sha256"])) if a != b]
+    assert not bad, f"what-ifs differing from the oracle: {bad[:10]}"
+    if spare >= 0:
+        assert sum(len(r.new_nodes) for r in res) == gold["new_nodes"] > 0
 
 
 @pytest.mark.gpu
