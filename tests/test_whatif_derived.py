@@ -135,6 +135,71 @@ def test_the_derivation_matches_each_whatif_flattened_by_itself(seed):
         S.check_whatif_derivation(parsed, pod_node, cs)
 
 
+def _exotic_snapshot(seed):
+    """Selectors by match expressions (In / NotIn / Exists), nil selectors, terms with namespace lists, pods in three namespaces, spreads over zone /
+    hostname / capacity type / arch, nodes without a hostname label (the name stands in), a node no provisioner owns, daemon-like pods with anti-affinity of
+    their own, cluster-pod records missing at random."""
+    import dataclasses
+    from karpenter_core_amd.model import (ClusterPod, Expr, LABEL_ARCH, LABEL_CAPACITY_TYPE, LABEL_HOSTNAME, PodAffinityTerm, SCHEDULE_ANYWAY, StateNode, WeightedPodAffinityTerm)
+    rs = np.random.RandomState(seed)
+    its, prov, nodes, bound = _snapshot(int(rs.randint(16, 80)), int(rs.randint(3, 8)), seed, spare=int(rs.choice([-1, 0, 3])))
+    zones = sorted({n.labels[LABEL_ZONE] for n in nodes})
+    nss = ["default", "other", "third"]
+    for n in nodes:
+        if rs.rand() < 0.1:
+            n.labels.pop(LABEL_HOSTNAME, None)
+    for pods in bound:
+        for p in pods:
+            p.namespace = nss[int(rs.choice(3, p=[0.7, 0.2, 0.1]))]
+            lab = p.labels["my-label"]
+            if lab not in "abc":
+                continue
+            r = rs.rand()
+            forms = [LabelSelector({"my-label": lab}), LabelSelector({}, [Expr("my-label", "In", [lab, "d"])]), LabelSelector({}, [Expr("my-label", "NotIn", ["e", "f", "g"])]),
+                     LabelSelector({}, [Expr("my-label", "Exists")]), None]
+            sel = forms[int(rs.randint(len(forms)))]
+            nsl = [[], ["default", "other"], ["third"]][int(rs.randint(3))]
+            if r < 0.2:
+                p.spread = [TopologySpreadConstraint(int(rs.randint(1, 4)), [LABEL_ZONE, LABEL_HOSTNAME, LABEL_CAPACITY_TYPE, LABEL_ARCH][int(rs.randint(4))], DO_NOT_SCHEDULE, sel)]
+            elif r < 0.3:
+                p.spread = [TopologySpreadConstraint(1, LABEL_ZONE, SCHEDULE_ANYWAY, sel)]
+            elif r < 0.4 and sel is not None:
+                p.affinity_required = [PodAffinityTerm([LABEL_ZONE, LABEL_HOSTNAME][int(rs.randint(2))], sel, nsl)]
+            elif r < 0.5 and sel is not None:
+                p.anti_required = [PodAffinityTerm([LABEL_ZONE, LABEL_HOSTNAME][int(rs.randint(2))], sel, nsl)]
+            elif r < 0.6 and sel is not None:
+                p.anti_preferred = [WeightedPodAffinityTerm(5, PodAffinityTerm(LABEL_HOSTNAME, sel, nsl))]
+            elif r < 0.7 and sel is not None:
+                p.affinity_preferred = [WeightedPodAffinityTerm(5, PodAffinityTerm(LABEL_ZONE, sel, nsl)), WeightedPodAffinityTerm(9, PodAffinityTerm(LABEL_HOSTNAME, sel, nsl))]
+    if rs.rand() < 0.5:
+        nodes.append(StateNode(name="unowned", labels={LABEL_ZONE: zones[0]}))
+        bound.append([dataclasses.replace(p, uid=f"extra-{i}") for i, p in enumerate(bound[0][:4])])
+    snap, pod_node = W.snapshot_problem(its, prov, nodes, bound, True)
+    for i in range(len(nodes) // 3):
+        snap.cluster_pods.append(ClusterPod(uid=f"ds-{i}", namespace=nss[int(rs.randint(3))], node_name=nodes[int(rs.randint(len(nodes)))].name, labels={"my-label": "abcdefg"[int(rs.randint(7))]},
+                                            anti_required=[PodAffinityTerm(LABEL_HOSTNAME, LabelSelector({"my-label": "a"}))] if rs.rand() < 0.1 else []))
+    if rs.rand() < 0.3:
+        snap.cluster_pods = [cp for cp in snap.cluster_pods if rs.rand() < 0.8]
+    return nodes, snap, pod_node
+
+
+def test_the_derivation_on_exotic_clusters():
+    """(CPU) the same check over the selector / namespace / label forms `_topology_snapshot` does not draw.  A snapshot the kernel's encoding refuses (a pod
+    constrained by more than three hostname-keyed groups) is refused by both routes and skipped here."""
+    checked = 0
+    for seed in range(3000, 3040):
+        rs = np.random.RandomState(seed + 7)
+        nodes, snap, pod_node = _exotic_snapshot(seed)
+        try:
+            parsed = S.ParsedProblem(snap)
+            for _ in range(20):
+                S.check_whatif_derivation(parsed, pod_node, [int(x) for x in rs.choice(len(nodes), size=int(rs.choice([1, 1, 2, 3, 6])), replace=False)])
+                checked += 1
+        except S.KSolveError as e:
+            assert e.code == S.KS_ERR_UNSUPPORTED, (seed, str(e))
+    assert checked >= 400
+
+
 def test_the_derivation_check_can_fail():
     """... and the check is not vacuous: against tables built for ANOTHER binding of the pods it reports a difference."""
     its, prov, nodes, bound, snap, pod_node = _topology_snapshot(40, 6, 7, spare=-1, anti=True)
