@@ -1342,6 +1342,10 @@ static std::string build_topo_tables(SnapshotBase& sb, const int32_t* pod_node) 
   if (G > 1024) return "more than 1024 topology groups";
   const uint32_t GW = (G + 63) / 64;
   if (b.shared_filter_differs) return "two pods share a spread group while their node filters differ: the group's filter is that of the first pod of each batch";
+  // A derived what-if runs on the SNAPSHOT's classes, whose record lists name every group of the snapshot that selects the pod -- a what-if flattened by
+  // itself lists only its own.  The kernel's per-class limit (KS_MAX_REC = 24 recorded groups) must hold for the longer lists.
+  for (uint32_t c = 0; c + 1 < E.cls_sel_off.size(); ++c)
+    if ((E.cls_sel_off[c + 1] - E.cls_sel_off[c]) + (E.cls_iown_off[c + 1] - E.cls_iown_off[c]) > 24) return "a pod is selected by more than 24 of the snapshot's topology groups (the kernel's per-class record list)";
   auto grp = [&](uint32_t gi) -> const Group& { return *b.groups[b.group_order[gi]]; };
   // Inverse groups (required anti-affinity, topology.go:181-199,202-229) EXIST only while an owner is in the batch or stays bound outside it.  A hostname-keyed
   // one whose counts are all zero constrains nothing (every hostname is registered with 0, nothing is narrowed), so it may simply exist in every what-if;

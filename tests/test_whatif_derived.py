@@ -200,6 +200,23 @@ def test_the_derivation_on_exotic_clusters():
     assert checked >= 400
 
 
+def test_record_lists_longer_than_the_kernels_limit_are_refused_at_open_time():
+    """(CPU) A derived what-if runs on the snapshot's classes, whose record lists name EVERY group of the snapshot that selects the pod; flattened by itself
+    it would list its own only.  Past the kernel's 24 recorded groups per class the derived route refuses at open time -- so `open_whatifs` falls back to
+    flattening -- instead of failing in the kernel at solve time."""
+    nodes, snap, pod_node = _exotic_snapshot(3022)
+    parsed = S.ParsedProblem(snap)
+    with pytest.raises(S.KSolveError) as e:
+        S.open_whatifs(parsed, pod_node, [[0], [1, 2]], derive=True)
+    assert e.value.code == S.KS_ERR_UNSUPPORTED and "more than 24" in str(e.value)
+    flats = S.open_whatifs(parsed, pod_node, [[0], [1, 2]])      # derive=None: the host route takes over
+    assert len(flats) == 2 and all(f.dims["G"] <= parsed_groups(snap) for f in flats)
+
+
+def parsed_groups(snap):
+    return S.FlatProblem(snap).dims["G"]
+
+
 def test_the_derivation_check_can_fail():
     """... and the check is not vacuous: against tables built for ANOTHER binding of the pods it reports a difference."""
     its, prov, nodes, bound, snap, pod_node = _topology_snapshot(40, 6, 7, spare=-1, anti=True)
