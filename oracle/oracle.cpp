@@ -1004,7 +1004,26 @@ struct Scheduler {
   //   out[0] violations (must be 0), out[1] dry runs compared, out[2] pods of watermark classes, out[3] of them with anti-affinity items
   //   mutate: also treat classes with spread / affinity items as watermark classes (the claim is false for them: the check must be able to tell)
   // ------------------------------------------------------------------------------------------------
-  void solve_watermark_check(long long* out, bool mutate) {
+  // the part of ExistingNode.Add before any topology step (existingnode.go:77-103): taints, host ports, volume limits, resources, the pod's own requirements
+  bool dry_existing_pre(const ExistingNode& n, PodState& ps) {
+    ksp::Pod& pod = ps.spec;
+    if (!taints_tolerates(n.taints, pod)) return false;
+    if (!n.ports.validate(pod, nullptr)) return false;
+    if (pod.volume_error) return false;
+    {
+      std::map<std::string, std::set<std::string>> u = n.volumes;
+      for (auto& v : pod.volumes) u[v.driver].insert(v.pvc);
+      for (auto& kv : u) { auto lim = n.volume_limits.find(kv.first); if (lim != n.volume_limits.end() && (int)kv.second.size() > lim->second) return false; }
+    }
+    ResList requests = res_merge(n.requests, requests_for_pods({&pod}));
+    if (!res_fits(requests, n.available)) return false;
+    Reqs nodeReqs = n.requirements; Reqs podReqs = new_pod_requirements(pod);
+    return reqs_compatible(cx, nodeReqs, podReqs);
+  }
+  // mode 2 (a lead for the next round): EVERY class whose own requirements are on well-known keys -- spread and affinity classes too -- keeps
+  // refusals monotone as long as the refusal happens BEFORE the topology steps.  out[4] counts the pre-topology refusals put on record, out[5] the later dry
+  // runs of a recorded (class, node) pair; a recorded node that accepts is a violation (out[0]).
+  void solve_watermark_check(long long* out, bool mutate, bool pre_only = false) {
     for (int i = 0; i < 8; ++i) out[i] = 0;
     std::vector<int> q(pods.size()); for (size_t i = 0; i < pods.size(); ++i) q[i] = (int)i;
     std::vector<ResList> rq(pods.size()); for (size_t i = 0; i < pods.size(); ++i) rq[i] = requests_for_pods({&pods[i].spec});
@@ -1029,7 +1048,7 @@ struct Scheduler {
         bool eligible = true, anti = false;
         Reqs pr = new_pod_requirements(ps.spec);
         for (auto& kv : pr.m) if (!cx.well_known.count(kv.first)) eligible = false;
-        for (auto& tc : topo.topologies) if (tc->owners.count(ps.spec.uid)) { if (tc->type == kAntiAffinity) anti = true; else if (!mutate) eligible = false; }
+        for (auto& tc : topo.topologies) if (tc->owners.count(ps.spec.uid)) { if (tc->type == kAntiAffinity) anti = true; else if (!mutate && !pre_only) eligible = false; }
         for (auto& tc : topo.inverse) if (tg_selects(*tc, ps.spec)) anti = true;
         if (eligible && !existing.empty()) {
           out[2]++; if (anti) out[3]++;
@@ -1037,8 +1056,9 @@ struct Scheduler {
           Stats keep = st;
           for (size_t i = 0; i < existing.size(); ++i) {
             const bool ok = dry_existing(*existing[i], ps); out[1]++;
+            if (rf[i]) out[5]++;
             if (ok && rf[i]) { out[0]++; if (out[0] <= 5) fprintf(stderr, "watermark rule violated: pod %d accepted by existing node %zu that refused its class before\n", pi, i); }
-            if (!ok) rf[i] = 1;
+            if (pre_only ? !dry_existing_pre(*existing[i], ps) : !ok) { if (!rf[i]) out[4]++; rf[i] = 1; }
           }
           st = keep;
         }
@@ -1439,7 +1459,7 @@ int ko_solve_spec2(const char* ksp_text, size_t len, int W, int flags, int maxcl
   try {
     ksp::Problem pr = ksp::Parser(ksp_text, len).parse();
     auto s = oracle::build(pr, false);
-    if (flags & 8) s->solve_watermark_check(counters, (flags & 16) != 0);
+    if (flags & 8) s->solve_watermark_check(counters, (flags & 16) != 0, (flags & 32) != 0);
     else if (flags & 2) s->solve_spec_v2(W, counters, flags, maxcls); else s->solve_spec(W, counters, flags, maxcls);
     std::string r = oracle::result_text(*s, 0.0);
     *out_text = strdup(r.c_str()); oracle::g_in = nullptr; return 0;

@@ -65,19 +65,21 @@ def solve_spec(problem, width: int = 8, flags: int = 0, max_classes: int = 0):
     return parse_result(text), {k: int(ctr[i]) for i, k in enumerate(names)}
 
 
-def watermark_check(problem, mutate: bool = False):
+def watermark_check(problem, mutate: bool = False, pre_topology_only: bool = False):
     """Model check of the kernel's watermark over the existing nodes (oracle.cpp solve_watermark_check): (result, counters).  mutate: also treat classes
-    with spread / affinity items as watermark classes -- the claim is false for them."""
+    with spread / affinity items as watermark classes -- the claim is false for them.  pre_topology_only: every class, but only refusals that happen before
+    the topology steps go on record (a rule the kernel does not use yet: DESIGN.md §8)."""
     from karpenter_core_amd.model import parse_result
     data = problem.to_ksp().encode()
     out = ctypes.c_void_p()
     ctr = (ctypes.c_longlong * 8)()
-    rc = lib().ko_solve_spec2(data, len(data), 0, 8 | (16 if mutate else 0), 0, ctr, ctypes.byref(out))
+    rc = lib().ko_solve_spec2(data, len(data), 0, 8 | (16 if mutate else 0) | (32 if pre_topology_only else 0), 0, ctr, ctypes.byref(out))
     text = ctypes.string_at(out).decode()
     lib().ko_free(out)
     if rc != 0:
         raise RuntimeError("oracle: " + text)
-    return parse_result(text), {"violations": int(ctr[0]), "dry_runs": int(ctr[1]), "watermark_pods": int(ctr[2]), "with_anti_affinity": int(ctr[3])}
+    return parse_result(text), {"violations": int(ctr[0]), "dry_runs": int(ctr[1]), "watermark_pods": int(ctr[2]), "with_anti_affinity": int(ctr[3]),
+                                "refusals_recorded": int(ctr[4]), "recorded_pairs_rechecked": int(ctr[5])}
 
 
 def solve(problem, inert_topology: bool = False, gosort: bool = False):

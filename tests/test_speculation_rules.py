@@ -117,3 +117,15 @@ def test_the_watermark_model_covers_anti_affinity_and_rejects_spread():
     checked = [O.watermark_check(_topology_whatif(s, list(range(0, 14))))[1] for s in (0, 3)]
     assert all(c["violations"] == 0 for c in checked) and all(c["with_anti_affinity"] > 0 for c in checked)
     assert O.watermark_check(_topology_whatif(0, list(range(0, 14))), mutate=True)[1]["violations"] > 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_refusals_before_the_topology_steps_are_monotone_for_every_class(seed):
+    """A lead for the next round, checked here so that the kernel can adopt it safely: whatever the class -- spread and affinity too -- an
+    existing node that refused it BEFORE the topology steps (taints, ports, volume limits, resources, the pod's own requirements) refuses it for the rest
+    of the Solve.  Classes with requirements on custom keys stay out (a node's requirement on a custom key can appear with another pod's NotIn)."""
+    pr = _topology_whatif(seed, list(range(0, 14)), spare=[-1, 2][seed % 2])
+    res, ctr = O.watermark_check(pr, pre_topology_only=True)
+    assert res.canonical() == O.solve(pr).canonical()
+    assert ctr["violations"] == 0, ctr
+    assert ctr["refusals_recorded"] > 0 and ctr["recorded_pairs_rechecked"] > 0
