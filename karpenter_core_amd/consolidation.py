@@ -273,6 +273,48 @@ def compute_consolidations(snapshot: Snapshot, candidate_sets: Sequence[Sequence
     return cmds, flats, results
 
 
+def simulate_candidates(snapshot: Snapshot, candidate_sets: Sequence[Sequence[int]]) -> List[Optional[SolveResult]]:
+    """simulateScheduling (helpers.go:42-99) for every candidate set in ONE batched launch over the shared snapshot; None where the reference returns
+    errCandidateNodeDeleting."""
+    from . import scheduler, workloads
+    PENDING = "~pending~"
+    deleting = [int(j) for j in snapshot.deleting]
+    nodes, bound = list(snapshot.nodes), list(snapshot.bound)
+    pend_idx = None
+    if snapshot.pending:
+        pend_idx = len(nodes)
+        nodes.append(StateNode(name=PENDING)); bound.append(list(snapshot.pending))
+    snap, pod_node = workloads.snapshot_problem(snapshot.instance_types, snapshot.provisioner, nodes, bound)
+    snap.cluster_pods = [cp for cp in snap.cluster_pods if cp.node_name != PENDING]
+    live = [i for i, cs in enumerate(candidate_sets) if not (set(cs) & set(deleting))]
+    sets = [([pend_idx] if pend_idx is not None else []) + list(candidate_sets[i]) + deleting for i in live]
+    flats = scheduler.open_whatifs(snap, pod_node, sets) if sets else []
+    got, _, _ = scheduler.solve_batch(flats) if flats else ([], 0, 0)
+    for f in flats:
+        f.close()
+    out: List[Optional[SolveResult]] = [None] * len(candidate_sets)
+    for i, r in zip(live, got):
+        out[i] = r
+    return out
+
+
+def replacement_command(snapshot: Snapshot, candidates: Sequence[int], simulate: Optional[Callable] = None):
+    """Drift.ComputeCommand / Expiration.ComputeCommand (drift.go:59-98, expiration.go:68-113) after their candidate filters and sort.  The reference
+    simulates candidate after candidate and stops at the first whose simulation runs; here every candidate is simulated in ONE batch (`simulate`, default
+    `simulate_candidates`) and the same first candidate decides: delete if its pods fit the rest of the cluster, otherwise replace it with EVERY node the
+    simulation opened (no price stage, any number of nodes; pods left unscheduled are only logged there).
+    -> (action, [node name], [(instance type options, canonical requirements)] per replacement node)"""
+    results = (simulate or simulate_candidates)(snapshot, [[i] for i in candidates])
+    for i, res in zip(candidates, results):
+        if res is None:                                        # errCandidateNodeDeleting: "just retry" with the next candidate
+            continue
+        name = snapshot.nodes[i].name
+        if not res.new_nodes:
+            return (ACTION_DELETE, [name], [])
+        return (ACTION_REPLACE, [name], [(list(n.instance_types), tuple(sorted((k, _req_tuple(r)) for k, r in n.requirements.items()))) for n in res.new_nodes])
+    return (ACTION_DO_NOTHING, [], [])
+
+
 def _filter_out_same_type(snapshot: Snapshot, flat, result, cmd: Command, cands: Sequence[CandidateNode]) -> List[str]:
     """filterOutSameType, multinodeconsolidation.go:132-165 (the second filterByPrice runs on the device as well)."""
     from . import scheduler

@@ -8,6 +8,7 @@ Follows the reference literally, one simulateScheduling (= one oracle Solve) per
   filterOutSameType       multinodeconsolidation.go:132-165
   firstNNodeConsolidationOption  multinodeconsolidation.go:74-114
   SingleNodeConsolidation.ComputeCommand (scan only)  singlenodeconsolidation.go:54-78
+  Drift / Expiration .ComputeCommand    drift.go:59-98, expiration.go:68-113
 Requirements are the string-keyed value sets of the oracle's KSR1 output; prices are Python floats (IEEE double,
 like Go's float64; the path only compares and sums them in candidate order)."""
 import math
@@ -128,6 +129,24 @@ def compute_consolidation(snapshot, cand_idx, result_sink=None):
     if req_has(ct, "spot") and req_has(ct, "on-demand"):
         reqs[LABEL_CAPACITY_TYPE] = Narrowed(["spot"])
     return ("replace", [c.name for c in cands], options, reqs)
+
+
+def replacement_command(snapshot, candidates):
+    """Drift.ComputeCommand / Expiration.ComputeCommand (drift.go:59-98, expiration.go:68-113) after their candidate filters and sort: the first candidate
+    whose simulation can be run decides -- delete if its pods fit the rest of the cluster, otherwise replace it with EVERY node the simulation opened (no
+    price stage, any number of nodes; pods left unscheduled are only logged).  -> (action, [node name], [(instance type options, requirements)] per new node)"""
+    for i in candidates:
+        try:
+            sink = []
+            compute_consolidation(snapshot, [i], sink)      # (runs simulateScheduling; its own verdict is not used here)
+        except ValueError:                                   # errCandidateNodeDeleting: "just retry" with the next candidate
+            continue
+        res = sink[0]
+        name = snapshot.nodes[i].name
+        if not res.new_nodes:
+            return ("delete", [name], [])
+        return ("replace", [name], [(list(n.instance_types), tuple(sorted(canon_reqs(dict(n.requirements)).items()))) for n in res.new_nodes])
+    return ("do-nothing", [], [])
 
 
 def filter_out_same_type(snapshot, options, reqs, cand_idx):

@@ -8,7 +8,7 @@ the live cluster and is not part of the path."""
 import numpy as np
 import pytest
 
-from karpenter_core_amd import fake, workloads as W
+from karpenter_core_amd import consolidation as C, fake, workloads as W
 from karpenter_core_amd.consolidation import Snapshot
 from karpenter_core_amd.model import (parse_quantity_milli, Container, LABEL_ARCH, LABEL_CAPACITY_TYPE, LABEL_HOSTNAME, LABEL_INSTANCE_TYPE, LABEL_OS,
                                       LABEL_PROVISIONER, LABEL_ZONE, Offering, Pod, StateNode)
@@ -369,3 +369,63 @@ def test_gpu_launch_pick_and_subset():
         for j, s_, w in zip(nodes, sets, wants):        # the literal restatement agrees with the expectation
             assert CR.instance_types_are_subset([names[i] for i in s_], res.new_nodes[j].instance_types) == w
         fp.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Drift / Expiration: the other two callers of simulateScheduling (drift.go:59-98, expiration.go:68-113)
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_simulate(snapshot, candidate_sets):
+    """simulate_candidates with the oracle behind it: what the batched GPU launch computes, one Solve at a time"""
+    out = []
+    for cs in candidate_sets:
+        if set(cs) & set(snapshot.deleting):
+            out.append(None)
+            continue
+        sink = []
+        CR.compute_consolidation(snapshot, list(cs), sink)
+        out.append(sink[0])
+    return out
+
+
+def replacement_scenarios():
+    out = {}
+    its = fake.instance_types_assorted()
+    big, big_of = most_expensive(its)
+    # "can delete drifted nodes" suite_test.go:243-275 / "can delete expired nodes" :503-534: an empty node -> nothing to replace
+    out["delete_empty"] = (snapshot(its, [node("n1", big, big_of.capacity_type, big_of.zone)], [[]]), [0], "delete", 0)
+    # "can replace drifted nodes" :277-330 / "can replace node for expiration" :580-632: one pod, nowhere else to go -> one replacement
+    out["replace_one"] = (snapshot(its, [node("n1", big, big_of.capacity_type, big_of.zone)], [[pod("p1")]]), [0], "replace", 1)
+    # "can replace drifted nodes with multiple nodes" :332-422 / "... for expiration with multiple nodes" :725-818: three 2-cpu pods, the only launchable
+    # type has 3 cpu -> three replacements (no "one node only" rule, no price stage here)
+    cur = fake.new_instance_type("current-on-demand", offerings=[Offering("on-demand", "test-zone-1a", 0.5, False)])
+    rep = fake.new_instance_type("replacement-on-demand", {"cpu": "3"}, offerings=[Offering("on-demand", "test-zone-1a", 0.3)])
+    out["replace_with_three"] = (snapshot([cur, rep], [node("n1", cur, "on-demand", "test-zone-1a", cpu="8")], [[pod("p1", "2"), pod("p2", "2"), pod("p3", "2")]]), [0], "replace", 3)
+    # "should expire one node at a time, starting with most expired" :536-578: the caller's order decides, the first candidate is the command
+    n1, n2 = node("to-expire", big, big_of.capacity_type, big_of.zone), node("not-yet", big, big_of.capacity_type, big_of.zone)
+    out["first_candidate_only"] = (snapshot(its, [n1, n2], [[], []]), [0, 1], "delete", 0)
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(replacement_scenarios()))
+def test_oracle_drift_and_expiration_commands(name):
+    snap, cands, want, n_new = replacement_scenarios()[name]
+    action, removed, replacements = CR.replacement_command(snap, cands)
+    assert action == want and len(replacements) == n_new
+    assert removed == [snap.nodes[cands[0]].name]
+    if name == "replace_with_three":
+        assert all(opts == ["replacement-on-demand"] for opts, _ in replacements)
+    # the product's control flow (one batched simulation of every candidate, the same first candidate decides) over the same simulations
+    assert C.replacement_command(snap, cands, simulate=_oracle_simulate) == (action, removed, replacements)
+
+
+def test_a_deleting_candidate_is_passed_over():
+    """errCandidateNodeDeleting -> `continue` (drift.go:73-77): the next candidate decides"""
+    its = fake.instance_types_assorted()
+    big, big_of = most_expensive(its)
+    snap = snapshot(its, [node("n1", big, big_of.capacity_type, big_of.zone), node("n2", big, big_of.capacity_type, big_of.zone)], [[pod("p1")], []])
+    snap.deleting = (0,)
+    want = CR.replacement_command(snap, [0, 1])
+    assert want[0] == "replace" and want[1] == ["n2"]      # n1's pod joins every simulation (helpers.go:81-84) and needs a node once n2 goes too
+    assert C.replacement_command(snap, [0, 1], simulate=_oracle_simulate) == want
+    snap.deleting = (0, 1)
+    assert CR.replacement_command(snap, [0, 1]) == ("do-nothing", [], []) == C.replacement_command(snap, [0, 1], simulate=_oracle_simulate)
