@@ -315,6 +315,29 @@ def replacement_command(snapshot: Snapshot, candidates: Sequence[int], simulate:
     return (ACTION_DO_NOTHING, [], [])
 
 
+def validate_command(snapshot: Snapshot, cmd: Command, candidates: Sequence[int], simulate: Optional[Callable] = None) -> bool:
+    """Validation.ValidateCommand (validation.go:109-172) on the cluster as it is NOW (the TTL wait before it stays with the caller): the command's nodes
+    that are still candidates are simulated again -- valid iff every pod schedules and the simulation needs no new node where none was expected, or exactly
+    one whose instance type options contain the command's (instanceTypesAreSubset: the simulation applies no price filter, so it may list more)."""
+    names = {snapshot.nodes[i].name: i for i in candidates}
+    idx = [names[n] for n in cmd.nodes_to_remove if n in names]
+    if not idx:
+        return False
+    (res,) = (simulate or simulate_candidates)(snapshot, [idx])
+    if res is None:
+        raise ValueError("candidate node is deleting")          # "simulating scheduling, %w"
+    removed = set(idx) | set(int(j) for j in snapshot.deleting)
+    if any(n.owned and n.labels.get(LABEL_INITIALIZED) != "true" for j, n in enumerate(snapshot.nodes) if j not in removed and n.in_state):
+        return False                                             # helpers.go:102-111: allPodsScheduled = false
+    if res.unscheduled:
+        return False
+    if not res.new_nodes:
+        return not cmd.replacement_types
+    if len(res.new_nodes) > 1 or not cmd.replacement_types:
+        return False
+    return set(cmd.replacement_types) <= set(res.new_nodes[0].instance_types)
+
+
 def _filter_out_same_type(snapshot: Snapshot, flat, result, cmd: Command, cands: Sequence[CandidateNode]) -> List[str]:
     """filterOutSameType, multinodeconsolidation.go:132-165 (the second filterByPrice runs on the device as well)."""
     from . import scheduler

@@ -9,6 +9,7 @@ Follows the reference literally, one simulateScheduling (= one oracle Solve) per
   firstNNodeConsolidationOption  multinodeconsolidation.go:74-114
   SingleNodeConsolidation.ComputeCommand (scan only)  singlenodeconsolidation.go:54-78
   Drift / Expiration .ComputeCommand    drift.go:59-98, expiration.go:68-113
+  Validation.ValidateCommand            validation.go:109-172
 Requirements are the string-keyed value sets of the oracle's KSR1 output; prices are Python floats (IEEE double,
 like Go's float64; the path only compares and sums them in candidate order)."""
 import math
@@ -147,6 +148,29 @@ def replacement_command(snapshot, candidates):
             return ("delete", [name], [])
         return ("replace", [name], [(list(n.instance_types), tuple(sorted(canon_reqs(dict(n.requirements)).items()))) for n in res.new_nodes])
     return ("do-nothing", [], [])
+
+
+def validate_command(snapshot, action, nodes_to_remove, replacement_types, candidates):
+    """Validation.ValidateCommand (validation.go:109-172) on the cluster as it is NOW: the command's nodes that are still candidates are simulated again.
+    Valid iff every pod schedules and the simulation needs no new node where none was expected, or exactly one whose instance type options contain the
+    command's (the simulation applies no price filter, so it may list more)."""
+    names = {snapshot.nodes[i].name: i for i in candidates}
+    idx = [names[n] for n in nodes_to_remove if n in names]      # mapNodes: the chosen nodes that are still candidates
+    if not idx:
+        return False
+    sink = []
+    compute_consolidation(snapshot, idx, sink)                   # (errCandidateNodeDeleting propagates as the error it is in the reference)
+    res = sink[0]
+    for j, n in enumerate(snapshot.nodes):                       # simulateScheduling's own readiness rule (helpers.go:102-111) -> allPodsScheduled = false
+        if j not in set(idx) and j not in set(getattr(snapshot, "deleting", ())) and n.in_state and n.owned and n.labels.get("karpenter.sh/initialized") != "true":
+            return False
+    if res.unscheduled:
+        return False
+    if not res.new_nodes:
+        return not replacement_types
+    if len(res.new_nodes) > 1 or not replacement_types:
+        return False
+    return instance_types_are_subset(replacement_types, res.new_nodes[0].instance_types)
 
 
 def filter_out_same_type(snapshot, options, reqs, cand_idx):

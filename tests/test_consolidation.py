@@ -429,3 +429,44 @@ def test_a_deleting_candidate_is_passed_over():
     assert C.replacement_command(snap, [0, 1], simulate=_oracle_simulate) == want
     snap.deleting = (0, 1)
     assert CR.replacement_command(snap, [0, 1]) == ("do-nothing", [], []) == C.replacement_command(snap, [0, 1], simulate=_oracle_simulate)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Validation.ValidateCommand: the fourth caller of simulateScheduling (validation.go:109-172)
+# ---------------------------------------------------------------------------------------------------------------------
+def _both_validate(snap, cmd, cands):
+    a = CR.validate_command(snap, cmd.action, cmd.nodes_to_remove, cmd.replacement_types, cands)
+    b = C.validate_command(snap, cmd, cands, simulate=_oracle_simulate)
+    assert a == b
+    return a
+
+
+def test_commands_are_validated_against_the_cluster_as_it_is_now():
+    """A command computed a TTL ago is simulated again before it runs ("should not consolidate if the action becomes invalid during the node TTL wait",
+    suite_test.go:2338-2395, is the reference's case of it): still valid on an unchanged cluster; invalid once the simulation needs another node count, a
+    node type outside the command's options, or leaves a pod unscheduled."""
+    snap, cands, _ = scenarios()["can_delete_nodes"]
+    cmd = C.Command(*CR.compute_consolidation(snap, cands)[:2])
+    assert cmd.action == "delete" and _both_validate(snap, cmd, cands)
+    snap.bound[1].extend(pod(f"late-{i}", "6") for i in range(5))        # pods arrived on the other node meanwhile: n1's pod no longer fits beside them
+    snap.nodes[1].available = dict(snap.nodes[1].available, cpu="1")
+    snap.bound[0][0] = pod("p1", "2")
+    assert not _both_validate(snap, cmd, cands)                           # the delete would now need a new node
+
+    snap, cands, _ = scenarios()["can_replace_node"]
+    action, removed, options, reqs = CR.compute_consolidation(snap, cands)
+    cmd = C.Command(action, removed, options)
+    assert action == "replace" and _both_validate(snap, cmd, cands)       # the simulation lists MORE types (no price filter): the command's are a subset
+    wrong = C.Command(action, removed, ["no-such-type"])
+    assert not _both_validate(snap, wrong, cands)                          # a type the simulation does not offer
+    assert not _both_validate(snap, C.Command("delete", removed), cands)   # expected no node, the simulation wants one
+    assert not _both_validate(snap, cmd, [])                               # none of the command's nodes is a candidate any more
+    snap.bound[0].append(pod("huge", "100000"))                            # a pod nothing can hold: not all pods schedule
+    assert not _both_validate(snap, cmd, cands)
+
+    snap, cands, _, _ = multi_scenarios()["merge_3_into_1"]
+    got = CR.first_n_node_consolidation_option(snap, cands)
+    cmd = C.Command(got[0], got[1], got[2])
+    assert got[0] == "replace" and _both_validate(snap, cmd, cands)
+    snap.bound[0].extend(pod(f"more-{i}", "20") for i in range(3))         # the three nodes now need more than one replacement
+    assert not _both_validate(snap, cmd, cands)
