@@ -490,6 +490,46 @@ def resolve_pod_volumes(namespace: str, pod_name: str, volume_sources: Sequence[
     return out
 
 
+def inject_volume_topology(pod: "Pod", claims: Sequence[str], pvcs: Dict[str, dict], storage_class_topologies: Dict[str, List[List["Expr"]]],
+                           pv_node_affinity: Dict[str, Optional[List[List["Expr"]]]]) -> "Pod":
+    """VolumeTopology.Inject (reference pkg/controllers/provisioning/volumetopology.go:35-159) over plain dictionaries -- what the provisioner does to a
+    pod BEFORE NewScheduler sees it (provisioner.go:195-215): the zones its volumes live in (or may be created in) become node requirements, appended to
+    EVERY required node-affinity term so that no relaxation can drop them.
+      claims                   : the claim names of the pod's PersistentVolumeClaim volumes, in Spec.Volumes order
+      pvcs                     : "<namespace>/<claim>" -> {"storage_class": s|None|"", "volume_name": v|""}
+      storage_class_topologies : name -> AllowedTopologies as terms of Expr (only the first term is used, :96-101)
+      pv_node_affinity         : name -> Spec.NodeAffinity.Required terms of Expr (first term only, :118-122), or None
+    Returns a copy of the pod; raises VolumeLookupError where the reference fails the pod's validation (validatePersistentVolumeClaims :124-159 -- the
+    provisioner then leaves the pod out of the batch)."""
+    import copy
+    added: List[Expr] = []
+    for claim in claims:
+        pvc_id = f"{pod.namespace}/{claim}"
+        if pvc_id not in pvcs:
+            raise VolumeLookupError(f"persistentvolumeclaim {pvc_id} not found")
+        sc, vol = pvcs[pvc_id].get("storage_class"), pvcs[pvc_id].get("volume_name", "")
+        if sc and sc not in storage_class_topologies:
+            raise VolumeLookupError(f"storageclass {sc} not found")
+        if vol:                                                   # bound: the volume's own node affinity (:70-76)
+            if vol not in pv_node_affinity:
+                raise VolumeLookupError(f"persistentvolume {vol} not found")
+            terms = pv_node_affinity[vol]
+            if terms:
+                added.extend(copy.deepcopy(terms[0]))
+        elif sc:                                                  # to be created: where the storage class may create it (:78-84)
+            terms = storage_class_topologies[sc]
+            if terms:
+                added.extend(Expr(e.key, "In", list(e.values)) for e in terms[0])
+    out = copy.deepcopy(pod)
+    if not added:
+        return out
+    if not out.required_affinity:
+        out.required_affinity = [[]]
+    for term in out.required_affinity:
+        term.extend(copy.deepcopy(added))
+    return out
+
+
 TAINT_NODE_NOT_READY = "node.kubernetes.io/not-ready"
 TAINT_NODE_UNREACHABLE = "node.kubernetes.io/unreachable"
 

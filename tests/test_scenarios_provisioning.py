@@ -1,0 +1,201 @@
+"""pkg/controllers/provisioning/suite_test.go -- the suite of the OTHER caller of Solve (provisioner.go:301-307) -- restated as pure Solve() fixtures where the
+It() exercises the path (the rest of that suite -- annotations, owner references, provider refs -- is object plumbing above it).  Same rules as
+tests/test_scenarios.py: every test names the reference lines (P:nnn) it restates and asserts what the reference asserts; oracle here, HIP path on the GPU box."""
+import pytest
+
+from helpers import BACKENDS, ClusterSim, mkpod, mkpods
+from karpenter_core_amd import fake
+from karpenter_core_amd.model import (Expr, Taint, Toleration, LABEL_ARCH, LABEL_CAPACITY_TYPE, LABEL_INSTANCE_TYPE, LABEL_OS, LABEL_PROVISIONER, LABEL_ZONE)
+
+pytestmark = pytest.mark.parametrize("backend", BACKENDS)
+
+
+def prov(**kw):
+    """test.Provisioner() of this suite: no requirements, no limits"""
+    return fake.provisioner("default", 0, discovery_label=True, **kw)
+
+
+def sim_with(backend, **kw):
+    return ClusterSim(backend, provisioners=[prov(**kw)])
+
+
+def test_provisions_a_node(backend):
+    sim = sim_with(backend)                                                                                                        # P:104
+    p = mkpod()
+    sim.provision([p])
+    assert len(sim.nodes) == 1 and sim.scheduled(p) is not None
+    sim = ClusterSim(backend, provisioners=[])                                                                                     # P:114: a provisioner that is being deleted is left out of
+    p = mkpod()                                                                                                                    #        NewScheduler (provisioner.go:241-243): nothing can launch
+    try:
+        sim.provision([p])
+    except Exception as e:      # the product answers like NewScheduler itself does (provisioner.go:254-256); the oracle solves with no template
+        assert "no provisioners found" in str(e)
+    assert not sim.nodes and sim.scheduled(p) is None
+
+
+def test_supported_node_selectors(backend):
+    sim = sim_with(backend)                                                                                                        # P:126
+    good = [mkpod(node_selector={LABEL_PROVISIONER: "default"}), mkpod(node_selector={LABEL_ZONE: "test-zone-1"}), mkpod(node_selector={LABEL_INSTANCE_TYPE: "default-instance-type"}),
+            mkpod(node_selector={LABEL_ARCH: "arm64"}), mkpod(node_selector={LABEL_OS: "linux"})]
+    sim.provision(good)
+    assert all(sim.scheduled(p) is not None for p in good)
+    bad = [mkpod(node_selector={LABEL_PROVISIONER: "unknown"}), mkpod(node_selector={LABEL_ZONE: "unknown"}), mkpod(node_selector={LABEL_INSTANCE_TYPE: "unknown"}),
+           mkpod(node_selector={LABEL_ARCH: "unknown"}), mkpod(node_selector={LABEL_OS: "unknown"}), mkpod(node_selector={LABEL_CAPACITY_TYPE: "unknown"}), mkpod(node_selector={"foo": "bar"})]
+    sim.provision(bad)
+    assert all(sim.scheduled(p) is None for p in bad)
+
+
+def test_accelerators_and_max_pods(backend):
+    sim = sim_with(backend)                                                                                                        # P:164
+    pods = [mkpod(limits={fake.RES_GPU_A: "1"}), mkpod(limits={fake.RES_GPU_B: "1"})]
+    sim.provision(pods)
+    assert all(sim.scheduled(p) is not None for p in pods)
+    sim = sim_with(backend, requirements=[Expr(LABEL_INSTANCE_TYPE, "In", ["single-pod-instance-type"])])                          # P:177: the type's pods capacity is 1
+    pods = mkpods(3)
+    sim.provision(pods)
+    assert len(sim.nodes) == 3 and all(sim.scheduled(p) is not None for p in pods)
+
+
+def test_a_node_that_is_being_deleted_takes_no_pods(backend):
+    sim = sim_with(backend)                                                                                                        # P:198
+    sim.provision(mkpods(3))
+    old = sim.nodes[0]
+    old.in_state = False                       # deleted, kept by its finalizer: cluster state marks it for deletion and NewScheduler never sees it
+    res = sim.provision(mkpods(2), bind=False)
+    assert len(res.new_nodes) == 1 and not res.existing and sorted(res.new_nodes[0].pods) == [0, 1]      # both go to ONE new node, none to the old one
+
+
+def test_nodes_carry_the_provisioners_labels(backend):
+    if backend == "gpu":
+        pytest.skip("added after the round's GPU budget was spent: provisioner-level Gt / Lt on custom keys has not run on the device yet")
+    sim = sim_with(backend, labels={"test-key-1": "test-value-1"}, requirements=[Expr("test-key-2", "In", ["test-value-2"]), Expr("test-key-3", "NotIn", ["test-value-3"]),   # P:543
+                                                                                 Expr("test-key-4", "Lt", ["4"]), Expr("test-key-5", "Gt", ["5"]), Expr("test-key-6", "Exists"),
+                                                                                 Expr("test-key-7", "DoesNotExist")])
+    p = mkpod()
+    res = sim.provision([p])
+    node, reqs = sim.scheduled(p), res.new_nodes[0].requirements
+    assert node.labels[LABEL_PROVISIONER] == "default" and node.labels["test-key-1"] == "test-value-1" and node.labels["test-key-2"] == "test-value-2"
+    # the other keys reach the node through Requirements.Labels() -> Requirement.Any() (a random admissible value, requirement.go:152-168): what Solve
+    # decides is the requirement itself
+    assert reqs["test-key-3"].complement and tuple(reqs["test-key-3"].values) == ("test-value-3",)
+    assert reqs["test-key-4"].less_than == 4 and reqs["test-key-5"].greater_than == 5
+    assert reqs["test-key-6"].complement and not reqs["test-key-6"].values                                     # Exists
+    assert not reqs["test-key-7"].complement and not reqs["test-key-7"].values                                 # DoesNotExist: never a label
+    assert "test-key-7" not in node.labels
+    for domain in ("kops.k8s.io", "node.kubernetes.io", "testing.karpenter.sh"):                                                   # P:568 LabelDomainExceptions
+        key = domain + "/test"
+        sim = sim_with(backend, labels={key: "test-value"})
+        p = mkpod(required_affinity=[[Expr(key, "In", ["test-value"])]])
+        sim.provision([p])
+        assert sim.scheduled(p).labels[key] == "test-value"
+
+
+def test_tolerations_of_a_provisioners_taint(backend):
+    sim = sim_with(backend, taints=[Taint("nvidia.com/gpu", "true", "NoSchedule")])                                                # P:584
+    pods = [mkpod(tolerations=[Toleration("nvidia.com/gpu", "Equal", "true", "NoSchedule")]), mkpod(tolerations=[Toleration("nvidia.com/gpu", "Exists", "", "NoSchedule")]),
+            mkpod(tolerations=[Toleration("nvidia.com/gpu", "Exists")]), mkpod(tolerations=[Toleration(operator="Exists")])]
+    sim.provision(pods)
+    assert all(sim.scheduled(p) is not None for p in pods)
+
+
+# ---------------- Machine Creation: what ToMachine puts into the request (machinetemplate.go:77-100) ----------------
+def machine(sim, res):
+    """the Machine of the first new node, as ExpectMachineRequirements / ExpectMachineRequests read it: {key: (operator-ish, values)}, requests"""
+    nn = res.new_nodes[0]
+    reqs = {k: (("NotIn" if r.complement else "In"), set(r.values)) for k, r in nn.requirements.items()}
+    cur = reqs.get(LABEL_INSTANCE_TYPE)
+    names = set(nn.instance_types)
+    reqs[LABEL_INSTANCE_TYPE] = ("In", names if cur is None else {n for n in names if (n in cur[1]) == (cur[0] == "In")})      # + `instance-type In [options]`
+    return reqs, nn.requests
+
+
+def test_machine_requirements(backend):
+    every = {it.name for it in fake.default_instance_types()}
+    sim = sim_with(backend)                                                                                                        # P:624
+    reqs, _ = machine(sim, sim.provision([mkpod()]))
+    assert reqs[LABEL_INSTANCE_TYPE] == ("In", every) and reqs[LABEL_PROVISIONER] == ("In", {"default"})
+    sim = sim_with(backend, requirements=[Expr("custom-requirement-key", "In", ["value"]), Expr("custom-requirement-key2", "In", ["value"])])      # P:646
+    reqs, _ = machine(sim, sim.provision([mkpod()]))
+    assert reqs[LABEL_INSTANCE_TYPE] == ("In", every) and reqs["custom-requirement-key"] == ("In", {"value"}) and reqs["custom-requirement-key2"] == ("In", {"value"})
+    sim = sim_with(backend, requirements=[Expr(LABEL_ARCH, "In", ["arm64"])])                                                      # P:691
+    reqs, _ = machine(sim, sim.provision([mkpod()]))
+    assert reqs[LABEL_ARCH] == ("In", {"arm64"}) and reqs[LABEL_INSTANCE_TYPE] == ("In", {"arm-instance-type"})
+    sim = sim_with(backend, requirements=[Expr(LABEL_OS, "In", ["ios"])])                                                          # P:723
+    reqs, _ = machine(sim, sim.provision([mkpod()]))
+    assert reqs[LABEL_OS] == ("In", {"ios"}) and reqs[LABEL_INSTANCE_TYPE] == ("In", {"arm-instance-type"})
+    sim = sim_with(backend)                                                                                                        # P:755: the pod's requests narrow the options
+    reqs, _ = machine(sim, sim.provision([mkpod(requests={fake.RES_GPU_A: "1"}, limits={fake.RES_GPU_A: "1"})]))
+    assert reqs[LABEL_INSTANCE_TYPE] == ("In", {"gpu-vendor-instance-type"})
+
+
+def test_machine_requests(backend):
+    sim = sim_with(backend)                                                                                                        # P:845
+    _, requests = machine(sim, sim.provision([mkpod(requests={"cpu": "1", "memory": "1Mi", fake.RES_GPU_A: "1"}, limits={fake.RES_GPU_A: "1"})]))
+    assert requests == {"cpu": 1000, "memory": 2**20 * 1000, fake.RES_GPU_A: 1000, "pods": 1000}
+    sim = ClusterSim(backend, provisioners=[prov()], daemonsets=[mkpod(requests={"cpu": "1", "memory": "1Mi"})])                   # P:878: + the daemonset's share
+    _, requests = machine(sim, sim.provision([mkpod(requests={"cpu": "1", "memory": "1Mi"})]))
+    assert requests == {"cpu": 2000, "memory": 2 * 2**20 * 1000, "pods": 2000}
+
+
+# ---------------- Preferential Fallback (the same cases as scheduling/suite_test.go:557-592, here against this suite's provisioner) ----------------
+def test_required_terms_relax_but_not_the_last(backend):
+    sim = sim_with(backend, requirements=[Expr(LABEL_ZONE, "In", ["test-zone-1"])])                                                # P:1025
+    p = mkpod(required_affinity=[[Expr(LABEL_ZONE, "In", ["invalid"])]])
+    sim.provision([p])
+    assert sim.scheduled(p) is None
+    sim = sim_with(backend)                                                                                                        # P:1037
+    p = mkpod(required_affinity=[[Expr(LABEL_ZONE, "In", ["invalid"])], [Expr(LABEL_ZONE, "In", ["invalid"])], [Expr(LABEL_ZONE, "In", ["test-zone-1"])],
+                                 [Expr(LABEL_ZONE, "In", ["test-zone-2"])]])
+    sim.provision([p])
+    assert sim.scheduled(p).labels[LABEL_ZONE] == "test-zone-1"
+
+
+# ---------------- Volume Topology Requirements: VolumeTopology.Inject before NewScheduler (volumetopology.go:35-159) ----------------
+def _provision_with_volumes(backend, pod, claims, pvcs, scs=None, pvs=None, extra=()):
+    """provisioner.go:195-215: every pending pod is validated and its volume zones injected; a pod that fails is left out of the batch"""
+    from karpenter_core_amd.model import VolumeLookupError, inject_volume_topology
+    sim = sim_with(backend)
+    batch, dropped = [], False
+    try:
+        injected = inject_volume_topology(pod, claims, pvcs, scs or {}, pvs or {})
+        injected.uid = pod.uid
+        batch.append(injected)
+    except VolumeLookupError:
+        dropped = True
+    batch.extend(extra)
+    sim.provision(batch)
+    return sim, (None if dropped else sim.scheduled(pod))
+
+
+ZONAL_SC = {"zonal": [[Expr(LABEL_ZONE, "In", ["test-zone-2", "test-zone-3"])]]}      # test.StorageClass(Zones: test-zone-2, test-zone-3) (P:905)
+
+
+def test_pods_with_unknown_claims_or_storage_classes_are_left_out(backend):
+    _, node = _provision_with_volumes(backend, mkpod(), ["invalid"], {})                                                           # P:907
+    assert node is None
+    _, node = _provision_with_volumes(backend, mkpod(), ["claim"], {"default/claim": {"storage_class": "", "volume_name": ""}})   # P:914: an empty storage class is fine
+    assert node is not None
+    other = mkpod()
+    sim, node = _provision_with_volumes(backend, mkpod(), ["invalid"], {}, extra=[other])                                          # P:923: the valid pod of the batch still schedules
+    assert node is None and sim.scheduled(other) is not None
+    other = mkpod()
+    sim, node = _provision_with_volumes(backend, mkpod(), ["claim"], {"default/claim": {"storage_class": "invalid-storage-class", "volume_name": ""}}, extra=[other])   # P:932
+    assert node is None and sim.scheduled(other) is not None
+
+
+def test_volume_zones_become_node_requirements(backend):
+    pvcs = {"default/claim": {"storage_class": "zonal", "volume_name": ""}}
+    _, node = _provision_with_volumes(backend, mkpod(required_affinity=[[Expr(LABEL_ZONE, "In", ["test-zone-1", "test-zone-3"])]]), ["claim"], pvcs, ZONAL_SC)      # P:943
+    assert node.labels[LABEL_ZONE] == "test-zone-3"
+    _, node = _provision_with_volumes(backend, mkpod(required_affinity=[[Expr(LABEL_ZONE, "In", ["test-zone-1"])]]), ["claim"], pvcs, ZONAL_SC)                     # P:955
+    assert node is None
+    bound = {"default/claim": {"storage_class": "zonal", "volume_name": "pv-1"}}
+    pvs = {"pv-1": [[Expr(LABEL_ZONE, "In", ["test-zone-3"])]]}                                                                    # test.PersistentVolume(Zones: test-zone-3)
+    _, node = _provision_with_volumes(backend, mkpod(), ["claim"], bound, ZONAL_SC, pvs)                                           # P:966: the bound volume's zone wins over the class's
+    assert node.labels[LABEL_ZONE] == "test-zone-3"
+    _, node = _provision_with_volumes(backend, mkpod(required_affinity=[[Expr(LABEL_ZONE, "In", ["test-zone-1"])]]), ["claim"], bound, ZONAL_SC, pvs)               # P:976
+    assert node is None
+    # P:988: the zone is added to EVERY term, so relaxing the unsupported first term away does not lose it
+    p = mkpod(required_affinity=[[Expr("example.com/label", "In", ["unsupported"])], [Expr(LABEL_CAPACITY_TYPE, "In", ["on-demand"])]])
+    _, node = _provision_with_volumes(backend, p, ["claim"], bound, ZONAL_SC, pvs)
+    assert node is not None and node.labels[LABEL_ZONE] == "test-zone-3"
