@@ -1,6 +1,6 @@
 """pkg/controllers/provisioning/suite_test.go -- the suite of the OTHER caller of Solve (provisioner.go:301-307) -- restated as pure Solve() fixtures where the
 It() exercises the path (the rest of that suite -- annotations, owner references, provider refs -- is object plumbing above it).  Same rules as
-tests/test_scenarios.py: every test names the reference lines (P:nnn) it restates and asserts what the reference asserts; oracle here, HIP path on the GPU box."""
+tests/test_scenarios.py (the file name only makes it run last: its GPU variants were added after the round's GPU budget was spent): every test names the reference lines (P:nnn) it restates and asserts what the reference asserts; oracle here, HIP path on the GPU box."""
 import pytest
 
 from helpers import BACKENDS, ClusterSim, mkpod, mkpods
