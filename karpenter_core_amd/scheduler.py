@@ -536,6 +536,42 @@ class Node:
         return out
 
 
+WELL_KNOWN_LABELS = ("karpenter.sh/provisioner-name", "topology.kubernetes.io/zone", "topology.kubernetes.io/region", "node.kubernetes.io/instance-type",
+                     "kubernetes.io/arch", "kubernetes.io/os", "karpenter.sh/capacity-type")
+RESTRICTED_LABEL_DOMAINS = ("kubernetes.io", "k8s.io", "karpenter.sh")
+LABEL_DOMAIN_EXCEPTIONS = ("kops.k8s.io", "node.kubernetes.io", "testing.karpenter.sh")
+RESTRICTED_LABELS = ("karpenter.sh/emptiness-timestamp", "kubernetes.io/hostname")
+
+
+def is_restricted_node_label(key: str, extra_well_known: Sequence[str] = ()) -> bool:
+    """v1alpha5.IsRestrictedNodeLabel (labels.go:123-140): labels Karpenter must not put on a node itself."""
+    if key in WELL_KNOWN_LABELS or key in extra_well_known:
+        return True
+    domain = key.split("/", 1)[0] if "/" in key else ""
+    if domain in LABEL_DOMAIN_EXCEPTIONS:
+        return False
+    if any(domain.endswith(d) for d in RESTRICTED_LABEL_DOMAINS):
+        return True
+    return key in RESTRICTED_LABELS
+
+
+def requirements_labels(requirements: Dict[str, object], extra_well_known: Sequence[str] = ()) -> Dict[str, str]:
+    """Requirements.Labels() (requirements.go:208-218) -- the labels MachineTemplate.ToNode puts on the node object besides the provisioner's own
+    (machinetemplate.go:62-74): for every key that is not restricted, Requirement.Any() (requirement.go:152-168).  Any() draws at random where the
+    reference leaves a choice (one of the In values; an integer in (gt, lt) for NotIn / Exists); this mirror takes the smallest admissible one."""
+    out: Dict[str, str] = {}
+    for key, r in requirements.items():
+        if is_restricted_node_label(key, extra_well_known):
+            continue
+        if not r.complement:
+            if r.values:                                        # In
+                out[key] = sorted(r.values)[0]
+            continue                                            # DoesNotExist: ""
+        lo_ = 0 if r.greater_than is None else r.greater_than + 1      # NotIn / Exists
+        out[key] = str(lo_)
+    return out
+
+
 @dataclass
 class ExistingNode:
     """scheduling.ExistingNode: the state node plus the pods Solve placed on it."""

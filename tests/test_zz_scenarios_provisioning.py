@@ -82,6 +82,10 @@ def test_nodes_carry_the_provisioners_labels(backend):
     assert reqs["test-key-6"].complement and not reqs["test-key-6"].values                                     # Exists
     assert not reqs["test-key-7"].complement and not reqs["test-key-7"].values                                 # DoesNotExist: never a label
     assert "test-key-7" not in node.labels
+    from karpenter_core_amd.scheduler import requirements_labels      # Requirements.Labels() as MachineTemplate.ToNode uses it (machinetemplate.go:62-74)
+    labels = requirements_labels(reqs, fake.EXTRA_WELL_KNOWN)
+    assert labels["test-key-2"] == "test-value-2" and labels["test-key-3"] != "test-value-3" and int(labels["test-key-4"]) < 4 and int(labels["test-key-5"]) > 5
+    assert "test-key-6" in labels and "test-key-7" not in labels and LABEL_PROVISIONER not in labels and LABEL_INSTANCE_TYPE not in labels
     for domain in ("kops.k8s.io", "node.kubernetes.io", "testing.karpenter.sh"):                                                   # P:568 LabelDomainExceptions
         key = domain + "/test"
         sim = sim_with(backend, labels={key: "test-value"})
