@@ -93,3 +93,26 @@ def test_node_selector_requirement_conversion():
     }
     for name, (req, expect) in want.items():
         assert req.node_selector_requirement() == expect, name
+
+
+def test_requirement_any():
+    """Requirement.Any as Requirements.Labels() uses it (requirement.go:152-168), pinned by requirement_test.go:408-425.  The reference draws at random where
+    it has a choice; the mirror (scheduler.requirements_labels) takes the smallest admissible value -- every assertion of the reference's test must hold."""
+    from karpenter_core_amd.model import RequirementOut as R
+    from karpenter_core_amd.scheduler import requirements_labels
+
+    def any_of(req):
+        return requirements_labels({"key": req}).get("key", "")
+    assert any_of(R("key", True, (), None, None)) != ""                     # exists
+    assert any_of(R("key", False, (), None, None)) == ""                    # doesNotExist
+    assert any_of(R("key", False, ("A",), None, None)) == "A" and any_of(R("key", False, ("B",), None, None)) == "B"
+    assert any_of(R("key", False, ("B", "A"), None, None)) in ("A", "B")
+    assert any_of(R("key", True, ("A",), None, None)) not in ("", "A")      # notInA
+    assert any_of(R("key", False, ("1",), None, None)) == "1" and any_of(R("key", False, ("9",), None, None)) == "9"
+    assert any_of(R("key", False, ("9", "1"), None, None)) in ("1", "9")
+    assert any_of(R("key", True, ("2", "1"), None, None)) not in ("", "1", "2")      # notIn12
+    assert int(any_of(R("key", True, (), 1, None))) >= 1 and 9 <= int(any_of(R("key", True, (), 9, None))) < 2**63 - 1
+    assert any_of(R("key", True, (), None, 1)) == "0" and 0 <= int(any_of(R("key", True, (), None, 9))) < 9
+    # a restricted key never becomes a label (Requirements.Labels, requirements.go:208-218)
+    assert requirements_labels({"kubernetes.io/hostname": R("kubernetes.io/hostname", False, ("n1",), None, None), "topology.kubernetes.io/zone": R("z", False, ("z1",), None, None),
+                                "node.kubernetes.io/custom": R("c", False, ("v",), None, None)}) == {"node.kubernetes.io/custom": "v"}
