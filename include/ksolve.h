@@ -259,10 +259,13 @@ typedef struct ks_whatif_batch ks_whatif_batch;
  * candidate set is derived on the device too -- which groups exist from the start (owned by a pod of the batch: topology.go:72-78) and countDomains over
  * the cluster pods that stay (topology.go:231-276) -- from per-node tables of the snapshot: */
 typedef struct ks_whatif_topo {
-  const int32_t* node_cnt;    /* [G][n_nodes] pods on the node that group g counts when they are NOT in the batch (selector, namespace, node filter, key present) */
+  const int32_t* node_cnt;    /* [G][n_nodes] pods on the node that group g counts when they are NOT in the batch (selector, namespace, node filter, key present);
+                                              inverse anti-affinity groups (g >= n_topologies): the bound pods on the node that OWN the group (topology.go:181-199) */
   const int32_t* node_dom;    /* [G][n_nodes] the node's domain for group g: value id of its label on the group's key, -1 if none; hostname-keyed groups: the
                                               pods on the node the group counts that are in NO batch (they count under its hostname even when the node is a candidate) */
-  const uint64_t* node_own;   /* [n_nodes][ceil(G/64)] groups (bit g) some pod bound to the node owns at its first relaxation stage */
+  const uint64_t* node_own;   /* [n_nodes][ceil(G/64)] groups (bit g) some pod bound to the node owns at its first relaxation stage.  An inverse group EXISTS in a
+                                              what-if only while an owner is in the batch (this bit) or stays bound (a positive count); a value-keyed one that does not
+                                              exist is marked for the pack kernel's evaluation to skip, a hostname-keyed one without counts constrains nothing */
   const int32_t* tot;         /* [G][64]      node_cnt summed per domain over every node */
   const int32_t* extra_tot;   /* [GH]         hostname-keyed groups: nodes that are no existing row and count > 0 */
   const int32_t* grph_base;   /* [GH][E]      hostname-keyed groups: what every existing row counts while its node stays; 0 = registered without pods,
