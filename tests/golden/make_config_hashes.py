@@ -29,7 +29,7 @@ CASES = {
     "config2_10k_500": lambda: W.config2(),
     "config3_100k_2k": lambda: W.config3(),
     "config5_5k_types": lambda: W.config5(pods=CONFIG5_PODS, sizes=50, seed=46),     # 5 000 instance types, full constraint set
-    "config5_250k_5k_types": lambda: W.config5(pods=250_000, sizes=50, seed=46),     # the largest size the oracle finishes within the hour (1 M needs most of a day)
+    "config5_250k_5k_types": lambda: W.config5(pods=250_000, sizes=50, seed=46),     # 2 h 23 min of the oracle in the build container (1 M needs most of a day)
 }
 CONFIG5_PODS = 100_000
 
