@@ -12,15 +12,17 @@ from karpenter_core_amd.model import (Container, DO_NOT_SCHEDULE, Expr, LABEL_AR
                                       Pod, PodAffinityTerm, PreferredTerm, Problem, SCHEDULE_ANYWAY, TopologySpreadConstraint, WeightedPodAffinityTerm)
 from oracle import oracle_py as O
 
-MID_SEEDS = list(range(48))
+MID_SEEDS = list(range(72))
 
 
 def mid_problem(seed: int, family: str = "") -> Problem:
-    """family "": the committed seeds (0-11 base, 12-35 wide, 36-47 general); "base": this generator for any seed (tools/debug_fuzz_campaign.py)."""
-    if seed >= 36 and family != "base":
-        return mid_problem_general(seed)
-    if seed >= 12 and family != "base":
-        return mid_problem_wide(seed)
+    """family "": the committed seeds (0-11 and 48-55 base, 12-35 and 56-63 wide, 36-47 and 64-71 general); "base": this generator for any seed
+    (tools/debug_fuzz_campaign.py)."""
+    if family != "base":
+        if seed >= 64 or 36 <= seed < 48:
+            return mid_problem_general(seed)
+        if seed >= 56 or 12 <= seed < 36:
+            return mid_problem_wide(seed)
     rs = np.random.RandomState(31000 + seed)
     sizes = int(rs.randint(2, 7))                       # small types -> many nodes
     zone_sets = [[W.ZONES[0]], [W.ZONES[1]], [W.ZONES[2]], W.ZONES[:2], W.ZONES]
