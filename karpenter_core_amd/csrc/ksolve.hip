@@ -42,7 +42,11 @@
 #define KS_MAX_TOPO 24       // topology groups evaluated per pod class
 #define KS_MAX_TOUCH 12      // distinct narrow keys a class may touch (own requirements + topology + recorded keys)
 
+#ifdef KS_SIM      /* tests/sim/hip_sim.h: the kernels of this file run on the host, a fibre per lane (test infrastructure; hipcc never defines it) */
+struct u32x4 { unsigned int x, y, z, w; };
+#else
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#endif
 #define RL(v, l) ((u32)__builtin_amdgcn_readlane((int)(v), (l)))   /* broadcast from a wave-uniform lane: v_readlane, no LDS round trip */
 /* a value the program knows to be wave-uniform but the compiler cannot (it came out of LDS / global memory): move it to
    SGPRs so that branches on it are scalar branches and address arithmetic is scalar */
@@ -66,7 +70,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #else
 #define PROBE(i) do { (void)tprobe; } while (0)
 #endif
+#ifdef KS_SIM
+#define GA
+#else
 #define GA __attribute__((address_space(1)))   /* global address space: loads become global_load, not flat_load */
+#endif
 typedef uint64_t u64; typedef uint32_t u32; typedef uint16_t u16; typedef int64_t i64; typedef int32_t i32; typedef uint8_t u8;
 
 static thread_local std::string g_err;
@@ -118,6 +126,8 @@ struct DevProb {
   u8* mc_why;        // [M*C]  KS_WHY_* of a fresh node of template m refusing class c before the topology step (0 if mc_ok)
   u32* mc_present; u32* mc_complement; u64* mc_mask; i32* mc_gt; i32* mc_lt; i32* mc_it;   // template ∩ class
   u64* grid;         // [M*C*TW]
+  // register-resident pack kernel (ks_pack_rr.inc): per-class briefs (ks_build_rr), per-class cached answers, template x class -> nrc, the nrcs' type rows, the node hand-over
+  void* rr_briefs; u32* rr_memo; u8* rr_mcnrc; u64* rr_types; u64* rr_nodes;
 };
 
 // Mutable state of one Solve (device memory).
@@ -878,8 +888,13 @@ __device__ __forceinline__ void eval_node(const DevProb& P, const DevState& S, c
 //          once per pod (before the candidate scan re-reads node records) and on rare paths.
 //   __syncthreads(): hand-off between the waves of a multi-wave workgroup (speculation rounds).
 #define CTR(i, v) do { if (lane == 0 && wv == 0) ls.ctr[(i)] += (v); } while (0)
+#ifdef KS_SIM
+#define LSYNC() do { uint64_t pm_; (void)ks_sim::exchange(0, &pm_); } while (0)
+#define GSYNC() do { uint64_t pm_; (void)ks_sim::exchange(0, &pm_); } while (0)
+#else
 #define LSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define GSYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")   /* wave-local: only wave 0 runs the sequential path */
+#endif
 
 // Publish the winning lane's evaluation: scalars by v_readlane into wave-uniform registers (Pub), the per-key
 // requirements by one parallel LDS copy (lane i moves touch entry i).  Also decides whether the instance-type
@@ -1012,6 +1027,11 @@ __device__ __forceinline__ void topology_record(const DevProb& P, const DevState
 
 // Minimum of a 32-bit value over the wave, returned wave-uniform: four row shifts and two row broadcasts on the data-parallel-primitive
 // path (no LDS round trips), the result sits in lane 63.  Every lane takes part (callers pass 0xFFFFFFFF for lanes that do not count).
+#ifdef KS_SIM
+__device__ __forceinline__ u32 wave_min_u32(u32 v) { return ks_sim::wave_min_u32(v); }
+__device__ __forceinline__ u32 wave_or_u32(u32 v) { return ks_sim::wave_or_u32(v); }
+__device__ __forceinline__ i64 wave_max_i64(i64 v) { return ks_sim::wave_max_i64(v); }
+#else
 __device__ __forceinline__ u32 wave_min_u32(u32 v) {
   const int id = (int)0xFFFFFFFFu;
   v = min(v, (u32)__builtin_amdgcn_update_dpp(id, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
@@ -1041,6 +1061,7 @@ __device__ __forceinline__ u32 lanes8_min_u32(u32 v) {
   return (u32)__builtin_amdgcn_readlane((int)v, 7);
 }
 __device__ __forceinline__ i64 wave_max_i64(i64 v) { for (int off = 32; off > 0; off >>= 1) { const i64 o = __shfl_xor(v, off); if (o > v) v = o; } return v; }
+#endif
 
 // Stage the pod's class plan in LDS (one coalesced copy) and evaluate the per-pod, node-independent part
 // of its topology groups (domainMinCount, topologygroup.go:184-200).
@@ -1175,8 +1196,13 @@ template <bool FAST, bool BOUNDS, int NW, int RM> struct alignas(16) PackLds {
   alignas(16) unsigned char rc_raw[NW > 1 ? sizeof(RoundCtlT<RM>) : 16]; LeaderShared ls; typename std::conditional<FAST, FastTabs, NoTabs>::type ft; DevProb P; DevState S;
   alignas(16) unsigned char wbs_raw[BOUNDS ? sizeof(WaveBounds) * NW : 16]; WaveShared shw[NW];      // (no Gt/Lt anywhere in the problem: the bounds slots are never touched)
 };
+#ifdef KS_SIM
+static unsigned char ks_dyn_lds[160 * 1024] __attribute__((aligned(16)));
+#else
 extern __shared__ __attribute__((aligned(16))) unsigned char ks_dyn_lds[];
+#endif
 
+#ifndef KS_SIM      /* (the emulator runs the register-resident kernel only: ks_pack's DPP reductions and speculation rounds stay GPU-only) */
 // LEAN: no class has host ports, a hostname selector or an instance-type requirement, no provisioner has limits,
 // R <= 4 and no statistics are requested -- the code for all of that (and half of every unrolled resource loop) is
 // compiled out.  One wave issues ~1 instruction per 5 cycles, so instructions, not bytes, are what a Solve costs.
@@ -2631,6 +2657,9 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     if (S.batch_meta) { S.batch_meta[0] = nnew; S.batch_meta[1] = q_len; for (int i = 0; i < 32; ++i) S.batch_meta[2 + i] = S.stats[i]; }
   }
 }
+#endif      // !KS_SIM
+
+#include "ks_pack_rr.inc"
 
 // ------------------------------------------------------------------------------------------------
 // probe kernels (truth-table checks on the device)
@@ -2887,6 +2916,8 @@ static int upload_impl(const ks_problem* p, int device, const ks_dev_problem* ba
   TRY(dev_alloc(d, MC, &h.mc_ok, 0)); TRY(dev_alloc(d, MC, &h.mc_why, 0)); TRY(dev_alloc(d, MC, &h.mc_present)); TRY(dev_alloc(d, MC, &h.mc_complement));
   TRY(dev_alloc(d, MC * K, &h.mc_mask)); TRY(dev_alloc(d, MC * K, &h.mc_gt)); TRY(dev_alloc(d, MC * K, &h.mc_lt)); TRY(dev_alloc(d, MC, &h.mc_it));
   TRY(dev_alloc(d, MC * TW, &h.grid, 0));
+  { u8* rb = nullptr; TRY(dev_alloc(d, (size_t)C * sizeof(RRBrief), &rb)); h.rr_briefs = rb; TRY(dev_alloc(d, (size_t)C * (sizeof(RRMemo) / 4), &h.rr_memo)); TRY(dev_alloc(d, MC, &h.rr_mcnrc));
+    TRY(dev_alloc(d, (size_t)RR_NRC * TW, &h.rr_types)); TRY(dev_alloc(d, (size_t)RR_NODES * 5, &h.rr_nodes)); }
   // state
   DevState& s = d->hs; const size_t NS = (size_t)E + h.NMAX;
   TRY(dev_alloc(d, P, &s.q)); TRY(dev_alloc(d, P, &s.lastlen)); TRY(dev_alloc(d, P, &s.lastgen)); TRY(dev_alloc(d, P, &s.pod_stage)); TRY(dev_alloc(d, P, &s.pod_node)); TRY(dev_alloc(d, P, &s.pod_seq)); TRY(dev_alloc(d, P, &s.pod_reason));
@@ -3151,6 +3182,7 @@ static void launch_static(const DevProb* probs, u32 n, const StaticDims& a, u32 
     hipLaunchKernelGGL(ks_build_plans, dim3((a.C + 63) / 64, n), dim3(64), 0, st, probs);
     hipLaunchKernelGGL(ks_link_ev, dim3((a.C + 63) / 64, n), dim3(64), 0, st, probs);      // (ev_tab comes zero-filled from the upload; a repeated build finds its own entries again)
     hipLaunchKernelGGL(ks_link_plans, dim3((a.C + 63) / 64, n), dim3(64), 0, st, probs);
+    hipLaunchKernelGGL(ks_build_rr, dim3((a.C + 63) / 64, n), dim3(64), 0, st, probs);
   }
   if (a.RT) hipLaunchKernelGGL(ks_build_ge_rows, dim3((u32)(((size_t)a.RT * 64 + 255) / 256), n), dim3(256), 0, st, probs);
   if (before_grid) hipEventRecord(before_grid, st);
@@ -3314,6 +3346,28 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   bool bounds = false; for (u32 i = 0; i < n; ++i) bounds = bounds || ds[i]->any_bounds;
   bool lean = true; for (u32 i = 0; i < n; ++i) lean = lean && ds[i]->lean_ok;
   if (getenv("KS_NO_LEAN")) lean = false;      // test hook: run the general variant on a problem the LEAN one would take
+  // The register-resident kernel (ks_pack_rr.inc) takes a single LEAN Solve without Gt/Lt bounds; it declines what it does not cover -- before
+  // or during the run, without having touched the inputs -- and ks_pack below takes over.  KS_NO_RR=1: ks_pack only (A/B, and the parity of both).
+  bool rr_done = false;
+  if (n == 1 && lean && !bounds && fast && !ds[0]->view && !(ds[0]->h.flags & KS_FLAG_STATS) && !getenv("KS_NO_RR") && ds[0]->h.rr_briefs) {
+    const u32 lds_rr = 44u * 1024u;
+    {
+      static std::mutex rr_mu; static std::vector<char> rr_attr;
+      std::lock_guard<std::mutex> g(rr_mu);
+      if ((size_t)device >= rr_attr.size()) rr_attr.resize(device + 1, 0);
+      if (!rr_attr[device]) { HIPCHK(hipFuncSetAttribute((const void*)ks_pack_rr, hipFuncAttributeMaxDynamicSharedMemorySize, 44 * 1024)); rr_attr[device] = 1; }
+    }
+    hipLaunchKernelGGL(ks_pack_rr, dim3(1), dim3(64 * RR_NW), lds_rr, st, dp, dsv, lds_rr);
+    u64 rr_err = 0;
+    HIPCHK(hipMemcpyAsync(&rr_err, ds[0]->hs.stats + KS_STAT_ERR, sizeof rr_err, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    rr_done = rr_err != KS_RR_DECLINED;
+  }
+#ifdef KS_SIM
+  if (!rr_done) return fail(KS_ERR_UNSUPPORTED, "emulator build: the problem is outside what ks_pack_rr covers (ks_pack is not emulated)");
+#else
+  if (!rr_done) {
   typedef void (*pack_fn)(const DevProb*, const DevState*, u32);
   static const pack_fn variants[8] = {ks_pack<false, false, false, 1>, ks_pack<false, true, false, 1>, ks_pack<true, false, false, 1>, ks_pack<true, true, false, 1>,
                                       ks_pack<false, false, true, 1>, ks_pack<false, true, true, 1>, ks_pack<true, false, true, 1>, ks_pack<true, true, true, 1>};
@@ -3343,6 +3397,8 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
     }
   }
   if (!multi) hipLaunchKernelGGL(variants[(lean ? 4 : 0) + (fast ? 2 : 0) + (bounds ? 1 : 0)], dim3(n), dim3(64), lds_bytes, st, dp, dsv, lds_bytes);
+  }
+#endif
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
