@@ -33,7 +33,7 @@ constexpr size_t kStack = 512 * 1024;
 constexpr unsigned kMaxThreads = 1024;
 enum Wait { RUN = 0, WAVE = 1, BLOCK = 2, DONE = 3 };
 struct Wave { uint64_t vals[2][64]; uint64_t present[2]; unsigned arrived = 0, gen = 0, nlive = 0; };
-struct Fiber { void* sp = nullptr; Wait wait = RUN; unsigned waitgen = 0; unsigned tid = 0; unsigned wgen = 0; };
+struct Fiber { void* sp = nullptr; Wait wait = RUN; unsigned waitgen = 0; unsigned tid = 0; unsigned wgen = 0; void* site = nullptr; };
 struct Block {
   std::vector<Fiber> f; std::vector<Wave> w; unsigned nthreads = 0, b_arrived = 0, b_gen = 0, b_nlive = 0;
   const std::function<void()>* body = nullptr; void* sched_sp = nullptr; unsigned cur = 0;
@@ -70,6 +70,7 @@ int lane_id() { return (int)(g_blk->cur & 63u); }
 
 const uint64_t* exchange(uint64_t v, uint64_t* present) {
   Block& B = *g_blk; Fiber& me = B.f[B.cur]; Wave& W = B.w[me.tid >> 6];
+  me.site = __builtin_return_address(0);
   const unsigned par = me.wgen & 1u, lane = me.tid & 63u;
   if (W.arrived == 0) W.present[par] = 0;
   W.vals[par][lane] = v; W.present[par] |= 1ull << lane;
@@ -83,6 +84,7 @@ const uint64_t* exchange(uint64_t v, uint64_t* present) {
 
 void block_barrier() {
   Block& B = *g_blk; Fiber& me = B.f[B.cur];
+  me.site = __builtin_return_address(0);
   const unsigned g = B.b_gen;
   if (++B.b_arrived == B.b_nlive) { B.b_arrived = 0; ++B.b_gen; }
   else { me.wait = BLOCK; me.waitgen = g; yield_to_sched(); me.wait = RUN; }
@@ -133,6 +135,9 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
       if (!any && done < nthreads) {
         fprintf(stderr, "ks_sim: deadlock in block (%u,%u,%u): %u of %u threads finished; a collective was reached in divergent control flow, or a barrier is missing a wave\n", bx, by, bz, done, nthreads);
         for (unsigned t = 0; t < nthreads; ++t) if (B.f[t].wait != DONE) { fprintf(stderr, "  first stuck thread %u: wait kind %d\n", t, (int)B.f[t].wait); break; }
+        for (unsigned w = 0; w < nw; ++w) { unsigned c[4] = {0, 0, 0, 0}; for (unsigned t = w * 64; t < std::min(nthreads, w * 64 + 64); ++t) c[(int)B.f[t].wait]++; fprintf(stderr, "  wave %u: %u runnable, %u at a wave collective, %u at the block barrier, %u done\n", w, c[0], c[1], c[2], c[3]);
+          if (c[1] && c[2]) { std::map<void*, unsigned> sites; for (unsigned t = w * 64; t < std::min(nthreads, w * 64 + 64); ++t) sites[B.f[t].site]++; for (auto& kv : sites) { if (kv.second <= 4) for (unsigned t = w * 64; t < std::min(nthreads, w * 64 + 64); ++t) if (B.f[t].site == kv.first) fprintf(stderr, "    (lane %u)\n", t & 63); } for (auto& kv : sites) fprintf(stderr, "    %u lanes wait at call site %p (addr2line -e <libksolve.so> <that minus the library's load address; /proc/self/maps below>)\n", kv.second, kv.first); } }
+        { FILE* mf = fopen("/proc/self/maps", "r"); char ln[512]; while (mf && fgets(ln, sizeof ln, mf)) if (strstr(ln, "libksolve") && strstr(ln, "r-xp")) fputs(ln, stderr); if (mf) fclose(mf); }
         abort();
       }
     }

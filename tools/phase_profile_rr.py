@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Round statistics of the register-resident pack kernel (ks_pack_rr) on config #3 and, with a KS_PROBES build, where a round's cycles go.
+usage: tools/phase_profile_rr.py [pods]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from karpenter_core_amd import scheduler as S, workloads as W
+
+pods = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+pr = W.config3(pods=pods)
+fp = S.FlatProblem(pr)
+fp.upload(0)
+fp.grid(want_bits=False)
+fp.solve(decode=False)
+r = fp.solve()
+st = r.stats
+tot = st["kernel_cycles"]
+rounds = max(st["eq_pods"], 1)
+print("kernel_ms", fp.kernel_ms, "nodes", len(r.new_nodes), "cycles", tot, "per pod", tot / pods)
+print("rounds", st["eq_pods"], "evaluating", st["reuse_exhausted"], "bubbles", st["reuse_seeds"], "phase A runs", st["reuse_hits"], "nrcs", st["cyc_pop"], "exact checks", st["cyc_stage"])
+names = [("leader: barrier wait", "cyc_evalout"), ("leader: winner", "cyc_full"), ("leader: resolve A", "cyc_commit"), ("leader: queue entry + brief", "cyc_order"),
+         ("leader: phase A + memo", "cyc_new"), ("leader: header", "p20"), ("worker 1: barrier wait", "p22"), ("worker 1: winner", "p23"),
+         ("worker 1: commit", "p24"), ("worker 1: evaluate", "p25"), ("worker 1: reduce + publish", "p26")]
+for nm, k in names:
+    print(f"{nm:32s} {st.get(k, 0) / rounds:9.0f} cycles / round")
