@@ -19,8 +19,8 @@ tot = st["kernel_cycles"]
 rounds = max(st["eq_pods"], 1)
 print("kernel_ms", fp.kernel_ms, "nodes", len(r.new_nodes), "cycles", tot, "per pod", tot / pods)
 print("rounds", st["eq_pods"], "evaluating", st["reuse_exhausted"], "bubbles", st["reuse_seeds"], "phase A runs", st["reuse_hits"], "nrcs", st["cyc_pop"], "exact checks", st["cyc_stage"])
-names = [("leader: barrier wait", "cyc_evalout"), ("leader: winner", "cyc_full"), ("leader: resolve A", "cyc_commit"), ("leader: queue entry + brief", "cyc_order"),
-         ("leader: phase A + memo", "cyc_new"), ("leader: header", "p20"), ("worker 1: barrier wait", "p22"), ("worker 1: winner", "p23"),
-         ("worker 1: commit", "p24"), ("worker 1: evaluate", "p25"), ("worker 1: reduce + publish", "p26")]
+names = [("leader: form the batch", "cyc_evalout"), ("leader: wait at B1", "cyc_full"), ("leader: prepare entries", "cyc_commit"), ("leader: picks (+ records)", "cyc_order"),
+         ("leader: resolve", "cyc_new"), ("worker 1: wait at B1", "p22"), ("worker 1: leader's order", "p23"),
+         ("worker 1: evaluate", "p24"), ("worker 1: picks", "p25"), ("worker 1: commit", "p26")]
 for nm, k in names:
     print(f"{nm:32s} {st.get(k, 0) / rounds:9.0f} cycles / round")
