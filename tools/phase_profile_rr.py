@@ -22,5 +22,7 @@ print("rounds", st["eq_pods"], "evaluating", st["reuse_exhausted"], "bubbles", s
 names = [("leader: form the batch", "cyc_evalout"), ("leader: wait at B1", "cyc_full"), ("leader: prepare entries", "cyc_commit"), ("leader: picks (+ records)", "cyc_order"),
          ("leader: resolve", "cyc_new"), ("worker 1: wait at B1", "p22"), ("worker 1: leader's order", "p23"),
          ("worker 1: evaluate", "p24"), ("worker 1: picks", "p25"), ("worker 1: commit", "p26")]
+names += [("  form: entry lookup", "cyc_kind0"), ("  form: flags / masks", "cyc_kind1"), ("  form: cached answers", "cyc_kind2"), ("  form: dyn1 answers", "n_kind1")]
+print("dyn1 answers", st.get("full_fails"), "issued again", st.get("scan_chunks"))
 for nm, k in names:
     print(f"{nm:32s} {st.get(k, 0) / rounds:9.0f} cycles / round")
