@@ -19,10 +19,13 @@ tot = st["kernel_cycles"]
 rounds = max(st["eq_pods"], 1)
 print("kernel_ms", fp.kernel_ms, "nodes", len(r.new_nodes), "cycles", tot, "per pod", tot / pods)
 print("rounds", st["eq_pods"], "evaluating", st["reuse_exhausted"], "bubbles", st["reuse_seeds"], "phase A runs", st["reuse_hits"], "nrcs", st["cyc_pop"], "exact checks", st["cyc_stage"])
-names = [("leader: form the batch (rest)", "cyc_evalout"), ("leader: wait at B1", "cyc_full"), ("leader: prepare entries", "cyc_commit"), ("leader: picks + records", "cyc_order"),
-         ("leader: resolve", "cyc_new"), ("worker 1: wait at B1", "p22"), ("worker 1: leader's order", "p23"),
-         ("worker 1: evaluate (new classes)", "p24"), ("worker 1: pick: candidate + atomic", "p25"), ("worker 1: pick: barrier", "p26"), ("worker 1: pick: decide", "n_kind2"), ("worker 1: commit + loop", "scan_chunks"),
-         ("  form: entry lookup", "cyc_kind0"), ("  form: flags / masks", "cyc_kind1"), ("  form: cached answers", "cyc_kind2"), ("  form: dyn1 answers", "n_kind1")]
-print("dyn1 answers", st.get("full_fails"), "| worker 1: commits", st.get("cyc_pop"), "touched evaluations", st.get("cyc_stage"), "| picks", st.get("queue_pops"))
+names = [("leader: form the batch (rest)", "cyc_evalout"), ("leader: wait at B1", "cyc_full"), ("leader: prepare entries", "cyc_commit"), ("leader: picks / run steps", "cyc_order"),
+         ("leader: resolve", "cyc_new"), ("leader: run records", "p25"), ("leader: after records", "p26"),
+         ("worker 1: evaluate (new classes)", "n_kind2"), ("worker 1: round tail (incl. runs)", "scan_chunks"),
+         ("worker 1 run: extraction", "cyc_kind0"), ("worker 1 run: barrier", "cyc_kind1"), ("worker 1 run: merge", "cyc_kind2"), ("worker 1 run: commit + retry", "n_kind1")]
+print("dyn1 answers", st.get("full_fails"), "| runs", st.get("p24"), "pods in runs", st.get("p22"), "steps", st.get("p23"))
 for nm, k in names:
     print(f"{nm:32s} {st.get(k, 0) / rounds:9.0f} cycles / round")
+steps = max(st.get("p23", 0), 1)
+for nm, k in (("extraction", "cyc_kind0"), ("barrier", "cyc_kind1"), ("merge", "cyc_kind2"), ("commit + retry", "n_kind1")):
+    print(f"  run step: {nm:20s} {st.get(k, 0) / steps:9.0f} cycles / step")
