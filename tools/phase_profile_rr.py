@@ -26,6 +26,9 @@ names = [("leader: form the batch (rest)", "cyc_evalout"), ("leader: wait at B1"
 print("dyn1 answers", st.get("full_fails"), "| runs", st.get("p24"), "pods in runs", st.get("p22"), "steps", st.get("p23"))
 for nm, k in names:
     print(f"{nm:32s} {st.get(k, 0) / rounds:9.0f} cycles / round")
+print("raw:", {k: v for k, v in st.items() if v})
+pr, pn = st.get("relaxations", 0) >> 32, st.get("relaxations", 0) & 0xFFFFFFFF
+print("run rounds: %d pods, %.0f cycles/pod | normal rounds: %d rounds, %d pods, %.0f cycles/pod, %.0f cycles/round" % (pr, st.get("attempts", 0) / max(pr, 1), st.get("n_kind2", 0), pn, st.get("types_scanned", 0) / max(pn, 1), st.get("types_scanned", 0) / max(st.get("n_kind2", 0), 1)))
 steps = max(st.get("p23", 0), 1)
 for nm, k in (("extraction", "cyc_kind0"), ("barrier", "cyc_kind1"), ("merge", "cyc_kind2"), ("commit + retry", "n_kind1")):
     print(f"  run step: {nm:20s} {st.get(k, 0) / steps:9.0f} cycles / step")
