@@ -149,6 +149,22 @@ def main():
         fp.solve(decode=False)
         resident.append(((time.perf_counter() - t1) * 1e3, fp.kernel_ms))
     _, grid_ms = fp.grid(want_bits=False)
+    # the register-resident pack kernel (ks_pack_rr, round 4; opt-in through KS_RR=1) on the same resident problem, beside the default kernel: not `value`
+    alt = None
+    try:
+        os.environ["KS_RR"] = "1"
+        fp.solve(decode=False)
+        ks = []
+        for _ in range(3):
+            fp.solve(decode=False)
+            ks.append(fp.kernel_ms)
+        ra = fp.solve()
+        alt = {"kernel": "ks_pack_rr (KS_RR=1): nodes in worker registers, arg-min over keys, RUN rounds", "kernel_ms": statistics.median(ks),
+               "decisions_per_s_kernel": dims["P"] / (statistics.median(ks) / 1e3), "same_result_as_the_default_kernel": ra.canonical() == res.canonical(),
+               "rounds": ra.stats.get("eq_pods"), "pods_placed_in_runs": ra.stats.get("p22"), "run_steps": ra.stats.get("p23"),
+               "took_the_problem": bool(ra.stats.get("eq_pods"))}
+    finally:
+        os.environ.pop("KS_RR", None)
     fp.close()
     fps, _ = S.solve_from_pods(parsed, local_rank, stats=True)
     st = fps.result().stats
@@ -198,6 +214,7 @@ def main():
                      "issue": issue,
                      "note": "one Solve() is a serial dependency chain executed by ONE 8-wave workgroup (1 of 256 CUs): instruction issue and "
                              "dependent-access latency bind it, the HBM fraction is reported because the contract asks for it (DESIGN.md)"},
+        "alt_kernel": alt,
         "grid": {"kernel": "ks_grid_mc+ks_grid_types", "ms": grid_ms, "algorithmic_bytes": grid_bytes,
                  "achieved_GBs": grid_bytes / (grid_ms / 1e3) / 1e9 if grid_ms else None},
     }
