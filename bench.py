@@ -52,7 +52,7 @@ def algorithmic_bytes(T, stats, placed):
 
 def kernel_source_sha16():
     h = hashlib.sha256()
-    for f in ("karpenter_core_amd/csrc/ksolve.hip", "karpenter_core_amd/csrc/ks_algebra.h"):
+    for f in ("karpenter_core_amd/csrc/ksolve.hip", "karpenter_core_amd/csrc/ks_pack_rr.inc", "karpenter_core_amd/csrc/ks_algebra.h"):
         h.update(open(os.path.join(ROOT, f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -149,22 +149,25 @@ def main():
         fp.solve(decode=False)
         resident.append(((time.perf_counter() - t1) * 1e3, fp.kernel_ms))
     _, grid_ms = fp.grid(want_bits=False)
-    # the register-resident pack kernel (ks_pack_rr, round 4; opt-in through KS_RR=1) on the same resident problem, beside the default kernel: not `value`
+    # which pack kernel took the Solve (ks_pack_rr, round 4, takes single LEAN Solves it covers; ks_pack everything else), and the OTHER one on the same
+    # resident problem beside it (KS_NO_RR=1): not `value`
+    took_rr = bool(res.stats.get("eq_pods"))
     alt = None
     try:
-        os.environ["KS_RR"] = "1"
+        os.environ["KS_NO_RR"] = "1"
         fp.solve(decode=False)
         ks = []
         for _ in range(3):
             fp.solve(decode=False)
             ks.append(fp.kernel_ms)
         ra = fp.solve()
-        alt = {"kernel": "ks_pack_rr (KS_RR=1): nodes in worker registers, arg-min over keys, RUN rounds", "kernel_ms": statistics.median(ks),
-               "decisions_per_s_kernel": dims["P"] / (statistics.median(ks) / 1e3), "same_result_as_the_default_kernel": ra.canonical() == res.canonical(),
-               "rounds": ra.stats.get("eq_pods"), "pods_placed_in_runs": ra.stats.get("p22"), "run_steps": ra.stats.get("p23"),
-               "took_the_problem": bool(ra.stats.get("eq_pods"))}
+        alt = {"kernel": "ks_pack<FAST, LEAN, 8 waves> (KS_NO_RR=1): speculation rounds over a 64-candidate window -- the kernel of rounds 1-3",
+               "kernel_ms": statistics.median(ks), "decisions_per_s_kernel": dims["P"] / (statistics.median(ks) / 1e3),
+               "same_result_as_the_default_kernel": ra.canonical() == res.canonical()}
     finally:
-        os.environ.pop("KS_RR", None)
+        os.environ.pop("KS_NO_RR", None)
+    pack_name = "ks_pack_rr" if took_rr else "ks_pack"
+    rr_stats = {"rounds": res.stats.get("eq_pods"), "pods_placed_in_runs": res.stats.get("p22"), "run_steps": res.stats.get("p23"), "runs": res.stats.get("p24")} if took_rr else None
     fp.close()
     fps, _ = S.solve_from_pods(parsed, local_rank, stats=True)
     st = fps.result().stats
@@ -207,7 +210,7 @@ def main():
         "resident": {"what": "pack loop only, flattened problem already resident in HBM (ks_solve_dev incl. read-back) -- round 1's window",
                      "decisions_per_s": dims["P"] / (statistics.median(r[0] for r in resident) / 1e3),
                      "wall_ms": statistics.median(r[0] for r in resident), "kernel_ms": statistics.median(r[1] for r in resident)},
-        "roofline": {"kernel": "ks_pack", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"kernel": pack_name, "kernel_stats": rr_stats, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": abytes, "formula": f"SURVEY 8d with R={ROOFLINE_R}, K={ROOFLINE_K}",
                      "kernel_ms_mean": phase["pack_kernel_ms"], "ref_attempts": st["attempts"], "ref_types_scanned": st["types_scanned"],

@@ -3348,12 +3348,12 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   bool lean = true; for (u32 i = 0; i < n; ++i) lean = lean && ds[i]->lean_ok;
   if (getenv("KS_NO_LEAN")) lean = false;      // test hook: run the general variant on a problem the LEAN one would take
   // The register-resident kernel (ks_pack_rr.inc) takes a single LEAN Solve without Gt/Lt bounds; it declines what it does not cover -- before
-  // or during the run, without having touched the inputs -- and ks_pack below takes over.  KS_NO_RR=1: ks_pack only (A/B, and the parity of both).
+  // or during the run, without having touched the inputs -- and ks_pack below takes over.
   bool rr_done = false;
 #ifdef KS_SIM
   const bool rr_on = true;                    // (the emulator build has no ks_pack)
 #else
-  const bool rr_on = getenv("KS_RR") != nullptr;      // opt-in: measured slower than ks_pack on BASELINE configs[2] so far
+  const bool rr_on = getenv("KS_NO_RR") == nullptr && getenv("KS_ONE_WAVE") == nullptr;   // KS_NO_RR=1: ks_pack only (A/B, and the parity of both kernels); KS_ONE_WAVE asks for ks_pack's single-wave variant
 #endif
   if (rr_on && n == 1 && lean && !bounds && fast && !ds[0]->view && !(ds[0]->h.flags & KS_FLAG_STATS) && ds[0]->h.rr_briefs) {
     const u32 lds_rr = 44u * 1024u;

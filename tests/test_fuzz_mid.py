@@ -184,6 +184,14 @@ def test_gpu_matches_oracle_mid(seed, monkeypatch):
         if gold["oracle_seconds"] < 3:
             ref = O.solve(p)
             assert got.canonical() == ref.canonical() and got.reasons == ref.reasons
+        if seed % 2 == 0:                              # ... and through ks_pack's 8-wave variant (ks_pack_rr takes the LEAN problems of this family since round 4)
+            monkeypatch.setenv("KS_NO_RR", "1")
+            fk = S.FlatProblem(p)
+            try:
+                assert fingerprints(fk.solve())["sha256"] == gold["sha256"]
+            finally:
+                fk.close()
+                monkeypatch.delenv("KS_NO_RR", raising=False)
         if seed < 6 or seed in (36, 41):               # the same problem, arena poisoned: nothing may depend on memory the kernels did not write
             monkeypatch.setenv("KS_POISON", "0xA5" if seed % 2 else "0xFF")
             fq = S.FlatProblem(p)

@@ -238,6 +238,18 @@ def test_full_size_configs_match_oracle_fingerprint(case):
     assert hashlib.sha256(json.dumps(res.canonical(), sort_keys=True).encode()).hexdigest() == gold["sha256"]
 
 
+def test_full_size_config3_through_ks_pack(monkeypatch):
+    """BASELINE configs[2] at its full size through ks_pack's 8-wave variant (the kernel of rounds 1-3; ks_pack_rr takes this Solve by default since round 4)."""
+    import hashlib
+    import json
+    import os
+    monkeypatch.setenv("KS_NO_RR", "1")
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config_hashes.json")))["config3_100k_2k"]
+    res = S.solve_problem(W.config3())
+    assert hashlib.sha256(json.dumps(res.canonical(), sort_keys=True).encode()).hexdigest() == gold["sha256"]
+    assert not res.stats.get("p22")
+
+
 def _golden(case):
     import json
     import os

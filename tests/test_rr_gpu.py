@@ -1,5 +1,5 @@
-"""(GPU) The register-resident pack kernel (ks_pack_rr, opt-in through KS_RR=1) against the oracle: the same C ABI, the same canonical result.  The kernel
-declines what it does not cover and ks_pack takes over, so every case below also passes when it declines -- `ran_rr` says whether it did."""
+"""(GPU) The register-resident pack kernel (ks_pack_rr: it takes the single LEAN Solves it covers since round 4; KS_NO_RR=1 leaves everything to ks_pack) against
+the oracle: the same C ABI, the same canonical result.  The kernel declines what it does not cover and ks_pack takes over -- `ran_rr` says which one ran."""
 import hashlib
 import json
 import os
@@ -24,7 +24,7 @@ def ran_rr(res) -> bool:
 @pytest.mark.parametrize("maker", [lambda: W.config1(pods=1000, types=50, seed=42), lambda: W.config3(pods=700, sizes=10, seed=7),
                                    lambda: W.config3(pods=3500, sizes=20, seed=44), lambda: W.config3(pods=20000, sizes=50, seed=45)])
 def test_rr_matches_oracle(maker, monkeypatch):
-    monkeypatch.setenv("KS_RR", "1")
+    monkeypatch.delenv("KS_NO_RR", raising=False)
     p = maker()
     got = S.solve_problem(p)
     assert got.canonical() == O.solve(p).canonical()
@@ -35,7 +35,7 @@ def test_rr_matches_oracle(maker, monkeypatch):
 def test_rr_mid_scale_family(seed, monkeypatch):
     """The mid-scale family of the timed kernel (tests/test_fuzz_mid.py) through ks_pack_rr: in-flight nodes, two provisioners, relaxations, exact-filter winners."""
     import test_fuzz_mid as T
-    monkeypatch.setenv("KS_RR", "1")
+    monkeypatch.delenv("KS_NO_RR", raising=False)
     p = T.mid_problem(seed)
     gold = T._gold()[str(seed)]
     got = S.solve_problem(p)
@@ -44,7 +44,7 @@ def test_rr_mid_scale_family(seed, monkeypatch):
 
 def test_rr_full_size_config3_fingerprint(monkeypatch):
     """BASELINE configs[2] at its full size (100 000 pods / 2 000 types) through ks_pack_rr: the oracle's offline fingerprint."""
-    monkeypatch.setenv("KS_RR", "1")
+    monkeypatch.delenv("KS_NO_RR", raising=False)
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config_hashes.json")))["config3_100k_2k"]
     res = S.solve_problem(W.config3())
     assert len(res.new_nodes) == gold["new_nodes"] and _fp(res) == gold["sha256"]
@@ -53,7 +53,7 @@ def test_rr_full_size_config3_fingerprint(monkeypatch):
 
 def test_rr_twice_on_one_resident_problem(monkeypatch):
     """A resident problem solved twice: the kernel re-initialises what it caches per class (rr_memo, rr_mcnrc)."""
-    monkeypatch.setenv("KS_RR", "1")
+    monkeypatch.delenv("KS_NO_RR", raising=False)
     p = W.config3(pods=3500, sizes=20, seed=44)
     fp = S.FlatProblem(p)
     try:
@@ -61,3 +61,14 @@ def test_rr_twice_on_one_resident_problem(monkeypatch):
         assert a.canonical() == b.canonical() == O.solve(p).canonical()
     finally:
         fp.close()
+
+
+def test_both_pack_kernels_agree(monkeypatch):
+    """The same problem through ks_pack_rr and, with KS_NO_RR=1, through ks_pack: one canonical result."""
+    p = W.config3(pods=20000, sizes=50, seed=46)
+    monkeypatch.delenv("KS_NO_RR", raising=False)
+    a = S.solve_problem(p)
+    monkeypatch.setenv("KS_NO_RR", "1")
+    b = S.solve_problem(p)
+    assert ran_rr(a) and not ran_rr(b)
+    assert a.canonical() == b.canonical() == O.solve(p).canonical()

@@ -6,8 +6,8 @@ import os, sys
 sys.path.insert(0, ".")
 from karpenter_core_amd import scheduler as S, workloads as W
 def run(p, rr):
-    if rr: os.environ["KS_RR"] = "1"
-    else: os.environ.pop("KS_RR", None)
+    if rr: os.environ.pop("KS_NO_RR", None)
+    else: os.environ["KS_NO_RR"] = "1"
     fp = S.FlatProblem(p); fp.upload(0); fp.grid(want_bits=False); fp.solve(decode=False)
     ms = []
     for _ in range(3): fp.solve(decode=False); ms.append(fp.kernel_ms)

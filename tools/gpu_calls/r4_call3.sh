@@ -8,8 +8,8 @@ import os, sys, time
 sys.path.insert(0, ".")
 from karpenter_core_amd import scheduler as S, workloads as W
 def run(p, rr):
-    if rr: os.environ["KS_RR"] = "1"
-    else: os.environ.pop("KS_RR", None)
+    if rr: os.environ.pop("KS_NO_RR", None)
+    else: os.environ["KS_NO_RR"] = "1"
     fp = S.FlatProblem(p); fp.upload(0); fp.grid(want_bits=False); fp.solve(decode=False); fp.solve(decode=False)
     ms = fp.kernel_ms; fp.close(); return ms
 for name, p in (("config1 shape, 100k generic pods / 2000 types", W.config1(pods=100000, types=2000, seed=42)), ("config3 100k", W.config3())):

@@ -14,6 +14,8 @@ The probe slots (ks_result.stats[8..31]) mean different things in the two kernel
 import os
 import sys
 
+os.environ.setdefault("KS_NO_RR", "1")      # (this tool reads ks_pack's probe slots; tools/phase_profile_rr.py is the one for ks_pack_rr)
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from karpenter_core_amd import scheduler as S, workloads as W
 
