@@ -30,7 +30,7 @@ list is `<count> item*`):
              I ninit {nreq {res qty}* nlim {res qty}*}*
              TS n {maxSkew key whenUnsatisfiable selector}*
              AFR n term*  AFP n {weight term}*  ANR n term*  ANP n {weight term}*
-             [VOL n {driver pvcId}* | VOL -1]          (optional: mounted CSI volumes, see Volume; -1 = a lookup failed)
+             VOL n {driver pvcId}* | VOL -1            (mounted CSI volumes, see Volume; -1 = a lookup failed; the parser accepts records without the section)
   node     : name inState nlabels {k v}* ntaints {key value effect}* available capacity daemonsetRequests
              nports {ip port proto}*  [VL n {driver count}*]  [VU n {driver pvcId}*]      (optional: volume limits / usage)
 """
@@ -249,9 +249,10 @@ class Pod:
         for wt in self.anti_preferred:
             w.write(f" {int(wt.weight)}")
             wt.term.ksp(w)
+        # (always written, also when empty: the parser tells an optional section from the next record's uid by peeking at a bare token, and a pod may be called "VOL")
         if self.volume_error:
             w.write(" VOL -1")
-        elif self.volumes:
+        else:
             w.write(f" VOL {len(self.volumes)}")
             for v in self.volumes:
                 w.write(f" {_tok(v.driver)} {_tok(v.pvc_id)}")
@@ -618,14 +619,12 @@ class Problem:
             w.write(f" {len(n.host_ports)}")
             for hp in n.host_ports:
                 w.write(f" {_tok(hp.host_ip)} {int(hp.port)} {_tok(hp.protocol)}")
-            if n.volume_limits:
-                w.write(f" VL {len(n.volume_limits)}")
-                for d in sorted(n.volume_limits):
-                    w.write(f" {_tok(d)} {int(n.volume_limits[d])}")
-            if n.volumes:
-                w.write(f" VU {len(n.volumes)}")
-                for v in n.volumes:
-                    w.write(f" {_tok(v.driver)} {_tok(v.pvc_id)}")
+            w.write(f" VL {len(n.volume_limits)}")      # (always written: see Pod.ksp)
+            for d in sorted(n.volume_limits):
+                w.write(f" {_tok(d)} {int(n.volume_limits[d])}")
+            w.write(f" VU {len(n.volumes)}")
+            for v in n.volumes:
+                w.write(f" {_tok(v.driver)} {_tok(v.pvc_id)}")
             w.write("\n")
         w.write(f"CPODS {len(self.cluster_pods)}\n")
         for cp in self.cluster_pods:

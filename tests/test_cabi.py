@@ -208,3 +208,17 @@ def test_headers_are_plain_c(tmp_path):
         assert "solve refused: -3" in out.stdout
     else:
         assert "solved in" in out.stdout
+
+
+def test_pod_and_node_named_like_section_keywords():
+    """KSP1's optional sections (VOL after a pod, VL / VU after a state node) are told from the next record by peeking at a bare token: the writer always emits them, so
+    a pod whose uid is "VOL" (or a node called "VL" / "VU") parses as what it is."""
+    from karpenter_core_amd import fake
+    from karpenter_core_amd.model import Container, Pod, Problem
+    from oracle import oracle_py as O
+    its = fake.default_instance_types()
+    pods = [Pod(uid="p0", containers=[Container(requests={"cpu": "1"})]), Pod(uid="VOL", containers=[Container(requests={"cpu": "1"})]),
+            Pod(uid="VL", containers=[Container(requests={"cpu": "1"})])]
+    pr = Problem(instance_types=its, provisioners=[fake.provisioner("default", len(its))], pods=pods, extra_well_known=fake.EXTRA_WELL_KNOWN)
+    r = O.solve(pr)
+    assert sorted(q for n in r.new_nodes for q in n.pods) == [0, 1, 2]
