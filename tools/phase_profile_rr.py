@@ -8,6 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from karpenter_core_amd import scheduler as S, workloads as W
 
 pods = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+if os.environ.get("KS_VARIANT"):      # an experiment build under karpenter_core_amd/_variants/<name> (e.g. a -DKS_PROBES one) instead of the library in the tree
+    S._HERE = os.path.join(os.path.dirname(S.__file__), "_variants", os.environ["KS_VARIANT"]); S._LIBS = None; S.libs()
 pr = W.config3(pods=pods)
 fp = S.FlatProblem(pr)
 fp.upload(0)
