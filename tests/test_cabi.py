@@ -222,3 +222,20 @@ def test_pod_and_node_named_like_section_keywords():
     pr = Problem(instance_types=its, provisioners=[fake.provisioner("default", len(its))], pods=pods, extra_well_known=fake.EXTRA_WELL_KNOWN)
     r = O.solve(pr)
     assert sorted(q for n in r.new_nodes for q in n.pods) == [0, 1, 2]
+
+
+def test_build_refuses_a_pack_kernel_that_fell_off_its_register_budget(tmp_path):
+    """ks_pack_rr keeps its nodes in registers, a few VGPRs below the limit; past it the allocator moves the arrays to scratch and the kernel runs three times slower
+    without any error.  build() reads the compiler's resource remarks: a library like that is removed and the build fails (the remarks below are the two the round saw)."""
+    def remarks(vgprs, spill, scratch):
+        pre = "csrc/ks_pack_rr.inc:1425:1: remark:     "
+        return "\n".join(["csrc/ks_pack_rr.inc:1425:1: remark: Function Name: _Z10ks_pack_rrPK7DevProbPK8DevStatej [-Rpass-analysis=kernel-resource-usage]",
+                          pre + f"VGPRs: {vgprs} [-Rpass-analysis=kernel-resource-usage]", pre + f"ScratchSize [bytes/lane]: {scratch} [-Rpass-analysis=kernel-resource-usage]",
+                          pre + f"VGPRs Spill: {spill} [-Rpass-analysis=kernel-resource-usage]"])
+    so = tmp_path / "libksolve.so"
+    so.write_bytes(b"x")
+    ge._check_register_budget(remarks(248, 0, 336), str(so))
+    assert so.exists()
+    with pytest.raises(RuntimeError, match="register budget"):
+        ge._check_register_budget(remarks(256, 1, 1356), str(so))
+    assert not so.exists()
