@@ -68,7 +68,57 @@ __global__ void k(u32* g, u64* out, int n_nodes) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += g[(q + j * 517 + i * 64) & (n_nodes * 64 - 1)]; q += s & 63; }
   t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 11: wave minimum (DPP reduce, 6 steps + readlane), dependent
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 8
+  for (int i = 0; i < N; ++i) {
+    u32 v = x + lane;
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false));
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false));
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false));
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));
+    x += __builtin_amdgcn_readlane(v, 63);
+  }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 12: a branch on a VALU-made condition of a wave-uniform value (v_cmp -> s_cbranch_vccnz), taken half the time
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < N; ++i) { const u32 u = __builtin_amdgcn_readfirstlane(x); if (((u + i) & 1u) == 0) { x = x * 3 + 1; } else { x = x ^ 0x1234u; } asm volatile("" ::: "memory"); }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 13: LDS write then read of the same word (a round trip through LDS, as between two dependent steps)
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 4
+  for (int i = 0; i < N; ++i) { lds[lane] = x; asm volatile("" ::: "memory"); x = lds[(lane + 1) & 63] + 1; }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 14: readlane with a lane index that was just computed (SGPR from VALU result)
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 8
+  for (int i = 0; i < N; ++i) { const int w = (int)(__builtin_amdgcn_readfirstlane(x) & 63u); x += __builtin_amdgcn_readlane(x, w); }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
   if (lane == 0) out[15] = x + y + p + q + z;
+}
+// Eight waves (the pack kernels' workgroup): what a barrier costs when everyone arrives together, and an LDS atomic minimum + barrier + read (one pick)
+__global__ __launch_bounds__(512) void k8(u64* out) {
+  __shared__ unsigned long long win[2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  u32 x = threadIdx.x + 1;
+  if (threadIdx.x < 2) win[threadIdx.x] = ~0ull;
+  __syncthreads();
+  u64 t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < 1024; ++i) { x = x * 3 + 1; __syncthreads(); }
+  u64 t1 = __builtin_readcyclecounter(); if (threadIdx.x == 0) out[0] = t1 - t0;
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < 1024; ++i) {
+    if (lane == 0) atomicMin(&win[i & 1], ((unsigned long long)(x + wv) << 32) | (u32)wv);
+    __syncthreads();
+    x += (u32)(win[i & 1] >> 32);
+    if (threadIdx.x == 0) win[(i + 1) & 1] = ~0ull;
+  }
+  t1 = __builtin_readcyclecounter(); if (threadIdx.x == 0) { out[1] = t1 - t0; out[2] = x; }
 }
 int main() {
   const int n_nodes = 2048 * 8; u32* g; u64* out; std::vector<u32> h(n_nodes * 64);
@@ -78,7 +128,13 @@ int main() {
   u64 o[16]; hipMemcpy(o, out, sizeof o, hipMemcpyDeviceToHost);
   const char* names[] = {"timer pair", "dep v_mad x4096", "dep 64-bit add x4096", "taken branch loop x4096", "dep LDS read x4096", "dep global load (4MB chase) x1024",
                          "ballot+ctz+readlane x4096", "divergent if/else x4096", "uniform skip branch x4096", "store+syncthreads x256", "8 indep global loads x256"};
+  const char* names2[] = {"wave min (6 DPP + readlane) x4096", "branch on v_cmp of uniform x4096", "LDS write->read round trip x4096", "readfirstlane->readlane x4096"};
   const int div[] = {1, 4096, 4096, 4096, 4096, 1024, 4096, 4096, 4096, 256, 256};
   for (int i = 0; i < 11; ++i) printf("%-36s total %8llu  per-iter %8.1f cycles\n", names[i], o[i], (double)o[i] / div[i]);
+  for (int i = 0; i < 4; ++i) printf("%-36s total %8llu  per-iter %8.1f cycles\n", names2[i], o[11 + i], (double)o[11 + i] / 4096);
+  for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(k8, dim3(1), dim3(512), 0, 0, out); hipDeviceSynchronize(); }
+  hipMemcpy(o, out, sizeof o, hipMemcpyDeviceToHost);
+  printf("%-36s total %8llu  per-iter %8.1f cycles\n", "8 waves: barrier x1024", o[0], (double)o[0] / 1024);
+  printf("%-36s total %8llu  per-iter %8.1f cycles\n", "8 waves: atomicMin+barrier+read x1024", o[1], (double)o[1] / 1024);
   return 0;
 }
