@@ -99,6 +99,70 @@ __global__ void k(u32* g, u64* out, int n_nodes) {
   t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
   if (lane == 0) out[15] = x + y + p + q + z;
 }
+// More single-wave primitives: what the alternatives to wave-uniform control flow cost
+typedef u32 u32x8 __attribute__((ext_vector_type(8)));
+__global__ void k2(const u32* __restrict__ g, u64* out) {
+  __shared__ u32 lds[256];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 256; i += 64) lds[i] = (i * 7 + 1) & 255;
+  __syncthreads();
+  u64 t0, t1; u32 x = lane + 1; int slot = 0;
+  // 0: scalar compare + branch NOT taken (the body is skipped never: condition false every time)
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < N; ++i) { if (__builtin_expect((i & 0x10000) != 0, 0)) { x = x * 7 + 3; } x += 2; asm volatile("" ::: "memory"); }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 1: scalar compare + branch on the loop counter, alternately taken (no VGPR involved in the condition)
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < N; ++i) { if (i & 1) { x = x * 7 + 3; } x += 2; asm volatile("" ::: "memory"); }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 2: a ladder of eight `if (idx == k)` blocks with tiny bodies, idx scalar (the pack kernels' slot ladders)
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < N; ++i) {
+    const int idx = i & 7;
+    if (idx == 0) x += 1; asm volatile("" ::: "memory"); if (idx == 1) x += 3; asm volatile("" ::: "memory"); if (idx == 2) x ^= 5; asm volatile("" ::: "memory"); if (idx == 3) x += 7; asm volatile("" ::: "memory");
+    if (idx == 4) x ^= 9; asm volatile("" ::: "memory"); if (idx == 5) x += 11; asm volatile("" ::: "memory"); if (idx == 6) x ^= 13; asm volatile("" ::: "memory"); if (idx == 7) x += 15; asm volatile("" ::: "memory");
+  }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 3: the same selection as eight v_cndmask on scalar conditions (no branch)
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 4
+  for (int i = 0; i < N; ++i) {
+    const int idx = i & 7; u32 d = 0;
+    d = idx == 0 ? 1u : d; d = idx == 1 ? 3u : d; d = idx == 2 ? 5u : d; d = idx == 3 ? 7u : d; d = idx == 4 ? 9u : d; d = idx == 5 ? 11u : d; d = idx == 6 ? 13u : d; d = idx == 7 ? 15u : d;
+    x += d + (x >> 7);
+  }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 4: a register vector indexed by a scalar (s_set_gpr_idx / v_movrel), read and written
+  u32x8 vec = {x, x + 1, x + 2, x + 3, x + 4, x + 5, x + 6, x + 7};
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 4
+  for (int i = 0; i < N; ++i) { const int idx = __builtin_amdgcn_readfirstlane((int)(i * 5)) & 7; x += vec[idx]; vec[(idx + 3) & 7] = x; }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 5: a dependent chain of scalar loads from global memory (s_load_dword: the index never touches a VGPR)
+  u32 sq = 0;
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 4
+  for (int i = 0; i < 1024; ++i) sq = g[__builtin_amdgcn_readfirstlane(sq) & 0xFFFFu];
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 6: an LDS word every lane reads (broadcast) made scalar by readfirstlane, dependent (how the kernels fetch a header word)
+  u32 hp = 0;
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 4
+  for (int i = 0; i < N; ++i) hp = __builtin_amdgcn_readfirstlane(lds[hp & 255]);
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  // 7: sixteen INDEPENDENT readlanes of one register (a class brief's fields), then their sum
+  t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < 1024; ++i) { u32 s = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += __builtin_amdgcn_readlane(x, j * 3);
+    x += s; }
+  t1 = __builtin_readcyclecounter(); if (lane == 0) out[slot] = t1 - t0; slot++;
+  if (lane == 0) out[15] = x + sq + hp + vec[3];
+}
 // Eight waves (the pack kernels' workgroup): what a barrier costs when everyone arrives together, and an LDS atomic minimum + barrier + read (one pick)
 __global__ __launch_bounds__(512) void k8(u64* out) {
   __shared__ unsigned long long win[2];
@@ -132,6 +196,12 @@ int main() {
   const int div[] = {1, 4096, 4096, 4096, 4096, 1024, 4096, 4096, 4096, 256, 256};
   for (int i = 0; i < 11; ++i) printf("%-36s total %8llu  per-iter %8.1f cycles\n", names[i], o[i], (double)o[i] / div[i]);
   for (int i = 0; i < 4; ++i) printf("%-36s total %8llu  per-iter %8.1f cycles\n", names2[i], o[11 + i], (double)o[11 + i] / 4096);
+  for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(k2, dim3(1), dim3(64), 0, 0, g, out); hipDeviceSynchronize(); }
+  hipMemcpy(o, out, sizeof o, hipMemcpyDeviceToHost);
+  const char* names3[] = {"scalar cmp+branch, not taken x4096", "scalar cmp+branch, alternating x4096", "ladder of 8 if(idx==k) x4096", "8 selects on scalar conds x4096", "vector[scalar idx] read+write x4096",
+                          "dep scalar global load x1024", "LDS broadcast->readfirstlane x4096", "16 indep readlanes + sum x1024"};
+  const int div3[] = {4096, 4096, 4096, 4096, 4096, 1024, 4096, 1024};
+  for (int i = 0; i < 8; ++i) printf("%-36s total %8llu  per-iter %8.1f cycles\n", names3[i], o[i], (double)o[i] / div3[i]);
   for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(k8, dim3(1), dim3(512), 0, 0, out); hipDeviceSynchronize(); }
   hipMemcpy(o, out, sizeof o, hipMemcpyDeviceToHost);
   printf("%-36s total %8llu  per-iter %8.1f cycles\n", "8 waves: barrier x1024", o[0], (double)o[0] / 1024);
