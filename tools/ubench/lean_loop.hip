@@ -8,6 +8,11 @@
 #include <cstdio>
 #include <vector>
 typedef unsigned long long u64; typedef unsigned int u32; typedef long long i64; typedef int i32;
+#ifdef R32
+typedef int res_t;        /* requests normalised to 32 bits */
+#else
+typedef long long res_t;
+#endif
 #ifndef NW
 #define NW 8        /* waves */
 #endif
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(64 * NW) void lean(const PodRec* __restrict__ pods,
   const int lane = threadIdx.x & 63; const u32 wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int i = threadIdx.x; i < 256; i += 64 * NW) acc_lds[i] = accept_of_class[i];
   // the nodes: node n -> slot n / 512, wave n % 8, lane (n % 512) / 8
-  u32 key[8], meta[8], hc[8][GW]; i64 room[8][4];
+  u32 key[8], meta[8], hc[8][GW]; res_t room[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const u32 n = (u32)i * 64u * NW + (u32)lane * NW + wv;
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(64 * NW) void lean(const PodRec* __restrict__ pods,
     key[i] = live ? ((1u + (n & 3u)) << 22) | (n << 3) | (u32)i : 0xFFFFFFFFu;
     meta[i] = n % 23u;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) room[i][r] = 400000 + (i64)(n * 37u % 1000u) * (r + 1);
+    for (int r = 0; r < 4; ++r) room[i][r] = (res_t)(400000 + (i64)(n * 37u % 1000u) * (r + 1));
 #pragma unroll
     for (int w = 0; w < GW; ++w) hc[i][w] = 0;
   }
@@ -56,8 +61,12 @@ __global__ __launch_bounds__(64 * NW) void lean(const PodRec* __restrict__ pods,
 #pragma unroll 1
   for (int p = 0; p < n_pods; ++p) {
     // ---- the pod's parameters, as scalars ----
+#ifdef CONST_POD
+    const PodRec& R = pods[2];      // (loop-invariant: what the per-pod scalar fetches cost is the difference)
+#else
     const PodRec& R = pods[p & 1023];
-    const i64 rq0 = R.rq[0], rq1 = R.rq[1], rq2 = R.rq[2], rq3 = R.rq[3];
+#endif
+    const res_t rq0 = (res_t)R.rq[0], rq1 = (res_t)R.rq[1], rq2 = (res_t)R.rq[2], rq3 = (res_t)R.rq[3];
     const u32 it0 = R.item[0], it1 = R.item[1], cls = R.cls; const i32 lim0 = (i32)R.lim[0], lim1 = (i32)R.lim[1];
     const u64 accv = acc_lds[cls & 255u];
     const u64 nacc = ~(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)accv)) | ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(accv >> 32)) << 32));
@@ -68,25 +77,44 @@ __global__ __launch_bounds__(64 * NW) void lean(const PodRec* __restrict__ pods,
     for (int i = 0; i < NPL; ++i) {
       bool rj = ((nacc >> (meta[i] & 63u)) & 1ull) != 0;
       rj |= rq0 > room[i][0]; rj |= rq1 > room[i][1]; rj |= rq2 > room[i][2]; rj |= rq3 > room[i][3];
+#ifndef NO_ITEMS
+#ifdef ITEMS_BRANCH
+      if (has0 || has1)      /* (wave-uniform: a pod without hostname items jumps over the item code) */
+#endif
+      {
+#ifdef TREE
+      const u32 a0 = (w0 & 1u) ? hc[i][1] : hc[i][0], a1 = (w0 & 1u) ? hc[i][3] : hc[i][2], a2 = (w0 & 1u) ? hc[i][5] : hc[i][4], a3 = (w0 & 1u) ? hc[i][7] : hc[i][6];
+      const u32 b0 = (w0 & 2u) ? a1 : a0, b1 = (w0 & 2u) ? a3 : a2; const u32 c0 = (w0 & 4u) ? b1 : b0;
+      const u32 d0 = (w1 & 1u) ? hc[i][1] : hc[i][0], d1 = (w1 & 1u) ? hc[i][3] : hc[i][2], d2 = (w1 & 1u) ? hc[i][5] : hc[i][4], d3 = (w1 & 1u) ? hc[i][7] : hc[i][6];
+      const u32 e0 = (w1 & 2u) ? d1 : d0, e1 = (w1 & 2u) ? d3 : d2; const u32 c1 = (w1 & 4u) ? e1 : e0;
+#else
       u32 c0 = hc[i][0], c1 = hc[i][0];
 #pragma unroll
       for (int w = 1; w < GW; ++w) { c0 = w0 == (u32)w ? hc[i][w] : c0; c1 = w1 == (u32)w ? hc[i][w] : c1; }
-#ifndef NO_ITEMS
+#endif
       rj |= has0 && (i32)((c0 >> sh0) & 0xFFu) > lim0;
       rj |= has1 && (i32)((c1 >> sh1) & 0xFFu) > lim1;
+      }
 #endif
       best = min(best, rj ? 0xFFFFFFFFu : key[i]);
     }
     // ---- the wave's, then the workgroup's least key ----
     const u32 wk = wave_min(best);
+#ifdef NO_XCHG
+    const u32 pk = wk, win = wk; if (wv != 0) { placed += win & 1u; continue; }      /* (no exchange: wave 0 commits its own winner, the others only evaluate) */
+#else
     if (lane == 0) pub[p & 1][wv] = wk;
     __syncthreads();
     const u32 pk = lane < NW ? pub[p & 1][lane] : 0xFFFFFFFFu;
     const u32 win = min8(pk);
+#endif
     if (win == 0xFFFFFFFFu) continue;      // (nothing accepts: the leader's business in the real thing)
     // ---- commit, by the lane that holds the node; nothing is evaluated again ----
     const u32 oslot = win & 7u, owv = (u32)__builtin_ctzll(__ballot(pk == win));      // (keys are unique: bucket | place | slot)
     ++placed;
+#ifdef NO_COMMIT
+    placed += oslot + owv; continue;
+#endif
     if (owv != wv) continue;
     const u32 olane = (u32)__builtin_ctzll(__ballot(best == wk));
     const bool mine = (u32)lane == olane;
@@ -108,6 +136,9 @@ __global__ __launch_bounds__(64 * NW) void lean(const PodRec* __restrict__ pods,
   if (sink == 0x12345678u) out[2] = sink;
 }
 
+#ifndef VARIANT
+#define VARIANT ""
+#endif
 int main() {
   const int n_pods = 20000, n_nodes = 64 * NW * NPL < 2100 ? 64 * NW * NPL : 2100;
   std::vector<PodRec> h(1024); std::vector<u64> acc(256);
@@ -123,7 +154,7 @@ int main() {
   hipMemcpy(dp, h.data(), h.size() * sizeof(PodRec), hipMemcpyHostToDevice); hipMemcpy(dacc, acc.data(), 256 * 8, hipMemcpyHostToDevice);
   u64 o[3] = {0, 0, 0};
   for (int rep = 0; rep < 3; ++rep) { hipLaunchKernelGGL(lean, dim3(1), dim3(64 * NW), 0, 0, dp, dacc, dout, n_pods, n_nodes); hipDeviceSynchronize(); hipMemcpy(o, dout, 24, hipMemcpyDeviceToHost);
-    printf("lean loop [%d waves, %d slots%s]: %d pods over %d nodes in registers: %llu cycles, %.0f cycles per pod (%llu placed)\n", NW, NPL,
+    printf("lean loop [%d waves, %d slots%s" VARIANT "]: %d pods over %d nodes in registers: %llu cycles, %.0f cycles per pod (%llu placed)\n", NW, NPL,
 #ifdef NO_ITEMS
  ", no hostname items",
 #else
