@@ -56,6 +56,13 @@ __global__ __launch_bounds__(64 * NW) void lean(const PodRec* __restrict__ pods,
 #pragma unroll
     for (int w = 0; w < GW; ++w) hc[i][w] = 0;
   }
+#ifdef ITEM_MASKS
+  // per hostname counter c = word * 4 + byte: which of this lane's slots hold a node whose counter c is >= 1 (z1) / >= 2 (z2): byte `byte` of z?[word], one bit per slot.
+  // An item with limit 0 or 1 (every BASELINE workload) is then ONE select + shift per pod instead of a counter extraction per slot; the commit keeps the masks up to date.
+  u32 z1[GW], z2[GW];
+#pragma unroll
+  for (int w = 0; w < GW; ++w) { z1[w] = 0; z2[w] = 0; }
+#endif
   __syncthreads();
   u32 placed = 0; const u64 t0 = __builtin_readcyclecounter();
 #pragma unroll 1
@@ -71,13 +78,25 @@ __global__ __launch_bounds__(64 * NW) void lean(const PodRec* __restrict__ pods,
     const u64 accv = acc_lds[cls & 255u];
     const u64 nacc = ~(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)accv)) | ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(accv >> 32)) << 32));
     const u32 w0 = it0 & 7u, sh0 = (it0 >> 8) & 31u, w1 = it1 & 7u, sh1 = (it1 >> 8) & 31u; const bool has0 = it0 >> 31, has1 = it1 >> 31;
+#ifdef ITEM_MASKS
+    u32 rejm = 0;      // the slots the pod's hostname items refuse
+    {
+      u32 s1 = z1[0], s2 = z2[0], t1 = z1[0], t2 = z2[0];
+#pragma unroll
+      for (int w = 1; w < GW; ++w) { s1 = w0 == (u32)w ? z1[w] : s1; s2 = w0 == (u32)w ? z2[w] : s2; t1 = w1 == (u32)w ? z1[w] : t1; t2 = w1 == (u32)w ? z2[w] : t2; }
+      const u32 m0 = ((lim0 <= 0 ? s1 : s2) >> (sh0 & 24u)) & 0xFFu, m1 = ((lim1 <= 0 ? t1 : t2) >> (sh1 & 24u)) & 0xFFu;      // (limits 0 / 1; larger ones would take the counter path)
+      rejm = (has0 ? m0 : 0u) | (has1 ? m1 : 0u);
+    }
+#endif
     // ---- every slot, from scratch ----
     u32 best = 0xFFFFFFFFu;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
       bool rj = ((nacc >> (meta[i] & 63u)) & 1ull) != 0;
       rj |= rq0 > room[i][0]; rj |= rq1 > room[i][1]; rj |= rq2 > room[i][2]; rj |= rq3 > room[i][3];
-#ifndef NO_ITEMS
+#ifdef ITEM_MASKS
+      rj |= ((rejm >> i) & 1u) != 0;
+#elif !defined(NO_ITEMS)
 #ifdef ITEMS_BRANCH
       if (has0 || has1)      /* (wave-uniform: a pod without hostname items jumps over the item code) */
 #endif
@@ -115,11 +134,40 @@ __global__ __launch_bounds__(64 * NW) void lean(const PodRec* __restrict__ pods,
 #ifdef NO_COMMIT
     placed += oslot + owv; continue;
 #endif
+#ifdef COMMIT_SELECT
+    // every wave, every slot, under a data predicate: no ladder, no merge points at which the compiler copies the register arrays
+    {
+      const u32 olane = (u32)__builtin_ctzll(__ballot(best == wk));
+      const bool own = owv == wv && (u32)lane == olane;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const bool m = own && oslot == (u32)i;
+        room[i][0] -= m ? rq0 : (res_t)0; room[i][1] -= m ? rq1 : (res_t)0; room[i][2] -= m ? rq2 : (res_t)0; room[i][3] -= m ? rq3 : (res_t)0;
+        key[i] = m ? (((key[i] >> 22) + 1u) << 22) | ((0x7FFFFu - (u32)p) << 3) | (key[i] & 7u) : key[i];
+        meta[i] = m ? (meta[i] + cls) % 23u : meta[i];
+#pragma unroll
+        for (int w = 0; w < GW; ++w) {
+          const bool hit = m && has0 && w0 == (u32)w;
+#ifdef ITEM_MASKS
+          const u32 cnt = (hc[i][w] >> sh0) & 0xFFu;
+          z1[w] |= hit ? (1u << i) << (sh0 & 24u) : 0u; z2[w] |= hit && cnt >= 1u ? (1u << i) << (sh0 & 24u) : 0u;
+#endif
+          hc[i][w] += hit ? (1u << sh0) : 0u;
+        }
+      }
+      continue;
+    }
+#endif
     if (owv != wv) continue;
     const u32 olane = (u32)__builtin_ctzll(__ballot(best == wk));
     const bool mine = (u32)lane == olane;
+#ifdef ITEM_MASKS
+#define MASKS_UPDATE(i, w) { const u32 cnt = (hc[i][w] >> sh0) & 0xFFu; z1[w] |= hit ? (1u << (i)) << (sh0 & 24u) : 0u; z2[w] |= hit && cnt >= 1u ? (1u << (i)) << (sh0 & 24u) : 0u; }
+#else
+#define MASKS_UPDATE(i, w)
+#endif
 #define COMMIT(i) if (oslot == (i)) { if (mine) { room[i][0] -= rq0; room[i][1] -= rq1; room[i][2] -= rq2; room[i][3] -= rq3; key[i] = (((key[i] >> 22) + 1u) << 22) | ((0x7FFFFu - (u32)p) << 3) | (key[i] & 7u); meta[i] = (meta[i] + cls) % 23u; } \
-      _Pragma("unroll") for (int w = 0; w < GW; ++w) { const bool hit = mine && has0 && w0 == (u32)w; hc[i][w] += hit ? (1u << sh0) : 0u; } }
+      _Pragma("unroll") for (int w = 0; w < GW; ++w) { const bool hit = mine && has0 && w0 == (u32)w; MASKS_UPDATE(i, w) hc[i][w] += hit ? (1u << sh0) : 0u; } }
     COMMIT(0) COMMIT(1)
 #if NPL > 2
     COMMIT(2) COMMIT(3)
@@ -132,6 +180,9 @@ __global__ __launch_bounds__(64 * NW) void lean(const PodRec* __restrict__ pods,
   u32 sink = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) sink += key[i] + meta[i] + (u32)room[i][0] + hc[i][3];
+#ifdef ITEM_MASKS
+  for (int w = 0; w < GW; ++w) sink += z1[w] ^ z2[w];
+#endif
   if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = placed; }
   if (sink == 0x12345678u) out[2] = sink;
 }
@@ -146,7 +197,7 @@ int main() {
     PodRec& r = h[i]; u32 s = i * 2654435761u;
     for (int k = 0; k < 4; ++k) r.rq[k] = 100 + (s >> (4 * k) & 255);
     const bool host = (i % 7) == 2 || (i % 7) == 3;
-    r.item[0] = host ? 0x80000000u | (((s >> 9) & 3u) * 8u) << 8 | ((s >> 5) & 7u) : 0u; r.item[1] = 0; r.lim[0] = 40; r.lim[1] = 0; r.cls = s >> 24;
+    r.item[0] = host ? 0x80000000u | (((s >> 9) & 3u) * 8u) << 8 | ((s >> 5) & 7u) : 0u; r.item[1] = 0; r.lim[0] = 1; r.lim[1] = 0; r.cls = s >> 24;
   }
   for (int i = 0; i < 256; ++i) acc[i] = ~0ull ^ (1ull << (i % 23));
   PodRec* dp; u64 *dacc, *dout;
