@@ -799,12 +799,14 @@ struct Scheduler {
   }
 
   // ---- Scheduler.add, scheduler.go:174-219 ----
+  FILE* trace = getenv("KO_TRACE") ? fopen(getenv("KO_TRACE"), "w") : nullptr;   // debugging aid: per add() the winner's position in the visiting order
   bool add(PodState& ps) {
     for (auto& n : existing) if (existing_add(*n, ps)) { ps.reasons = 0; return true; }
     // sort.Slice(newNodes, len(Pods) asc) -- canonical: stable
     if (gosort) go_sort_slice((int)new_nodes.size(), [&](int i, int j) { return new_nodes[i]->pods.size() < new_nodes[j]->pods.size(); }, [&](int i, int j) { std::swap(new_nodes[i], new_nodes[j]); });
     else std::stable_sort(new_nodes.begin(), new_nodes.end(), [](const std::unique_ptr<Node>& a, const std::unique_ptr<Node>& b) { return a->pods.size() < b->pods.size(); });
-    for (auto& n : new_nodes) if (node_add(*n, ps)) { ps.reasons = 0; return true; }
+    { int pos = 0; for (auto& n : new_nodes) { if (node_add(*n, ps)) { ps.reasons = 0; if (trace) fprintf(trace, "%d %d %zu %zu %d\n", ps.index, pos, new_nodes.size(), n->pods.size(), (int)n->seq); return true; } ++pos; } }
+    if (trace) fprintf(trace, "%d -1 %zu 0 -1\n", ps.index, new_nodes.size());
     ps.reasons = 0; uint32_t ti = 0;
     for (auto& t : templates) {
       const uint32_t shift = 4 * ti++;
