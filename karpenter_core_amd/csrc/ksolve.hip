@@ -127,7 +127,7 @@ struct DevProb {
   u32* mc_present; u32* mc_complement; u64* mc_mask; i32* mc_gt; i32* mc_lt; i32* mc_it;   // template ∩ class
   u64* grid;         // [M*C*TW]
   // register-resident pack kernel (ks_pack_rr.inc): per-class briefs (ks_build_rr), per-class cached answers, template x class -> nrc, the nrcs' type rows, the node hand-over
-  void* rr_briefs; u32* rr_memo; u8* rr_mcnrc; u64* rr_types; u64* rr_nodes; u32* rr_tab; u32* rr_tab2; u32* rr_mi; u8* rr_mcch;      // rr_tab: interns requirement classes (ks_link_rr); rr_mi[c]: the class whose cached answers class c shares; rr_mcch: template x class -> nrc of a fresh node with the pod on it
+  void* rr_briefs; u32* rr_memo; u8* rr_mcnrc; u64* rr_types; u64* rr_nodes; u32* rr_tab; u32* rr_tab2; u32* rr_mi; u8* rr_mcch; u32* rr_hot;      // rr_hot[c][8]: what the head window's straight-line loop reads of a class, unpacked once (ks_build_rr) | rr_tab: interns requirement classes (ks_link_rr); rr_mi[c]: the class whose cached answers class c shares; rr_mcch: template x class -> nrc of a fresh node with the pod on it
 };
 
 // Mutable state of one Solve (device memory).
@@ -2916,7 +2916,7 @@ static int upload_impl(const ks_problem* p, int device, const ks_dev_problem* ba
   TRY(dev_alloc(d, MC, &h.mc_ok, 0)); TRY(dev_alloc(d, MC, &h.mc_why, 0)); TRY(dev_alloc(d, MC, &h.mc_present)); TRY(dev_alloc(d, MC, &h.mc_complement));
   TRY(dev_alloc(d, MC * K, &h.mc_mask)); TRY(dev_alloc(d, MC * K, &h.mc_gt)); TRY(dev_alloc(d, MC * K, &h.mc_lt)); TRY(dev_alloc(d, MC, &h.mc_it));
   TRY(dev_alloc(d, MC * TW, &h.grid, 0));
-  { u8* rb = nullptr; TRY(dev_alloc(d, (size_t)C * sizeof(RRBrief), &rb)); h.rr_briefs = rb; TRY(dev_alloc(d, (size_t)C * (sizeof(RRMemo) / 4), &h.rr_memo)); TRY(dev_alloc(d, MC, &h.rr_mcnrc)); TRY(dev_alloc(d, MC, &h.rr_mcch)); TRY(dev_alloc(d, (size_t)h.ev_tab_size, &h.rr_tab, 0)); TRY(dev_alloc(d, (size_t)h.ev_tab_size, &h.rr_tab2, 0)); TRY(dev_alloc(d, (size_t)C, &h.rr_mi));
+  { u8* rb = nullptr; TRY(dev_alloc(d, (size_t)C * sizeof(RRBrief), &rb)); h.rr_briefs = rb; TRY(dev_alloc(d, (size_t)C * (sizeof(RRMemo) / 4), &h.rr_memo)); TRY(dev_alloc(d, MC, &h.rr_mcnrc)); TRY(dev_alloc(d, MC, &h.rr_mcch)); TRY(dev_alloc(d, (size_t)h.ev_tab_size, &h.rr_tab, 0)); TRY(dev_alloc(d, (size_t)h.ev_tab_size, &h.rr_tab2, 0)); TRY(dev_alloc(d, (size_t)C, &h.rr_mi)); TRY(dev_alloc(d, (size_t)C * 8, &h.rr_hot));
     TRY(dev_alloc(d, (size_t)RR_NRC * TW, &h.rr_types)); TRY(dev_alloc(d, (size_t)RR_NODES * 5, &h.rr_nodes)); }
   // state
   DevState& s = d->hs; const size_t NS = (size_t)E + h.NMAX;

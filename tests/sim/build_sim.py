@@ -26,7 +26,7 @@ def build(force: bool = False, opt: str = "-O1") -> str:
           [os.path.join(HERE, "hip_sim.h"), os.path.join(HERE, "hip_sim.cpp"), os.path.join(ROOT, "include", "ksolve.h")]
     if force or _newer(ks_so, src):
         subprocess.check_call(["g++", opt, "-g", "-std=c++17", "-fPIC", "-shared", "-w", "-DKS_SIM", "-I" + os.path.join(HERE, "fakeinc"),
-                               "-include", os.path.join(HERE, "hip_sim.h"), "-x", "c++", src[0], os.path.join(HERE, "hip_sim.cpp"),
+                               "-DRR_WINDOW=1", "-include", os.path.join(HERE, "hip_sim.h"), "-x", "c++", src[0], os.path.join(HERE, "hip_sim.cpp"),
                                "-o", ks_so, "-pthread"])
     kh_so = os.path.join(OUT, "libkshost.so")
     host = os.path.join(PKG, "host")
