@@ -31,12 +31,12 @@ ks_sim_switch:
 
 constexpr size_t kStack = 512 * 1024;
 constexpr unsigned kMaxThreads = 1024;
-enum Wait { RUN = 0, WAVE = 1, BLOCK = 2, DONE = 3 };
+enum Wait { RUN = 0, WAVE = 1, BLOCK = 2, DONE = 3, YIELDED = 4 };
 struct Wave { uint64_t vals[2][64]; uint64_t present[2]; unsigned arrived = 0, gen = 0, nlive = 0; };
 struct Fiber { void* sp = nullptr; Wait wait = RUN; unsigned waitgen = 0; unsigned tid = 0; unsigned wgen = 0; void* site = nullptr; };
 struct Block {
   std::vector<Fiber> f; std::vector<Wave> w; unsigned nthreads = 0, b_arrived = 0, b_gen = 0, b_nlive = 0;
-  const std::function<void()>* body = nullptr; void* sched_sp = nullptr; unsigned cur = 0;
+  const std::function<void()>* body = nullptr; void* sched_sp = nullptr; unsigned cur = 0, pass = 0;
 };
 Block* g_blk = nullptr;
 char* g_stacks = nullptr;
@@ -62,6 +62,7 @@ bool runnable(const Block& B, const Fiber& f) {
   if (f.wait == RUN) return true;
   if (f.wait == WAVE) return B.w[f.tid >> 6].gen != f.waitgen;
   if (f.wait == BLOCK) return B.b_gen != f.waitgen;
+  if (f.wait == YIELDED) return B.pass != f.waitgen;      // (a polling loop's turn is over until the scheduler has gone round the other waves)
   return false;
 }
 }  // namespace
@@ -81,6 +82,9 @@ const uint64_t* exchange(uint64_t v, uint64_t* present) {
   *present = W.present[par];
   return W.vals[par];
 }
+
+// A lane in a polling loop (waiting for another wave to write something, no barrier in between) gives the other waves a turn: on the GPU that is an s_sleep.
+void yield() { Block& B = *g_blk; Fiber& me = B.f[B.cur]; me.site = __builtin_return_address(0); me.wait = YIELDED; me.waitgen = B.pass; yield_to_sched(); me.wait = RUN; }
 
 void block_barrier() {
   Block& B = *g_blk; Fiber& me = B.f[B.cur];
@@ -114,7 +118,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     const unsigned nw = (unsigned)B.w.size();
     unsigned done = 0, wave0 = seed % nw;
     while (done < nthreads) {
-      bool any = false;
+      bool any = false; ++B.pass;
       for (unsigned wi = 0; wi < nw; ++wi) {
         const unsigned w = (wave0 + wi) % nw;
         bool progressed = true;
@@ -135,7 +139,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
       if (!any && done < nthreads) {
         fprintf(stderr, "ks_sim: deadlock in block (%u,%u,%u): %u of %u threads finished; a collective was reached in divergent control flow, or a barrier is missing a wave\n", bx, by, bz, done, nthreads);
         for (unsigned t = 0; t < nthreads; ++t) if (B.f[t].wait != DONE) { fprintf(stderr, "  first stuck thread %u: wait kind %d\n", t, (int)B.f[t].wait); break; }
-        for (unsigned w = 0; w < nw; ++w) { unsigned c[4] = {0, 0, 0, 0}; for (unsigned t = w * 64; t < std::min(nthreads, w * 64 + 64); ++t) c[(int)B.f[t].wait]++; fprintf(stderr, "  wave %u: %u runnable, %u at a wave collective, %u at the block barrier, %u done\n", w, c[0], c[1], c[2], c[3]);
+        for (unsigned w = 0; w < nw; ++w) { unsigned c[5] = {0, 0, 0, 0, 0}; for (unsigned t = w * 64; t < std::min(nthreads, w * 64 + 64); ++t) c[(int)B.f[t].wait]++; fprintf(stderr, "  wave %u: %u runnable, %u at a wave collective, %u at the block barrier, %u done\n", w, c[0], c[1], c[2], c[3]);
           if (c[1] && c[2]) { std::map<void*, unsigned> sites; for (unsigned t = w * 64; t < std::min(nthreads, w * 64 + 64); ++t) sites[B.f[t].site]++; for (auto& kv : sites) { if (kv.second <= 4) for (unsigned t = w * 64; t < std::min(nthreads, w * 64 + 64); ++t) if (B.f[t].site == kv.first) fprintf(stderr, "    (lane %u)\n", t & 63); } for (auto& kv : sites) fprintf(stderr, "    %u lanes wait at call site %p (addr2line -e <libksolve.so> <that minus the library's load address; /proc/self/maps below>)\n", kv.second, kv.first); } }
         { FILE* mf = fopen("/proc/self/maps", "r"); char ln[512]; while (mf && fgets(ln, sizeof ln, mf)) if (strstr(ln, "libksolve") && strstr(ln, "r-xp")) fputs(ln, stderr); if (mf) fclose(mf); }
         abort();

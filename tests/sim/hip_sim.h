@@ -76,6 +76,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 // rendezvous of the calling lane's wave: deposits v, returns the wave's 64 deposited values and the mask of lanes that took part
 const uint64_t* exchange(uint64_t v, uint64_t* present);
 void block_barrier();
+void yield();
 int lane_id();
 static inline uint64_t ballot(bool p) { uint64_t pm; const uint64_t* a = exchange(p ? 1 : 0, &pm); uint64_t m = 0; for (int i = 0; i < 64; ++i) if (((pm >> i) & 1) && a[i]) m |= 1ull << i; return m; }
 static inline uint64_t shfl64(uint64_t v, int src) { uint64_t pm; const uint64_t* a = exchange(v, &pm); src &= 63; return ((pm >> src) & 1) ? a[src] : v; }
