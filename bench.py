@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--whatifs", type=int, default=512, help="consolidation what-ifs (BASELINE configs[3]); 0 skips the N=1 what-if leg")
     ap.add_argument("--config5", type=int, default=0, metavar="PODS", help="BASELINE configs[4] instead of configs[2]: PODS pods (1000000 = the stated size), 5 000 instance types, full "
                     "constraint set, one Solve on one GPU through the general 4-wave kernel; prints the contract line for THAT workload (generation takes minutes)")
+    ap.add_argument("--config5-sample", type=int, default=250_000, metavar="PODS", help="also solve BASELINE configs[4]'s generator at PODS pods (250000: the size with an oracle "
+                    "fingerprint) and put the object `config5` on the line; 0 skips it (about a minute of generation and a 3 s Solve)")
     ap.add_argument("--whatifs-only", action="store_true", help="diagnostic: only the N=1 what-if leg (prints its object alone, not the contract line)")
     args = ap.parse_args()
 
@@ -167,7 +169,12 @@ def main():
     finally:
         os.environ.pop("KS_NO_RR", None)
     pack_name = "ks_pack_rr" if took_rr else "ks_pack"
-    rr_stats = {"rounds": res.stats.get("eq_pods"), "pods_placed_in_runs": res.stats.get("p22"), "run_steps": res.stats.get("p23"), "runs": res.stats.get("p24")} if took_rr else None
+    ws = res.stats.get("cyc_kind2", 0)
+    rr_stats = {"rounds": res.stats.get("eq_pods"), "pods_placed_in_runs": res.stats.get("p22"), "run_steps": res.stats.get("p23"), "runs": res.stats.get("p24"),
+                "pods_placed_by_the_head_window": res.stats.get("cyc_kind0"), "window_phases": res.stats.get("cyc_kind1"),
+                "window_phases_ended_because": {"the_leaders_business": ws & 0x1FFFFF, "nothing_in_the_window_accepts": (ws >> 21) & 0x1FFFFF, "exact_filter": ws >> 42}} if took_rr else None
+    # what a caller pays to read the result as KSR1 text (Node.Pods, InstanceTypeOptions, Requirements, Requests for every node): outside `value`, reported
+    t1 = time.perf_counter(); fp.result(); egress_text_ms = (time.perf_counter() - t1) * 1e3
     fp.close()
     fps, _ = S.solve_from_pods(parsed, local_rank, stats=True)
     st = fps.result().stats
@@ -218,6 +225,8 @@ def main():
                      "note": "one Solve() is a serial dependency chain executed by ONE 8-wave workgroup (1 of 256 CUs): instruction issue and "
                              "dependent-access latency bind it, the HBM fraction is reported because the contract asks for it (DESIGN.md)"},
         "alt_kernel": alt,
+        "egress": {"what": "ksh_result_text + its parse in the Python mirror for the whole result (every pod, every node): the boundary's output side, NOT inside `value` (the timed "
+                           "window ends with the binary result on the host)", "ms": egress_text_ms},
         "grid": {"kernel": "ks_grid_mc+ks_grid_types", "ms": grid_ms, "algorithmic_bytes": grid_bytes,
                  "achieved_GBs": grid_bytes / (grid_ms / 1e3) / 1e9 if grid_ms else None},
     }
@@ -225,6 +234,16 @@ def main():
     out["value_with_ingress"] = out["ingress"]["decisions_per_s_with_ingress"]
     if args.whatifs:
         out["whatif_batch"] = whatif_leg(args, 0, 1, local_rank, torch, None, S, W)
+    if args.config5_sample:
+        try:
+            sub = argparse.Namespace(**{**vars(args), "config5": args.config5_sample, "steps": 1, "warmup": 1})
+            c5 = config5_leg(sub, local_rank, torch, S, W)
+            out["config5"] = {"what": "BASELINE configs[4]'s generator at the size the oracle's offline fingerprint exists for (the stated 1 M pods: `bench.py --config5 1000000`, "
+                                      "profiles/); one Solve from the pod list, not `value`", "pods": c5["config"]["pods"], "instance_types": c5["config"]["instance_types"],
+                              "decisions_per_s": c5["value"], "ms_per_solve": c5["ms_per_step"], "new_nodes": c5["config"]["new_nodes"], "unschedulable": c5["config"]["unschedulable"],
+                              "oracle_fingerprint": c5["oracle_fingerprint"], "phases_ms_mean": c5["phases_ms_mean"], "roofline": c5["roofline"], "prep_seconds_untimed": c5["prep_seconds_untimed"]}
+        except Exception as e:      # (the object is a diagnostic: the contract line must not die with it)
+            out["config5"] = {"error": str(e)[:300]}
     if not args.no_cpu_baseline:
         from oracle import oracle_py
         sample = W.config3(pods=args.cpu_sample_pods, sizes=args.sizes, seed=44)

@@ -81,6 +81,30 @@ int ksh_open_parsed(void* parsed, uint32_t flags, void** out_handle);           
 int ksh_open(const char* ksp_text, size_t len, uint32_t flags, void** out_handle);      /* parse + flatten (no GPU needed) */
 void ksh_close(void* handle);
 const ks_problem* ksh_problem(void* handle);                                           /* the flat problem (owned by the handle) */
+/* ---- the result as arrays (round 5): what Scheduler.Solve returns (scheduler.go:96: []*Node, []*ExistingNode; Node.Pods / InstanceTypeOptions / Requirements / Requests,
+ * machinetemplate.go:77-100 reads them) without the KSR1 text.  Pointers into the handle's result buffers, valid until the handle is solved again or closed.  Node n of the
+ * CSR: existing node n (caller's state-node order) for n < n_existing, else new node n - n_existing (creation order); its pods are pod indices (caller's order) in COMMIT
+ * order (Node.Pods).  node_types: bit i = the caller's instance type i (the shim keeps the provisioner's own order when it filters: lo.Filter, node.go:138).  Requirement
+ * records are masks over a key's interned values: ksh_name(handle, 0, k, 0) names key k, ksh_name(handle, 1, k, v) value v (a key encoded over value classes names one
+ * member per class: such keys -- only reachable through Gt / Lt on labels with more than 64 values -- are listed in full by ksh_result_text), ksh_name(handle, 2, r, 0)
+ * resource r.  Not for what-ifs derived on the device (their consumer reads ksh_result_summaries' fixed-size records). */
+typedef struct ksh_result_arrays {
+  uint32_t n_pods, n_existing, n_new, n_unscheduled, types_words, n_resources, n_keys, pad;
+  const int32_t* pod_node;                 /* [n_pods] -1 unscheduled | existing node e | n_existing + new node j */
+  const int32_t* pod_stage;                /* [n_pods] the relaxation stage the pod ended at (Preferences.Relax, preferences.go:36-56: the shim applies it back to pod.Spec) */
+  const uint32_t* pod_reason;              /* [n_pods] ks_result.pod_reason (KS_WHY_* per machine template) for recordSchedulingResults (scheduler.go:135-172) */
+  const int32_t* unscheduled;              /* [n_unscheduled] the queue as Solve left it (queue.go:70-72) */
+  const uint32_t* node_pods_off;           /* [n_existing + n_new + 1] */
+  const int32_t* node_pods;                /* pod indices, node by node, commit order */
+  const int32_t* node_tmpl;                /* [n_new] machine template = provisioner in weight order */
+  const uint64_t* node_types;              /* [n_new][types_words] InstanceTypeOptions */
+  const int64_t* node_requests; const uint32_t* node_requests_present;      /* [n_new][n_resources] milli-units | bit r: the resource is in the list */
+  const uint32_t* node_present; const uint32_t* node_complement; const uint64_t* node_mask; const int32_t* node_gt; const int32_t* node_lt;   /* [n_new](*[n_keys]) Requirements after FinalizeScheduling */
+  const int32_t* node_it_state;            /* [n_new] the requirement on the instance-type key as a lattice state (0: none; ksh_result_text spells it out) */
+} ksh_result_arrays;
+int ksh_result_arrays_get(void* handle, ksh_result_arrays* out);
+const char* ksh_name(void* handle, int what /* 0 key, 1 value b of key a, 2 resource */, uint32_t a, uint32_t b);
+int ksh_rr_status(void* handle, int out[2]);                                           /* ks_problem_rr_status of the handle's device problem: out[0] ks_pack_rr was launched, out[1] why it declined (0: it took the Solve) */
 void ksh_dims(void* handle, uint32_t dims[10]);                                        /* P,C,T,M,E,K,R,G,GH,S */
 uint64_t ksh_fingerprint(void* handle);                                                /* hash of every array of the flat problem */
 int ksh_upload(void* handle, int device);                                              /* idempotent; a second call with another device is an error */

@@ -238,6 +238,11 @@ typedef struct ks_dev_problem ks_dev_problem;
 int ks_device_count(void);                                     /* number of gfx950 devices visible, 0 if none */
 int ks_current_device(void);                                   /* the calling thread's current HIP device (hipGetDevice), 0 if none */
 int ks_problem_device(const ks_dev_problem* d);                /* device an uploaded problem lives on */
+/* Which pack kernel took the last solve of `d`.  A single LEAN Solve is first offered to the register-resident kernel (ks_pack_rr), which DECLINES what it does not
+ * cover -- before or during its run, leaving no trace in the result -- whereupon the general kernel (ks_pack) solves it.  *started: ks_pack_rr was launched;
+ * *decline_code: 0 it took the Solve, else why it declined (the codes are listed in karpenter_core_amd/csrc/ks_pack_rr.inc; e.g. 1 static limits, 4 more nodes than it
+ * holds, 8 its watchdog).  Diagnostics only: the result is the same either way (scheduler.go:96-219). */
+int ks_problem_rr_status(const ks_dev_problem* d, int* started, int* decline_code);
 int ks_problem_upload(const ks_problem* p, int device, ks_dev_problem** out);
 void ks_problem_free(ks_dev_problem* d);
 /* Consolidation what-ifs over ONE cluster snapshot (deprovisioning/helpers.go:42-99) differ in their pods and in which state nodes stay, not in

@@ -2739,6 +2739,7 @@ struct ks_dev_problem {
   bool lean_ok = false;          // none of the rarely used features is present -> the LEAN kernel variant (see ks_pack)
   u32 pp_cap = 0;
   bool view = false;             // a what-if derived from a resident snapshot (ks_whatifs_open): memory and stream belong to its ks_whatif_batch
+  int rr_started = 0, rr_code = 0; // the last solve: ks_pack_rr was launched | why it declined (0: it took the Solve; the codes are in ks_pack_rr.inc)
   bool no_multi = false;         // ... over a snapshot with topology groups: the class briefs (round eligibility, certain records) were built for the snapshot's group activity, not this what-if's -- single-wave kernel only
 };
 
@@ -2779,6 +2780,7 @@ extern "C" int ks_device_count(void) {
 
 extern "C" int ks_current_device(void) { int d = 0; if (hipGetDevice(&d) != hipSuccess) return 0; return d; }
 extern "C" int ks_problem_device(const ks_dev_problem* d) { return d ? d->device : -1; }
+extern "C" int ks_problem_rr_status(const ks_dev_problem* d, int* started, int* decline_code) { if (!d) return fail(KS_ERR_INVALID, "null problem"); if (started) *started = d->rr_started; if (decline_code) *decline_code = d->rr_code; return KS_OK; }
 
 static int validate(const ks_problem* p) {
   if (!p) return fail(KS_ERR_INVALID, "null problem");
@@ -3351,6 +3353,7 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   // The register-resident kernel (ks_pack_rr.inc) takes a single LEAN Solve without Gt/Lt bounds; it declines what it does not cover -- before
   // or during the run, without having touched the inputs -- and ks_pack below takes over.
   bool rr_done = false;
+  for (u32 i = 0; i < n; ++i) { ds[i]->rr_started = 0; ds[i]->rr_code = 0; }
 #ifdef KS_SIM
   const bool rr_on = true;                    // (the emulator build has no ks_pack)
 #else
@@ -3365,11 +3368,12 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
       if (!rr_attr[device]) { HIPCHK(hipFuncSetAttribute((const void*)ks_pack_rr, hipFuncAttributeMaxDynamicSharedMemorySize, 44 * 1024)); rr_attr[device] = 1; }
     }
     hipLaunchKernelGGL(ks_pack_rr, dim3(1), dim3(64 * RR_NW), lds_rr, st, dp, dsv, lds_rr);
-    u64 rr_err = 0;
-    HIPCHK(hipMemcpyAsync(&rr_err, ds[0]->hs.stats + KS_STAT_ERR, sizeof rr_err, hipMemcpyDeviceToHost, st));
+    u64 rr_err[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // stats[7..14]: the error word ... the decline code
+    HIPCHK(hipMemcpyAsync(rr_err, ds[0]->hs.stats + KS_STAT_ERR, sizeof rr_err, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
-    rr_done = rr_err != KS_RR_DECLINED;
+    rr_done = rr_err[0] != KS_RR_DECLINED;
+    ds[0]->rr_started = 1; ds[0]->rr_code = rr_done ? 0 : (int)rr_err[14 - KS_STAT_ERR];
   }
 #ifdef KS_SIM
   if (!rr_done) return fail(KS_ERR_UNSUPPORTED, "emulator build: the problem is outside what ks_pack_rr covers (ks_pack is not emulated)");

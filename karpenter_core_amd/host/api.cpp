@@ -24,6 +24,7 @@ struct Handle {
   std::shared_ptr<void> base_dev;      // what-ifs over a snapshot: the snapshot's own flattening, resident on the device (shared catalogue + derived tables)
   bool solved = false;                 // rb holds the result of a successful solve (the result buffers are raw memory until then)
   bool dev_result = false;             // the device holds the result of a successful solve (price filter / launch pick / records read it there)
+  std::vector<uint32_t> csr_off; std::vector<int32_t> csr_pods;      // ksh_result_arrays: the pods of every node in commit order (built on demand from pod_seq)
   ~Handle() { if (dev && !delta) ks_problem_free(dev); }
 };
 // KSR1 text of the result in h->rb.  A derived what-if numbers its pods in the snapshot's queue order; callers number a what-if's pods in
@@ -510,6 +511,42 @@ extern "C" int ks_debug_classes(ks_dev_problem*, void*, void*);
 int ksh_debug_classes(void* hv, void* briefs, void* plans) { Handle* h = (Handle*)hv; if (!h->dev) return KS_ERR_INVALID; return ks_debug_classes(h->dev, briefs, plans); }
 
 // dims for tests / bench: [P,C,T,M,E,K,R,G,GH,S]
+// The result as ARRAYS (round 5): what scheduler.Solve returns -- Node.Pods in commit order, InstanceTypeOptions, Requests, Requirements, the relaxation stage every pod
+// ended at, the per-pod failure reasons -- without a text round trip.  Pointers into the handle's own result buffers: valid until the handle is solved again or closed.
+int ksh_result_arrays_get(void* hv, ksh_result_arrays* out) {
+  Handle* h = (Handle*)hv;
+  if (!h || !out) return set_err(KS_ERR_INVALID, "null argument");
+  if (!h->solved || !h->rb) return set_err(KS_ERR_INVALID, "result arrays before a solve");
+  if (h->delta) return set_err(KS_ERR_UNSUPPORTED, "a what-if derived on the device numbers its pods in the snapshot's queue order: read it through ksh_result_text / ksh_result_summaries");
+  const ks_problem& p = h->enc->prob; const ks_result& r = h->rb->r;
+  const uint32_t nn = p.E + r.n_new;
+  h->csr_off.assign((size_t)nn + 1, 0);
+  uint32_t placed = 0;
+  for (uint32_t i = 0; i < p.P; ++i) if (r.pod_node[i] >= 0) { h->csr_off[(size_t)r.pod_node[i] + 1]++; ++placed; }
+  for (uint32_t n = 0; n < nn; ++n) h->csr_off[n + 1] += h->csr_off[n];
+  // commit order within a node = ascending commit number; the numbers are unique over the Solve, so one pass in that order fills every node's list in place
+  std::vector<int32_t> by_seq(placed, -1);
+  for (uint32_t i = 0; i < p.P; ++i) if (r.pod_node[i] >= 0) { const int32_t sq = r.pod_seq[i]; if (sq < 0 || (uint32_t)sq >= placed || by_seq[sq] >= 0) return set_err(KS_ERR_INTERNAL, "commit numbers are not a permutation"); by_seq[sq] = (int32_t)i; }
+  h->csr_pods.assign(placed, -1);
+  { std::vector<uint32_t> fill(h->csr_off.begin(), h->csr_off.end() - 1); for (uint32_t sq = 0; sq < placed; ++sq) { const int32_t i = by_seq[sq]; h->csr_pods[fill[r.pod_node[i]]++] = i; } }
+  memset(out, 0, sizeof *out);
+  out->n_pods = p.P; out->n_existing = p.E; out->n_new = r.n_new; out->n_unscheduled = r.n_unscheduled; out->types_words = (p.T + 63) / 64; out->n_resources = p.R; out->n_keys = p.K;
+  out->pod_node = r.pod_node; out->pod_stage = r.pod_stage; out->pod_reason = r.pod_reason; out->unscheduled = r.unscheduled;
+  out->node_pods_off = h->csr_off.data(); out->node_pods = h->csr_pods.data();
+  out->node_tmpl = r.node_tmpl; out->node_types = r.node_types; out->node_requests = r.node_requests; out->node_requests_present = r.node_requests_present;
+  out->node_present = r.node_present; out->node_complement = r.node_complement; out->node_mask = r.node_mask; out->node_gt = r.node_gt; out->node_lt = r.node_lt; out->node_it_state = r.node_it_state;
+  return KS_OK;
+}
+// the names behind the arrays: requirement key k, its interned value v (a value class names its first member; ksh_result_text lists every member), resource r;
+// NULL when out of range (owned by the handle)
+const char* ksh_name(void* hv, int what /* 0 key, 1 value of key a, 2 resource */, uint32_t a, uint32_t b) {
+  const ksh::Encoded& E = ((Handle*)hv)->enc->names();
+  if (what == 0) return a < E.key_names.size() ? E.key_names[a].c_str() : nullptr;
+  if (what == 1) return (a < E.key_values.size() && b < E.key_values[a].size()) ? E.key_values[a][b].c_str() : nullptr;
+  if (what == 2) return a < E.res_names.size() ? E.res_names[a].c_str() : nullptr;
+  return nullptr;
+}
+int ksh_rr_status(void* hv, int* out2) { Handle* h = (Handle*)hv; if (!h || !h->dev) return KS_ERR_INVALID; return ks_problem_rr_status(h->dev, out2, out2 + 1); }
 void ksh_dims(void* hv, uint32_t* d) { const ks_problem& p = ((Handle*)hv)->enc->prob; uint32_t v[10] = {p.P, p.C, p.T, p.M, p.E, p.K, p.R, p.G, p.GH, p.S}; memcpy(d, v, sizeof v); }
 
 }  // extern "C"

@@ -64,6 +64,10 @@ def libs():
         kh.ksh_price_filter.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32),
                                         ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
         kh.ksh_dims.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        kh.ksh_rr_status.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        kh.ksh_result_arrays_get.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        kh.ksh_name.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+        kh.ksh_name.restype = ctypes.c_char_p
         kh.ksh_open_whatifs.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
                                         ctypes.POINTER(ctypes.c_int32), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
         kh.ksh_parse.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
@@ -152,6 +156,42 @@ class FlatProblem:
         text = ctypes.string_at(out).decode()
         kh.ksh_free(out)
         return parse_result(text)
+
+    def rr_status(self):
+        """(ks_pack_rr was launched for the last solve, why it declined -- 0: it took the Solve; codes in csrc/ks_pack_rr.inc).  include/ksolve.h ks_problem_rr_status."""
+        out = (ctypes.c_int * 2)()
+        rc = libs()[1].ksh_rr_status(self._h, out)
+        if rc != KS_OK:
+            raise KSolveError(rc, "ksh_rr_status")
+        return bool(out[0]), int(out[1])
+
+    def result_arrays(self) -> dict:
+        """The result through the binary door (include/kshost.h ksh_result_arrays_get): numpy copies of the arrays plus the key / resource names."""
+        import numpy as np
+
+        class RA(ctypes.Structure):
+            _fields_ = [(n, ctypes.c_uint32) for n in ("n_pods", "n_existing", "n_new", "n_unscheduled", "types_words", "n_resources", "n_keys", "pad")] + \
+                       [(n, ctypes.c_void_p) for n in ("pod_node", "pod_stage", "pod_reason", "unscheduled", "node_pods_off", "node_pods", "node_tmpl", "node_types", "node_requests",
+                                                       "node_requests_present", "node_present", "node_complement", "node_mask", "node_gt", "node_lt", "node_it_state")]
+        kh = libs()[1]
+        ra = RA()
+        rc = kh.ksh_result_arrays_get(self._h, ctypes.byref(ra))
+        if rc != KS_OK:
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+
+        def arr(ptr, n, dt):
+            if not n or not ptr:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n,)).copy()
+        P, E, N, K, R, TW = ra.n_pods, ra.n_existing, ra.n_new, ra.n_keys, ra.n_resources, ra.types_words
+        off = arr(ra.node_pods_off, E + N + 1, np.uint32)
+        return {"n_existing": E, "n_new": N, "pod_node": arr(ra.pod_node, P, np.int32), "pod_stage": arr(ra.pod_stage, P, np.int32), "pod_reason": arr(ra.pod_reason, P, np.uint32),
+                "unscheduled": arr(ra.unscheduled, ra.n_unscheduled, np.int32), "node_pods_off": off, "node_pods": arr(ra.node_pods, int(off[-1]) if len(off) else 0, np.int32),
+                "node_tmpl": arr(ra.node_tmpl, N, np.int32), "node_types": arr(ra.node_types, N * TW, np.uint64).reshape(N, TW), "node_requests": arr(ra.node_requests, N * R, np.int64).reshape(N, R),
+                "node_requests_present": arr(ra.node_requests_present, N, np.uint32), "node_present": arr(ra.node_present, N, np.uint32), "node_complement": arr(ra.node_complement, N, np.uint32),
+                "node_mask": arr(ra.node_mask, N * K, np.uint64).reshape(N, K),
+                "key_names": [(kh.ksh_name(self._h, 0, k, 0) or b"").decode() for k in range(K)], "resource_names": [(kh.ksh_name(self._h, 2, r, 0) or b"").decode() for r in range(R)],
+                "key_value": lambda k, v: (kh.ksh_name(self._h, 1, k, v) or b"").decode()}
 
     def result(self) -> SolveResult:
         """Decode the result the handle holds (after `solve(decode=False)` or `solve_from_pods`)."""

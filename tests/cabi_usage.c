@@ -40,7 +40,22 @@ int main(int argc, char** argv) {
 
   double ms[6]; void* solved = NULL;
   int rc = ksh_solve_from_batch(env, batch, 0, 0, &solved, ms);
-  if (rc == KS_OK) { char* out = NULL; ksh_result_text(solved, &out); printf("solved in %.2f ms\n%.60s...\n", ms[5], out); ksh_free(out); ksh_close(solved); }
+  if (rc == KS_OK) {
+    char* out = NULL; ksh_result_text(solved, &out); printf("solved in %.2f ms\n%.60s...\n", ms[5], out); ksh_free(out);
+    /* ... and the same result as arrays (no text): every node's pods in commit order, its InstanceTypeOptions, requests and requirement records */
+    ksh_result_arrays ra; int started = 0, why = 0, st2[2];
+    if (ksh_result_arrays_get(solved, &ra) == KS_OK) {
+      for (uint32_t nd = ra.n_existing; nd < ra.n_existing + ra.n_new; ++nd) {
+        const uint32_t j = nd - ra.n_existing; uint32_t ntypes = 0;
+        for (uint32_t w = 0; w < ra.types_words; ++w) ntypes += (uint32_t)__builtin_popcountll(ra.node_types[(size_t)j * ra.types_words + w]);
+        printf("new node %u: template %d, %u pods (first: pod %d), %u instance type options\n", j, ra.node_tmpl[j], ra.node_pods_off[nd + 1] - ra.node_pods_off[nd],
+               ra.node_pods_off[nd + 1] > ra.node_pods_off[nd] ? ra.node_pods[ra.node_pods_off[nd]] : -1, ntypes);
+        for (uint32_t k = 0; k < ra.n_keys; ++k) if ((ra.node_present[j] >> k) & 1u) printf("  requirement on %s: complement %u, values mask %llx\n", ksh_name(solved, 0, k, 0), (ra.node_complement[j] >> k) & 1u, (unsigned long long)ra.node_mask[(size_t)j * ra.n_keys + k]);
+      }
+    }
+    if (ksh_rr_status(solved, st2) == KS_OK) { started = st2[0]; why = st2[1]; printf("register-resident pack kernel: launched %d, declined with %d\n", started, why); }
+    ksh_close(solved);
+  }
   else printf("solve refused: %d (%s)\n", rc, ksh_last_error());
 
   ksh_close(h); ksh_pods_free(batch); ksh_parsed_free(env); free(text);

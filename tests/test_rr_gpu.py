@@ -74,3 +74,102 @@ def test_both_pack_kernels_agree(monkeypatch):
     b = S.solve_problem(p)
     assert ran_rr(a) and not ran_rr(b)
     assert a.canonical() == b.canonical() == O.solve(p).canonical()
+
+
+# ---- what ks_pack_rr declines, and that the Solve does not notice (ks_problem_rr_status: it was launched, why it gave the Solve back; the result is ks_pack's) ----
+def _solve_with_status(p):
+    fp = S.FlatProblem(p)
+    try:
+        res = fp.solve()
+        return res, fp.rr_status()
+    finally:
+        fp.close()
+
+
+def _anti_affinity_herd(n):
+    """n pods that each need a node of their own (self-selecting hostname anti-affinity on one label): n machines."""
+    from karpenter_core_amd import fake
+    from karpenter_core_amd.model import Container, LabelSelector, Pod, PodAffinityTerm, Problem, LABEL_HOSTNAME
+    its = fake.instance_types(5)
+    pods = [Pod(uid=f"pod-{i:07d}", labels={"app": "x"}, containers=[Container(requests={"cpu": "100m", "memory": "64Mi"})],
+                anti_required=[PodAffinityTerm(LABEL_HOSTNAME, LabelSelector({"app": "x"}))]) for i in range(n)]
+    return Problem(instance_types=its, provisioners=[fake.provisioner("default", len(its))], pods=pods, extra_well_known=fake.EXTRA_WELL_KNOWN)
+
+
+def _crowded_node(n):
+    """n tiny pods and one instance type that holds them all: more pods on one node than a key's count field (1023)."""
+    from karpenter_core_amd import fake
+    from karpenter_core_amd.model import Container, Pod, Problem
+    its = [fake.new_instance_type("huge", {"cpu": "4000", "memory": "4000Gi", "pods": str(n + 10)})]
+    pods = [Pod(uid=f"pod-{i:07d}", containers=[Container(requests={"cpu": "10m", "memory": "8Mi"})]) for i in range(n)]
+    return Problem(instance_types=its, provisioners=[fake.provisioner("default", len(its))], pods=pods, extra_well_known=fake.EXTRA_WELL_KNOWN)
+
+
+@pytest.mark.parametrize("name,maker,code", [
+    ("more_existing_nodes_than_it_holds", lambda: W.whatif(*W.cluster_snapshot(existing=80, sizes=10, seed=5), candidates=[0, 1, 2], with_cluster_pods=False), 1),
+    ("more_nodes_than_the_registers_hold", lambda: _anti_affinity_herd(3700), 4),
+    ("more_pods_on_a_node_than_the_count_field", lambda: _crowded_node(1100), 2),
+])
+def test_rr_declines_and_ks_pack_takes_over(name, maker, code, monkeypatch):
+    if os.environ.get("KS_TEST_SIM"):
+        pytest.skip("the emulator build has no ks_pack to give the Solve back to")
+    monkeypatch.delenv("KS_NO_RR", raising=False)
+    p = maker()
+    res, (started, why) = _solve_with_status(p)
+    assert started and why == code, (started, why)
+    assert not ran_rr(res)                       # (nothing of the declined run is in the statistics: they are ks_pack's)
+    if len(p.pods) <= 2000:
+        assert res.canonical() == O.solve(p).canonical()
+    else:                                        # (the reference-shaped oracle needs minutes for thousands of one-pod nodes: ks_pack alone is the yardstick, and the shape)
+        monkeypatch.setenv("KS_NO_RR", "1")
+        alone, (started2, _) = _solve_with_status(p)
+        assert not started2 and res.canonical() == alone.canonical()
+        assert len(res.new_nodes) == len(p.pods) and all(len(n.pods) == 1 for n in res.new_nodes)
+
+
+def test_rr_status_says_when_it_took_the_solve(monkeypatch):
+    monkeypatch.delenv("KS_NO_RR", raising=False)
+    p = W.config3(pods=700, sizes=10, seed=7)
+    res, (started, why) = _solve_with_status(p)
+    assert started and why == 0 and ran_rr(res)
+    if not os.environ.get("KS_TEST_SIM"):
+        monkeypatch.setenv("KS_NO_RR", "1")
+        res, (started, why) = _solve_with_status(p)
+        assert not started and not ran_rr(res)
+
+
+def test_head_window_is_exercised(monkeypatch):
+    """Round 5: most pods of the config #3 shape that are no plain replicas are placed by the leader's head window (stats slot 27), the plain stretches in RUN rounds (22)."""
+    monkeypatch.delenv("KS_NO_RR", raising=False)
+    res = S.solve_problem(W.config3(pods=20000, sizes=50, seed=45))
+    assert res.stats.get("cyc_kind0", 0) > 4000 and res.stats.get("p22", 0) > 4000
+
+
+def test_result_arrays_say_what_the_text_says(monkeypatch):
+    """The binary result door (ksh_result_arrays_get): Node.Pods in commit order, InstanceTypeOptions, requests, requirement records, stages, unscheduled queue -- field for
+    field what ksh_result_text decodes (that one is compared with the oracle everywhere else)."""
+    monkeypatch.delenv("KS_NO_RR", raising=False)
+    p = W.config3(pods=3500, sizes=20, seed=44)
+    fp = S.FlatProblem(p)
+    try:
+        res = fp.solve()
+        ra = fp.result_arrays()
+        names = [it.name for it in p.instance_types]
+        assert ra["n_new"] == len(res.new_nodes) and ra["n_existing"] == 0
+        off, pods = ra["node_pods_off"], ra["node_pods"]
+        for j, n in enumerate(res.new_nodes):
+            assert list(pods[off[j]:off[j + 1]]) == list(n.pods)
+            mask = ra["node_types"][j]
+            assert {names[i] for i in range(len(names)) if (int(mask[i // 64]) >> (i % 64)) & 1} == set(n.instance_types)
+            req = {ra["resource_names"][r]: int(ra["node_requests"][j][r]) for r in range(len(ra["resource_names"])) if (int(ra["node_requests_present"][j]) >> r) & 1}
+            assert req == dict(n.requests)
+            for k, key in enumerate(ra["key_names"]):
+                if (int(ra["node_present"][j]) >> k) & 1:
+                    q = n.requirements[key]
+                    assert bool((int(ra["node_complement"][j]) >> k) & 1) == bool(q.complement)
+                    assert {ra["key_value"](k, v) for v in range(64) if (int(ra["node_mask"][j][k]) >> v) & 1} == set(q.values)
+                else:
+                    assert key not in n.requirements
+        assert list(ra["unscheduled"]) == list(res.unscheduled) and list(ra["pod_stage"]) == list(res.final_stage)
+    finally:
+        fp.close()
