@@ -36,6 +36,8 @@ extern KsSimIdx threadIdx, blockIdx, blockDim, gridDim;
 #define __shared__ static
 #define __HIP_MEMORY_SCOPE_WORKGROUP 0
 #define __hip_atomic_fetch_add(p, v, o, s) ks_sim_fetch_add((p), (v))
+#define __hip_atomic_store(p, v, o, s) (*(volatile __typeof__(*(p))*)(p) = (v))
+#define __hip_atomic_load(p, o, s) (*(volatile const __typeof__(*(p))*)(p))
 #define __builtin_readcyclecounter() ((unsigned long long)__builtin_ia32_rdtsc())
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __threadfence_block() do { } while (0)

@@ -13,6 +13,6 @@ fp = S.FlatProblem(p); fp.upload(0); fp.grid(want_bits=False); fp.solve(decode=F
 ms = []
 for _ in range(3): fp.solve(decode=False); ms.append(fp.kernel_ms)
 st = fp.solve().stats
-print("%-12s min %.2f ms  rounds %s window pods %s phases %s" % (v, min(ms), st.get("eq_pods"), st.get("cyc_kind0"), st.get("cyc_kind1")))
+print("%-12s min %.2f ms  rounds %s window pods %s phases %s queries %s" % (v, min(ms), st.get("eq_pods"), st.get("cyc_kind0"), st.get("cyc_kind1"), st.get("n_kind1")))
 PY
 done | tee gpurun_out/r5ab/variants.log
