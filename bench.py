@@ -13,7 +13,7 @@ as `resident` -- it is NOT `value`.  decisions = len(pods) per Solve, the refere
 (scheduling_benchmark_test.go:170).
 
 N>1: a single Solve() is a serial dependency chain and does not shard ("replicas only").  What shards is
-consolidation's what-if fan-out (BASELINE configs[3]): the 512 what-ifs over one 2048-node snapshot are dealt out i mod N,
+consolidation's what-if fan-out (BASELINE configs[3]): the 512 what-ifs over one 2048-node snapshot are dealt to the ranks by predicted work (LPT),
 every rank solves its shard in ONE batched launch, and ONE RCCL all-gather of fixed-size result records `[id, n_new,
 n_unscheduled, first node's InstanceTypeOptions]` closes the step.  Fixed total work: "strong" scaling; `value` = decisions of
 all 512 what-ifs / max-over-ranks time; its N=1 reference is the `whatif_batch` object of the N=1 line.
@@ -388,8 +388,10 @@ def dry_fanout(args, rank, world):
     dist.init_process_group("gloo")
     from karpenter_core_amd import consolidation as C
     total = args.whatifs or 512
-    mine = list(range(rank, total, world))
-    per = (total + world - 1) // world
+    from karpenter_core_amd import workloads as W
+    dealt = C.deal([len(cs) for cs in W.config4_sets(total, 2048, 45)], world)      # (the real leg weighs a what-if by its pods; the rehearsal by its candidate nodes)
+    mine = dealt[rank]
+    per = max(len(d) for d in dealt)
     rec = torch.zeros((len(mine), 3), dtype=torch.int64)
     rec[:, 0] = torch.tensor(mine, dtype=torch.int64)
     table = C.all_gather_records(rec, per)
@@ -479,17 +481,24 @@ def whatif_leg(args, rank, world, local_rank, torch, dist, S, W):
 
 
 def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
-    """N>1: the 512 what-ifs dealt out i mod N (strong scaling), one batched launch per rank, ONE all-gather of result records."""
+    """N>1: the 512 what-ifs dealt to the ranks by predicted work (strong scaling), one batched launch per rank, ONE all-gather of result records; the same leg under weak
+    scaling (every rank all 512) beside it."""
     parsed, pod_node, T, sets = whatif_snapshot(args, S, W)
     total_whatifs = len(sets)
-    mine = list(range(rank, total_whatifs, world))
+    from karpenter_core_amd import consolidation as C
+    # dealt by predicted work -- the pods of a what-if's candidate nodes --, longest first to the least loaded rank (round 5; i mod N before): the step is no longer its
+    # longest what-if plus whatever happened to sit beside it
+    pods_on = {}
+    for nd in pod_node:
+        pods_on[nd] = pods_on.get(nd, 0) + 1
+    weights = [sum(pods_on.get(c, 0) for c in cs) for cs in sets]
+    dealt = C.deal(weights, world)
+    mine = dealt[rank]
     flats = S.open_whatifs(parsed, pod_node, [sets[i] for i in mine], device=local_rank)
     S.upload_batch(flats, local_rank)
     words = (T + 63) // 64
-    per = (total_whatifs + world - 1) // world
+    per = max(len(d) for d in dealt)
     pods_mine = sum(f.dims["P"] for f in flats)
-
-    from karpenter_core_amd import consolidation as C
 
     on_device = dist.get_backend() == "nccl"
     dev = f"cuda:{local_rank}"
@@ -550,6 +559,39 @@ def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
               "decisions_per_s": sum(f.dims["P"] for f in allf) * args.steps / e1, "records_equal_gathered": bool((one == table).all().item())}
         for f in allf:
             f.close()
+    # ---- the same leg under WEAK scaling: every rank solves ALL the what-ifs over its own copy of the snapshot (N times the work on N GPUs), one all-gather of all records ----
+    weak = None
+    try:
+        allw = S.open_whatifs(parsed, pod_node, sets, device=local_rank)
+        S.upload_batch(allw, local_rank)
+        idsw = [rank * total_whatifs + i for i in range(total_whatifs)]
+        localw = torch.full((total_whatifs, width), -1, dtype=torch.int64, device=dev)
+        gatheredw = torch.empty((world * total_whatifs, width), dtype=torch.int64, device=dev)
+
+        def stepw():
+            S.solve_batch_resident(allw); S.result_records_dev(allw, idsw, words, localw)
+            if on_device:
+                dist.all_gather_into_tensor(gatheredw, localw)
+            else:
+                parts = [torch.empty_like(localw) for _ in range(world)]
+                dist.all_gather(parts, localw)
+        for _ in range(max(1, args.warmup)):
+            stepw()
+        dist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            stepw()
+        torch.cuda.synchronize(); dist.barrier()
+        tw = torch.tensor([time.perf_counter() - t1], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        pods_all = sum(f.dims["P"] for f in allw)
+        weak = {"what": f"every rank solves all {total_whatifs} what-ifs over its own copy of the snapshot ({world}x the work), one all-gather of {world * total_whatifs} records",
+                "scaling": "weak", "whatifs_per_gpu": total_whatifs, "ms_per_step": float(tw.item()) / args.steps * 1e3,
+                "decisions_per_s": world * pods_all * args.steps / float(tw.item())}
+        for f in allw:
+            f.close()
+    except Exception as e:      # (diagnostic object: the contract line must not die with it)
+        weak = {"error": str(e)[:300]}
     dist.barrier()
     if rank != 0:
         return
@@ -566,9 +608,9 @@ def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
     out = {"metric": "pod-placement decisions/sec (Solve())", "value": total_pods * args.steps / elapsed, "unit": "decisions/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-           "config": {"workload": f"BASELINE configs[3]: {total_whatifs} consolidation what-ifs over 2048 existing nodes / {T} instance types, dealt out i mod {world}; "
+           "config": {"workload": f"BASELINE configs[3]: {total_whatifs} consolidation what-ifs over 2048 existing nodes / {T} instance types, dealt to the ranks by predicted work (pods; longest first to the least loaded rank); "
                                   "one batched launch per rank + ONE RCCL all-gather of result records", "whatifs": total_whatifs, "decisions_per_step": total_pods,
-                      "records_gathered": got, "parallelism": f"{world} ranks x {per} what-ifs", "single_gpu_same_workload": n1,
+                      "records_gathered": got, "parallelism": f"{world} ranks x <= {per} what-ifs", "pods_per_rank": None, "single_gpu_same_workload": n1, "weak": weak,
                       "n1_reference": "the `whatif_batch` object of the --gpus 1 line (same workload on one GPU); a single Solve() does not shard (replicas only)"},
            "roofline": {"kernel": "ks_pack<single wave> x what-ifs of rank 0 in one launch", "bound": "hbm", "achieved": abytes / k_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": abytes / k_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": abytes, "kernel_ms_mean": k_s * 1e3,

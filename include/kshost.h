@@ -125,6 +125,9 @@ int ksh_result_summaries(void** handles, uint32_t n, uint64_t* out /* [n][2 + wo
  * the one all-gather a what-if fan-out needs, with no host hop */
 int ksh_solve_batch_resident(void** handles, uint32_t n, float* kernel_ms, double* wall_ms);
 int ksh_result_records_dev(void** handles, uint32_t n, const uint64_t* ids, uint32_t words, void* d_out);
+/* ... and the fan-out over several GPUs in one call (ks_solve_batch_sharded, include/ksolve.h): shard s = handles[shard_off[s] .. shard_off[s + 1]), all of a shard resident on
+ * one device; ks_deal_lpt (ksolve.h) deals what-ifs to shards by predicted work.  out_rows[n][3 + words], ordered by id. */
+int ksh_solve_whatifs_sharded(void** handles, const uint32_t* shard_off, uint32_t nshards, const uint64_t* ids, uint32_t words, uint64_t* out_rows, float* kernel_ms_max);
 
 /* ---- consolidation ---- */
 int ksh_open_whatifs(const char* snapshot_text, size_t len, uint32_t flags, uint32_t n, const uint32_t* cand_off /* [n+1] */, const uint32_t* cand,

@@ -298,6 +298,15 @@ int ks_solve_batch_dev(ks_dev_problem* const* d, uint32_t n, ks_result* const* o
  * caller-owned DEVICE buffer d_out[n][3 + words] of uint64: [ids[i], n_new, n_unscheduled, new node 0's InstanceTypeOptions (zero if none)].
  * The buffer is complete when the call returns -- it can be handed to RCCL as is (no host hop). */
 int ks_batch_records_dev(ks_dev_problem* const* ds, uint32_t n, const uint64_t* ids, uint32_t words, void* d_out);
+/* ---- the what-if fan-out over several GPUs in ONE call (SURVEY 8b `ks_solve_batch(shared, whatifs, n, out, ngpus)`; deprovisioning/helpers.go:42-115 per what-if,
+ * multinodeconsolidation.go:74-114 / singlenodeconsolidation.go:54-78 are the callers that would batch them).  The what-ifs are resident as shards, one list of device
+ * problems per GPU (every problem of a shard on the same device: ks_whatifs_open over that GPU's copy of the snapshot, or ks_problem_upload).  Every shard is solved in one
+ * batched launch on its own device and stream, concurrently (a thread per shard); the fixed-size decision records -- [id, n_new, n_unscheduled, new node 0's
+ * InstanceTypeOptions (words)] -- are built on each device and gathered into out_rows[sum shard_n][3 + words], ordered by id.  kernel_ms_max: the slowest shard's launch.
+ * ks_deal_lpt decides which shard a what-if goes to from a predicted weight (e.g. its pods): longest first, each to the least loaded shard. */
+void ks_deal_lpt(const uint64_t* weight, uint32_t n, uint32_t nshards, uint32_t* shard_of);
+int ks_solve_batch_sharded(ks_dev_problem* const* const* shards, const uint32_t* shard_n, const uint64_t* const* shard_ids, uint32_t nshards, uint32_t words,
+                           uint64_t* out_rows, float* kernel_ms_max);
 int ks_solve_batch(const ks_problem* const* p, uint32_t n, ks_result* const* out);
 
 /* The static pod-class x instance-type feasibility grid for fresh nodes of every template:

@@ -27,6 +27,20 @@ def shard(n: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n, world))
 
 
+def deal(weights: Sequence[int], world: int) -> List[List[int]]:
+    """Which rank solves which what-if, by predicted work (e.g. the pods of its candidate nodes): longest first, each to the least loaded rank (ties: the lower rank) --
+    the LPT rule, the same as include/ksolve.h ks_deal_lpt.  Round-robin (`shard`) leaves a step as long as its longest what-if plus whatever i mod N put beside it;
+    this puts the longest what-if (nearly) alone.  Returns the what-if ids of every rank, ascending."""
+    order = sorted(range(len(weights)), key=lambda i: (-int(weights[i]), i))
+    load = [0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += int(weights[i]) or 1
+    return [sorted(x) for x in out]
+
+
 def record_width(n_instance_types: int) -> int:
     return 3 + (n_instance_types + 63) // 64
 

@@ -2686,6 +2686,7 @@ __global__ void ks_probe_has_kernel(ks_req1 a, const i32* vint, u32 nv, ks_req_f
 // hipHostMalloc per Solve would cost more than the upload itself, so freed blocks are kept (per device, by power-of-two size
 // class, a few of each) and handed out again.  Thread-safe; blocks never migrate between devices.
 #include <mutex>
+#include <thread>
 #include <map>
 namespace {
 struct DevPool {
@@ -3451,6 +3452,56 @@ extern "C" int ks_batch_records_dev(ks_dev_problem* const* ds, uint32_t n, const
   HIPCHK(hipMemcpyAsync(t_desc.p, hd.data(), n * sizeof(RecordDesc), hipMemcpyHostToDevice, ds[0]->stream));
   hipLaunchKernelGGL(ks_records, dim3(n), dim3(64), 0, ds[0]->stream, t_desc.as<RecordDesc>(), (u64*)d_out, words);
   HIPCHK(hipStreamSynchronize(ds[0]->stream)); HIPCHK(hipGetLastError());      // the buffer is complete when this returns: the caller's own stream may read it
+  return KS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The what-if fan-out in the C ABI (SURVEY 8b `ks_solve_batch(shared, whatifs, n, out, ngpus)`, 8e row 1; deprovisioning/helpers.go:42-115,
+// multinodeconsolidation.go:74-114): the caller's what-ifs are resident as SHARDS -- one list of device problems per GPU (ks_whatifs_open on that
+// GPU's copy of the snapshot) -- and one call solves every shard in ONE batched launch on its own device and stream, builds the fixed-size decision
+// records there, and gathers them into ONE host table ordered by id.  A thread per shard; no Python, no torch.  (bench.py's N-rank step does the same
+// over processes, with one RCCL all-gather instead of the device-to-host copies: one process per GPU is the launch contract there.)
+// ks_deal_lpt: which shard a what-if goes to -- longest predicted work first, each to the least loaded shard (ties: the lower index), so that a
+// batch is not its longest what-if plus whatever i mod N happened to put beside it.
+// ------------------------------------------------------------------------------------------------
+extern "C" void ks_deal_lpt(const uint64_t* weight, uint32_t n, uint32_t nshards, uint32_t* shard_of) {
+  if (!nshards) return;
+  std::vector<u32> order(n); for (u32 i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return weight[a] > weight[b]; });
+  std::vector<u64> load(nshards, 0);
+  for (u32 i : order) { u32 best = 0; for (u32 s = 1; s < nshards; ++s) if (load[s] < load[best]) best = s; shard_of[i] = best; load[best] += weight[i] ? weight[i] : 1; }
+}
+extern "C" int ks_solve_batch_sharded(ks_dev_problem* const* const* shards, const uint32_t* shard_n, const uint64_t* const* shard_ids, uint32_t nshards, uint32_t words,
+                                      uint64_t* out_rows, float* kernel_ms_max) {
+  if (!nshards) return KS_OK;
+  if (!shards || !shard_n || !shard_ids || !out_rows) return fail(KS_ERR_INVALID, "null argument");
+  const size_t width = 3 + (size_t)words;
+  std::vector<size_t> off(nshards + 1, 0); for (u32 s = 0; s < nshards; ++s) off[s + 1] = off[s] + shard_n[s];
+  std::vector<int> rcs(nshards, KS_OK); std::vector<std::string> msgs(nshards); std::vector<float> kms(nshards, 0.0f);
+  std::vector<u64> rows(off[nshards] * width);
+  auto run = [&](u32 s) {
+    const u32 n = shard_n[s]; if (!n) return;
+    float k = 0.0f;
+    int rc = ks_solve_batch_dev(shards[s], n, nullptr, &k);
+    if (rc == KS_OK) {
+      const int device = shards[s][0]->device;
+      TmpDev buf(device);
+      rc = buf.alloc(n * width * sizeof(u64));
+      if (rc == KS_OK) rc = ks_batch_records_dev(shards[s], n, shard_ids[s], words, buf.p);
+      if (rc == KS_OK && hipMemcpy(rows.data() + off[s] * width, buf.p, n * width * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) { rc = KS_ERR_DEVICE; g_err = "records: device to host"; }
+    }
+    rcs[s] = rc; if (rc != KS_OK) msgs[s] = g_err; kms[s] = k;
+  };
+  std::vector<std::thread> th;
+  for (u32 s = 1; s < nshards; ++s) th.emplace_back(run, s);
+  run(0);
+  for (auto& t : th) t.join();
+  for (u32 s = 0; s < nshards; ++s) if (rcs[s] != KS_OK) return fail(rcs[s], "shard " + std::to_string(s) + ": " + msgs[s]);
+  // one table, ordered by id (what the all-gather + sort of the N-rank path leaves)
+  std::vector<size_t> idx(off[nshards]); for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+  std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return rows[a * width] < rows[b * width]; });
+  for (size_t i = 0; i < idx.size(); ++i) memcpy(out_rows + i * width, rows.data() + idx[i] * width, width * sizeof(u64));
+  if (kernel_ms_max) { float m = 0; for (float k : kms) m = std::max(m, k); *kernel_ms_max = m; }
   return KS_OK;
 }
 

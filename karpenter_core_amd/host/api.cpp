@@ -546,6 +546,20 @@ const char* ksh_name(void* hv, int what /* 0 key, 1 value of key a, 2 resource *
   if (what == 2) return a < E.res_names.size() ? E.res_names[a].c_str() : nullptr;
   return nullptr;
 }
+// The what-if fan-out in one call (ks_solve_batch_sharded): shard s = handles[shard_off[s] .. shard_off[s + 1]) (every handle of a shard uploaded to the same device),
+// ids[] names each handle's what-if; out_rows[n][3 + words] comes back ordered by id.
+int ksh_solve_whatifs_sharded(void** hv, const uint32_t* shard_off, uint32_t nshards, const uint64_t* ids, uint32_t words, uint64_t* out_rows, float* kernel_ms_max) {
+  if (!hv || !shard_off || !ids || !out_rows) return set_err(KS_ERR_INVALID, "null argument");
+  const uint32_t n = shard_off[nshards];
+  std::vector<ks_dev_problem*> ds(n);
+  for (uint32_t i = 0; i < n; ++i) { Handle* h = (Handle*)hv[i]; if (!h->dev) return set_err(KS_ERR_INVALID, "a what-if that is not resident (ksh_upload / ksh_upload_batch / ksh_open_whatifs_derived first)"); ds[i] = h->dev; h->solved = false; h->dev_result = false; }
+  std::vector<ks_dev_problem* const*> sp(nshards); std::vector<uint32_t> sn(nshards); std::vector<const uint64_t*> si(nshards);
+  for (uint32_t s = 0; s < nshards; ++s) { sp[s] = ds.data() + shard_off[s]; sn[s] = shard_off[s + 1] - shard_off[s]; si[s] = ids + shard_off[s]; }
+  int rc = ks_solve_batch_sharded(sp.data(), sn.data(), si.data(), nshards, words, out_rows, kernel_ms_max);
+  if (rc != KS_OK) return set_err(rc, ks_last_error());
+  for (uint32_t i = 0; i < n; ++i) ((Handle*)hv[i])->dev_result = true;
+  return KS_OK;
+}
 int ksh_rr_status(void* hv, int* out2) { Handle* h = (Handle*)hv; if (!h || !h->dev) return KS_ERR_INVALID; return ks_problem_rr_status(h->dev, out2, out2 + 1); }
 void ksh_dims(void* hv, uint32_t* d) { const ks_problem& p = ((Handle*)hv)->enc->prob; uint32_t v[10] = {p.P, p.C, p.T, p.M, p.E, p.K, p.R, p.G, p.GH, p.S}; memcpy(d, v, sizeof v); }
 

@@ -65,6 +65,9 @@ def libs():
                                         ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
         kh.ksh_dims.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         kh.ksh_rr_status.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        kh.ksh_solve_whatifs_sharded.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        ks.ks_deal_lpt.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+        ks.ks_deal_lpt.restype = None
         kh.ksh_result_arrays_get.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         kh.ksh_name.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
         kh.ksh_name.restype = ctypes.c_char_p
@@ -397,6 +400,34 @@ def solve_batch(flats: Sequence[FlatProblem], decode: bool = True):
             res.append(parse_result(ctypes.string_at(outs[i]).decode()))
             kh.ksh_free(outs[i])
     return res, float(kms.value), float(wms.value)
+
+
+def deal_lpt(weights: Sequence[int], nshards: int) -> List[int]:
+    """Which shard (GPU / rank) each what-if goes to: longest predicted work first, each to the least loaded shard (include/ksolve.h ks_deal_lpt) -- instead of i mod N, which
+    leaves a batch as long as its longest what-if plus whatever happened to be dealt beside it."""
+    n = len(weights)
+    w = (ctypes.c_uint64 * max(1, n))(*[int(x) for x in weights])
+    out = (ctypes.c_uint32 * max(1, n))()
+    libs()[0].ks_deal_lpt(w, n, nshards, out)
+    return [int(out[i]) for i in range(n)]
+
+
+def solve_whatifs_sharded(shards: Sequence[Sequence[FlatProblem]], ids: Sequence[Sequence[int]], words: int):
+    """The what-if fan-out in one C call (include/kshost.h ksh_solve_whatifs_sharded): every shard's what-ifs (resident on that shard's device) in one batched launch, all
+    shards concurrently, the decision records gathered into one table ordered by id.  Returns ([n, 3 + words] uint64 numpy table, slowest shard's kernel milliseconds)."""
+    import numpy as np
+    kh = libs()[1]
+    flat = [f for sh in shards for f in sh]
+    n = len(flat)
+    hs = (ctypes.c_void_p * max(1, n))(*[f._h for f in flat])
+    off = (ctypes.c_uint32 * (len(shards) + 1))(*([0] + list(np.cumsum([len(sh) for sh in shards]))))
+    idv = (ctypes.c_uint64 * max(1, n))(*[int(i) for sh in ids for i in sh])
+    rows = np.zeros((n, 3 + words), dtype=np.uint64)
+    kms = ctypes.c_float()
+    rc = kh.ksh_solve_whatifs_sharded(hs, off, len(shards), idv, words, rows.ctypes.data_as(ctypes.c_void_p), ctypes.byref(kms))
+    if rc != KS_OK:
+        raise KSolveError(rc, kh.ksh_last_error().decode())
+    return rows, float(kms.value)
 
 
 def result_records(flats: Sequence[FlatProblem], ids: Sequence[int], words: int):

@@ -125,3 +125,49 @@ def test_bench_gpus_2_fanout_on_one_gpu():
     assert out["n_gpus"] == 2 and out["config"]["records_gathered"] == 512
     assert out["config"]["single_gpu_same_workload"]["records_equal_gathered"] is True
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+def test_lpt_deal_balances_and_matches_the_c_abi():
+    """Round 5: what-ifs are dealt by predicted work, longest first to the least loaded rank (consolidation.deal == include/ksolve.h ks_deal_lpt): every id once, the longest
+    what-if's rank carries little else, loads within the longest item of each other."""
+    from karpenter_core_amd import scheduler as S
+    sets = W.config4_sets(512, 2048, 45)
+    weights = [len(cs) * 20 for cs in sets]
+    for world in (1, 2, 4, 8):
+        dealt = C.deal(weights, world)
+        assert sorted(sum(dealt, [])) == list(range(512))
+        loads = [sum(weights[i] for i in d) for d in dealt]
+        assert max(loads) - min(loads) <= max(weights)
+        if world == 2:
+            assert (max(loads) - min(loads)) / max(loads) < 0.10
+        of = S.deal_lpt(weights, world)
+        assert [sorted(i for i in range(512) if of[i] == r) for r in range(world)] == dealt
+
+
+@pytest.mark.gpu
+def test_whatifs_sharded_in_one_c_call():
+    """The fan-out in the C ABI (ksh_solve_whatifs_sharded): two shards -- both on the one GPU of this box -- solved concurrently, their records gathered into one table by
+    id: equal to the records of the unsharded batch."""
+    from karpenter_core_amd import scheduler as S
+    its, prov, nodes, bound = W.cluster_snapshot(existing=96, sizes=10, seed=13)
+    snap, pod_node = W.snapshot_problem(its, prov, nodes, bound, False)
+    sets = [list(range(0, i + 1)) for i in range(12)] + [[i] for i in (20, 33, 47, 60)]
+    parsed = S.ParsedProblem(snap)
+    words = (len(its) + 63) // 64
+    weights = [sum(len(bound[c]) for c in cs) for cs in sets]
+    dealt = C.deal(weights, 2)
+    shards = [S.open_whatifs(parsed, pod_node, [sets[i] for i in d], device=0) for d in dealt]
+    allf = S.open_whatifs(parsed, pod_node, sets, device=0)
+    try:
+        for sh in shards:
+            S.upload_batch(sh, 0)
+        S.upload_batch(allf, 0)
+        rows, kms = S.solve_whatifs_sharded(shards, dealt, words)
+        S.solve_batch_resident(allf)
+        import torch
+        one = torch.full((len(sets), 3 + words), -1, dtype=torch.int64, device="cuda:0")
+        S.result_records_dev(allf, list(range(len(sets))), words, one)
+        assert rows.astype("int64").tolist() == one.cpu().tolist() and kms > 0
+    finally:
+        for f in allf + [f for sh in shards for f in sh]:
+            f.close()

@@ -20,23 +20,31 @@ def one(job):
     try:
         want = O.solve(pr)
     except Exception as e:      # noqa: BLE001
-        return fam, seed, "oracle-error " + repr(e)[:120], 0, 0.0
+        return fam, seed, "oracle-error " + repr(e)[:120], 0, 0.0, "-"
+    kern = "?"
     try:
-        got = S.solve_problem(pr)
+        fp = S.FlatProblem(pr)
+        try:
+            got = fp.solve()
+            started, why = fp.rr_status()      # which pack kernel took it: ks_pack_rr (code 0), ks_pack after a decline (why), ks_pack alone
+            kern = "rr" if started and why == 0 else (f"rr-declined-{why}" if started else "ks_pack")
+        finally:
+            fp.close()
     except S.KSolveError as e:
-        return fam, seed, ("unsupported" if e.code == S.KS_ERR_UNSUPPORTED else "gpu-error " + str(e)[:120]), len(pr.pods), time.time() - t0
+        return fam, seed, ("unsupported" if e.code == S.KS_ERR_UNSUPPORTED else "gpu-error " + str(e)[:120]), len(pr.pods), time.time() - t0, kern
     ok = got.canonical() == want.canonical() and got.reasons == want.reasons
-    return fam, seed, "ok" if ok else "MISMATCH", len(pr.pods), time.time() - t0
+    return fam, seed, "ok" if ok else "MISMATCH", len(pr.pods), time.time() - t0, kern
 
 
 if __name__ == "__main__":
     import multiprocessing as mp
     first, count = int(sys.argv[1]), int(sys.argv[2]); procs = int(sys.argv[3]) if len(sys.argv) > 3 else 24
     jobs = [(fam, first + i) for i in range(count) for fam in ("base", "wide", "general", "small")]
-    t0 = time.time(); bad = []; n = {}
+    t0 = time.time(); bad = []; n = {}; kerns = {}
     with mp.get_context("spawn").Pool(procs) as pool:
-        for fam, seed, verdict, npods, dt in pool.imap_unordered(one, jobs):
+        for fam, seed, verdict, npods, dt, kern in pool.imap_unordered(one, jobs):
             n[verdict.split()[0]] = n.get(verdict.split()[0], 0) + 1
+            kerns[kern] = kerns.get(kern, 0) + 1
             if verdict != "ok":
                 bad.append((fam, seed, verdict)); print(fam, seed, verdict, npods, f"{dt:.1f}s", flush=True)
-    print("campaign", first, count, "verdicts", n, f"{time.time() - t0:.0f}s", "bad", bad[:20])
+    print("campaign", first, count, "verdicts", n, "pack kernel", kerns, f"{time.time() - t0:.0f}s", "bad", bad[:20])
