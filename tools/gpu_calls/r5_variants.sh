@@ -12,7 +12,9 @@ p = W.config3()
 fp = S.FlatProblem(p); fp.upload(0); fp.grid(want_bits=False); fp.solve(decode=False)
 ms = []
 for _ in range(3): fp.solve(decode=False); ms.append(fp.kernel_ms)
-st = fp.solve().stats
-print("%-12s min %.2f ms  rounds %s window pods %s phases %s queries %s" % (v, min(ms), st.get("eq_pods"), st.get("cyc_kind0"), st.get("cyc_kind1"), st.get("n_kind1")))
+res = fp.solve(); st = res.stats
+import hashlib, json
+h = hashlib.sha256(json.dumps(res.canonical(), sort_keys=True).encode()).hexdigest()[:8]
+print("%-12s min %.2f ms  rounds %s window pods %s phases %s queries %s fingerprint %s" % (v, min(ms), st.get("eq_pods"), st.get("cyc_kind0"), st.get("cyc_kind1"), st.get("n_kind1"), h))
 PY
 done | tee gpurun_out/r5ab/variants.log
