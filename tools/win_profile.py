@@ -28,5 +28,10 @@ for nm, k in rows:
     if not nm.startswith("  "): acc += v
     print(f"{nm:40s} {v / M:9.2f} M cycles  {100.0 * v / tot:5.1f} %   {v / wp:8.0f} / window pod  {v / wph:8.0f} / phase")
 print(f"{'sum':40s} {acc / M:9.2f} M of {tot / M:.2f} M")
+if os.environ.get("KS_WQ"):      # a -DKS_PROBES_WQ build: the same slots hold what happens AROUND the window's loop
+    print("around the loop (the formation rows above are NOT formation in this build):")
+    for nm, k in (("rr_window_fast, entry to exit", "cyc_evalout"), ("waiting for the workers' answer", "cyc_full"), ("the hand-over of the answer's node", "cyc_commit"),
+                  ("a machine opened + joined", "cyc_order"), ("rr_window_gen", "cyc_new"), ("the rest of the wrapper", "p20")):
+        print(f"  {nm:38s} {st.get(k, 0) / M:9.2f} M cycles")
 print("run rounds cycles %.1f M, normal rounds (incl. window phases) %.1f M" % (st.get("attempts", 0) / M, st.get("types_scanned", 0) / M))
 print("raw:", {k: v for k, v in st.items() if v})
