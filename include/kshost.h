@@ -71,6 +71,17 @@ typedef struct ksh_pod_block {
   const int64_t* creation_ts;   /* [n_pods] */
 } ksh_pod_block;
 int ksh_pods_ingest(const ksh_pod_block* blocks, uint32_t n_blocks, void** out_batch, double* ms /* ingest time or NULL */);
+/* ---- binary ingress for the ENVIRONMENT (round 5): instance types + offerings (cloudprovider/types.go:72-145), provisioners (machinetemplate.go:46-62), state nodes
+ * (state/node.go:61-159), the cluster's pods with required anti-affinity (topology.go:231-276), daemonset pods, SimulationMode -- ONE stream of u32 words over ONE string
+ * table (grammar: karpenter_core_amd/host/kspb.hpp, EnvReader).  The handle is what ksh_parse returns for the KSP1 text of the same objects with `PODS 0`: the environment
+ * argument of ksh_solve_from_batch / ksh_open_batch, freed by ksh_parsed_free.  No text is written or parsed on this path. */
+typedef struct ksh_env_block {
+  uint32_t n_strings, n_words;
+  const uint32_t* str_off;      /* [n_strings + 1] byte offsets into str_bytes */
+  const char* str_bytes;
+  const uint32_t* words;        /* [n_words] */
+} ksh_env_block;
+int ksh_env_ingest(const ksh_env_block* env, void** out_parsed, double* ms /* ingest time or NULL */);
 void ksh_pods_free(void* batch);
 int ksh_pods_count(void* batch, uint32_t* n_pods, uint32_t* n_specs);
 int ksh_solve_from_batch(void* parsed_env, void* batch, int device, uint32_t flags, void** out_handle, double* ms /* as ksh_solve_from_pods */);

@@ -89,6 +89,19 @@ int ksh_parse(const char* ksp_text, size_t len, void** out) {
   try { auto p = std::make_unique<Parsed>(); p->pr = std::make_shared<const ksp::Problem>(ksp::Parser(ksp_text, len).parse()); *out = p.release(); return KS_OK; }
   catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
 }
+int ksh_env_ingest(const ksh_env_block* env, void** out, double* ms) {
+  if (out) *out = nullptr;
+  if (!out || !env || !env->str_off || !env->words || (!env->str_bytes && env->n_strings)) return set_err(KS_ERR_INVALID, "null argument");
+  try {
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0; i < env->n_strings; ++i) if (env->str_off[i + 1] < env->str_off[i]) return set_err(KS_ERR_INVALID, "env block: string offsets not ascending");
+    ksh_pod_block strings{}; strings.n_strings = env->n_strings; strings.str_off = env->str_off; strings.str_bytes = env->str_bytes;
+    auto p = std::make_unique<Parsed>();
+    p->pr = std::make_shared<const ksp::Problem>(ksp::EnvReader(strings, env->words, env->words + env->n_words).read_env());
+    if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out = p.release(); return KS_OK;
+  } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
+}
 void ksh_parsed_free(void* p) { delete (Parsed*)p; }
 // ms[0..5]: flatten (host) | upload | static tables + feasibility grid | pack kernel (HIP events) | whole ks_solve_dev incl. read-back | total wall
 }  // extern "C"

@@ -70,7 +70,7 @@ class SpecReader {
     if (w_ != e_) throw Error("pod block: trailing words in a spec record");
     return p;
   }
- private:
+ protected:
   const ksh_pod_block& b_; const uint32_t* w_; const uint32_t* e_;
   uint32_t u() { if (w_ >= e_) throw Error("pod block: spec record ends early"); return *w_++; }
   int32_t i() { return (int32_t)u(); }
@@ -81,6 +81,70 @@ class SpecReader {
   Expr expr() { Expr x; x.key = s(); const uint32_t op = u(); if (op > 5) throw Error("pod block: bad operator"); x.op = (Op)op; for (uint32_t n = cnt(); n; --n) x.values.push_back(s()); return x; }
   Selector selector() { Selector x; const uint32_t nil = u(); if (nil > 1) throw Error("pod block: bad selector tag"); x.nil = nil == 1; if (!x.nil) { x.match_labels = map(); for (uint32_t n = cnt(); n; --n) x.match_exprs.push_back(expr()); } return x; }
   AffinityTerm term() { AffinityTerm t; t.topology_key = s(); for (uint32_t n = cnt(); n; --n) t.namespaces.push_back(s()); t.selector = selector(); return t; }
+};
+
+// The ENVIRONMENT through the same kind of door (include/kshost.h `ksh_env_block`; round 5): everything NewScheduler reads besides the pending pods -- what a shim holds as
+// []*cloudprovider.InstanceType (types.go:72-145), []v1alpha5.Provisioner, []*state.Node, the cluster's pods with required anti-affinity (topology.go:231-276) and the
+// daemonset pods -- as ONE stream of u32 words over ONE string table (the record grammar of the pod blocks: S string id, I int32, U uint32, MAP, reslist, expr, term):
+//
+//   env        := N {well_known:S}  N {instance_type}  N {provisioner}  N {state_node}  N {cluster_pod}  N {daemon}  simulation_mode:U
+//   instance_type := name:S N {expr} N { capacity_type:S zone:S price_lo:U price_hi:U available:U } reslist reslist          (price: the IEEE-754 bits of the float64; capacity, overhead)
+//   provisioner   := name:S weight:I MAP N {expr} N {taint} has_limits:U reslist N {instance_type_index:U}                     (labels, requirements, taints, limits, its instance types)
+//   taint         := key:S value:S effect:S
+//   state_node    := name:S in_state:U MAP N {taint} reslist reslist reslist N { ip:S port:I proto:S } N { driver:S count:I } N { driver:S claim:S }
+//                                                                                   (labels, taints, available, capacity, daemonset requests, host ports, volume limits, volumes in use)
+//   cluster_pod   := uid:S ns:S node_name:S MAP N {term}
+//   daemon        := uid:S ts_lo:U ts_hi:U nwords:U spec                           (spec: the pod blocks' record, nwords words)
+//
+// The result is the ksp::Problem ksh_parse builds from the KSP1 text of the same objects with `PODS 0` (tests/test_env_block.py: equal flat problems, equal results).
+class EnvReader : public SpecReader {
+ public:
+  EnvReader(const ksh_pod_block& strings, const uint32_t* w, const uint32_t* e) : SpecReader(strings, w, e) {}
+  Problem read_env() {
+    Problem pr;
+    for (uint32_t n = cnt(); n; --n) pr.extra_well_known.push_back(s());
+    { const uint32_t n = cnt(); pr.instance_types.reserve(n);
+      for (uint32_t k = 0; k < n; ++k) {
+        InstanceType it; it.name = s();
+        for (uint32_t m = cnt(); m; --m) it.requirements.push_back(expr());
+        for (uint32_t m = cnt(); m; --m) { Offering o; o.capacity_type = s(); o.zone = s(); const uint64_t lo = u(), hi = u(), bits = lo | (hi << 32); std::memcpy(&o.price, &bits, 8); o.available = u() != 0; it.offerings.push_back(std::move(o)); }
+        it.capacity = res(); it.overhead = res();
+        pr.instance_types.push_back(std::move(it));
+      } }
+    for (uint32_t n = cnt(); n; --n) {
+      Provisioner pv; pv.name = s(); pv.weight = i(); pv.labels = map();
+      for (uint32_t m = cnt(); m; --m) pv.requirements.push_back(expr());
+      for (uint32_t m = cnt(); m; --m) pv.taints.push_back(taint());
+      pv.has_limits = u() != 0; pv.limits = res(); if (!pv.has_limits && !pv.limits.empty()) throw Error("env block: limits listed for a provisioner without limits");
+      for (uint32_t m = cnt(); m; --m) { const uint32_t ix = u(); if (ix >= pr.instance_types.size()) throw Error("env block: instance type index out of range"); pv.instance_types.push_back((int32_t)ix); }
+      pr.provisioners.push_back(std::move(pv));
+    }
+    for (uint32_t n = cnt(); n; --n) {
+      StateNode sn; sn.name = s(); sn.in_state = u() != 0; sn.labels = map();
+      for (uint32_t m = cnt(); m; --m) sn.taints.push_back(taint());
+      sn.available = res(); sn.capacity = res(); sn.daemonset_requests = res();
+      for (uint32_t m = cnt(); m; --m) { HostPort h; h.ip = s(); h.port = i(); h.proto = s(); sn.host_ports.push_back(std::move(h)); }
+      for (uint32_t m = cnt(); m; --m) { std::string d = s(); sn.volume_limits.emplace_back(std::move(d), i()); }
+      for (uint32_t m = cnt(); m; --m) { Volume v; v.driver = s(); v.pvc = s(); sn.volumes.push_back(std::move(v)); }
+      pr.nodes.push_back(std::move(sn));
+    }
+    for (uint32_t n = cnt(); n; --n) {
+      ClusterPod cp; cp.uid = s(); cp.ns = s(); cp.node_name = s(); cp.labels = map();
+      for (uint32_t m = cnt(); m; --m) cp.anti_required.push_back(term());
+      pr.cluster_pods.push_back(std::move(cp));
+    }
+    for (uint32_t n = cnt(); n; --n) {
+      std::string uid = s(); const uint64_t lo = u(), hi = u(); const uint32_t nw = cnt();
+      Pod d = SpecReader(b_, w_, w_ + nw).read(); w_ += nw;
+      d.uid = std::move(uid); d.creation_ts = (int64_t)(lo | (hi << 32));
+      pr.daemons.push_back(std::move(d));
+    }
+    pr.simulation_mode = u() != 0;
+    if (w_ != e_) throw Error("env block: trailing words");
+    return pr;
+  }
+ private:
+  Taint taint() { Taint t; t.key = s(); t.value = s(); t.effect = s(); return t; }
 };
 
 }  // namespace ksp

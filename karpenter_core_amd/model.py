@@ -390,6 +390,88 @@ def pods_to_blocks(pods: Sequence["Pod"], n_blocks: int = 1) -> List[dict]:
     return out
 
 
+class EnvBlockWriter(PodBlockWriter):
+    """Binary ENVIRONMENT ingress (include/kshost.h `ksh_env_block`, grammar in karpenter_core_amd/host/kspb.hpp EnvReader): instance types with their offerings,
+    provisioners, state nodes, cluster pods, daemonset pods and SimulationMode as one stream of u32 words over one string table -- what a cgo shim would fill from its
+    []*cloudprovider.InstanceType / []v1alpha5.Provisioner / []*state.Node instead of printing KSP1 text."""
+
+    def _taints(self, w, ts):
+        w.append(len(ts))
+        for t in ts:
+            w.extend((self._s(t.key), self._s(t.value), self._s(t.effect)))
+
+    def write(self, pr: "Problem") -> dict:
+        import struct
+        import numpy as np
+        w = self._words
+        w.append(len(pr.extra_well_known))
+        w.extend(self._s(k) for k in pr.extra_well_known)
+        w.append(len(pr.instance_types))
+        for it in pr.instance_types:
+            w.extend((self._s(it.name), len(it.requirements)))
+            for e in it.requirements:
+                self._expr(w, e)
+            w.append(len(it.offerings))
+            for o in it.offerings:
+                bits = struct.unpack("<Q", struct.pack("<d", float(o.price)))[0]
+                w.extend((self._s(o.capacity_type), self._s(o.zone), bits & 0xFFFFFFFF, bits >> 32, 1 if o.available else 0))
+            self._res(w, it.capacity)
+            self._res(w, it.overhead)
+        w.append(len(pr.provisioners))
+        for p in pr.provisioners:
+            w.extend((self._s(p.name), int(p.weight) & 0xFFFFFFFF))
+            self._map(w, p.labels)
+            w.append(len(p.requirements))
+            for e in p.requirements:
+                self._expr(w, e)
+            self._taints(w, p.taints)
+            w.append(0 if p.limits is None else 1)
+            self._res(w, p.limits or {})
+            w.append(len(p.instance_types))
+            w.extend(int(i) for i in p.instance_types)
+        w.append(len(pr.nodes))
+        for n in pr.nodes:
+            w.extend((self._s(n.name), 1 if n.in_state else 0))
+            self._map(w, n.labels)
+            self._taints(w, n.taints)
+            self._res(w, n.available)
+            self._res(w, n.capacity)
+            self._res(w, n.daemonset_requests)
+            w.append(len(n.host_ports))
+            for hp in n.host_ports:
+                w.extend((self._s(hp.host_ip), int(hp.port) & 0xFFFFFFFF, self._s(hp.protocol)))
+            w.append(len(n.volume_limits))
+            for d in sorted(n.volume_limits):
+                w.extend((self._s(d), int(n.volume_limits[d]) & 0xFFFFFFFF))
+            w.append(len(n.volumes))
+            for v in n.volumes:
+                w.extend((self._s(v.driver), self._s(v.pvc_id)))
+        w.append(len(pr.cluster_pods))
+        for cp in pr.cluster_pods:
+            w.extend((self._s(cp.uid), self._s(cp.namespace), self._s(cp.node_name)))
+            self._map(w, cp.labels)
+            w.append(len(cp.anti_required))
+            for t in cp.anti_required:
+                self._term(w, t)
+        w.append(len(pr.daemonset_pods))
+        for d in pr.daemonset_pods:
+            ts = int(d.creation_ts) & 0xFFFFFFFFFFFFFFFF
+            w.extend((self._s(d.uid), ts & 0xFFFFFFFF, ts >> 32, 0))
+            at = len(w)
+            self.add(d)                       # (the spec record; add() also notes uid / timestamp / offset for a pod block: not used here)
+            w[at - 1] = len(w) - at
+        w.append(1 if pr.simulation_mode else 0)
+        so = np.zeros(len(self._strs) + 1, dtype=np.uint32)
+        np.cumsum([len(b) for b in self._strs], out=so[1:])
+        return {"n_strings": len(self._strs), "n_words": len(w), "str_off": so, "str_bytes": np.frombuffer(b"".join(self._strs) + b"\0", dtype=np.uint8).copy(),
+                "words": np.asarray(w, dtype=np.uint32)}
+
+
+def env_to_block(pr: "Problem") -> dict:
+    """Everything of `pr` but its pending pods as one binary block (`ksh_env_ingest`)."""
+    return EnvBlockWriter().write(pr)
+
+
 def _ksp_reslist(rl: Dict[str, str], w):
     w.write(f" {len(rl)}")
     for k in sorted(rl):

@@ -94,6 +94,7 @@ def libs():
         kh.ksh_open_whatifs_derived.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
                                                 ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         kh.ksh_pods_ingest.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_double)]
+        kh.ksh_env_ingest.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_double)]
         kh.ksh_pods_free.argtypes = [ctypes.c_void_p]
         kh.ksh_pods_count.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
         kh.ksh_solve_from_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_double)]
@@ -236,6 +237,20 @@ class ParsedProblem:
     def from_text(cls, ksp_text: bytes) -> "ParsedProblem":
         return cls(None, _text=ksp_text)
 
+    @classmethod
+    def from_env_block(cls, block: dict) -> "ParsedProblem":
+        """The environment through the binary door (`ksh_env_ingest`; block from `model.env_to_block`): no KSP1 text on the way.  `ingest_ms`: the library's time."""
+        kh = libs()[1]
+        eb = _EnvBlock(block["n_strings"], block["n_words"], block["str_off"].ctypes.data, block["str_bytes"].ctypes.data, block["words"].ctypes.data)
+        self = cls.__new__(cls)
+        self._p = ctypes.c_void_p()
+        ms = ctypes.c_double()
+        rc = kh.ksh_env_ingest(ctypes.byref(eb), ctypes.byref(self._p), ctypes.byref(ms))
+        if rc != KS_OK:
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+        self.ingest_ms = float(ms.value)
+        return self
+
     def close(self):
         if self._p:
             libs()[1].ksh_parsed_free(self._p)
@@ -270,6 +285,10 @@ def solve_from_pods(parsed: ParsedProblem, device: int = 0, stats: bool = False,
 class _PodBlock(ctypes.Structure):      # include/kshost.h ksh_pod_block
     _fields_ = [("n_pods", ctypes.c_uint32), ("n_strings", ctypes.c_uint32), ("str_off", ctypes.c_void_p), ("str_bytes", ctypes.c_void_p),
                 ("spec_off", ctypes.c_void_p), ("spec_words", ctypes.c_void_p), ("uid", ctypes.c_void_p), ("creation_ts", ctypes.c_void_p)]
+
+
+class _EnvBlock(ctypes.Structure):
+    _fields_ = [("n_strings", ctypes.c_uint32), ("n_words", ctypes.c_uint32), ("str_off", ctypes.c_void_p), ("str_bytes", ctypes.c_void_p), ("words", ctypes.c_void_p)]
 
 
 class PodBatch:

@@ -40,6 +40,7 @@ def test_rr_mid_scale_family(seed, monkeypatch):
     gold = T._gold()[str(seed)]
     got = S.solve_problem(p)
     assert T.fingerprints(got) == {"sha256": gold["sha256"], "reasons_sha256": gold["reasons_sha256"]}
+    assert ran_rr(got) == (seed != 13)           # (13 is of the wide family and not LEAN: ks_pack's from the start)
 
 
 def test_rr_full_size_config3_fingerprint(monkeypatch):
@@ -125,6 +126,22 @@ def test_rr_declines_and_ks_pack_takes_over(name, maker, code, monkeypatch):
         alone, (started2, _) = _solve_with_status(p)
         assert not started2 and res.canonical() == alone.canonical()
         assert len(res.new_nodes) == len(p.pods) and all(len(n.pods) == 1 for n in res.new_nodes)
+
+
+@pytest.mark.parametrize("seed,code", [(10, 3), (50, 3), (12, 7), (57, 7)])
+def test_rr_declines_met_in_the_mid_scale_families(seed, code, monkeypatch):
+    """Declines nobody constructed: committed seeds of tests/test_fuzz_mid.py on which ks_pack_rr starts and gives the Solve back mid-run -- 3: a pod with more than 8
+    exact-filter exclusions; 7: a class outside its feature set reaches the head of the queue (the wide family's) -- and ks_pack's result is the oracle's (offline fingerprints)."""
+    if os.environ.get("KS_TEST_SIM"):
+        pytest.skip("the emulator build has no ks_pack to give the Solve back to")
+    import test_fuzz_mid as T
+    monkeypatch.delenv("KS_NO_RR", raising=False)
+    p = T.mid_problem(seed)
+    gold = T._gold()[str(seed)]
+    res, (started, why) = _solve_with_status(p)
+    assert started and why == code, (started, why)
+    assert not ran_rr(res)
+    assert T.fingerprints(res) == {"sha256": gold["sha256"], "reasons_sha256": gold["reasons_sha256"]}
 
 
 def test_rr_status_says_when_it_took_the_solve(monkeypatch):
