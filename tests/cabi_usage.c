@@ -9,7 +9,7 @@
 #include "kshost.h"
 
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: cabi_usage <file.ksp>\n"); return 2; }
+  if (argc < 2) { fprintf(stderr, "usage: cabi_usage <file.ksp> [file.envblock]\n"); return 2; }
   FILE* f = fopen(argv[1], "rb"); if (!f) return 2;
   fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
   char* text = (char*)malloc((size_t)n + 1); if (fread(text, 1, (size_t)n, f) != (size_t)n) return 2; text[n] = 0; fclose(f);
@@ -36,6 +36,24 @@ int main(int argc, char** argv) {
   if (ksh_open_batch(env, batch, 0, &h) != KS_OK) { fprintf(stderr, "flatten: %s\n", ksh_last_error()); return 1; }
   uint32_t dims[10]; ksh_dims(h, dims);
   const ks_problem* p = ksh_problem(h);
+
+  /* the same environment through ITS binary door (argv[2]: n_strings, n_words, str_off[n_strings + 1], words[n_words], string bytes -- what a shim builds in memory):
+     the flat problem over it must be the one over the parsed text, array for array */
+  if (argc > 2) {
+    FILE* g = fopen(argv[2], "rb"); if (!g) return 2;
+    uint32_t hd[2]; if (fread(hd, 4, 2, g) != 2) return 2;
+    uint32_t* so = (uint32_t*)malloc(((size_t)hd[0] + 1) * 4); uint32_t* wd = (uint32_t*)malloc(((size_t)hd[1] + 1) * 4);
+    if (fread(so, 4, (size_t)hd[0] + 1, g) != (size_t)hd[0] + 1 || fread(wd, 4, hd[1], g) != hd[1]) return 2;
+    char* sb = (char*)malloc((size_t)so[hd[0]] + 1); if (fread(sb, 1, so[hd[0]], g) != so[hd[0]]) return 2; fclose(g);
+    ksh_env_block eb; memset(&eb, 0, sizeof eb);
+    eb.n_strings = hd[0]; eb.n_words = hd[1]; eb.str_off = so; eb.str_bytes = sb; eb.words = wd;
+    void* env2 = NULL; double env_ms = 0; void* h2 = NULL;
+    if (ksh_env_ingest(&eb, &env2, &env_ms) != KS_OK) { fprintf(stderr, "env ingest: %s\n", ksh_last_error()); return 1; }
+    if (ksh_open_batch(env2, batch, 0, &h2) != KS_OK) { fprintf(stderr, "flatten over the binary environment: %s\n", ksh_last_error()); return 1; }
+    printf("binary environment: %s flat problem\n", ksh_fingerprint(h2) == ksh_fingerprint(h) ? "the same" : "ANOTHER");
+    if (ksh_fingerprint(h2) != ksh_fingerprint(h)) return 1;
+    ksh_close(h2); ksh_parsed_free(env2); free(so); free(wd); free(sb);
+  }
   printf("pods %u specs %u flat P=%u C=%u T=%u K=%u devices %d\n", np, ns, dims[0], dims[1], p->T, p->K, ks_device_count());
 
   double ms[6]; void* solved = NULL;

@@ -190,7 +190,7 @@ def test_flattening_fingerprints_are_pinned():
 
 
 def test_headers_are_plain_c(tmp_path):
-    """include/*.h must be usable from C (what cgo compiles): tests/cabi_usage.c -- parse an environment, hand one pod over through the binary door,
+    """include/*.h must be usable from C (what cgo compiles): tests/cabi_usage.c -- parse an environment (and take the same one in through ksh_env_ingest), hand one pod over through the binary door,
     flatten, ask for a Solve -- is compiled as C99 with -Wall -Werror -pedantic, linked against both libraries and run.  Without a GPU the Solve
     must be refused with KS_ERR_DEVICE (no CPU path); with one it solves."""
     import dataclasses
@@ -201,9 +201,15 @@ def test_headers_are_plain_c(tmp_path):
                            "-o", exe, "-L", pkg, "-lkshost", "-lksolve", "-Wl,-rpath," + pkg])
     env_file = tmp_path / "env.ksp"
     env_file.write_text(dataclasses.replace(W.config1(pods=1, types=5), pods=[]).to_ksp())
-    out = subprocess.run([exe, str(env_file)], capture_output=True, text=True)
+    import numpy as np
+    from karpenter_core_amd.model import env_to_block
+    blk = env_to_block(W.config1(pods=1, types=5))
+    blk_file = tmp_path / "env.block"
+    blk_file.write_bytes(np.asarray([blk["n_strings"], blk["n_words"]], dtype=np.uint32).tobytes() + blk["str_off"].tobytes() + blk["words"].tobytes() + blk["str_bytes"].tobytes())
+    out = subprocess.run([exe, str(env_file), str(blk_file)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "pods 1 specs 1 flat P=1 C=1 T=5" in out.stdout
+    assert "binary environment: the same flat problem" in out.stdout
     if S.device_count() == 0:
         assert "solve refused: -3" in out.stdout
     else:
