@@ -181,6 +181,11 @@ typedef struct ks_problem {
 
 #define KS_FLAG_SIMULATION 1u /* SchedulerOptions.SimulationMode (scheduler.go:37-40); informational */
 #define KS_FLAG_STATS 2u      /* also count the reference algorithm's attempts / scanned types (DESIGN.md roofline) */
+/* kernel choice PER PROBLEM (round 5; the environment variables KS_NO_RR / KS_ONE_WAVE / KS_NO_LEAN still switch the whole process for A/B runs): for a library
+ * two goroutines share -- the provisioner's Solve and a deprovisioner's what-ifs -- a choice has to travel with the problem, not with the process */
+#define KS_FLAG_NO_RR 4u      /* do not start ks_pack_rr: ks_pack takes the Solve from the start */
+#define KS_FLAG_ONE_WAVE 8u   /* ks_pack's single-wave variant (what a batch runs per what-if) for a single Solve */
+#define KS_FLAG_NO_LEAN 16u   /* the general variant on a problem the LEAN one would take */
 
 /* Result of one Solve: caller allocates the arrays (sizes below), the library fills them. */
 typedef struct ks_result {

@@ -3350,15 +3350,17 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   for (u32 i = 0; i < n; ++i) { const DevProb& q = ds[i]->h; if (q.G > KS_FAST_G || q.GH > KS_FAST_G || (q.SC > 1 && (size_t)q.S * q.SC > KS_FAST_S * KS_FAST_S) || (size_t)q.R * q.ge_max > KS_FAST_RT || (size_t)q.R * q.ge_max * 8 + 8192 > lds_bytes) fast = false; }
   bool bounds = false; for (u32 i = 0; i < n; ++i) bounds = bounds || ds[i]->any_bounds;
   bool lean = true; for (u32 i = 0; i < n; ++i) lean = lean && ds[i]->lean_ok;
-  if (getenv("KS_NO_LEAN")) lean = false;      // test hook: run the general variant on a problem the LEAN one would take
+  u32 any_flags = 0; for (u32 i = 0; i < n; ++i) any_flags |= ds[i]->h.flags;
+  if (getenv("KS_NO_LEAN") || (any_flags & KS_FLAG_NO_LEAN)) lean = false;      // run the general variant on a problem the LEAN one would take (ksolve.h; the variable: test hook for the whole process)
   // The register-resident kernel (ks_pack_rr.inc) takes a single LEAN Solve without Gt/Lt bounds; it declines what it does not cover -- before
   // or during the run, without having touched the inputs -- and ks_pack below takes over.
   bool rr_done = false;
   for (u32 i = 0; i < n; ++i) { ds[i]->rr_started = 0; ds[i]->rr_code = 0; }
+  const bool one_wave = getenv("KS_ONE_WAVE") != nullptr || (any_flags & KS_FLAG_ONE_WAVE);
 #ifdef KS_SIM
   const bool rr_on = true;                    // (the emulator build has no ks_pack)
 #else
-  const bool rr_on = getenv("KS_NO_RR") == nullptr && getenv("KS_ONE_WAVE") == nullptr;   // KS_NO_RR=1: ks_pack only (A/B, and the parity of both kernels); KS_ONE_WAVE asks for ks_pack's single-wave variant
+  const bool rr_on = getenv("KS_NO_RR") == nullptr && !(any_flags & KS_FLAG_NO_RR) && !one_wave;   // KS_NO_RR=1: ks_pack only (A/B, and the parity of both kernels); KS_ONE_WAVE asks for ks_pack's single-wave variant
 #endif
   if (rr_on && n == 1 && lean && !bounds && fast && !ds[0]->view && !(ds[0]->h.flags & KS_FLAG_STATS) && ds[0]->h.rr_briefs) {
     const u32 lds_rr = 44u * 1024u;
@@ -3397,7 +3399,7 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   }
   // A single Solve whose problem takes the LEAN, FAST, no-bounds kernel gets 8 waves: waves 1..7 join wave 0 for the
   // speculation rounds (see ks_pack).  T <= 8192 keeps a node's surviving-type mask in two registers per lane.
-  bool multi = n == 1 && fast && ds[0]->h.TW <= 128 && !(ds[0]->h.flags & KS_FLAG_STATS) && !getenv("KS_ONE_WAVE") && !ds[0]->no_multi;
+  bool multi = n == 1 && fast && ds[0]->h.TW <= 128 && !(ds[0]->h.flags & KS_FLAG_STATS) && !one_wave && !ds[0]->no_multi;
   if (multi) {
     const u32 lds_mw = 44u * 1024u;
     if ((size_t)ds[0]->h.R * ds[0]->h.ge_max * 8 + 8192 > lds_mw) multi = false;

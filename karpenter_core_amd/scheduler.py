@@ -28,7 +28,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = None
 
 KS_OK, KS_ERR_INVALID, KS_ERR_UNSUPPORTED, KS_ERR_DEVICE, KS_ERR_CAPACITY = 0, -1, -2, -3, -4
-KS_FLAG_SIMULATION, KS_FLAG_STATS = 1, 2
+KS_FLAG_SIMULATION, KS_FLAG_STATS, KS_FLAG_NO_RR, KS_FLAG_ONE_WAVE, KS_FLAG_NO_LEAN = 1, 2, 4, 8, 16
 
 
 class KSolveError(RuntimeError):
@@ -110,14 +110,14 @@ def device_count() -> int:
 class FlatProblem:
     """A Solve() problem flattened to the C-ABI `ks_problem` (host side only until `upload`)."""
 
-    def __init__(self, problem: Optional[Problem], stats: bool = False, _handle=None):
+    def __init__(self, problem: Optional[Problem], stats: bool = False, _handle=None, flags: int = 0):
         ks, kh = libs()
         if _handle is not None:
             self._h = _handle
         else:
             text = problem.to_ksp().encode()
             self._h = ctypes.c_void_p()
-            flags = KS_FLAG_STATS if stats else 0
+            flags = (KS_FLAG_STATS if stats else 0) | flags      # (KS_FLAG_NO_RR / _ONE_WAVE / _NO_LEAN: the kernel choice travels with the problem)
             rc = kh.ksh_open(text, len(text), flags, ctypes.byref(self._h))
             if rc != KS_OK:
                 raise KSolveError(rc, kh.ksh_last_error().decode())

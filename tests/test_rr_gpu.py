@@ -155,6 +155,24 @@ def test_rr_status_says_when_it_took_the_solve(monkeypatch):
         assert not started and not ran_rr(res)
 
 
+def test_kernel_choice_travels_with_the_problem(monkeypatch):
+    """ksolve.h KS_FLAG_NO_RR / KS_FLAG_ONE_WAVE / KS_FLAG_NO_LEAN: the choice of pack kernel as a flag of the problem (two threads sharing the library cannot use a
+    process-wide environment variable); every choice gives the oracle's result."""
+    if os.environ.get("KS_TEST_SIM"):
+        pytest.skip("the emulator build has one pack kernel")
+    monkeypatch.delenv("KS_NO_RR", raising=False)
+    p = W.config3(pods=3500, sizes=20, seed=44)
+    want = O.solve(p).canonical()
+    for flags, rr in ((0, True), (S.KS_FLAG_NO_RR, False), (S.KS_FLAG_ONE_WAVE, False), (S.KS_FLAG_NO_LEAN, False)):
+        fp = S.FlatProblem(p, flags=flags)
+        try:
+            res = fp.solve()
+            assert fp.rr_status()[0] == (1 if rr else 0), flags
+            assert res.canonical() == want, flags
+        finally:
+            fp.close()
+
+
 def test_head_window_is_exercised(monkeypatch):
     """Round 5: most pods of the config #3 shape that are no plain replicas are placed by the leader's head window (stats slot 27), the plain stretches in RUN rounds (22)."""
     monkeypatch.delenv("KS_NO_RR", raising=False)
