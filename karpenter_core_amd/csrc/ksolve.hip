@@ -1031,6 +1031,7 @@ __device__ __forceinline__ void topology_record(const DevProb& P, const DevState
 __device__ __forceinline__ u32 wave_min_u32(u32 v) { return ks_sim::wave_min_u32(v); }
 __device__ __forceinline__ u32 wave_or_u32(u32 v) { return ks_sim::wave_or_u32(v); }
 __device__ __forceinline__ i64 wave_max_i64(i64 v) { return ks_sim::wave_max_i64(v); }
+__device__ __forceinline__ u32 lanes8_min_u32(u32 v) { return ks_sim::wave_min_u32((threadIdx.x & 63) < 8 ? v : 0xFFFFFFFFu); }      // (every lane takes part in the exchange; lanes 0..7 count)
 #else
 __device__ __forceinline__ u32 wave_min_u32(u32 v) {
   const int id = (int)0xFFFFFFFFu;
@@ -1202,7 +1203,7 @@ static unsigned char ks_dyn_lds[160 * 1024] __attribute__((aligned(16)));
 extern __shared__ __attribute__((aligned(16))) unsigned char ks_dyn_lds[];
 #endif
 
-#ifndef KS_SIM      /* (the emulator runs the register-resident kernel only: ks_pack's DPP reductions and speculation rounds stay GPU-only) */
+#if !defined(KS_SIM) || defined(KS_SIM_PACK)      /* (the emulator's default build runs the register-resident kernel only; -DKS_SIM_PACK compiles ks_pack for it too: round 5) */
 // LEAN: no class has host ports, a hostname selector or an instance-type requirement, no provisioner has limits,
 // R <= 4 and no statistics are requested -- the code for all of that (and half of every unrolled resource loop) is
 // compiled out.  One wave issues ~1 instruction per 5 cycles, so instructions, not bytes, are what a Solve costs.
@@ -1376,7 +1377,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             const int l = __builtin_ctzll(rem); const u32 v = RL(evc, l);
             const u64 same = ballot64(evc == v) & rem;
             if ((same >> lane) & 1ull) b_w = nw;
-            if (lane == 0) rc.wcls[wpar][nw] = RL(cls, l);
+            { const u32 c_l = RL(cls, l); if (lane == 0) rc.wcls[wpar][nw] = c_l; }      // (the lane read outside the predicate: the emulator's readlane is a wave collective)
             rem &= ~same; ++nw;
           }
           if (rem) rn = (u32)__builtin_ctzll(rem);            // the first pod of one class too many ends the round
@@ -2325,7 +2326,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
         // While the workers filter, plan the step after this round as if the round commits (a filter comes back empty a handful of times
         // per Solve; the plan is then redone): queue entries and class briefs of the next pods are requested a whole phase early.
         if ((u32)lane < n_ok) { const u32 ck = (u32)(b_e >> 32) & 0x7FFFFFFFu; atomicAnd(&ls.hard[(ck >> 5) & 7u], ~(1u << (ck & 31u))); }
-        if (nocand_cls != 0xFFFFFFFFu && lane == 0) { LSYNC(); ls.hard[(nocand_cls >> 5) & 7u] |= 1u << (nocand_cls & 31u); }
+        if (nocand_cls != 0xFFFFFFFFu) { LSYNC(); if (lane == 0) ls.hard[(nocand_cls >> 5) & 7u] |= 1u << (nocand_cls & 31u); }      // (nocand_cls is wave-uniform: the hand-off outside the lane predicate)
         sp_head = q_head + n_ok; if (sp_head >= nP) sp_head -= nP; sp_len = q_len - n_ok; sp_seq = seq + n_ok;
         { u32 idx = sp_head + lane; if (idx >= nP) idx -= nP; if (idx >= nP) idx = 0; pq_e = tb.q[idx]; pq_ok = true; }
         if (n_ok == 0) seq_credit = 1;                 // the head pod needs more than the window offers: take it sequentially
@@ -2508,7 +2509,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
               const u32 ii = (u32)lane; const bool in = ii >= pmin && ii < endp; u32 v = 0;
               if (in) v = ORD_RD(ii);
               if (ord_in_lds) LSYNC(); else GSYNC();
-              u32 ins = 0; for (u32 j = 1; j + 1 < nb; ++j) { if (ii >= RL(st_l, (int)j)) ins = RL(ins_l, (int)j); }
+              u32 ins = 0; for (u32 j = 1; j + 1 < nb; ++j) { const u32 sj = RL(st_l, (int)j), ij = RL(ins_l, (int)j); if (ii >= sj) ins = ij; }      // (both lane reads by every lane)
               const bool is_m = (Mpos >> ii) & 1ull;
               const u32 rem_before = (u32)__builtin_popcountll(Mpos & ((1ull << ii) - 1ull));
               if (in && !is_m) ORD_WR(ii - rem_before + ins, v);
@@ -2529,20 +2530,21 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
             if (ord_in_lds) LSYNC(); else GSYNC();
             }
             // new bucket starts for the counts in (cmin, cmax + 1]
-            for (u32 b = cmin + 1 + lane; b <= cmax + 1; b += 64) {
-              const u32 os = b <= maxc + 1 ? bst_rd(b) : nnew;
+            for (u32 b0 = cmin + 1; b0 <= cmax + 1; b0 += 64) {      // (lane l takes bucket b0 + l; the loop itself is wave-uniform: lane reads inside it)
+              const u32 b = b0 + (u32)lane; const bool inb = b <= cmax + 1;
+              const u32 os = (inb && b <= maxc + 1) ? bst_rd(b) : nnew;
               const u32 rem_before = os >= 64 ? nM : (u32)__builtin_popcountll(Mpos & ((1ull << os) - 1ull));
               u32 below = 0;      // moved nodes whose final count is < b
               if (nb <= 64) below = ins_keep;       // (b = cmin + 1 + lane: the count of final counts <= cmin + lane is this lane's ins_l)
               else for (u64 q = M; q; q &= q - 1) { const int x = __builtin_ctzll(q); if (RL(c_cnt, x) < b) ++below; }
-              bst_wr(b, os - rem_before + below);
+              if (inb) bst_wr(b, os - rem_before + below);
             }
             if (ord_in_lds) LSYNC(); else GSYNC();
             if (cmax > maxc) maxc = cmax;
             // the moved nodes: front of their final bucket, the most recent move first
-            if (mvd) {
-              u32 rank = 0; for (u64 q = M; q; q &= q - 1) { const int x = __builtin_ctzll(q); if (RL(c_cnt, x) == c_cnt && RL(c_last, x) > c_last) ++rank; }
-              ORD_WR(bst_rd(c_cnt) + rank, jw_l);
+            {     // (the lane reads by EVERY lane, the moved ones use them: the emulator's readlane is a wave collective, and M is wave-uniform)
+              u32 rank = 0; for (u64 q = M; q; q &= q - 1) { const int x = __builtin_ctzll(q); const u32 cx = RL(c_cnt, x), lx = RL(c_last, x); if (cx == c_cnt && lx > c_last) ++rank; }
+              if (mvd) ORD_WR(bst_rd(c_cnt) + rank, jw_l);
             }
             if (ord_in_lds) LSYNC(); else GSYNC();
           }
@@ -2657,7 +2659,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
     if (S.batch_meta) { S.batch_meta[0] = nnew; S.batch_meta[1] = q_len; for (int i = 0; i < 32; ++i) S.batch_meta[2 + i] = S.stats[i]; }
   }
 }
-#endif      // !KS_SIM
+#endif      // !KS_SIM || KS_SIM_PACK
 
 #include "ks_pack_rr.inc"
 
@@ -3356,11 +3358,20 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   // or during the run, without having touched the inputs -- and ks_pack below takes over.
   bool rr_done = false;
   for (u32 i = 0; i < n; ++i) { ds[i]->rr_started = 0; ds[i]->rr_code = 0; }
-  const bool one_wave = getenv("KS_ONE_WAVE") != nullptr || (any_flags & KS_FLAG_ONE_WAVE);
+  const bool asked_one_wave = getenv("KS_ONE_WAVE") != nullptr || (any_flags & KS_FLAG_ONE_WAVE);      // KS_ONE_WAVE asks for ks_pack's single-wave variant
+  const bool asked_no_rr = getenv("KS_NO_RR") != nullptr || (any_flags & KS_FLAG_NO_RR);                 // KS_NO_RR=1: ks_pack only (A/B, and the parity of both kernels)
 #ifdef KS_SIM
-  const bool rr_on = true;                    // (the emulator build has no ks_pack)
+  // The emulator runs ks_pack_rr and (-DKS_SIM_PACK, round 5) ks_pack's single-wave variants -- what a what-if batch runs, LEAN and general.  The multi-wave variants'
+  // speculation rounds lean on hand-offs between lanes in lockstep that the fibre emulator does not model yet: their results differ THERE, not on the GPU.
+  const bool one_wave = true;
+#ifdef KS_SIM_PACK
+  const bool rr_on = !asked_no_rr && !asked_one_wave;
 #else
-  const bool rr_on = getenv("KS_NO_RR") == nullptr && !(any_flags & KS_FLAG_NO_RR) && !one_wave;   // KS_NO_RR=1: ks_pack only (A/B, and the parity of both kernels); KS_ONE_WAVE asks for ks_pack's single-wave variant
+  const bool rr_on = true;                    // (no ks_pack in this build)
+#endif
+#else
+  const bool one_wave = asked_one_wave;
+  const bool rr_on = !asked_no_rr && !asked_one_wave;
 #endif
   if (rr_on && n == 1 && lean && !bounds && fast && !ds[0]->view && !(ds[0]->h.flags & KS_FLAG_STATS) && ds[0]->h.rr_briefs) {
     const u32 lds_rr = 44u * 1024u;
@@ -3378,8 +3389,8 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
     rr_done = rr_err[0] != KS_RR_DECLINED;
     ds[0]->rr_started = 1; ds[0]->rr_code = rr_done ? 0 : (int)rr_err[14 - KS_STAT_ERR];
   }
-#ifdef KS_SIM
-  if (!rr_done) return fail(KS_ERR_UNSUPPORTED, "emulator build: the problem is outside what ks_pack_rr covers (ks_pack is not emulated)");
+#if defined(KS_SIM) && !defined(KS_SIM_PACK)
+  if (!rr_done) return fail(KS_ERR_UNSUPPORTED, "emulator build: the problem is outside what ks_pack_rr covers (ks_pack is not emulated in this build)");
 #else
   if (!rr_done) {
   typedef void (*pack_fn)(const DevProb*, const DevState*, u32);

@@ -14,7 +14,7 @@ def pytest_configure(config):
 
 
 # KS_TEST_SIM=1: run the `-m gpu` tests against the EMULATOR build of the kernels (tests/sim: the HIP source compiled by g++, a fibre per lane) -- test
-# infrastructure for containers without a GPU.  Only the register-resident pack kernel is emulated: a problem it declines is reported as skipped.
+# infrastructure for containers without a GPU.  ks_pack_rr and ks_pack's single-wave variants are emulated (tests/sim/build_sim.py); what neither takes is reported as skipped.
 if os.environ.get("KS_TEST_SIM"):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import simlib

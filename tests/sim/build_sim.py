@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: builds tests/sim/_build/libksolve.so -- karpenter_core_amd/csrc/ksolve.hip compiled by g++ against the lane-fibre
-emulator (tests/sim/hip_sim.h) -- and a copy of libkshost.so next to it, so that the C-ABI parity tests can drive the register-resident
-pack kernel on the host, against the CPU oracle, in a container without a GPU.  Nothing outside tests/ uses this."""
+emulator (tests/sim/hip_sim.h) -- and a copy of libkshost.so next to it, so that the C-ABI parity tests can drive the pack kernels
+(ks_pack_rr and, since round 5, ks_pack: -DKS_SIM_PACK) on the host, against the CPU oracle, in a container without a GPU.  Nothing outside tests/ uses this."""
 import os
 import shutil
 import subprocess
@@ -26,7 +26,7 @@ def build(force: bool = False, opt: str = "-O1") -> str:
           [os.path.join(HERE, "hip_sim.h"), os.path.join(HERE, "hip_sim.cpp"), os.path.join(ROOT, "include", "ksolve.h")]
     if force or _newer(ks_so, src):
         subprocess.check_call(["g++", opt, "-g", "-std=c++17", "-fPIC", "-shared", "-w", "-DKS_SIM", "-I" + os.path.join(HERE, "fakeinc"),
-                               "-DRR_WINDOW=1", "-include", os.path.join(HERE, "hip_sim.h"), "-x", "c++", src[0], os.path.join(HERE, "hip_sim.cpp"),
+                               "-DRR_WINDOW=1", "-DKS_SIM_PACK", "-include", os.path.join(HERE, "hip_sim.h"), "-x", "c++", src[0], os.path.join(HERE, "hip_sim.cpp"),
                                "-o", ks_so, "-pthread"])
     kh_so = os.path.join(OUT, "libkshost.so")
     host = os.path.join(PKG, "host")

@@ -1,5 +1,8 @@
 // hip_sim.cpp -- TEST INFRASTRUCTURE ONLY: the fibre scheduler behind tests/sim/hip_sim.h (see there).
 #include "hip_sim.h"
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 
 KsSimIdx threadIdx, blockIdx, blockDim, gridDim;
 
@@ -101,6 +104,12 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   if (!g_stacks) {
     g_stacks = (char*)mmap(nullptr, kStack * kMaxThreads, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (g_stacks == (char*)MAP_FAILED) { perror("ks_sim: mmap"); abort(); }
+  }
+  // KS_SIM_ALARM=<seconds>: a kernel that spins (no collective, no barrier: the deadlock report never fires) is stopped and says where the running lane stands
+  if (const char* al = getenv("KS_SIM_ALARM")) {
+    signal(SIGALRM, [](int) { void* bt[48]; const int n = backtrace(bt, 48); const char m[] = "ks_sim: KS_SIM_ALARM went off; the running lane stands at (addr2line -e <libksolve.so> <address minus the load address>):\n";
+                              (void)!write(2, m, sizeof m - 1); backtrace_symbols_fd(bt, n, 2); _exit(3); });
+    alarm((unsigned)atoi(al));
   }
   static unsigned seed = getenv("KS_SIM_SEED") ? (unsigned)atoi(getenv("KS_SIM_SEED")) : 0u;
   gridDim = {grid.x, grid.y, grid.z}; blockDim = {block.x, block.y, block.z};

@@ -71,7 +71,7 @@ static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hi
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
-#define hipFuncSetAttribute(f, a, v) hipSuccess
+#define hipFuncSetAttribute(...) hipSuccess
 
 namespace ks_sim {
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
