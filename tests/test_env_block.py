@@ -52,6 +52,19 @@ def test_binary_environment_flattens_to_the_same_problem():
             a.close(); b.close(); c.close(); batch.close(); env_text.close(); env_bin.close()
 
 
+def test_binary_environment_over_the_small_fuzz_family():
+    """64 randomised environments (existing nodes with taints / host ports / volumes, two provisioners with limits and taints, daemonsets): binary == text, array for array."""
+    for seed in range(64):
+        pr = fuzz_problem(seed)
+        env_bin = S.ParsedProblem.from_env_block(env_to_block(pr))
+        batch = S.PodBatch(pods_to_blocks(pr.pods, 1))
+        a, c = S.open_batch(env_bin, batch), S.FlatProblem(pr)
+        try:
+            assert a.fingerprint() == c.fingerprint(), seed
+        finally:
+            a.close(); c.close(); batch.close(); env_bin.close()
+
+
 def test_the_environment_alone_is_a_valid_problem():
     """An environment without a batch is the text's `PODS 0`: it flattens (ksh_open_parsed) to the same empty Solve."""
     pr = dataclasses.replace(fuzz_problem(7), pods=[])
