@@ -58,3 +58,26 @@ def test_the_unpinned_region_is_real():
     a, b = O.solve(p), O.solve(p, gosort=True)
     assert len(a.new_nodes) > 12 and sorted(a.unscheduled) == sorted(b.unscheduled)
     assert abs(len(a.new_nodes) - len(b.new_nodes)) <= 0.05 * len(a.new_nodes)
+
+
+def test_go_harness_exporter_round_trips():
+    """tools/go_harness/export_fixture.py (the fixture the build-tagged Go test reads the day a toolchain exists): the JSON holds every field of the problem's pods, instance
+    types and provisioners -- rebuilt from it, the problem solves to the lines `--want` prints."""
+    import dataclasses
+    import json
+    import os
+    import subprocess
+    import sys
+    from karpenter_core_amd import model as Mo, workloads as W
+    from oracle import oracle_py as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exp = os.path.join(root, "tools", "go_harness", "export_fixture.py")
+    js = json.loads(subprocess.check_output([sys.executable, exp, "config3", "--pods", "300"], text=True))
+    want = subprocess.check_output([sys.executable, exp, "config3", "--pods", "300", "--want"], text=True).strip().splitlines()
+    p = W.config3(300)
+    assert len(js["pods"]) == len(p.pods) and len(js["instance_types"]) == len(p.instance_types) and len(js["provisioners"]) == len(p.provisioners)
+    assert js["pods"][7] == json.loads(json.dumps(dataclasses.asdict(p.pods[7]))) and js["instance_types"][3] == json.loads(json.dumps(dataclasses.asdict(p.instance_types[3])))
+    res = O.solve(p)
+    assert len(want) == len(res.new_nodes) + 1 and want[-1].startswith("UNSCHEDULED")
+    n0 = res.new_nodes[0]
+    assert want[0].split(" | ")[1].split() == [p.pods[i].uid for i in n0.pods] and want[0].split(" | ")[2].split() == sorted(n0.instance_types)
