@@ -245,3 +245,13 @@ def test_build_refuses_a_pack_kernel_that_fell_off_its_register_budget(tmp_path)
     with pytest.raises(RuntimeError, match="register budget"):
         ge._check_register_budget(remarks(256, 1, 1356), str(so))
     assert not so.exists()
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md is the map from the C ABI to the reference's symbols: an entry point the headers declare and the document does not mention is a gap in that map."""
+    import re
+    names = set()
+    for h in ("ksolve.h", "kshost.h"):
+        names |= set(re.findall(r"\b(ksh?_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", h)).read()))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert not [n for n in sorted(names) if n not in doc]
