@@ -3374,12 +3374,25 @@ extern "C" int ks_solve_batch_dev(ks_dev_problem* const* ds, uint32_t n, ks_resu
   const bool rr_on = !asked_no_rr && !asked_one_wave;
 #endif
   if (rr_on && n == 1 && lean && !bounds && fast && !ds[0]->view && !(ds[0]->h.flags & KS_FLAG_STATS) && ds[0]->h.rr_briefs) {
-    const u32 lds_rr = 44u * 1024u;
+    // dynamic LDS: the Allocatable ladders (R x ge_max x 8 bytes), at most what the kernel's static LDS object leaves of the CU's 160 KiB (a problem whose ladders
+    // do not fit is declined by the kernel itself: its eligibility test reads the size it was given)
+    u32 lds_rr = 0;
     {
-      static std::mutex rr_mu; static std::vector<char> rr_attr;
+      static std::mutex rr_mu; static std::vector<u32> rr_attr;
       std::lock_guard<std::mutex> g(rr_mu);
       if ((size_t)device >= rr_attr.size()) rr_attr.resize(device + 1, 0);
-      if (!rr_attr[device]) { HIPCHK(hipFuncSetAttribute((const void*)ks_pack_rr, hipFuncAttributeMaxDynamicSharedMemorySize, 44 * 1024)); rr_attr[device] = 1; }
+      if (!rr_attr[device]) {
+#ifdef KS_SIM
+        const u32 room = 44u * 1024u;
+#else
+        hipFuncAttributes fa; HIPCHK(hipFuncGetAttributes(&fa, (const void*)ks_pack_rr));
+        if (fa.sharedSizeBytes + 1024u > 160u * 1024u) return fail(KS_ERR_DEVICE, "ks_pack_rr: the static LDS object leaves no room for the ladders");
+        const u32 room = std::min<u32>(44u * 1024u, (u32)(160u * 1024u - fa.sharedSizeBytes) & ~255u);
+#endif
+        HIPCHK(hipFuncSetAttribute((const void*)ks_pack_rr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)room)); rr_attr[device] = room;
+      }
+      const u32 need = (u32)(((size_t)ds[0]->h.R * ds[0]->h.ge_max * 8 + 64 + 255) & ~(size_t)255);
+      lds_rr = std::min(rr_attr[device], need);
     }
     hipLaunchKernelGGL(ks_pack_rr, dim3(1), dim3(64 * RR_NW), lds_rr, st, dp, dsv, lds_rr);
     u64 rr_err[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // stats[7..14]: the error word ... the decline code

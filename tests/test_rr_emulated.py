@@ -49,7 +49,7 @@ def emulated():
     env = dict(os.environ)
     env.pop("KS_TEST_SIM", None)
     code = CHILD % {"root": ROOT, "tests": HERE}
-    pr = subprocess.run([sys.executable, "-c", code, json.dumps(CASES)], capture_output=True, text=True, env=env, timeout=1500)
+    pr = subprocess.run([sys.executable, "-c", code, json.dumps(CASES)], capture_output=True, text=True, env=env, timeout=900)
     line = [l for l in pr.stdout.splitlines() if l.startswith("RESULT ")]
     assert line, pr.stdout[-2000:] + pr.stderr[-2000:]
     return json.loads(line[-1][7:])
