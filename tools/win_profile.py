@@ -28,6 +28,8 @@ for nm, k in rows:
     if not nm.startswith("  "): acc += v
     print(f"{nm:40s} {v / M:9.2f} M cycles  {100.0 * v / tot:5.1f} %   {v / wp:8.0f} / window pod  {v / wph:8.0f} / phase")
 print(f"{'sum':40s} {acc / M:9.2f} M of {tot / M:.2f} M")
+if not os.environ.get("KS_WQ"):      # (a -DKS_PROBES_WIN build of round 6: the run statistics' slots hold the loop's waits by cause; part of "parameters + control word")
+    print("  the loop waits for: the static part %.2f M | the dyn1 answers %.2f M | answers behind their group's version %.2f M cycles" % (st.get("p22", 0) / M, st.get("p23", 0) / M, st.get("p24", 0) / M))
 if os.environ.get("KS_WQ"):      # a -DKS_PROBES_WQ build: the same slots hold what happens AROUND the window's loop
     print("around the loop (the formation rows above are NOT formation in this build):")
     for nm, k in (("rr_window_fast, entry to exit", "cyc_evalout"), ("waiting for the workers' answer", "cyc_full"), ("the hand-over of the answer's node", "cyc_commit"),
