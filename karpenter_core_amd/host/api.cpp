@@ -112,8 +112,10 @@ template <class ENC> static int solve_from(ENC&& make_encoded, int device, void*
     auto t0 = now();
     auto h = std::make_unique<Handle>();
     h->enc = make_encoded();
+    auto t0b = now();
     h->rb = h->enc->make_result();
     auto t1 = now();
+    if (getenv("KSH_TIMING")) fprintf(stderr, "  solve_from: encode %.2f ms, make_result %.2f ms\n", since(t0, t0b), since(t0b, t1));
     int rc = ks_problem_upload(&h->enc->prob, device, &h->dev); if (rc != KS_OK) return set_err(rc, ks_last_error());
     auto t2 = now();
     float grid_ms = 0; rc = ks_feasibility_grid(h->dev, nullptr, &grid_ms); if (rc != KS_OK) return set_err(rc, ks_last_error());
