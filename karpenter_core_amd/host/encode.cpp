@@ -1205,7 +1205,9 @@ EnvCache::EnvCache() {}
 EnvCache::~EnvCache() {}
 static std::unique_ptr<Encoded> encode_cached(std::unique_ptr<Encoded> e, uint32_t flags, EnvCache* cache) {
   static const bool off = getenv("KSH_NO_ENV_CACHE") != nullptr;
-  Builder b(*e, flags);
+  // (the builder's working set -- a deep copy of every distinct spec, the per-pod tables -- is handed to the Encoded and freed with it, when the caller closes the
+  // handle: tearing it down here is a millisecond of free() inside Solve's window for nothing)
+  auto bp = std::make_shared<Builder>(*e, flags); Builder& b = *bp; e->builder_keep = bp;
   if (!cache || off) { b.run(); return e; }
   const bool timing = getenv("KSH_TIMING") != nullptr; auto t0 = std::chrono::steady_clock::now();
   b.dedupe_specs(); b.specs_done = true; b.collect_active(); b.active_done = true;

@@ -17,6 +17,7 @@ res = fp.solve(); st = res.stats
 h = hashlib.sha256(json.dumps(res.canonical(), sort_keys=True).encode()).hexdigest()
 want = json.load(open("tests/golden/config_hashes.json"))
 ok = [k for k, x in want.items() if x == h or (isinstance(x, dict) and h in json.dumps(x))]
-print("%-12s min %.2f ms  all %s  rounds %s window pods %s phases %s queries %s runs %s run pods %s  fingerprint %s %s" % (v, min(ms), ["%.1f" % m for m in ms], st.get("eq_pods"), st.get("cyc_kind0"), st.get("cyc_kind1"), st.get("n_kind1"), st.get("p24"), st.get("p22"), h[:8], ok))
+b = st.get("p25", 0)
+print("%-12s min %.2f ms  all %s  rounds %s window pods %s phases %s queries %s (census answered %s) runs %s run pods %s | phases ended: plain stretch %d, the loop's stop %d, spare places taken %d, topology pod %d, no template %d | fingerprint %s %s" % (v, min(ms), ["%.1f" % m for m in ms], st.get("eq_pods"), st.get("cyc_kind0"), st.get("cyc_kind1"), st.get("n_kind1"), st.get("p26"), st.get("p24"), st.get("p22"), b & 4095, (b >> 12) & 4095, (b >> 24) & 4095, (b >> 36) & 4095, (b >> 48) & 4095, h[:8], ok))
 PY
 done | tee gpurun_out/r6ab/variants.log
