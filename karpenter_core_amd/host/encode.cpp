@@ -907,7 +907,10 @@ struct Builder {
     sublap("pass B");
     // classes
     E.cls_hn_off.assign(1, 0); E.cls_port_off.assign(1, (uint32_t)E.ports.size()); E.cls_vol_off.assign(1, 0);
-    for (auto& si : specs) for (auto& st : si.stages) si.cls.push_back(class_of(st));
+    { std::vector<size_t> soff(specs.size() + 1, 0); for (size_t s2 = 0; s2 < specs.size(); ++s2) soff[s2 + 1] = soff[s2] + specs[s2].stages.size();
+      std::vector<ClassPre> pre(soff.back());
+      parallel_chunks(specs.size(), [&](size_t b, size_t e, uint32_t) { for (size_t s2 = b; s2 < e; ++s2) for (size_t k = 0; k < specs[s2].stages.size(); ++k) class_pre(specs[s2].stages[k], pre[soff[s2] + k]); }, 64);
+      for (size_t s2 = 0; s2 < specs.size(); ++s2) for (size_t k = 0; k < specs[s2].stages.size(); ++k) specs[s2].cls.push_back(class_of(specs[s2].stages[k], pre[soff[s2] + k])); }
     // pods -> stage chains, queue order
     sublap("classes"); E.pod_stage_off.resize((size_t)P + 1); E.pod_stage_off[0] = 0;
     for (uint32_t i = 0; i < P; ++i) E.pod_stage_off[i + 1] = E.pod_stage_off[i] + (uint32_t)specs[pod_spec[i]].cls.size();
@@ -988,20 +991,28 @@ struct Builder {
     pod_rank.resize(P); for (uint32_t i = 0; i < P; ++i) pod_rank[E.queue[i]] = i;
   }
 
-  uint32_t class_of(const StageInfo& st) {
+  // class_of in two halves: the PURE one -- the signature of everything Node.Add reads of the stage but the ids the serial half hands out (label set, topology groups) --
+  // runs on the worker pool for every stage at once (strings, quantities, tolerations: what class_of spent its time on); the serial half interns.
+  struct ClassPre { std::string ls, sig; ksp::ResList req; uint64_t tol = 0; std::vector<uint32_t> ve; std::vector<uint64_t> pe; };
+  void class_pre(const StageInfo& st, ClassPre& o) const {
     const Pod& p = st.spec;
     // label set (namespace + labels decide which selectors select the pod)
-    std::string ls = p.ns; ls += '\3'; sig_map(ls, p.labels);
-    int lsid; auto li = labelset_id.find(ls); if (li == labelset_id.end()) { lsid = (int)labelsets.size(); labelsets.emplace_back(p.ns, p.labels); labelset_id[ls] = lsid; } else lsid = li->second;
+    o.ls = p.ns; o.ls += '\3'; sig_map(o.ls, p.labels);
     // signature of everything Node.Add reads
-    std::string sig; sig.reserve(256);
+    std::string& sig = o.sig; sig.reserve(256);
     for (auto& kv : st.reqs.m) { sig += kv.first; sig += '\1'; sig += kv.second.identity(); sig += '\2'; } sig += '\4';
-    ksp::ResList req = RequestsForPod(p); sig_res(sig, req);
+    o.req = RequestsForPod(p); sig_res(sig, o.req);
     uint64_t tol = 0; for (size_t i = 0; i < taints.size(); ++i) { if ((int)i == blocked_taint) continue; bool ok = false; for (auto& t : p.tolerations) ok = ok || ToleratesTaint(t, taints[i]); if (ok) tol |= 1ull << i; }
+    o.tol = tol;
     sig += std::to_string(tol); sig += '\4';
-    const std::vector<uint32_t> ve = pods_have_volumes ? vol_entries(p) : std::vector<uint32_t>();
-    for (auto e : ve) { sig += std::to_string(e); sig += ','; } sig += '\4';
-    std::vector<uint64_t> pe; for (auto& c : p.containers) for (auto& hp : c.ports) if (hp.port != 0) pe.push_back(port_entry(hp.ip, hp.port, hp.proto));
+    if (pods_have_volumes) o.ve = vol_entries(p);
+    for (auto e : o.ve) { sig += std::to_string(e); sig += ','; } sig += '\4';
+  }      // (host ports: port_entry hands out ids in order of first use -- the serial half's)
+  uint32_t class_of(const StageInfo& st, ClassPre& pre) {
+    const Pod& p = st.spec;
+    int lsid; auto li = labelset_id.find(pre.ls); if (li == labelset_id.end()) { lsid = (int)labelsets.size(); labelsets.emplace_back(p.ns, p.labels); labelset_id[pre.ls] = lsid; } else lsid = li->second;
+    std::string& sig = pre.sig; const ksp::ResList& req = pre.req; const uint64_t tol = pre.tol; const std::vector<uint32_t>& ve = pre.ve; std::vector<uint64_t>& pe = pre.pe;
+    for (auto& c : p.containers) for (auto& hp : c.ports) if (hp.port != 0) pe.push_back(port_entry(hp.ip, hp.port, hp.proto));
     for (auto e : pe) { sig += std::to_string(e); sig += ','; } sig += '\4';
     sig += std::to_string(lsid); sig += '\4';
     for (int g : st.sg.own) { sig += std::to_string(g); sig += ','; } sig += '\4';
@@ -1207,7 +1218,7 @@ static std::unique_ptr<Encoded> encode_cached(std::unique_ptr<Encoded> e, uint32
   static const bool off = getenv("KSH_NO_ENV_CACHE") != nullptr;
   // (the builder's working set -- a deep copy of every distinct spec, the per-pod tables -- is handed to the Encoded and freed with it, when the caller closes the
   // handle: tearing it down here is a millisecond of free() inside Solve's window for nothing)
-  auto bp = std::make_shared<Builder>(*e, flags); Builder& b = *bp; e->builder_keep = bp;
+  auto bp = std::make_shared<Builder>(*e, flags); Builder& b = *bp; if (!getenv("KSH_NO_KEEP")) e->builder_keep = bp;
   if (!cache || off) { b.run(); return e; }
   const bool timing = getenv("KSH_TIMING") != nullptr; auto t0 = std::chrono::steady_clock::now();
   b.dedupe_specs(); b.specs_done = true; b.collect_active(); b.active_done = true;
