@@ -50,6 +50,27 @@ def algorithmic_bytes(T, stats, placed):
     return stats["queue_pops"] * b_pod + stats["attempts"] * b_node + stats["types_scanned"] * b_it + placed * b_node
 
 
+def pmc_leg(leg, kernel_ms):
+    """Counter passes of another leg's dominant kernel (tools/profile_bench.sh: `whatifs` = the single-wave batch kernel of the 512 what-ifs, `config5` = the general
+    4-wave kernel at 250 000 pods), from the latest profiles/*_bench_pmc.json IF it was recorded with this kernel source: (traffic bytes per launch, issue object, source) or (None, None, None)."""
+    try:
+        pmc_name = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_pmc.json"))[-1]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
+        if pmc.get("kernel_source_sha16") != kernel_source_sha16():
+            return None, None, None
+        L = pmc["legs"][leg]
+        issue = None
+        if L.get("instructions") and kernel_ms:
+            clk = pmc.get("ks_pack_per_launch", {}).get("shader_clock_ghz", 2.4); cus = L.get("workgroups", 1)
+            issue = {"instructions_per_launch": L["instructions"], "instruction_mix": L.get("instruction_mix"), "workgroups": cus, "waves_per_workgroup": L.get("waves_per_workgroup"),
+                     "achieved_ipc_per_workgroup": L["instructions"] / cus / (kernel_ms / 1e3 * clk * 1e9),
+                     "wait_fraction": L.get("wait_fraction"),
+                     "note": "one workgroup per Solve on its own CU: a CU issues up to 4 instructions per cycle (one per SIMD), a single wave at most 1"}
+        return L.get("hbm_bytes_fetch_x2_plus_write"), issue, f"profiles/{pmc_name} legs.{leg} ({L.get('kernel')}; FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, same kernel source)"
+    except Exception:
+        return None, None, None
+
+
 def kernel_source_sha16():
     h = hashlib.sha256()
     for f in ("karpenter_core_amd/csrc/ksolve.hip", "karpenter_core_amd/csrc/ks_pack_rr.inc", "karpenter_core_amd/csrc/ks_algebra.h"):
@@ -330,7 +351,8 @@ def config5_leg(args, device, torch, S, W):
             "p50_solve_latency_ms": statistics.median(lat), "phases_ms_mean": {k: statistics.mean(r[k] for r in rows) for k in S.TIMING_KEYS}, "prep_seconds_untimed": prep_s,
             "oracle_fingerprint": gold,
             "roofline": {"kernel": "ks_pack<general, 4 waves>", "bound": "hbm", "achieved": abytes / (kms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": abytes / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": abytes, "kernel_ms_mean": kms,
+                         "frac": abytes / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": (pmc_leg("config5", kms)[0] if dims["P"] == 250_000 else None), "traffic_source": (pmc_leg("config5", kms)[2] if dims["P"] == 250_000 else None),
+                         "issue": (pmc_leg("config5", kms)[1] if dims["P"] == 250_000 else None), "algorithmic_bytes_per_launch": abytes, "kernel_ms_mean": kms,
                          "ref_attempts": st["attempts"], "ref_types_scanned": st["types_scanned"], "formula": f"SURVEY 8d with R={ROOFLINE_R}, K={ROOFLINE_K}"}}
 
 
@@ -495,8 +517,12 @@ def whatif_leg(args, rank, world, local_rank, torch, dist, S, W):
                         "kernel_ms": kms, "wall_ms": wms, "decisions_per_s_kernel": pods_mine / (kms / 1e3), "decisions_per_s_wall": pods_mine / (wms / 1e3),
                         "whatifs_per_s_wall": len(flats) / (wms / 1e3)},
            "roofline": {"kernel": "ks_pack<single wave> x what-ifs in one launch", "bound": "hbm", "achieved": abytes / (kms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": abytes / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": abytes, "kernel_ms": kms,
+                        "frac": abytes / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_leg("whatifs", kms)[0], "traffic_source": pmc_leg("whatifs", kms)[2], "issue": pmc_leg("whatifs", kms)[1],
+                        "algorithmic_bytes_per_launch": abytes, "kernel_ms": kms,
                         "formula": f"SURVEY 8d with R={ROOFLINE_R}, K={ROOFLINE_K}, summed over the what-ifs",
+                        "bound_as_it_is": "the batch is its LONGEST what-if: one wave placing its pods one after the other (a chain of dependent instructions at about one per ten cycles) while the "
+                                          "other 511 workgroups have long finished; `achieved` / `frac` price the REFERENCE algorithm's bytes -- the attempts the watermark and the run commit skip are in "
+                                          "them -- against the kernel's time, `traffic` is what the counters saw move",
                         "note": "a batch takes as long as its longest what-if (one wave each); the watermark / run commit skip most of the attempts the reference makes"}}
     for f in flats:
         f.close()

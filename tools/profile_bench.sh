@@ -15,6 +15,15 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o b
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- python $R/bench.py $SOLVE > $OUT/bench_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_BRANCH --output-format csv -d $OUT/insts -o bench -- python $R/bench.py $SOLVE > $OUT/bench_insts.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/cycles -o bench -- python $R/bench.py $SOLVE > $OUT/bench_cycles.log 2>&1
+# the same four passes for the two other dominant kernels: the single-wave batch kernel of the 512 what-ifs, the general 4-wave kernel of config #5 at 250 000 pods
+WI="--whatifs-only"; C5="--config5 250000 --steps 1 --warmup 0"
+for leg in wi c5; do
+  if [ $leg = wi ]; then A="$WI"; else A="$C5"; fi
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$leg -o bench -- python $R/bench.py $A > $OUT/bench_fetch_$leg.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write_$leg -o bench -- python $R/bench.py $A > $OUT/bench_write_$leg.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_BRANCH --output-format csv -d $OUT/insts_$leg -o bench -- python $R/bench.py $A > $OUT/bench_insts_$leg.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/cycles_$leg -o bench -- python $R/bench.py $A > $OUT/bench_cycles_$leg.log 2>&1
+done
 # keep only what the summariser reads (gpurun_out is capped at 64 MiB)
 find $OUT -name "*.csv" ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -delete
 find $OUT -name "*.db" -delete
