@@ -34,6 +34,7 @@
 #include <string>
 #include <vector>
 #include <type_traits>
+#include <system_error>
 
 #include "../../include/ksolve.h"
 #include "ks_algebra.h"
@@ -3518,10 +3519,15 @@ extern "C" int ks_solve_batch_sharded(ks_dev_problem* const* const* shards, cons
     }
     rcs[s] = rc; if (rc != KS_OK) msgs[s] = g_err; kms[s] = k;
   };
-  std::vector<std::thread> th;
-  for (u32 s = 1; s < nshards; ++s) th.emplace_back(run, s);
-  run(0);
+  // shard 0 on the caller's thread -- whose current device is put back afterwards (a solve selects its shard's device) --, the others on threads of their own; a thread that
+  // cannot be started is an error code, not an exception through the C boundary
+  int caller_dev = -1; const bool have_dev = hipGetDevice(&caller_dev) == hipSuccess;
+  std::vector<std::thread> th; bool spawn_failed = false;
+  try { for (u32 s = 1; s < nshards; ++s) th.emplace_back(run, s); } catch (const std::system_error&) { spawn_failed = true; }
+  if (!spawn_failed) run(0);
   for (auto& t : th) t.join();
+  if (have_dev) (void)hipSetDevice(caller_dev);
+  if (spawn_failed) return fail(KS_ERR_DEVICE, "a shard's thread could not be started");
   for (u32 s = 0; s < nshards; ++s) if (rcs[s] != KS_OK) return fail(rcs[s], "shard " + std::to_string(s) + ": " + msgs[s]);
   // one table, ordered by id (what the all-gather + sort of the N-rank path leaves)
   std::vector<size_t> idx(off[nshards]); for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
