@@ -149,6 +149,28 @@ def config3(pods: int = 100_000, sizes: int = 50, seed: int = 44) -> Problem:
                    extra_well_known=fake.EXTRA_WELL_KNOWN)
 
 
+def hostname_herd(pods: int = 600, labels: int = 3, seed: int = 3) -> Problem:
+    """Small pods that crowd the hostname-keyed groups: a third carry self-selecting hostname anti-affinity on one of `labels` values (a node takes one pod per value: the
+    machines multiply, and once every node has its pod of a value the next pod of that value is taken by NOBODY), a third a hostname spread with maxSkew 1 on the
+    same labels, the rest nothing.  What round 6's census of zero counters (ks_pack_rr: RRLds::hz) is about: counters leave 0 in the head window, in run steps, in
+    normal rounds and when a machine opens with its first pod."""
+    rs = np.random.RandomState(seed)
+    its = fake.instance_types(8)
+    ps: List[Pod] = []
+    for i in range(pods):
+        uid = f"pod-{i:07d}"
+        c = Container(requests={"cpu": f"{[50, 100, 200][rs.randint(3)]}m", "memory": f"{[32, 64][rs.randint(2)]}Mi"})
+        v = LABEL_VALUES[rs.randint(labels)]
+        k = rs.randint(3)
+        if k == 0:
+            ps.append(Pod(uid=uid, labels={"my-affininity": v}, containers=[c], anti_required=[PodAffinityTerm(LABEL_HOSTNAME, LabelSelector({"my-affininity": v}))]))
+        elif k == 1:
+            ps.append(Pod(uid=uid, labels={"my-label": v}, containers=[c], spread=[TopologySpreadConstraint(1, LABEL_HOSTNAME, DO_NOT_SCHEDULE, LabelSelector({"my-label": v}))]))
+        else:
+            ps.append(Pod(uid=uid, labels={"my-label": v}, containers=[c]))
+    return Problem(instance_types=its, provisioners=[fake.provisioner("default", len(its))], pods=ps, extra_well_known=fake.EXTRA_WELL_KNOWN)
+
+
 # ---- config #5: 1M pods, 5k instance types, full constraint set ----
 def config5(pods: int = 1_000_000, sizes: int = 50, seed: int = 46) -> Problem:
     rs = np.random.RandomState(seed)

@@ -28,7 +28,7 @@ for name, kind, args in cases:
     p = getattr(W, kind)(**args) if kind != "mid" else T.mid_problem(args["seed"])
     try:
         r = S.solve_problem(p)
-        out[name] = {"fp": fp(r), "rounds": r.stats.get("eq_pods", 0), "run_pods": r.stats.get("p22", 0)}
+        out[name] = {"fp": fp(r), "rounds": r.stats.get("eq_pods", 0), "run_pods": r.stats.get("p22", 0), "window_pods": r.stats.get("cyc_kind0", 0), "census_answered": r.stats.get("p26", 0), "queries": r.stats.get("n_kind1", 0)}
     except Exception as e:
         out[name] = {"error": str(e)[:200]}
 print("RESULT " + json.dumps(out))
@@ -41,6 +41,10 @@ CASES = [
     ("config3_3500", "config3", {"pods": 3500, "sizes": 20, "seed": 44}),
     ("mid_0", "mid", {"seed": 0}),
     ("mid_3", "mid", {"seed": 3}),
+    # round 6: hostname-keyed groups crowded until nobody takes the next pod -- the census of zero counters answers instead of the workers (the emulator build also CHECKS
+    # the census at the end of the kernel: every node takes its zero counters out again, what is left must be nothing -- a Solve with a census that is off fails loudly)
+    ("herd_600", "hostname_herd", {"pods": 600, "labels": 3, "seed": 3}),
+    ("herd_900", "hostname_herd", {"pods": 900, "labels": 5, "seed": 8}),
 ]
 
 
@@ -73,6 +77,13 @@ def test_rr_kernel_source_matches_oracle_on_the_emulator(emulated, name, kind, a
 def test_rr_runs_are_exercised(emulated):
     """The generic replicas of the config #3 shape go through RUN rounds (several pods per barrier): the test above covers that path, not only the one-pod picks."""
     assert emulated["config3_3500"]["run_pods"] > 1000
+
+
+def test_rr_prepared_pods_and_the_census_are_exercised(emulated):
+    """Round 6: the head window's pods arrive prepared by the worker waves (RRPx) -- the config #3 shape places a third of its pods that way, its zonal-spread pods through the
+    per-domain answers --, and on the hostname herds the census of zero counters answers the leader's "does anybody take this pod" (statistics slot 26)."""
+    assert emulated["config3_3500"]["window_pods"] > 1000
+    assert emulated["herd_600"]["census_answered"] > 0 and emulated["herd_900"]["census_answered"] > 0
 
 
 # ---- round 5: ks_pack on the emulator too (tests/sim/build_sim.py -DKS_SIM_PACK): its single-wave variants -- what a what-if batch runs, LEAN and general -- and the hand-over

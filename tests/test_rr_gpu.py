@@ -177,6 +177,28 @@ def test_head_window_is_exercised(monkeypatch):
     assert res.stats.get("cyc_kind0", 0) > 4000 and res.stats.get("p22", 0) > 4000
 
 
+@pytest.mark.parametrize("pods,labels,seed", [(2000, 3, 3), (3000, 6, 9)])
+def test_census_of_zero_counters_answers_for_the_workers(pods, labels, seed, monkeypatch):
+    """Round 6: hostname-keyed groups crowded until NO node takes the next anti-affinity pod -- the leader's census of zero counters (statistics slot 26) opens the
+    machine without asking the workers; counters leave 0 in the head window, in run steps, in rounds and on fresh machines.  The result is the oracle's."""
+    monkeypatch.delenv("KS_NO_RR", raising=False)
+    p = W.hostname_herd(pods=pods, labels=labels, seed=seed)
+    res, (started, why) = _solve_with_status(p)
+    assert started and why == 0, (started, why)
+    assert res.stats.get("p26", 0) > 0
+    assert res.canonical() == O.solve(p).canonical()
+
+
+def test_prepared_pods_reach_the_head_window(monkeypatch):
+    """Round 6: the window's pods are prepared by the worker waves (RRPx); why its phases end is in statistics slot 25 (12 bits each: a plain stretch | the loop's own
+    stop | the spare places taken | a topology pod nothing in the window takes | no template)."""
+    monkeypatch.delenv("KS_NO_RR", raising=False)
+    res = S.solve_problem(W.config3(pods=20000, sizes=50, seed=45))
+    b = res.stats.get("p25", 0)
+    ended = [(b >> (12 * i)) & 4095 for i in range(5)]
+    assert res.stats.get("cyc_kind0", 0) > 4000 and sum(ended) == res.stats.get("cyc_kind1", 0), (ended, res.stats.get("cyc_kind1"))
+
+
 def test_result_arrays_say_what_the_text_says(monkeypatch):
     """The binary result door (ksh_result_arrays_get): Node.Pods in commit order, InstanceTypeOptions, requests, requirement records, stages, unscheduled queue -- field for
     field what ksh_result_text decodes (that one is compared with the oracle everywhere else)."""
