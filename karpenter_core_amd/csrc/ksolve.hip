@@ -2646,6 +2646,8 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
   // ---------------- results ----------------
   if (wv != 0) return;
   GSYNC();
+  // (the leader's state is wave-uniform on the GPU; the lane-fibre emulator keeps a copy per lane, and a requeue on the sequential path updates lane 0's: re-read from it)
+  q_len = UF(q_len); q_head = UF(q_head); nnew = UF(nnew);
   for (u32 i = lane; i < q_len; i += 64) { u32 idx = q_head + i; if (idx >= nP) idx -= nP; S.unscheduled[i] = (i32)tb.q[idx]; }
   for (u32 j = lane; j < nnew; j += 64) {        // de-interleave the new nodes' records into the SoA result arrays
     const Rec r = slot_rec(S, tb, tb.E + j);
