@@ -1211,14 +1211,38 @@ struct Builder {
 
 // The flattening of an environment (catalogue, universes, templates, state-node rows, instance-type lattice) for ONE universe signature, kept
 // with the caller's objects: the next batch with the same signature adopts it instead of encoding 2 000 instance types again.
+// Teardown off the caller's thread: what a flattening no longer needs is handed over and destroyed here (one thread per process, started on first use; a process
+// that inherited the object through fork() without its thread starts its own).
+class Reaper {
+ public:
+  static Reaper& get() { static Reaper* r = new Reaper(); return *r; }      // (never destroyed: the thread may outlive static destructors)
+  void take(std::shared_ptr<void> p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(m_);
+    if (pid_ != getpid()) { pid_ = getpid(); q_.clear(); started_ = false; }
+    q_.push_back(std::move(p));
+    if (!started_) { try { std::thread([this] { loop(); }).detach(); started_ = true; } catch (...) { q_.clear(); return; } }      // (no thread: destroyed here, by clear())
+    cv_.notify_one();
+  }
+ private:
+  void loop() {
+    for (;;) {
+      std::vector<std::shared_ptr<void>> mine;
+      { std::unique_lock<std::mutex> g(m_); cv_.wait(g, [&] { return !q_.empty(); }); mine.swap(q_); }
+      mine.clear();
+    }
+  }
+  std::mutex m_; std::condition_variable cv_; std::vector<std::shared_ptr<void>> q_; bool started_ = false; pid_t pid_ = getpid();
+};
 struct EnvBase { std::string sig; uint32_t flags = 0; std::shared_ptr<Encoded> enc; std::unique_ptr<Builder> builder; };
 EnvCache::EnvCache() {}
 EnvCache::~EnvCache() {}
 static std::unique_ptr<Encoded> encode_cached(std::unique_ptr<Encoded> e, uint32_t flags, EnvCache* cache) {
   static const bool off = getenv("KSH_NO_ENV_CACHE") != nullptr;
-  // (the builder's working set -- a deep copy of every distinct spec, the per-pod tables -- is handed to the Encoded and freed with it, when the caller closes the
-  // handle: tearing it down here is a millisecond of free() inside Solve's window for nothing)
-  auto bp = std::make_shared<Builder>(*e, flags); Builder& b = *bp; if (!getenv("KSH_NO_KEEP")) e->builder_keep = bp;
+  // (the builder's working set -- a deep copy of every distinct spec, the per-pod tables -- is torn down on a thread of its own, while the GPU solves: a millisecond
+  // of free() that Solve's caller need not wait for)
+  auto bp = std::make_shared<Builder>(*e, flags); Builder& b = *bp;
+  struct Hand { std::shared_ptr<Builder>& p; ~Hand() { Reaper::get().take(std::move(p)); } } hand{bp};      // (on every way out)
   if (!cache || off) { b.run(); return e; }
   const bool timing = getenv("KSH_TIMING") != nullptr; auto t0 = std::chrono::steady_clock::now();
   b.dedupe_specs(); b.specs_done = true; b.collect_active(); b.active_done = true;

@@ -80,7 +80,6 @@ struct Encoded {
     RawBuf<uint64_t> node_types, node_mask; RawBuf<int64_t> node_requests; RawBuf<uint32_t> node_requests_present, node_present, node_complement, pod_reason;
     ks_result r{};
   };
-  std::shared_ptr<void> builder_keep;      // the builder that made this flattening (its working set is freed with the Encoded, not inside the Solve that made it)
   std::unique_ptr<ResultBuf> make_result() const;
   std::string decode(const ks_result& r, double solve_seconds) const;   // KSR1 text (see model.py parse_result)
 };
