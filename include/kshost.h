@@ -124,6 +124,10 @@ int ksh_upload_batch(void** handles, uint32_t n, int device, uint32_t nthreads);
 int ksh_solve(void* handle, char** out_text /* KSR1 or NULL */, float* kernel_ms, double* wall_ms);
 int ksh_solve_batch(void** handles, uint32_t n, char** out_texts /* n entries or NULL */, float* kernel_ms, double* wall_ms);
 int ksh_grid(void* handle, uint64_t* out /* [M][C][ceil(T/64)] or NULL */, float* kernel_ms);
+/* The grid's rows split over GPUs (ks_feasibility_grid_rows / _install of ksolve.h for a handle): rows [row_lo, row_hi) of the M * C rows computed on the
+ * handle's device and copied out (host and / or device destination, either may be NULL); rows computed elsewhere installed (complete != 0 with the last of them). */
+int ksh_grid_rows(void* handle, uint32_t row_lo, uint32_t row_hi, uint64_t* out_rows, void* out_rows_dev, float* kernel_ms);
+int ksh_grid_install(void* handle, uint32_t row_lo, uint32_t row_hi, const uint64_t* rows, const void* rows_dev, int complete);
 int ksh_solve_ksp(const char* ksp_text, size_t len, uint32_t flags, char** out_text);  /* one shot: KSP1 in, KSR1 out */
 
 /* ---- results ---- */

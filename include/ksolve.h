@@ -317,6 +317,12 @@ int ks_solve_batch(const ks_problem* const* p, uint32_t n, ks_result* const* out
 /* The static pod-class x instance-type feasibility grid for fresh nodes of every template:
  * out_grid[(m*C + c)*TW + w].  Exposed for parity tests and roofline measurement. */
 int ks_feasibility_grid(ks_dev_problem* d, uint64_t* out_grid, float* kernel_ms);
+/* SURVEY 8e row 2 -- the static grid's rows split over GPUs (node.go:137-159 for a fresh node of template m and a pod of class c is row m * C + c, ceil(T/64) words):
+ * ks_feasibility_grid_rows computes rows [row_lo, row_hi) on this device (every other static table in full) and copies them to host memory (out_rows) and / or into
+ * device memory of the caller's (out_rows_dev: e.g. its slice of the buffer ONE all-gather fills); ks_feasibility_grid_install puts rows computed elsewhere in place
+ * (from host or device memory; complete != 0: every row is in, the problem solves without building its grid again). */
+int ks_feasibility_grid_rows(ks_dev_problem* d, uint32_t row_lo, uint32_t row_hi, uint64_t* out_rows, void* out_rows_dev, float* kernel_ms);
+int ks_feasibility_grid_install(ks_dev_problem* d, uint32_t row_lo, uint32_t row_hi, const uint64_t* rows, const void* rows_dev, int complete);
 
 /* Consolidation price stage on results that are still on the device (deprovisioning/helpers.go:148-157 filterByPrice over
  * :292-315 worstLaunchPrice; callers consolidation.go:238 and multinodeconsolidation.go:164): for problem i, of new node

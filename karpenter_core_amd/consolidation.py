@@ -76,6 +76,26 @@ def all_gather_records(records: torch.Tensor, per_rank: int) -> torch.Tensor:
     return table[torch.argsort(table[:, 0])]
 
 
+def all_gather_grid_rows(rows, device: str = "cpu"):
+    """The one exchange step of the sharded static grid (scheduler.sharded_grid): this rank's bit-rows (numpy uint64 [m, TW]; the ranks' shares differ by at
+    most one row) all-gathered ONCE over the process group -- RCCL over xGMI with device="cuda", gloo on the CPU -- and handed back as one numpy array per rank, in rank order."""
+    import numpy as np
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return [rows]
+    tw = rows.shape[1]
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=device)
+    counts = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)                                  # (the shares' sizes are a function of M * C and the world size; gathered so that a mismatch is loud, not silent)
+    counts = [int(c.item()) for c in counts]
+    per = max(counts)
+    local = torch.zeros((per, tw), dtype=torch.int64, device=device)
+    local[: rows.shape[0]] = torch.from_numpy(rows.view(np.int64)).to(device)
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    return [g[:c].cpu().numpy().view(np.uint64) for g, c in zip(gathered, counts)]
+
+
 def solve_whatifs(problems: Sequence[Problem], solve_many: Callable[[List[Problem]], List[SolveResult]],
                   device: str = "cpu") -> torch.Tensor:
     """Solve all what-ifs across the process group; every rank returns the full [n, width] record table."""

@@ -286,7 +286,7 @@ __host__ __device__ inline u32 ks_grid_chunks(size_t MC, u32 TW, u32 wave_target
 //   hasOffering = some available offering whose zone / capacity-type the node allows (node.go:151)
 // Wave (w, chunk): lane owns type t = 64*w + lane for the whole kernel; (m,c) records are wave-uniform.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ks_grid_types(const DevProb* probs, u32 wave_target) {
+__global__ __launch_bounds__(256) void ks_grid_types(const DevProb* probs, u32 wave_target, u32 row_lo, u32 row_hi) {      // rows [row_lo, row_hi) of the grid (the rows split over GPUs; everything: 0, ~0)
   const DevProb& P = probs[blockIdx.y];
   const size_t MC0 = (size_t)P.M * P.C; if (MC0 == 0) return;
   const u32 chunks = ks_grid_chunks(MC0, P.TW, wave_target);
@@ -302,8 +302,8 @@ __global__ __launch_bounds__(256) void ks_grid_types(const DevProb* probs, u32 w
   for (int k = 0; k < KS_MAX_KEYS; ++k) tmask[k] = (valid && (u32)k < P.K) ? P.it_mask[(size_t)k * P.T + t] : 0;
 #pragma unroll
   for (int r = 0; r < KS_MAX_RES; ++r) talloc[r] = (valid && (u32)r < P.R) ? P.it_alloc[(size_t)r * P.T + t] : 0;
-  const size_t MC = (size_t)P.M * P.C;
-  for (size_t mc = chunk; mc < MC; mc += chunks) {
+  const size_t MCall = (size_t)P.M * P.C, MC = MCall < (size_t)row_hi ? MCall : (size_t)row_hi;
+  for (size_t mc = (size_t)row_lo + chunk; mc < MC; mc += chunks) {
     const u32 m = mc / P.C, c = mc % P.C;
     bool ok = valid && P.mc_ok[mc] && ((P.tmpl_types[(size_t)m * P.TW + w] >> lane) & 1ull);
     if (__builtin_amdgcn_readfirstlane(P.mc_ok[mc]) == 0) { if (lane == 0) P.grid[mc * P.TW + w] = 0; continue; }
@@ -3184,7 +3184,7 @@ static void static_dims_of(const DevProb& h, StaticDims& a) {
   if (!h.derived_shared) { a.rows = std::max(a.rows, h.K * 64 + 2 * h.K + 64); a.RT = std::max(a.RT, h.R * h.T); }
   a.C = std::max(a.C, h.C); a.MC = std::max(a.MC, (size_t)h.M * h.C); a.TW = std::max(a.TW, h.TW);
 }
-static void launch_static(const DevProb* probs, u32 n, const StaticDims& a, u32 wave_target, hipStream_t st, hipEvent_t before_grid) {
+static void launch_static(const DevProb* probs, u32 n, const StaticDims& a, u32 wave_target, hipStream_t st, hipEvent_t before_grid, u32 row_lo = 0, u32 row_hi = 0xFFFFFFFFu) {
   if (a.rows) hipLaunchKernelGGL(ks_build_type_tables, dim3((a.rows * 64 + 255) / 256, n), dim3(256), 0, st, probs);
   if (a.C) {
     hipLaunchKernelGGL(ks_build_plans, dim3((a.C + 63) / 64, n), dim3(64), 0, st, probs);
@@ -3199,16 +3199,16 @@ static void launch_static(const DevProb* probs, u32 n, const StaticDims& a, u32 
   if (a.MC) {
     hipLaunchKernelGGL(ks_grid_mc, dim3((u32)((a.MC + 255) / 256), n), dim3(256), 0, st, probs);
     const size_t waves = (size_t)a.TW * ks_grid_chunks(a.MC, a.TW, wave_target);      // (an upper bound over the batch: a problem's surplus waves return at once)
-    hipLaunchKernelGGL(ks_grid_types, dim3((u32)((waves * 64 + 255) / 256), n), dim3(256), 0, st, probs, wave_target);
+    hipLaunchKernelGGL(ks_grid_types, dim3((u32)((waves * 64 + 255) / 256), n), dim3(256), 0, st, probs, wave_target, row_lo, row_hi);
   }
 }
 // Build the derived tables + the feasibility grid (idempotent).  Returns the grid kernels' time.
-static int build_static(ks_dev_problem* d, float* grid_ms) {
+static int build_static(ks_dev_problem* d, float* grid_ms, u32 row_lo = 0, u32 row_hi = 0xFFFFFFFFu) {
   HIPCHK(hipSetDevice(d->device));
   hipEvent_t e0 = nullptr, e1 = nullptr; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   StaticDims a; static_dims_of(d->h, a);
-  launch_static(d->d_prob, 1, a, 8192, d->stream, e0);
-  d->tables_built = true;
+  launch_static(d->d_prob, 1, a, 8192, d->stream, e0, row_lo, row_hi);
+  d->tables_built = row_lo == 0 && (size_t)row_hi >= (size_t)d->h.M * d->h.C;      // (a row range: the grid is whole once the other rows are installed)
   HIPCHK(hipEventRecord(e1, d->stream));
   HIPCHK(hipStreamSynchronize(d->stream));
   HIPCHK(hipGetLastError());
@@ -3227,6 +3227,30 @@ extern "C" int ks_feasibility_grid(ks_dev_problem* d, uint64_t* out_grid, float*
   if (!d) return fail(KS_ERR_INVALID, "null device problem");
   TRY(build_static(d, kernel_ms));
   if (out_grid) HIPCHK(hipMemcpy(out_grid, d->h.grid, (size_t)d->h.M * d->h.C * d->h.TW * sizeof(u64), hipMemcpyDeviceToHost));
+  return KS_OK;
+}
+
+// the static grid's rows (template x class pairs, TW words each) split over GPUs.  Rows [row_lo, row_hi) are computed HERE -- every other static table in
+// full: they are per class, not per class x type -- and copied out, to host memory and / or into device memory of the caller's (a slice of the buffer an all-gather fills).
+extern "C" int ks_feasibility_grid_rows(ks_dev_problem* d, uint32_t row_lo, uint32_t row_hi, uint64_t* out_rows, void* out_rows_dev, float* kernel_ms) {
+  if (!d) return fail(KS_ERR_INVALID, "null device problem");
+  const size_t MC = (size_t)d->h.M * d->h.C, TW = d->h.TW;
+  if (row_lo > row_hi || row_hi > MC) return fail(KS_ERR_INVALID, "grid rows out of range");
+  TRY(build_static(d, kernel_ms, row_lo, row_hi));
+  const size_t bytes = (size_t)(row_hi - row_lo) * TW * sizeof(u64); const u64* src = d->h.grid + (size_t)row_lo * TW;
+  if (out_rows && bytes) HIPCHK(hipMemcpy(out_rows, src, bytes, hipMemcpyDeviceToHost));
+  if (out_rows_dev && bytes) HIPCHK(hipMemcpy(out_rows_dev, src, bytes, hipMemcpyDeviceToDevice));
+  return KS_OK;
+}
+// ... and rows computed elsewhere installed (from host or device memory).  `complete` != 0: every row is in now -- the problem solves without building its grid again.
+extern "C" int ks_feasibility_grid_install(ks_dev_problem* d, uint32_t row_lo, uint32_t row_hi, const uint64_t* rows, const void* rows_dev, int complete) {
+  if (!d) return fail(KS_ERR_INVALID, "null device problem");
+  const size_t MC = (size_t)d->h.M * d->h.C, TW = d->h.TW;
+  if (row_lo > row_hi || row_hi > MC || (!rows && !rows_dev && row_hi > row_lo)) return fail(KS_ERR_INVALID, "grid rows out of range (or no source)");
+  HIPCHK(hipSetDevice(d->device));
+  const size_t bytes = (size_t)(row_hi - row_lo) * TW * sizeof(u64); u64* dst = d->h.grid + (size_t)row_lo * TW;
+  if (bytes) { if (rows_dev) HIPCHK(hipMemcpy(dst, rows_dev, bytes, hipMemcpyDeviceToDevice)); else HIPCHK(hipMemcpy(dst, rows, bytes, hipMemcpyHostToDevice)); }
+  if (complete) d->tables_built = true;
   return KS_OK;
 }
 

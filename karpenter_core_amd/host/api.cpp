@@ -516,6 +516,20 @@ int ksh_grid(void* hv, uint64_t* out, float* kernel_ms) {
   return KS_OK;
 }
 
+// The grid's rows split over GPUs: a range of rows computed on the handle's device / rows computed elsewhere installed.
+int ksh_grid_rows(void* hv, uint32_t row_lo, uint32_t row_hi, uint64_t* out_rows, void* out_rows_dev, float* kernel_ms) {
+  Handle* h = (Handle*)hv; int rc = h->dev ? KS_OK : ksh_upload(hv, ks_current_device()); if (rc != KS_OK) return rc;
+  rc = ks_feasibility_grid_rows(h->dev, row_lo, row_hi, out_rows, out_rows_dev, kernel_ms);
+  if (rc != KS_OK) return set_err(rc, ks_last_error());
+  return KS_OK;
+}
+int ksh_grid_install(void* hv, uint32_t row_lo, uint32_t row_hi, const uint64_t* rows, const void* rows_dev, int complete) {
+  Handle* h = (Handle*)hv; int rc = h->dev ? KS_OK : ksh_upload(hv, ks_current_device()); if (rc != KS_OK) return rc;
+  rc = ks_feasibility_grid_install(h->dev, row_lo, row_hi, rows, rows_dev, complete);
+  if (rc != KS_OK) return set_err(rc, ks_last_error());
+  return KS_OK;
+}
+
 // One-shot convenience: KSP1 text in, KSR1 text out.
 int ksh_solve_ksp(const char* ksp_text, size_t len, uint32_t flags, char** out_text) {
   void* h = nullptr; int rc = ksh_open(ksp_text, len, flags, &h); if (rc != KS_OK) return rc;

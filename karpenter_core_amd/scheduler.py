@@ -61,6 +61,8 @@ def libs():
         kh.ksh_solve.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
         kh.ksh_solve_batch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)]
         kh.ksh_grid.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        kh.ksh_grid_rows.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        kh.ksh_grid_install.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         kh.ksh_price_filter.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint32),
                                         ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
         kh.ksh_dims.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
@@ -219,6 +221,46 @@ class FlatProblem:
         if rc != KS_OK:
             raise KSolveError(rc, kh.ksh_last_error().decode())
         return arr, float(ms.value)
+
+
+    def grid_rows(self, lo: int, hi: int, dev_ptr: int = 0):
+        """ksh_grid_rows: rows [lo, hi) of the M * C grid rows computed on this handle's device; returns (numpy uint64 [hi - lo, TW], kernel ms).  dev_ptr: also
+        copied device to device to that address (a slice of an all-gather's buffer)."""
+        import numpy as np
+        kh = libs()[1]
+        tw = (self.dims["T"] + 63) // 64
+        arr = np.zeros((hi - lo, tw), dtype=np.uint64)
+        ms = ctypes.c_float()
+        rc = kh.ksh_grid_rows(self._h, ctypes.c_uint32(lo), ctypes.c_uint32(hi), ctypes.c_void_p(arr.ctypes.data if hi > lo else None), ctypes.c_void_p(dev_ptr or None), ctypes.byref(ms))
+        if rc != KS_OK:
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+        return arr, float(ms.value)
+
+    def grid_install(self, lo: int, hi: int, rows=None, dev_ptr: int = 0, complete: bool = False):
+        """ksh_grid_install: rows computed elsewhere put in place (numpy uint64 [hi - lo, TW] or a device address); complete: every row is in."""
+        import numpy as np
+        kh = libs()[1]
+        if rows is not None:
+            rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        rc = kh.ksh_grid_install(self._h, ctypes.c_uint32(lo), ctypes.c_uint32(hi), ctypes.c_void_p(rows.ctypes.data if rows is not None and hi > lo else None), ctypes.c_void_p(dev_ptr or None),
+                                 ctypes.c_int(1 if complete else 0))
+        if rc != KS_OK:
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+
+
+def sharded_grid(fp: "FlatProblem", rank: int, world: int, all_gather):
+    """the static feasibility grid of a Solve built by `world` GPUs -- rank r computes rows [r * MC / world, (r + 1) * MC / world) of the M * C grid rows on ITS
+    device from its copy of the (small) class and catalogue tables, ONE all-gather of the bit-rows (`all_gather(numpy rows of this rank) -> list of every rank's rows, in rank
+    order`: torch.distributed over RCCL / gloo in bench.py and the tests), every rank installs the others' rows.  Returns the kernel milliseconds of this rank's share."""
+    mc = fp.dims["M"] * fp.dims["C"]
+    cut = [mc * r // world for r in range(world + 1)]
+    rows, ms = fp.grid_rows(cut[rank], cut[rank + 1])
+    parts = all_gather(rows)
+    for r, part in enumerate(parts):
+        if r != rank:
+            fp.grid_install(cut[r], cut[r + 1], rows=part)
+    fp.grid_install(0, 0, complete=True)
+    return ms
 
 
 class ParsedProblem:

@@ -171,3 +171,79 @@ def test_whatifs_sharded_in_one_c_call():
     finally:
         for f in allf + [f for sh in shards for f in sh]:
             f.close()
+
+
+# ---- the static feasibility grid's rows split over the ranks, ONE all-gather of bit-rows (scheduler.sharded_grid, consolidation.all_gather_grid_rows) ----
+class _FakeGrid:
+    """Stands in for a FlatProblem on the CPU: row i of the grid is a function of i; what gets installed is recorded."""
+    def __init__(self, m, c, t):
+        import numpy as np
+        self.dims = {"M": m, "C": c, "T": t}; self.tw = (t + 63) // 64
+        self.table = np.zeros((m * c, self.tw), dtype=np.uint64); self.complete = False
+
+    @staticmethod
+    def row(i, tw):
+        import numpy as np
+        return (np.arange(tw, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(i * 2654435761 + 1)) | (np.uint64(1) << np.uint64(63))
+
+    def grid_rows(self, lo, hi, dev_ptr=0):
+        import numpy as np
+        rows = np.stack([self.row(i, self.tw) for i in range(lo, hi)]) if hi > lo else np.zeros((0, self.tw), dtype=np.uint64)
+        self.table[lo:hi] = rows
+        return rows, 0.0
+
+    def grid_install(self, lo, hi, rows=None, dev_ptr=0, complete=False):
+        if hi > lo:
+            self.table[lo:hi] = rows
+        self.complete = self.complete or complete
+
+
+def _grid_worker(rank, world, port, out):
+    from karpenter_core_amd import scheduler as S
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fp = _FakeGrid(3, 37, 200)      # 111 rows over 2 ranks: 55 + 56
+        S.sharded_grid(fp, rank, world, C.all_gather_grid_rows)
+        out[rank] = (fp.table.tolist(), fp.complete)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_grid_is_the_whole_grid():
+    import numpy as np
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_grid_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    want = np.stack([_FakeGrid.row(i, 4) for i in range(111)]).tolist()
+    assert out[0] == (want, True) and out[1] == (want, True)
+
+
+def _grid_gpu_worker(rank, world, port, out):
+    import hashlib, json
+    from karpenter_core_amd import scheduler as S
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = W.config2(pods=3000, sizes=10, seed=43)
+        fp = S.FlatProblem(p); fp.upload(0)
+        ms = S.sharded_grid(fp, rank, world, C.all_gather_grid_rows)      # this rank's share of the rows on the device, the others' installed from the ONE gather
+        res = fp.solve()                                                     # (the Solve does not build the grid again: every row is in)
+        out[rank] = (hashlib.sha256(json.dumps(res.canonical(), sort_keys=True).encode()).hexdigest(), ms >= 0.0)
+        fp.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_grid_on_one_gpu_solves_like_the_oracle():
+    """SURVEY 8e row 2, rehearsed on the 1-GPU box: two ranks share the device, each builds its half of the feasibility grid's rows there, ONE all-gather (gloo) of the bit-rows,
+    each installs the other's -- and the Solve over the gathered grid is the oracle's, on both ranks (a row left out or misplaced changes InstanceTypeOptions)."""
+    import hashlib, json
+    from oracle import oracle_py
+    p = W.config2(pods=3000, sizes=10, seed=43)
+    want = hashlib.sha256(json.dumps(oracle_py.solve(p).canonical(), sort_keys=True).encode()).hexdigest()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_grid_gpu_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] == (want, True) and out[1] == (want, True)
