@@ -225,7 +225,7 @@ def main():
     out = {
         "metric": "pod-placement decisions/sec (Solve())", "value": value, "unit": "decisions/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "scaling_note": "N=1: one Solve on one GPU (a single Solve is replicas-only, SURVEY 8e); the key is kept for the contract", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "scaling": "n/a", "scaling_note": "N=1: one Solve on one GPU (a single Solve is replicas-only, SURVEY 8e): nothing scales; the N>1 line (the what-if fan-out) says strong / weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]: {dims['P']} pods, {dims['T']} instance types, zonal+hostname topology spread and "
                                f"hostname pod anti-affinity (workloads.config3 seed 44)", "pods": dims["P"], "instance_types": dims["T"],
                    "pod_classes": dims["C"], "topology_groups": dims["G"], "new_nodes": len(res.new_nodes),
@@ -641,6 +641,32 @@ def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
             f.close()
     except Exception as e:      # (diagnostic object: the contract line must not die with it)
         weak = {"error": str(e)[:300]}
+    # ---- SURVEY 8e row 2 beside it: the static feasibility grid of ONE Solve (BASELINE configs[1]: 10 000 pods / 500 types) built by all ranks -- each its share of the rows on
+    # its GPU, ONE all-gather of the bit-rows, every rank installs the others' -- and the Solve over the gathered grid against the same Solve with the grid built on one GPU ----
+    grid_sh = None
+    try:
+        import hashlib
+        p2 = W.config2()
+        fg = S.FlatProblem(p2); fg.upload(local_rank)
+        gdev = "cuda" if on_device else "cpu"
+        t1 = time.perf_counter()
+        gms = S.sharded_grid(fg, rank, world, lambda rows: C.all_gather_grid_rows(rows, gdev))
+        torch.cuda.synchronize(); t_sh = (time.perf_counter() - t1) * 1e3
+        h_sh = int(hashlib.sha256(json.dumps(fg.solve().canonical(), sort_keys=True).encode()).hexdigest()[:15], 16)
+        fg.close()
+        one_g = S.FlatProblem(p2); one_g.upload(local_rank)
+        _, gms1 = one_g.grid(want_bits=False)
+        h_one = int(hashlib.sha256(json.dumps(one_g.solve().canonical(), sort_keys=True).encode()).hexdigest()[:15], 16)
+        one_g.close()
+        hv = torch.tensor([h_sh, h_one], device=red_dev, dtype=torch.int64)
+        hs = [torch.empty_like(hv) for _ in range(world)]
+        dist.all_gather(hs, hv)
+        grid_sh = {"what": "SURVEY 8e row 2: the feasibility grid's rows (template x class pairs) of one Solve split over the ranks, one all-gather of bit-rows (scheduler.sharded_grid)",
+                   "workload": "BASELINE configs[1]: 10000 pods / 500 instance types", "rows": fg.dims["M"] * fg.dims["C"], "row_words": (fg.dims["T"] + 63) // 64,
+                   "this_ranks_rows_kernel_ms": gms, "sharded_build_wall_ms": t_sh, "whole_grid_on_one_gpu_kernel_ms": gms1,
+                   "solve_equal_on_every_rank_and_to_the_single_gpu_grid": bool(all(int(x[0]) == h_one and int(x[1]) == h_one for x in hs))}
+    except Exception as e:      # (diagnostic object: the contract line must not die with it)
+        grid_sh = {"error": str(e)[:300]}
     dist.barrier()
     if rank != 0:
         return
@@ -659,7 +685,7 @@ def whatif_fanout(args, rank, world, local_rank, torch, dist, S, W):
            "vs_baseline": None, "dtype": "int64", "data": "synthetic",
            "config": {"workload": f"BASELINE configs[3]: {total_whatifs} consolidation what-ifs over 2048 existing nodes / {T} instance types, dealt to the ranks by predicted work (pods; longest first to the least loaded rank); "
                                   "one batched launch per rank + ONE RCCL all-gather of result records", "whatifs": total_whatifs, "decisions_per_step": total_pods,
-                      "records_gathered": got, "parallelism": f"{world} ranks x <= {per} what-ifs", "pods_per_rank": None, "single_gpu_same_workload": n1, "weak": weak,
+                      "records_gathered": got, "parallelism": f"{world} ranks x <= {per} what-ifs", "pods_per_rank": None, "single_gpu_same_workload": n1, "weak": weak, "grid_sharded": grid_sh,
                       "n1_reference": "the `whatif_batch` object of the --gpus 1 line (same workload on one GPU); a single Solve() does not shard (replicas only)"},
            "roofline": {"kernel": "ks_pack<single wave> x what-ifs of rank 0 in one launch", "bound": "hbm", "achieved": abytes / k_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": abytes / k_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": abytes, "kernel_ms_mean": k_s * 1e3,
