@@ -89,7 +89,7 @@ def test_rr_prepared_pods_and_the_census_are_exercised(emulated):
 # ---- round 5: ks_pack on the emulator too (tests/sim/build_sim.py -DKS_SIM_PACK): its single-wave variants -- what a what-if batch runs, LEAN and general -- and the hand-over
 # from ks_pack_rr after a decline.  (The multi-wave variants' speculation rounds are not emulated: ksolve.hip says why.  Of the small family's seeds 0..31, 30 agree with the
 # oracle on the emulator; 5 differs and 11 spins THERE -- on the GPU the single-wave run of both equals the oracle (tools/debug_one_wave_fuzz.py): a hand-off between lanes in
-# lockstep in the limits / bounds path that the fibre emulator does not model, not diagnosed.  KS_SIM_ALARM=<s> makes a spinning emulated kernel say where it stands.) ----
+# lockstep in the limits / bounds path that the fibre emulator does not model.  Round 6 narrowed seed 5 down: one node ends with its requests counted TWICE (same pods on it) -- an update every lane of a lockstep wave performs once and the emulator once per fibre that reaches it; the statement itself is not found yet.  KS_SIM_ALARM=<s> makes a spinning emulated kernel say where it stands.) ----
 CHILD_PACK = r"""
 import hashlib, json, os, sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
