@@ -69,6 +69,8 @@ typedef struct ksh_pod_block {
   const uint32_t* spec_words;
   const uint32_t* uid;          /* [n_pods] string ids */
   const int64_t* creation_ts;   /* [n_pods] */
+  uint64_t str_bytes_len;       /* bytes behind str_bytes, words behind spec_words: a block whose offsets reach beyond them is refused (round 6; ADVICE r05: without them */
+  uint64_t spec_words_len;      /* the library could only check that the offsets ascend) */
 } ksh_pod_block;
 int ksh_pods_ingest(const ksh_pod_block* blocks, uint32_t n_blocks, void** out_batch, double* ms /* ingest time or NULL */);
 /* ---- binary ingress for the ENVIRONMENT (round 5): instance types + offerings (cloudprovider/types.go:72-145), provisioners (machinetemplate.go:46-62), state nodes
@@ -80,6 +82,7 @@ typedef struct ksh_env_block {
   const uint32_t* str_off;      /* [n_strings + 1] byte offsets into str_bytes */
   const char* str_bytes;
   const uint32_t* words;        /* [n_words] */
+  uint64_t str_bytes_len;       /* bytes behind str_bytes: str_off[n_strings] must not reach beyond */
 } ksh_env_block;
 int ksh_env_ingest(const ksh_env_block* env, void** out_parsed, double* ms /* ingest time or NULL */);
 void ksh_pods_free(void* batch);

@@ -95,7 +95,8 @@ int ksh_env_ingest(const ksh_env_block* env, void** out, double* ms) {
   try {
     auto t0 = std::chrono::steady_clock::now();
     for (uint32_t i = 0; i < env->n_strings; ++i) if (env->str_off[i + 1] < env->str_off[i]) return set_err(KS_ERR_INVALID, "env block: string offsets not ascending");
-    ksh_pod_block strings{}; strings.n_strings = env->n_strings; strings.str_off = env->str_off; strings.str_bytes = env->str_bytes;
+    if (env->n_strings && env->str_off[env->n_strings] > env->str_bytes_len) return set_err(KS_ERR_INVALID, "env block: string offsets reach beyond str_bytes_len");
+    ksh_pod_block strings{}; strings.n_strings = env->n_strings; strings.str_off = env->str_off; strings.str_bytes = env->str_bytes; strings.str_bytes_len = env->str_bytes_len;
     auto p = std::make_unique<Parsed>();
     p->pr = std::make_shared<const ksp::Problem>(ksp::EnvReader(strings, env->words, env->words + env->n_words).read_env());
     if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

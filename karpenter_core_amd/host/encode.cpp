@@ -1287,6 +1287,9 @@ std::shared_ptr<const ksp::PodBatch> ingest_pod_blocks(const ksh_pod_block* bloc
     if (B.n_pods && (!B.spec_off || !B.spec_words || !B.uid || !B.creation_ts)) throw ksp::Error("pod block: null array");
     if (B.n_strings && (!B.str_off || !B.str_bytes)) throw ksp::Error("pod block: null string table");
     for (uint32_t i = 0; i < B.n_strings; ++i) if (B.str_off[i] > B.str_off[i + 1]) throw ksp::Error("pod block: string offsets must ascend");
+    if (B.n_strings && B.str_off[B.n_strings] > B.str_bytes_len) throw ksp::Error("pod block: string offsets reach beyond str_bytes_len");
+    for (uint32_t i = 0; i < B.n_pods; ++i) if (B.spec_off[i] > B.spec_off[i + 1]) throw ksp::Error("pod block: record offsets must ascend");
+    if (B.n_pods && B.spec_off[B.n_pods] > B.spec_words_len) throw ksp::Error("pod block: record offsets reach beyond spec_words_len");
     pod0[b + 1] = pod0[b] + B.n_pods;
   }
   const size_t P = pod0[nb];

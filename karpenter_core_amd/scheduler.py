@@ -283,7 +283,8 @@ class ParsedProblem:
     def from_env_block(cls, block: dict) -> "ParsedProblem":
         """The environment through the binary door (`ksh_env_ingest`; block from `model.env_to_block`): no KSP1 text on the way.  `ingest_ms`: the library's time."""
         kh = libs()[1]
-        eb = _EnvBlock(block["n_strings"], block["n_words"], block["str_off"].ctypes.data, block["str_bytes"].ctypes.data, block["words"].ctypes.data)
+        eb = _EnvBlock(block["n_strings"], block["n_words"], block["str_off"].ctypes.data, block["str_bytes"].ctypes.data, block["words"].ctypes.data,
+                       int(block.get("str_bytes_len", block["str_bytes"].size)))
         self = cls.__new__(cls)
         self._p = ctypes.c_void_p()
         ms = ctypes.c_double()
@@ -326,11 +327,12 @@ def solve_from_pods(parsed: ParsedProblem, device: int = 0, stats: bool = False,
 
 class _PodBlock(ctypes.Structure):      # include/kshost.h ksh_pod_block
     _fields_ = [("n_pods", ctypes.c_uint32), ("n_strings", ctypes.c_uint32), ("str_off", ctypes.c_void_p), ("str_bytes", ctypes.c_void_p),
-                ("spec_off", ctypes.c_void_p), ("spec_words", ctypes.c_void_p), ("uid", ctypes.c_void_p), ("creation_ts", ctypes.c_void_p)]
+                ("spec_off", ctypes.c_void_p), ("spec_words", ctypes.c_void_p), ("uid", ctypes.c_void_p), ("creation_ts", ctypes.c_void_p),
+                ("str_bytes_len", ctypes.c_uint64), ("spec_words_len", ctypes.c_uint64)]
 
 
 class _EnvBlock(ctypes.Structure):
-    _fields_ = [("n_strings", ctypes.c_uint32), ("n_words", ctypes.c_uint32), ("str_off", ctypes.c_void_p), ("str_bytes", ctypes.c_void_p), ("words", ctypes.c_void_p)]
+    _fields_ = [("n_strings", ctypes.c_uint32), ("n_words", ctypes.c_uint32), ("str_off", ctypes.c_void_p), ("str_bytes", ctypes.c_void_p), ("words", ctypes.c_void_p), ("str_bytes_len", ctypes.c_uint64)]
 
 
 class PodBatch:
@@ -342,7 +344,8 @@ class PodBatch:
         arr = (_PodBlock * max(1, len(blocks)))()
         for i, b in enumerate(blocks):
             arr[i] = _PodBlock(b["n_pods"], b["n_strings"], b["str_off"].ctypes.data, b["str_bytes"].ctypes.data, b["spec_off"].ctypes.data,
-                               b["spec_words"].ctypes.data, b["uid"].ctypes.data, b["creation_ts"].ctypes.data)
+                               b["spec_words"].ctypes.data, b["uid"].ctypes.data, b["creation_ts"].ctypes.data,
+                               int(b.get("str_bytes_len", b["str_bytes"].size)), int(b.get("spec_words_len", b["spec_words"].size)))
         self._b = ctypes.c_void_p()
         ms = ctypes.c_double()
         rc = kh.ksh_pods_ingest(ctypes.cast(arr, ctypes.c_void_p), len(blocks), ctypes.byref(self._b), ctypes.byref(ms))

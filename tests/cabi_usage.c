@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
   const uint32_t uid[1] = {2};
   const int64_t ts[1] = {0};
   ksh_pod_block blk; memset(&blk, 0, sizeof blk);
-  blk.n_pods = 1; blk.n_strings = 3; blk.str_off = str_off; blk.str_bytes = strs; blk.spec_off = spec_off; blk.spec_words = words; blk.uid = uid; blk.creation_ts = ts;
+  blk.n_pods = 1; blk.n_strings = 3; blk.str_off = str_off; blk.str_bytes = strs; blk.spec_off = spec_off; blk.spec_words = words; blk.uid = uid; blk.creation_ts = ts; blk.str_bytes_len = sizeof strs - 1; blk.spec_words_len = sizeof words / sizeof words[0];
   void* batch = NULL; double ingest_ms = 0;
   if (ksh_pods_ingest(&blk, 1, &batch, &ingest_ms) != KS_OK) { fprintf(stderr, "ingest: %s\n", ksh_last_error()); return 1; }
   uint32_t np = 0, ns = 0; ksh_pods_count(batch, &np, &ns);
@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     if (fread(so, 4, (size_t)hd[0] + 1, g) != (size_t)hd[0] + 1 || fread(wd, 4, hd[1], g) != hd[1]) return 2;
     char* sb = (char*)malloc((size_t)so[hd[0]] + 1); if (fread(sb, 1, so[hd[0]], g) != so[hd[0]]) return 2; fclose(g);
     ksh_env_block eb; memset(&eb, 0, sizeof eb);
-    eb.n_strings = hd[0]; eb.n_words = hd[1]; eb.str_off = so; eb.str_bytes = sb; eb.words = wd;
+    eb.n_strings = hd[0]; eb.n_words = hd[1]; eb.str_off = so; eb.str_bytes = sb; eb.words = wd; eb.str_bytes_len = so[hd[0]];
     void* env2 = NULL; double env_ms = 0; void* h2 = NULL;
     if (ksh_env_ingest(&eb, &env2, &env_ms) != KS_OK) { fprintf(stderr, "env ingest: %s\n", ksh_last_error()); return 1; }
     if (ksh_open_batch(env2, batch, 0, &h2) != KS_OK) { fprintf(stderr, "flatten over the binary environment: %s\n", ksh_last_error()); return 1; }

@@ -80,7 +80,7 @@ def test_the_environment_alone_is_a_valid_problem():
         kh.ksh_close(ha); kh.ksh_close(hb); a.close(); b.close()
 
 
-@pytest.mark.parametrize("damage", ["truncated", "string_id", "type_index", "count", "trailing", "offsets"])
+@pytest.mark.parametrize("damage", ["truncated", "string_id", "type_index", "count", "trailing", "offsets", "beyond_the_strings"])
 def test_malformed_environment_blocks_are_refused(damage):
     pr = fuzz_problem(3)
     blk = env_to_block(pr)
@@ -103,6 +103,8 @@ def test_malformed_environment_blocks_are_refused(damage):
         so = blk["str_off"].copy(); so[2] = so[1] - 1 if so[1] > 0 else 0xFFFFFFFF; blk["str_off"] = so
         if so[2] >= so[1]:
             pytest.skip("cannot build a descending offset here")
+    elif damage == "beyond_the_strings":                                      # ascending offsets whose last one lies behind the string bytes the block says it has (round 6: str_bytes_len)
+        blk["str_bytes_len"] = int(blk["str_off"][-1]) - 1
     with pytest.raises(S.KSolveError) as e:
         S.ParsedProblem.from_env_block(blk)
     assert e.value.code == S.KS_ERR_INVALID

@@ -103,6 +103,10 @@ def test_malformed_blocks_are_refused():
     w = blk["spec_words"].copy(); w[int(blk["spec_off"][0]) + 1] = 1 << 30                    # a count that runs past the record
     with pytest.raises(S.KSolveError):
         S.PodBatch([dict(blk, spec_words=w)])
+    with pytest.raises(S.KSolveError):                                                        # round 6: offsets that ascend but reach beyond the buffers the block says it has
+        S.PodBatch([dict(blk, str_bytes_len=int(blk["str_off"][-1]) - 1)])
+    with pytest.raises(S.KSolveError):
+        S.PodBatch([dict(blk, spec_words_len=int(blk["spec_off"][-1]) - 1)])
     req = [tuple(sorted(p.containers[0].requests.items())) for p in pr.pods]
     i, j = next((i, j) for i in range(50) for j in range(i + 1, 50) if req[i] == req[j])
     dup = dict(blk, uid=np.where(np.arange(50) == j, blk["uid"][i], blk["uid"]).astype(np.uint32))   # two pods that tie on cpu / memory / timestamp share a uid: the queue order is not total
