@@ -1,5 +1,5 @@
 """Fuzz campaign beyond the committed seeds (debug tool: imports the oracle): mid-scale problems of the three families of tests/test_fuzz_mid.py and
-the small family of tests/test_fuzz.py, GPU == oracle on each, in worker processes (the oracle and the generators are CPU work; the GPU solves are
+the small family of tests/test_fuzz.py, the ks_pack_rr-covered family of tests/test_fuzz_rr.py (round 6), GPU == oracle on each, in worker processes (the oracle and the generators are CPU work; the GPU solves are
 short).   python tools/debug_fuzz_campaign.py FIRST_SEED COUNT [PROCS]"""
 import os
 import sys
@@ -15,8 +15,9 @@ def one(job):
     from karpenter_core_amd import scheduler as S
     import test_fuzz_mid as M
     import test_fuzz as F
+    import test_fuzz_rr as R
     t0 = time.time()
-    pr = {"base": lambda: M.mid_problem(seed, "base"), "wide": lambda: M.mid_problem_wide(seed), "general": lambda: M.mid_problem_general(seed), "small": lambda: F.fuzz_problem(seed)}[fam]()
+    pr = {"base": lambda: M.mid_problem(seed, "base"), "wide": lambda: M.mid_problem_wide(seed), "general": lambda: M.mid_problem_general(seed), "small": lambda: F.fuzz_problem(seed), "rr": lambda: R.rr_problem(seed)}[fam]()
     try:
         want = O.solve(pr)
     except Exception as e:      # noqa: BLE001
@@ -39,7 +40,7 @@ def one(job):
 if __name__ == "__main__":
     import multiprocessing as mp
     first, count = int(sys.argv[1]), int(sys.argv[2]); procs = int(sys.argv[3]) if len(sys.argv) > 3 else 24
-    jobs = [(fam, first + i) for i in range(count) for fam in ("base", "wide", "general", "small")]
+    jobs = [(fam, first + i) for i in range(count) for fam in ("base", "wide", "general", "small", "rr")]
     t0 = time.time(); bad = []; n = {}; kerns = {}
     with mp.get_context("spawn").Pool(procs) as pool:
         for fam, seed, verdict, npods, dt, kern in pool.imap_unordered(one, jobs):
