@@ -171,6 +171,31 @@ int ksh_open_whatifs_parsed(void* parsed_snapshot, uint32_t flags, uint32_t n, c
  * in ksh_last_error(); KS_ERR_UNSUPPORTED for a snapshot ksh_open_whatifs_derived refuses. */
 int ksh_check_whatif_derivation(void* parsed_snapshot, uint32_t flags, const uint32_t* cand, uint32_t ncand, const int32_t* pod_node);
 
+/* ---- the snapshot kept current by EVENTS ("cached incremental SoA builder fed from state.Cluster") ----
+ * Replaces, for the snapshot consolidation simulates over, what the reference does between two passes of the deprovisioner (deprovisioning/controller.go:64,
+ * every 10 s): state.Cluster hears UpdateNode / DeleteNode / UpdatePod / DeletePod (pkg/controllers/state/cluster.go:151-200) and patches its nodes in place
+ * (state/node.go:161-182 updateForPod / cleanupForPod; Available() = Allocatable - the requests of the pods bound, node.go:113); the next pass then flattens
+ * everything again (helpers.go:42-99 -> provisioner.go:237-296).  Here the events patch the objects ksh_parse holds AND the snapshot's flattening follows them.
+ * `ksd_text`:  KSD1 <n>  { NODE+ <KSP1 NODE record without its keyword>  |  NODE- <node name>  |  BIND <node name> POD <KSP1 pod record>  |  UNBIND <pod uid> }*  END
+ *   NODE+   a state node joins (slot = the next node index; slots are never reused, candidate sets keep naming nodes by slot)
+ *   NODE-   a state node leaves; the pods bound to it are unbound with it
+ *   BIND    a pod is bound to a node: it joins the snapshot's pods (index = the next one), the node's available resources shrink by RequestsForPods(pod),
+ *           its host ports and volumes join the node's usage
+ *   UNBIND  the reverse
+ * The first call hands the snapshot's bindings over (`pod_node`, as the what-if calls take it); from then on the library holds them -- every call that takes a
+ * `pod_node` accepts NULL for "the library's", ksh_snapshot_bindings reads them.  info[0] = events applied (an event that cannot be applied ends the call with
+ * KS_ERR_INVALID; the ones before it stay), info[1] / info[2] = node / pod slots, info[3] = 1 when the snapshot's flattening was CONTINUED from the one before:
+ * pods already seen keep their specs, the catalogue's arrays, the universes and the old nodes' requirement rows are taken over (possible while the events bring no
+ * label key / value / resource name the universes lack; otherwise, and when no flattening existed yet, the next what-if call flattens from scratch -- same result
+ * either way, tests/test_env_apply.py compares the two byte for byte).  The objects are patched in place: do not call while another thread solves over this
+ * snapshot; handles opened before the call keep what they were opened with.  KS_ERR_INVALID "spare room ... used up": the snapshot was parsed with room for a
+ * quarter more nodes / pods (at least 256 / 4096); ingest it again. */
+int ksh_env_apply(void* parsed_snapshot, const int32_t* pod_node /* first call: the bindings; later NULL */, const char* ksd_text, size_t len, uint32_t info[4] /* or NULL */);
+int ksh_snapshot_bindings(void* parsed_snapshot, int32_t* out /* [cap] or NULL */, uint32_t cap, uint32_t* n_pods /* or NULL */, uint32_t* n_nodes /* or NULL */);
+/* Diagnostic (tests): FNV-1a over the snapshot's flattening -- the flat problem and the per-node tables behind the device derivation; `cold` != 0: of a
+ * flattening made from scratch for the comparison (nothing cached is touched). */
+int ksh_snapshot_fingerprint(void* parsed_snapshot, const int32_t* pod_node /* or NULL */, uint32_t flags, int cold, uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

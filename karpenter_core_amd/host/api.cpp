@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 
 #include "encode.hpp"
 
@@ -83,7 +84,12 @@ struct Parsed {
   std::shared_ptr<const ksp::Problem> pr;
   std::mutex mu; std::shared_ptr<const ksh::SnapshotBase> sb; std::vector<int32_t> sb_pod_node; uint32_t sb_flags = 0;
   ksh::EnvCache env;      // the flattening of everything but the pods, reused by the next batch with the same universe signature
+  // ksh_env_apply (round 6): once events were applied the library holds the bindings itself -- bind[i] = the node pod i is bound to, -1 for a pod that was unbound
+  // (it stays in place: nothing that points into the problem may move) -- and the names of what is alive
+  bool bind_set = false, had_cluster_pods = false; std::vector<int32_t> bind; std::unordered_map<std::string, uint32_t> live_node, live_pod; uint64_t tombstones = 0; uint32_t applied = 0;
 };
+// the bindings a what-if call means: the caller's array, or -- after ksh_env_apply -- the library's own
+static const int32_t* bindings_of(Parsed* P, const int32_t* pod_node) { return pod_node ? pod_node : (P->bind_set ? P->bind.data() : nullptr); }
 int ksh_parse(const char* ksp_text, size_t len, void** out) {
   *out = nullptr;
   try { auto p = std::make_unique<Parsed>(); p->pr = std::make_shared<const ksp::Problem>(ksp::Parser(ksp_text, len).parse()); *out = p.release(); return KS_OK; }
@@ -218,10 +224,11 @@ static int open_whatifs_over(std::shared_ptr<const ksp::Problem> snapshot, uint3
     std::shared_ptr<const ksh::SnapshotBase> sb;
     if (cache) {
       std::lock_guard<std::mutex> g(cache->mu);
+      pod_node = bindings_of(cache, pod_node); if (!pod_node && !snapshot->pods.empty()) return set_err(KS_ERR_INVALID, "no bindings (pod_node)");
       const size_t np = snapshot->pods.size();
       if (cache->sb && cache->sb_flags == flags && cache->sb_pod_node.size() == np && std::equal(pod_node, pod_node + np, cache->sb_pod_node.begin())) sb = cache->sb;
-      else { sb = ksh::make_snapshot_base(snapshot, pod_node, flags); cache->sb = sb; cache->sb_flags = flags; cache->sb_pod_node.assign(pod_node, pod_node + np); }
-    } else sb = ksh::make_snapshot_base(snapshot, pod_node, flags);
+      else { sb = ksh::make_snapshot_base(snapshot, pod_node, flags, cache->sb_flags == flags ? cache->sb.get() : nullptr); cache->sb = sb; cache->sb_flags = flags; cache->sb_pod_node.assign(pod_node, pod_node + np); }
+    } else { if (!pod_node && !snapshot->pods.empty()) return set_err(KS_ERR_INVALID, "no bindings (pod_node)"); sb = ksh::make_snapshot_base(snapshot, pod_node, flags); }
     if (timing) { auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "  what-ifs: snapshot base %8.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; }
     std::atomic<uint32_t> next{0}; std::atomic<int> rc{KS_OK}; std::vector<std::string> errs(n);
     auto work = [&]() {
@@ -294,6 +301,110 @@ static int resident_base(const ksh::Encoded* base, int device, std::shared_ptr<v
   return KS_OK;
 }
 extern "C" {
+// ---- the snapshot kept current by events instead of re-ingested (state.Cluster's UpdateNode / DeleteNode / UpdatePod / DeletePod, cluster.go) ----
+// The problem object is patched in place -- new nodes and pods are appended (the vectors were parsed with room: nothing moves), what leaves stays as a tombstone
+// (a node out of state, a pod bound nowhere) -- and the snapshot's flattening, if there is one, is continued from the one before (ksh::make_snapshot_base `before`).
+// Not to be called while another thread uses handles opened over this snapshot; handles opened BEFORE the call keep solving what they were opened for.
+int ksh_env_apply(void* parsed, const int32_t* pod_node, const char* ksd_text, size_t len, uint32_t info[4]) {
+  if (info) info[0] = info[1] = info[2] = info[3] = 0;
+  if (!parsed || !ksd_text) return set_err(KS_ERR_INVALID, "null argument");
+  Parsed* P = (Parsed*)parsed;
+  try {
+    std::vector<ksp::DeltaEvent> ev = ksp::Parser(ksd_text, len).parse_delta();
+    std::lock_guard<std::mutex> g(P->mu);
+    ksp::Problem& pr = const_cast<ksp::Problem&>(*P->pr);      // (the only writer; see above)
+    if (!P->bind_set) {
+      if (!pod_node && !pr.pods.empty()) return set_err(KS_ERR_INVALID, "the first ksh_env_apply needs the bindings (pod_node) of the snapshot's pods");
+      P->bind.assign(pod_node, pod_node + pr.pods.size());
+      for (size_t i = 0; i < pr.pods.size(); ++i) if (P->bind[i] >= (int32_t)pr.nodes.size()) return set_err(KS_ERR_INVALID, "pod_node out of range");
+      for (size_t i = 0; i < pr.nodes.size(); ++i) if (pr.nodes[i].in_state && !P->live_node.emplace(pr.nodes[i].name, (uint32_t)i).second) { P->live_node.clear(); return set_err(KS_ERR_INVALID, "two state nodes share a name"); }
+      for (size_t i = 0; i < pr.pods.size(); ++i) if (P->bind[i] >= 0 && !P->live_pod.emplace(pr.pods[i].uid, (uint32_t)i).second) { P->live_node.clear(); P->live_pod.clear(); return set_err(KS_ERR_INVALID, "two bound pods share a uid"); }
+      P->had_cluster_pods = !pr.cluster_pods.empty(); P->bind_set = true;
+    } else if (pod_node && !std::equal(pod_node, pod_node + pr.pods.size(), P->bind.begin())) return set_err(KS_ERR_INVALID, "the bindings passed differ from the ones the library holds since the last ksh_env_apply (pass NULL)");
+    auto unbind = [&](uint32_t i) {
+      ksp::Pod& p = pr.pods[i]; ksp::StateNode& n = pr.nodes[P->bind[i]];
+      const ksp::ResList req = ksh::RequestsForPod(p);      // state.Node.cleanupForPod (node.go:175-182): Available() = Allocatable - the requests of the pods still there
+      for (auto& kv : n.available) { auto r = req.find(kv.first); if (r != req.end()) kv.second += r->second; }
+      for (auto& c : p.containers) for (auto& hp : c.ports) if (hp.port != 0) for (size_t k = 0; k < n.host_ports.size(); ++k) if (n.host_ports[k].ip == hp.ip && n.host_ports[k].port == hp.port && n.host_ports[k].proto == hp.proto) { n.host_ports.erase(n.host_ports.begin() + k); break; }
+      for (auto& v : p.volumes) for (size_t k = 0; k < n.volumes.size(); ++k) if (n.volumes[k].driver == v.driver && n.volumes[k].pvc == v.pvc) { n.volumes.erase(n.volumes.begin() + k); break; }
+      if (P->had_cluster_pods) for (size_t k = 0; k < pr.cluster_pods.size(); ++k) if (pr.cluster_pods[k].uid == p.uid) { pr.cluster_pods.erase(pr.cluster_pods.begin() + k); break; }
+      P->live_pod.erase(p.uid); P->bind[i] = -1;
+      p.uid = std::string("\1unbound-") + std::to_string(++P->tombstones);      // (uids stay unique: the same pod may be bound again)
+    };
+    uint32_t done = 0; std::string why;
+    for (auto& e : ev) {
+      if (e.kind == ksp::DeltaEvent::NodeAdd) {
+        if (P->live_node.count(e.node.name)) { why = "NODE+: a state node named " + e.node.name + " exists"; break; }
+        if (pr.nodes.size() == pr.nodes.capacity()) { why = "NODE+: the snapshot's spare room for nodes is used up (ingest it again)"; break; }
+        e.node.in_state = true; P->live_node.emplace(e.node.name, (uint32_t)pr.nodes.size()); pr.nodes.push_back(std::move(e.node));
+      } else if (e.kind == ksp::DeltaEvent::NodeRemove) {
+        auto it = P->live_node.find(e.name); if (it == P->live_node.end()) { why = "NODE-: no state node named " + e.name; break; }
+        const uint32_t nd = it->second;
+        for (uint32_t i = 0; i < P->bind.size(); ++i) if (P->bind[i] == (int32_t)nd) unbind(i);      // (its pods go with it)
+        pr.nodes[nd].in_state = false; P->live_node.erase(it);
+        pr.nodes[nd].name = std::string("\1gone-") + std::to_string(++P->tombstones) + ":" + pr.nodes[nd].name;      // (the name may come back)
+      } else if (e.kind == ksp::DeltaEvent::PodBind) {
+        auto it = P->live_node.find(e.name); if (it == P->live_node.end()) { why = "BIND: no state node named " + e.name; break; }
+        if (P->live_pod.count(e.pod.uid)) { why = "BIND: pod " + e.pod.uid + " is bound already (UNBIND it first)"; break; }
+        if (pr.pods.size() == pr.pods.capacity()) { why = "BIND: the snapshot's spare room for pods is used up (ingest it again)"; break; }
+        ksp::StateNode& n = pr.nodes[it->second];
+        const ksp::ResList req = ksh::RequestsForPod(e.pod);      // state.Node.updateForPod (node.go:161-173)
+        for (auto& kv : n.available) { auto r = req.find(kv.first); if (r != req.end()) kv.second -= r->second; }
+        for (auto& c : e.pod.containers) for (auto& hp : c.ports) if (hp.port != 0) n.host_ports.push_back(hp);
+        for (auto& v : e.pod.volumes) n.volumes.push_back(v);
+        if (P->had_cluster_pods) { ksp::ClusterPod cp; cp.uid = e.pod.uid; cp.ns = e.pod.ns; cp.node_name = n.name; cp.labels = e.pod.labels; cp.anti_required = e.pod.anti_required; pr.cluster_pods.push_back(std::move(cp)); }
+        P->live_pod.emplace(e.pod.uid, (uint32_t)pr.pods.size()); pr.pods.push_back(std::move(e.pod)); P->bind.push_back((int32_t)it->second);
+      } else {
+        auto it = P->live_pod.find(e.name); if (it == P->live_pod.end()) { why = "UNBIND: no bound pod with uid " + e.name; break; }
+        unbind(it->second);
+      }
+      ++done;
+    }
+    P->applied += done; { std::lock_guard<std::mutex> ge(P->env.mu); P->env.base.reset(); }      // (a Solve over these objects flattens its environment again)
+    // the snapshot's flattening follows, continued from the one before when there is one
+    bool continued = false;
+    if (P->sb) {
+      std::shared_ptr<const ksh::SnapshotBase> before = P->sb;
+      try { P->sb = ksh::make_snapshot_base(P->pr, P->bind.data(), P->sb_flags, before.get()); P->sb_pod_node = P->bind; continued = ksh::snapshot_continued(*P->sb); }
+      catch (...) { P->sb.reset(); P->sb_pod_node.clear(); throw; }
+    }
+    if (info) { info[0] = done; info[1] = (uint32_t)pr.nodes.size(); info[2] = (uint32_t)pr.pods.size(); info[3] = continued ? 1u : 0u; }
+    if (done != ev.size()) return set_err(KS_ERR_INVALID, "event " + std::to_string(done) + ": " + why + " (the events before it were applied)");
+    return KS_OK;
+  } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());
+  } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
+}
+// the bindings the library holds after ksh_env_apply: out[0 .. n_pods) (cap entries at most); the sizes either way
+int ksh_snapshot_bindings(void* parsed, int32_t* out, uint32_t cap, uint32_t* n_pods, uint32_t* n_nodes) {
+  if (!parsed) return set_err(KS_ERR_INVALID, "null argument");
+  Parsed* P = (Parsed*)parsed; std::lock_guard<std::mutex> g(P->mu);
+  if (n_pods) *n_pods = (uint32_t)P->pr->pods.size();
+  if (n_nodes) *n_nodes = (uint32_t)P->pr->nodes.size();
+  if (out) { if (!P->bind_set) return set_err(KS_ERR_INVALID, "no ksh_env_apply yet: the caller holds the bindings"); std::copy_n(P->bind.begin(), std::min<size_t>(cap, P->bind.size()), out); }
+  return KS_OK;
+}
+// FNV-1a over the snapshot's flattening (the flat problem + the tables the device derivation reads); `cold` != 0: of a flattening made from scratch for the comparison
+// (tests: a continued flattening must equal it).  The snapshot must have been flattened (a what-if batch opened) or is flattened now.
+int ksh_snapshot_fingerprint(void* parsed, const int32_t* pod_node, uint32_t flags, int cold, uint64_t* out) {
+  if (!parsed || !out) return set_err(KS_ERR_INVALID, "null argument");
+  try {
+    Parsed* P = (Parsed*)parsed; std::lock_guard<std::mutex> g(P->mu);
+    const int32_t* pn = bindings_of(P, pod_node); if (!pn && !P->pr->pods.empty()) return set_err(KS_ERR_INVALID, "no bindings");
+    std::shared_ptr<const ksh::SnapshotBase> sb;
+    if (cold) sb = ksh::make_snapshot_base(P->pr, pn, flags);
+    else {
+      const size_t np = P->pr->pods.size();
+      if (!(P->sb && P->sb_flags == flags && P->sb_pod_node.size() == np && std::equal(pn, pn + np, P->sb_pod_node.begin()))) { P->sb = ksh::make_snapshot_base(P->pr, pn, flags); P->sb_flags = flags; P->sb_pod_node.assign(pn, pn + np); }
+      sb = P->sb;
+    }
+    const ksh::DeltaInputs in = ksh::delta_inputs(*sb);
+    uint64_t a; { Handle tmp; tmp.enc.reset(const_cast<ksh::Encoded*>(in.base.get())); a = ksh_fingerprint(&tmp); tmp.enc.release(); }
+    *out = a ^ (ksh::snapshot_fingerprint(*sb) * 0x9E3779B97F4A7C15ull);
+    return KS_OK;
+  } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());
+  } catch (const std::exception& e) { return set_err(KS_ERR_INVALID, e.what()); }
+}
+
 // What-ifs DERIVED on the device from the resident snapshot (include/ksolve.h ks_whatifs_open): no per-what-if flattening, an upload of KBs.
 // Same contract as ksh_open_whatifs_parsed, with the problems already resident on `device`; KS_ERR_UNSUPPORTED (nothing opened) when the
 // snapshot's what-ifs do not differ by their candidate sets alone -- the caller then uses ksh_open_whatifs_parsed.
@@ -305,9 +416,10 @@ int ksh_open_whatifs_derived(void* parsed, uint32_t flags, uint32_t n, const uin
     if (flags & KS_FLAG_STATS) return set_err(KS_ERR_UNSUPPORTED, "derived what-ifs carry no reference-algorithm statistics");
     std::shared_ptr<const ksh::SnapshotBase> sb;
     { std::lock_guard<std::mutex> g(P->mu);
+      pod_node = bindings_of(P, pod_node); if (!pod_node && !snapshot->pods.empty()) return set_err(KS_ERR_INVALID, "no bindings (pod_node)");
       const size_t np = snapshot->pods.size();
       if (P->sb && P->sb_flags == flags && P->sb_pod_node.size() == np && std::equal(pod_node, pod_node + np, P->sb_pod_node.begin())) sb = P->sb;
-      else { auto ts = std::chrono::steady_clock::now(); sb = ksh::make_snapshot_base(snapshot, pod_node, flags); P->sb = sb; P->sb_flags = flags; P->sb_pod_node.assign(pod_node, pod_node + np);
+      else { auto ts = std::chrono::steady_clock::now(); sb = ksh::make_snapshot_base(snapshot, pod_node, flags, P->sb_flags == flags ? P->sb.get() : nullptr); P->sb = sb; P->sb_flags = flags; P->sb_pod_node.assign(pod_node, pod_node + np);
              if (getenv("KSH_TIMING")) fprintf(stderr, "  derived what-ifs: %-28s %8.2f ms\n", "snapshot flattened (once)", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count()); } }
     const bool timing = getenv("KSH_TIMING") != nullptr; auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "  derived what-ifs: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; };
@@ -349,9 +461,10 @@ int ksh_check_whatif_derivation(void* parsed, uint32_t flags, const uint32_t* ca
     Parsed* P = (Parsed*)parsed; std::shared_ptr<const ksp::Problem> snapshot = P->pr;
     std::shared_ptr<const ksh::SnapshotBase> sb;
     { std::lock_guard<std::mutex> g(P->mu);
+      pod_node = bindings_of(P, pod_node); if (!pod_node && !snapshot->pods.empty()) return set_err(KS_ERR_INVALID, "no bindings (pod_node)");
       const size_t np = snapshot->pods.size();
       if (P->sb && P->sb_flags == flags && P->sb_pod_node.size() == np && std::equal(pod_node, pod_node + np, P->sb_pod_node.begin())) sb = P->sb;
-      else { sb = ksh::make_snapshot_base(snapshot, pod_node, flags); P->sb = sb; P->sb_flags = flags; P->sb_pod_node.assign(pod_node, pod_node + np); } }
+      else { sb = ksh::make_snapshot_base(snapshot, pod_node, flags, P->sb_flags == flags ? P->sb.get() : nullptr); P->sb = sb; P->sb_flags = flags; P->sb_pod_node.assign(pod_node, pod_node + np); } }
     const std::string why = ksh::check_derived_topology(*sb, cand, ncand, flags);
     return why.empty() ? KS_OK : set_err(why.rfind("not derivable", 0) == 0 ? KS_ERR_UNSUPPORTED : KS_ERR_INVALID, why);
   } catch (const ksh::Unsupported& e) { return set_err(KS_ERR_UNSUPPORTED, e.what());

@@ -310,6 +310,12 @@ struct Builder {
   std::vector<uint32_t> pod_rank;                     // base only: a pod's position in the snapshot-wide queue order
   std::vector<int> base_existing_of;                  // base only: node index -> row of the base's existing-node tables (-1: not owned)
   std::vector<ksp::ResList> base_remaining;           // base only: remainingResources with every node in state
+  // ---- a snapshot's flattening after ksh_env_apply (round 6): `prev` is the flattening of the SAME ksp::Problem object before the events -- pods and nodes were
+  // appended to it or left in place as tombstones, nothing moved.  Whatever of this run is a function of things that did not change is taken from it, provided the
+  // universes come out the same (`warm`); every shortcut reproduces what the full run would have written, byte for byte (tests/test_env_apply.py compares fingerprints).
+  const Builder* prev = nullptr; bool warm = false, keep_warm_state = false;
+  std::vector<Hash128> spec_hs; std::vector<int32_t> spec_tab; std::vector<uint32_t> spec_first;      // kept by dedupe_specs: the hash of every spec's first pod, the table over them, the first pods
+  std::string act_sig; std::map<std::string, int> act_key_id, act_res_id; size_t n_nodes_built = 0, n_pods_built = 0;      // kept by run(): what collect_active left, how large the problem was
 
   Builder(Encoded& e, uint32_t f) : E(e), pr(*e.src), flags(f), lite(e.batch.get()) {}
   std::chrono::steady_clock::time_point tl_ = std::chrono::steady_clock::now();
@@ -372,7 +378,28 @@ struct Builder {
     return s;
   }
   void collect_universes() { collect_active(); collect_passive(); }
+  // May this run continue `prev`?  After collect_active: the same problem object, what the batch / provisioners / daemonsets name unchanged (keys with their ids,
+  // named values, bounds, topology keys, resources), and nothing a new node carries is new to a universe.
+  bool can_continue() const {
+    if (!prev || &prev->pr != &pr || prev->flags != flags || prev->act_sig.empty() || prev->base || prev->lite) return false;
+    if (key_id != prev->act_key_id || res_id != prev->act_res_id || active_signature() != prev->act_sig) return false;
+    if (prev->n_nodes_built > pr.nodes.size() || prev->T != pr.instance_types.size()) return false;
+    for (size_t i = prev->n_nodes_built; i < pr.nodes.size(); ++i) {
+      const auto& n = pr.nodes[i];
+      for (auto& kv : n.labels) { const std::string k = ksp::normalize_key(kv.first);
+        auto it = prev->key_id.find(k); if (it != prev->key_id.end() && !prev->key_vals[it->second].count(kv.second)) return false;
+        auto raw = prev->key_id.find(kv.first); if (raw != prev->key_id.end() && raw->first != k && !prev->key_vals[raw->second].count(kv.second)) return false; }
+      for (const ksp::ResList* l : {&n.available, &n.capacity, &n.daemonset_requests}) for (auto& kv : *l) if (!prev->res_id.count(kv.first)) return false;
+    }
+    return true;
+  }
   void collect_passive() {
+    if (warm) {      // the catalogue's and the old nodes' contributions are in the previous universes, the new nodes add nothing (can_continue): adopt them and the tables made from them
+      const Encoded& B = prev->E;
+      key_vals = prev->key_vals; res_id = prev->res_id; K = prev->K; R = prev->R; T = prev->T; TW = prev->TW;
+      E.key_names = B.key_names; E.key_values = B.key_values; E.key_nvalues = B.key_nvalues; E.value_int = B.value_int; E.key_members = B.key_members; E.key_class = B.key_class; E.key_ints = B.key_ints; E.res_names = B.res_names;
+      return;
+    }
     // Instance types last: a label key that ONLY instance types carry (real catalogues have many, often with hundreds of
     // values -- the fake provider's `integer` has one per type) can never meet a node requirement: node requirements come from
     // provisioners, pods, topology keys and existing-node labels, and Intersects / Compatible only look at keys both sides
@@ -504,8 +531,15 @@ struct Builder {
   }
 
   // ---------- instance types ----------
-  std::vector<Requirements> it_requirements;
+  std::shared_ptr<std::vector<Requirements>> it_requirements_p = std::make_shared<std::vector<Requirements>>();      // (shared with the flattening that continues this one, `prev`)
   void encode_instance_types() {
+    if (warm) {      // same catalogue object, same universes: the arrays are the previous flattening's
+      const Encoded& B = prev->E;
+      E.it_present = B.it_present; E.it_complement = B.it_complement; E.it_mask = B.it_mask; E.it_offer = B.it_offer; E.it_alloc = B.it_alloc; E.it_cap = B.it_cap; E.it_price = B.it_price; E.it_price_lo = B.it_price_lo;
+      it_requirements_p = prev->it_requirements_p;
+      return;
+    }
+    std::vector<Requirements>& it_requirements = *it_requirements_p;
     E.it_present.assign(T, 0); E.it_complement.assign(T, 0); E.it_mask.assign((size_t)K * T, 0); E.it_offer.assign(T, 0);
     E.it_alloc.assign((size_t)R * T, 0); E.it_cap.assign((size_t)R * T, 0);
     const int kz = key_id.at(ksp::kZone), kc = key_id.at(ksp::kCapacityType);
@@ -543,7 +577,8 @@ struct Builder {
     for (auto& p : pr.provisioners) E.templates.push_back(&p);
     std::stable_sort(E.templates.begin(), E.templates.end(), [](const ksp::Provisioner* a, const ksp::Provisioner* b) { return a->weight > b->weight; });   // OrderByWeight
     if (E.templates.empty()) throw ksp::Error("no provisioners found");
-    const uint32_t M = (uint32_t)E.templates.size();
+    const uint32_t M = (uint32_t)E.templates.size(); const std::vector<Requirements>& it_requirements = *it_requirements_p;
+    if (warm) domains = prev->domains;      // (only this function writes it, from the provisioners and the catalogue)
     E.tmpl_types.assign((size_t)M * TW, 0);
     for (uint32_t m = 0; m < M; ++m) {
       const auto& p = *E.templates[m];
@@ -556,7 +591,7 @@ struct Builder {
       // topology domain universe, provisioner.go:267-276
       // (a catalogue repeats a handful of zones / architectures / ... thousands of times: values already seen for a key are recognised by a
       // hashed view of the set's own strings before the ordered set is asked)
-      { struct Seen { const std::string* key; std::set<std::string>* dom; std::unordered_set<std::string_view> vals; };
+      if (!warm) { struct Seen { const std::string* key; std::set<std::string>* dom; std::unordered_set<std::string_view> vals; };
         std::vector<Seen> seen;
         for (int idx : p.instance_types) for (auto& kv : it_requirements[idx].m) {
           Seen* sn = nullptr; for (auto& c : seen) if (*c.key == kv.first) { sn = &c; break; }
@@ -564,7 +599,7 @@ struct Builder {
           for (auto& v : kv.second.values) if (!sn->vals.count(std::string_view(v))) { auto ins = sn->dom->insert(v); sn->vals.insert(std::string_view(*ins.first)); }
         } }
       Requirements preq = Requirements::FromExprs(p.requirements);
-      for (auto& kv : preq.m) if (kv.second.Operator() == Op::In) for (auto& v : kv.second.values) domains[kv.first].insert(v);
+      if (!warm) for (auto& kv : preq.m) if (kv.second.Operator() == Op::In) for (auto& v : kv.second.values) domains[kv.first].insert(v);
     }
   }
 
@@ -651,7 +686,7 @@ struct Builder {
   void encode_existing() {
     if (base) {      // the name / hostname indices are the snapshot's; only the row numbering depends on which nodes left
       existing_row.assign(pr.nodes.size(), -1);
-      for (size_t i = 0; i < pr.nodes.size(); ++i) if (!(*removed)[i] && base->node_owned[i]) { existing_row[i] = (int)E.existing.size(); E.existing.push_back((int)i); }
+      for (size_t i = 0; i < pr.nodes.size(); ++i) if (!(*removed)[i] && base->base_existing_of[i] >= 0) { existing_row[i] = (int)E.existing.size(); E.existing.push_back((int)i); }      // (a row of the base: owned AND in state -- a node ksh_env_apply took out of state stays in the list)
       E.en_port_off.assign(1, 0);
       for (int i : E.existing) { for (auto& hp : pr.nodes[i].host_ports) E.ports.push_back(port_entry(hp.ip, hp.port, hp.proto)); E.en_port_off.push_back((uint32_t)E.ports.size()); }
       return;
@@ -684,7 +719,7 @@ struct Builder {
       std::copy_n(&B.en_avail[(size_t)b * R], R, &E.en_avail[(size_t)e * R]); std::copy_n(&B.en_requests[(size_t)b * R], R, &E.en_requests[(size_t)e * R]);
     }
     std::vector<ksp::ResList> remaining = base->base_remaining;
-    if (!env_mode) for (size_t i = 0; i < pr.nodes.size(); ++i) if ((*removed)[i] && base->node_owned[i]) {      // (env mode: the same nodes are in state as in the cached flattening)
+    if (!env_mode) for (size_t i = 0; i < pr.nodes.size(); ++i) if ((*removed)[i] && base->base_existing_of[i] >= 0) {      // (env mode: the same nodes are in state as in the cached flattening)
       auto pl = pr.nodes[i].labels.find(ksp::kProvisionerName);
       for (uint32_t m = 0; m < M; ++m) if (E.templates[m]->has_limits && E.templates[m]->name == pl->second) for (auto& kv : remaining[m]) { auto c = pr.nodes[i].capacity.find(kv.first); if (c != pr.nodes[i].capacity.end()) kv.second += c->second; }
     }
@@ -709,6 +744,25 @@ struct Builder {
     for (uint32_t m = 0; m < M; ++m) if (E.templates[m]->has_limits) remaining[m] = E.templates[m]->limits;
     for (uint32_t e = 0; e < NE; ++e) {
       const auto& n = pr.nodes[E.existing[e]];
+      const int pb = (warm && pr.daemons.empty() && (size_t)E.existing[e] < prev->base_existing_of.size()) ? prev->base_existing_of[E.existing[e]] : -1;
+      if (pb >= 0) {
+        // The node was a row of the previous flattening and its labels are what they were: the row's requirement words are copied; what numbers things in order of
+        // first use (the instance-type state, taints) or changes with the pods bound to the node (available) is worked out as always.
+        const ReqSetsStore& B = prev->E.en; ReqSetsStore& st = E.en; const uint32_t idx = st.n++;
+        st.present.push_back(B.present[pb]); st.complement.push_back(B.complement[pb]);
+        st.mask.insert(st.mask.end(), B.mask.begin() + (size_t)pb * K, B.mask.begin() + (size_t)(pb + 1) * K); st.gt.insert(st.gt.end(), B.gt.begin() + (size_t)pb * K, B.gt.begin() + (size_t)(pb + 1) * K);
+        st.lt.insert(st.lt.end(), B.lt.begin() + (size_t)pb * K, B.lt.begin() + (size_t)(pb + 1) * K); st.it_state.push_back(0);
+        { StrMap one; for (auto& kv : n.labels) if (ksp::normalize_key(kv.first) == ksp::kInstanceType) one.emplace(kv.first, kv.second);
+          if (!one.empty()) { const Requirements r1 = Requirements::FromLabels(one); auto f = r1.m.find(ksp::kInstanceType); if (f != r1.m.end()) st.it_state[idx] = it_state_of(f->second); } }
+        E.en_taints.push_back(taint_mask(n.taints) | (over_volume_limit(n) ? blocked_mask() : 0ull));
+        res_vec(n.available, E.en_avail, nullptr);
+        ksp::ResList dr; dr["pods"] = 0;
+        ksp::ResList rem = Subtract(dr, n.daemonset_requests); for (auto& kv : rem) if (kv.second < 0) kv.second = 0;
+        uint32_t pm; res_vec(rem, E.en_requests, &pm); E.en_requests_present.push_back(pm);
+        auto pl = n.labels.find(ksp::kProvisionerName);
+        for (uint32_t m = 0; m < M; ++m) if (E.templates[m]->has_limits && E.templates[m]->name == pl->second) remaining[m] = Subtract(remaining[m], n.capacity);
+        continue;
+      }
       Requirements full = Requirements::FromLabels(n.labels);
       Requirements hostless; for (auto& kv : full.m) if (kv.first != ksp::kHostname) hostless.m.emplace(kv.first, kv.second);
       push_reqs(E.en, restrict_to_known_keys(hostless), nullptr, false, false);
@@ -845,6 +899,32 @@ struct Builder {
       sublap("specs from the snapshot");
       return;
     }
+    if (prev && !pods_have_volumes && !prev->pods_have_volumes && !prev->spec_tab.empty() && prev->n_pods_built <= P && pr.cluster_pods.empty() == prev->batch_uids.tab.empty()) {
+      // The pods the previous flattening saw keep their specs (first occurrences in pod order: appending pods cannot renumber them); only the new ones are hashed,
+      // looked up among the specs' first pods and confirmed field by field.
+      const uint32_t P0 = (uint32_t)prev->n_pods_built;
+      pod_spec.assign(prev->pod_spec.begin(), prev->pod_spec.begin() + P0); pod_spec.resize(P, -1);
+      spec_first = prev->spec_first; spec_hs = prev->spec_hs; spec_tab = prev->spec_tab;
+      uint64_t cap = spec_tab.size();
+      if (cap < 4ull * P) {      // (the table's size is a function of P: a fresh run would have sized it so; its content is rebuilt in spec order)
+        while (cap < 4ull * P) cap <<= 1;
+        spec_tab.assign(cap, -1);
+        for (size_t s2 = 0; s2 < spec_first.size(); ++s2) { uint64_t j = spec_hs[s2].a & (cap - 1); while (spec_tab[j] >= 0) j = (j + 1) & (cap - 1); spec_tab[j] = (int32_t)s2; }
+      }
+      for (uint32_t i = P0; i < P; ++i) {
+        const Hash128 h = spec_hash(*podp[i]);
+        uint64_t j = h.a & (cap - 1); int found = -1;
+        for (;; j = (j + 1) & (cap - 1)) { const int32_t sidx = spec_tab[j]; if (sidx < 0) break; const Hash128& o = spec_hs[sidx]; if (o.a == h.a && o.b == h.b) { found = sidx; break; } }
+        if (found >= 0 && !same_pod(*podp[spec_first[found]], *podp[i])) { found = -1; for (size_t s2 = 0; s2 < spec_first.size() && found < 0; ++s2) if (same_pod(*podp[spec_first[s2]], *podp[i])) found = (int)s2; if (found < 0) { found = (int)spec_first.size(); spec_first.push_back(i); spec_hs.push_back(h); } }      // (a collision: the full run's own way out)
+        else if (found < 0) { found = (int)spec_first.size(); spec_tab[j] = found; spec_first.push_back(i); spec_hs.push_back(h); }
+        pod_spec[i] = found;
+      }
+      if (!pr.cluster_pods.empty()) build_uid_table(P, true);
+      const std::vector<uint32_t>& first = spec_first;
+      sublap("specs from the flattening before"); specs.resize(first.size());
+      parallel_chunks(first.size(), [&](size_t b, size_t e, uint32_t) { for (size_t s2 = b; s2 < e; ++s2) { StageInfo st; st.spec = *podp[first[s2]]; st.spec.uid.clear(); specs[s2].stages.push_back(std::move(st)); } }, 128);
+      return;
+    }
     std::vector<Hash128> hs(P);
     parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) {
       if (pods_have_volumes) { const std::vector<uint32_t> ve = vol_entries(*podp[i]); hs[i] = spec_hash(*podp[i], &ve); } else hs[i] = spec_hash(*podp[i]);
@@ -872,6 +952,10 @@ struct Builder {
       pod_spec[i] = found;
     }
     sublap("confirm"); specs.resize(first.size());
+    if (keep_warm_state) {      // (what the next flattening of this snapshot starts from; a spec found by the collision path has no slot in the table -- such a run is not continued)
+      bool clean = true; for (uint32_t i = 0; i < P && clean; ++i) if (bad[i]) clean = false;
+      if (clean) { spec_first = first; spec_tab = tab; spec_hs.resize(first.size()); for (size_t s2 = 0; s2 < first.size(); ++s2) spec_hs[s2] = hs[first[s2]]; }
+    }
     parallel_chunks(first.size(), [&](size_t b, size_t e, uint32_t) { for (size_t s2 = b; s2 < e; ++s2) { StageInfo st; st.spec = *podp[first[s2]]; st.spec.uid.clear(); specs[s2].stages.push_back(std::move(st)); } }, 128);      // (a spec is a deep copy of a pod: strings, vectors)
   }
 
@@ -1108,7 +1192,7 @@ struct Builder {
       E.shared_lattice = true; E.prob.S = base->E.prob.S; E.prob.SC = base->E.prob.SC;
       return;
     }
-    const std::vector<Requirements>& it_requirements = base ? base->it_requirements : this->it_requirements;
+    const std::vector<Requirements>& it_requirements = base ? *base->it_requirements_p : *this->it_requirements_p;
     // Node states are closed under intersection with every pod-side requirement (a node only ever narrows its
     // instance-type requirement by a class's, node.go:79 / existingnode.go:102); it_state_of appends while we iterate.
     if (it_reqs.empty()) it_reqs.push_back(Requirement());   // state 0 placeholder ("absent")
@@ -1192,7 +1276,9 @@ struct Builder {
     }
     if (!specs_done) { dedupe_specs(); lap("dedupe_specs"); }
     if (!active_done) collect_active();
-    collect_passive(); lap("collect_universes");
+    if (keep_warm_state) { act_sig = active_signature(); act_key_id = key_id; act_res_id = res_id; n_nodes_built = pr.nodes.size(); n_pods_built = podp.size(); }
+    warm = can_continue();
+    collect_passive(); lap(warm ? "universes (continued)" : "collect_universes");
     encode_instance_types(); lap("encode_instance_types");
     it_reqs.push_back(Requirement()); it_cols.push_back(Requirement());   // state / column 0 == key absent
     encode_templates(); lap("encode_templates");
@@ -1367,6 +1453,7 @@ std::shared_ptr<const ksp::PodBatch> ingest_pod_blocks(const ksh_pod_block* bloc
 }
 
 struct SnapshotBase {
+  bool continued = false;      // the flattening continued the one before (ksh_env_apply) instead of starting over
   std::shared_ptr<const ksp::Problem> snapshot; std::shared_ptr<Encoded> enc; std::unique_ptr<Builder> builder;
   std::vector<std::vector<uint32_t>> by_node;      // pods bound to each node, in pod order
   std::vector<int32_t> node_row, node_tmpl; std::vector<int64_t> node_cap; bool delta_ok = false; std::string delta_why;      // (delta_inputs)
@@ -1396,6 +1483,7 @@ static std::string build_topo_tables(SnapshotBase& sb, const int32_t* pod_node) 
   sb.t_extra_tot.assign(GH, 0); sb.t_grph_base.assign((size_t)GH * NE, 0);
   for (size_t i = 0; i < pr.pods.size(); ++i) {
     const auto& sg = b.specs[b.pod_spec[i]].stages[0].sg;      // (required anti-affinity terms survive every relaxation: the first stage owns what all stages own)
+    if (pod_node[i] < 0) continue;      // (bound nowhere any more)
     for (const auto* l : {&sg.own, &sg.iown}) for (int g : *l) { const uint32_t gi = (uint32_t)b.group_remap[g]; sb.t_node_own[(size_t)pod_node[i] * GW + (gi >> 6)] |= 1ull << (gi & 63u); }
   }
   // does group g count pods on node n at all (key present, node filter), and under which domain
@@ -1454,17 +1542,21 @@ static std::string build_topo_tables(SnapshotBase& sb, const int32_t* pod_node) 
   sb.topo.extra_tot = sb.t_extra_tot.data(); sb.topo.grph_base = sb.t_grph_base.data(); sb.has_topo = true;
   return "";
 }
-std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp::Problem> snapshot, const int32_t* pod_node, uint32_t flags) {
+std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp::Problem> snapshot, const int32_t* pod_node, uint32_t flags, const SnapshotBase* before) {
   auto sb = std::make_shared<SnapshotBase>(); sb->snapshot = snapshot;
   sb->by_node.resize(snapshot->nodes.size());
-  for (size_t i = 0; i < snapshot->pods.size(); ++i) { if (pod_node[i] < 0 || (size_t)pod_node[i] >= snapshot->nodes.size()) throw ksp::Error("pod_node out of range"); sb->by_node[pod_node[i]].push_back((uint32_t)i); }
+  // pod_node[i] = -1: a pod that is bound nowhere any more (ksh_env_apply keeps it in place: nothing that points into the problem moves); it is in no what-if's batch
+  for (size_t i = 0; i < snapshot->pods.size(); ++i) { if (pod_node[i] < 0) continue; if ((size_t)pod_node[i] >= snapshot->nodes.size()) throw ksp::Error("pod_node out of range"); sb->by_node[pod_node[i]].push_back((uint32_t)i); }
   sb->enc = std::make_shared<Encoded>(); sb->enc->src = snapshot;
-  sb->builder = std::make_unique<Builder>(*sb->enc, flags); sb->builder->run();
+  sb->builder = std::make_unique<Builder>(*sb->enc, flags); sb->builder->keep_warm_state = true;
+  if (before && before->snapshot.get() == snapshot.get() && !getenv("KSH_NO_WARM_SNAPSHOT")) sb->builder->prev = before->builder.get();
+  sb->builder->run(); sb->continued = sb->builder->warm;
+  sb->builder->prev = nullptr;      // (this flattening now stands alone: `before` may go)
   {   // what deriving what-ifs on the device needs (delta_inputs)
     const Builder& b = *sb->builder; const Encoded& E = *sb->enc; const uint32_t R = b.R, M = (uint32_t)E.templates.size(); const size_t NN = snapshot->nodes.size();
     sb->node_row.assign(b.base_existing_of.begin(), b.base_existing_of.end()); sb->node_row.resize(NN, -1);
     sb->node_tmpl.assign(NN, -1); sb->node_cap.assign(NN * R, 0);
-    for (size_t i = 0; i < NN; ++i) if (b.node_owned[i]) {
+    for (size_t i = 0; i < NN; ++i) if (b.base_existing_of[i] >= 0) {
       auto pl = snapshot->nodes[i].labels.find(ksp::kProvisionerName);
       for (uint32_t m = 0; m < M; ++m) if (E.templates[m]->has_limits && E.templates[m]->name == pl->second) {
         sb->node_tmpl[i] = (int32_t)m;
@@ -1476,6 +1568,16 @@ std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp
     if (sb->delta_ok && !b.groups.empty()) { const std::string why = build_topo_tables(*sb, pod_node); if (!why.empty()) { sb->delta_ok = false; sb->delta_why = why; } }
   }
   return sb;
+}
+bool snapshot_continued(const SnapshotBase& sb) { return sb.continued; }
+uint64_t snapshot_fingerprint(const SnapshotBase& sb) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void* p, size_t bytes) { const unsigned char* c = (const unsigned char*)p; for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; } };
+  auto vec = [&](const auto& v) { uint64_t n = v.size(); mix(&n, 8); if (n) mix(v.data(), n * sizeof(v[0])); };
+  vec(sb.node_row); vec(sb.node_tmpl); vec(sb.node_cap); vec(sb.builder->pod_rank); vec(sb.builder->pod_spec); for (auto& l : sb.by_node) vec(l);
+  const uint8_t ok = sb.delta_ok, topo = sb.has_topo; mix(&ok, 1); mix(&topo, 1); mix(sb.delta_why.data(), sb.delta_why.size());
+  vec(sb.t_node_cnt); vec(sb.t_node_dom); vec(sb.t_tot); vec(sb.t_extra_tot); vec(sb.t_grph_base); vec(sb.t_node_own);
+  return h;
 }
 DeltaInputs delta_inputs(const SnapshotBase& sb) {
   DeltaInputs d; d.base = sb.enc; d.n_nodes = (uint32_t)sb.snapshot->nodes.size(); d.node_row = sb.node_row.data(); d.by_node = &sb.by_node; d.pod_rank = sb.builder->pod_rank.data();

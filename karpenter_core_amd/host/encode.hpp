@@ -100,7 +100,11 @@ uint32_t host_threads();
 // in the batch -- is flattened once; a what-if (its candidate nodes leave the state nodes, their pods become the pending batch) then only redoes
 // what depends on the candidate set: the pod classes / queue / topology groups of ITS pods and remainingResources.  Thread-safe after construction.
 struct SnapshotBase;
-std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp::Problem> snapshot, const int32_t* pod_node, uint32_t flags);
+// `before`: the flattening of the SAME problem object before ksh_env_apply appended nodes / pods to it (nothing else may have changed but the pods' nodes and the
+// nodes' available resources / in_state): what does not depend on the events is taken from it when the universes come out the same.  pod_node[i] = -1: bound nowhere.
+std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp::Problem> snapshot, const int32_t* pod_node, uint32_t flags, const SnapshotBase* before = nullptr);
+bool snapshot_continued(const SnapshotBase& sb);      // did the flattening take the short road
+uint64_t snapshot_fingerprint(const SnapshotBase& sb);      // FNV-1a over the flat problem and the per-node tables behind the device derivation (tests: short road == full run)
 std::unique_ptr<Encoded> encode_whatif(const SnapshotBase& sb, const uint32_t* cand, uint32_t ncand, uint32_t flags);
 // What deriving what-ifs on the device (include/ksolve.h ks_whatifs_open) needs of a snapshot's flattening.  `eligible`: its what-ifs differ in
 // nothing but the pod subset, the removed nodes, remainingResources and -- derived on the device from per-node tables -- which topology groups exist from

@@ -10,6 +10,7 @@
 // scheduling tests use "1.8G", "100M", "10Mi", "1.1": suite_test.go:1084,1125).  Sub-milli
 // precision is rejected loudly instead of being rounded.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -117,6 +118,9 @@ struct StateNode {
 };
 struct ClusterPod { std::string uid, ns, node_name; StrMap labels; std::vector<AffinityTerm> anti_required; };
 
+// One event of a cluster's life between two snapshots (ksh_env_apply; state.Cluster's UpdateNode / DeleteNode / UpdatePod / DeletePod, cluster.go)
+struct DeltaEvent { enum Kind { NodeAdd, NodeRemove, PodBind, PodUnbind } kind = NodeAdd; StateNode node; Pod pod; std::string name; };
+
 struct Problem {
   std::vector<std::string> extra_well_known;
   std::vector<InstanceType> instance_types;
@@ -179,6 +183,27 @@ class Parser {
  public:
   Parser(const char* text, size_t len) : p_(text), e_(text + len) {}
 
+  // What state.Cluster hears between two passes over the cluster (cluster.go UpdateNode / DeleteNode / UpdatePod / DeletePod), as KSD1 text:
+  //   KSD1 <n events>  { NODE+ <NODE record> | NODE- <node name> | BIND <node name> POD <pod record> | UNBIND <pod uid> }*  END
+  // The records are KSP1's own (the NODE record without its leading keyword, the POD record with it).
+  std::vector<DeltaEvent> parse_delta() {
+    std::vector<DeltaEvent> ev;
+    expect("KSD1");
+    for (int n = count(); n > 0; --n) {
+      DeltaEvent e; const std::string k = tok();
+      if (k == "NODE+") { e.kind = DeltaEvent::NodeAdd; e.node = node(); }
+      else if (k == "NODE-") { e.kind = DeltaEvent::NodeRemove; e.name = str(); }
+      else if (k == "BIND") { e.kind = DeltaEvent::PodBind; e.name = str(); expect("POD"); e.pod = pod(); }
+      else if (k == "UNBIND") { e.kind = DeltaEvent::PodUnbind; e.name = str(); }
+      else throw Error("KSD1: expected NODE+|NODE-|BIND|UNBIND got " + k);
+      ev.push_back(std::move(e));
+    }
+    expect("END");
+    return ev;
+  }
+  // (a snapshot is patched in place by ksh_env_apply: the vectors it appends to keep room, so that nothing that points into them moves)
+  static size_t spare(size_t n, size_t least) { return n + std::max(least, n / 4); }
+
   Problem parse() {
     Problem pr;
     expect("KSP1");
@@ -210,17 +235,8 @@ class Parser {
       pr.provisioners.push_back(std::move(pv));
     }
     expect("NODES");
-    for (int nn = count(); nn > 0; --nn) {
-      expect("NODE");
-      StateNode sn; sn.name = str(); sn.in_state = count() != 0;
-      sn.labels = strmap();
-      for (int n = count(); n > 0; --n) sn.taints.push_back(taint());
-      sn.available = reslist(); sn.capacity = reslist(); sn.daemonset_requests = reslist();
-      for (int n = count(); n > 0; --n) sn.host_ports.push_back(hostport());
-      if (next_is("VL")) { expect("VL"); for (int n = count(); n > 0; --n) { std::string d = str(); sn.volume_limits.emplace_back(d, (int32_t)integer()); } }
-      if (next_is("VU")) { expect("VU"); for (int n = count(); n > 0; --n) { Volume v; v.driver = str(); v.pvc = str(); sn.volumes.push_back(std::move(v)); } }
-      pr.nodes.push_back(std::move(sn));
-    }
+    { const int nn = count(); pr.nodes.reserve(spare(nn, 256));
+      for (int i = 0; i < nn; ++i) { expect("NODE"); pr.nodes.push_back(node()); } }
     expect("CPODS");
     for (int nc = count(); nc > 0; --nc) {
       expect("CPOD");
@@ -232,7 +248,7 @@ class Parser {
     for (int nd = count(); nd > 0; --nd) { expect("POD"); pr.daemons.push_back(pod()); }
     expect("SIM"); pr.simulation_mode = count() != 0;
     expect("PODS");
-    int npods = count(); pr.pods.reserve(npods);
+    int npods = count(); pr.pods.reserve(spare(npods, 4096));
     for (int i = 0; i < npods; ++i) { expect("POD"); pr.pods.push_back(pod()); }
     expect("END");
     return pr;
@@ -280,6 +296,16 @@ class Parser {
     AffinityTerm t; t.topology_key = str();
     for (int n = count(); n > 0; --n) t.namespaces.push_back(str());
     t.selector = selector(); return t;
+  }
+  StateNode node() {
+    StateNode sn; sn.name = str(); sn.in_state = count() != 0;
+    sn.labels = strmap();
+    for (int n = count(); n > 0; --n) sn.taints.push_back(taint());
+    sn.available = reslist(); sn.capacity = reslist(); sn.daemonset_requests = reslist();
+    for (int n = count(); n > 0; --n) sn.host_ports.push_back(hostport());
+    if (next_is("VL")) { expect("VL"); for (int n = count(); n > 0; --n) { std::string d = str(); sn.volume_limits.emplace_back(d, (int32_t)integer()); } }
+    if (next_is("VU")) { expect("VU"); for (int n = count(); n > 0; --n) { Volume v; v.driver = str(); v.pvc = str(); sn.volumes.push_back(std::move(v)); } }
+    return sn;
   }
   Pod pod() {
     Pod p; p.uid = str(); p.ns = str(); p.creation_ts = integer();

@@ -627,6 +627,52 @@ def state_node_taints(node_taints: Sequence["Taint"], startup_taints: Sequence["
     return [t for t in node_taints if not any(e.key == t.key and e.value == t.value and e.effect == t.effect for e in ephemeral)]
 
 
+def _ksp_node(n: "StateNode", w):
+    """The NODE record of KSP1 without its keyword (also the body of a KSD1 `NODE+` event)."""
+    w.write(f"{_tok(n.name)} {1 if n.in_state else 0} {len(n.labels)}")
+    for k in sorted(n.labels):
+        w.write(f" {_tok(k)} {_tok(n.labels[k])}")
+    w.write(f" {len(n.taints)}")
+    for t in n.taints:
+        w.write(f" {_tok(t.key)} {_tok(t.value)} {_tok(t.effect)}")
+    _ksp_reslist(n.available, w)
+    _ksp_reslist(n.capacity, w)
+    _ksp_reslist(n.daemonset_requests, w)
+    w.write(f" {len(n.host_ports)}")
+    for hp in n.host_ports:
+        w.write(f" {_tok(hp.host_ip)} {int(hp.port)} {_tok(hp.protocol)}")
+    w.write(f" VL {len(n.volume_limits)}")      # (always written: see Pod.ksp)
+    for d in sorted(n.volume_limits):
+        w.write(f" {_tok(d)} {int(n.volume_limits[d])}")
+    w.write(f" VU {len(n.volumes)}")
+    for v in n.volumes:
+        w.write(f" {_tok(v.driver)} {_tok(v.pvc_id)}")
+
+
+def delta_to_ksd(events: Sequence[tuple]) -> str:
+    """KSD1 text for `scheduler.ParsedProblem.apply` (kshost.h `ksh_env_apply`): what state.Cluster hears between two passes over the cluster
+    (cluster.go UpdateNode / DeleteNode / UpdatePod / DeletePod).  Events, in order:
+        ("node+", StateNode) | ("node-", node_name) | ("bind", node_name, Pod) | ("unbind", pod_uid)"""
+    w = io.StringIO()
+    w.write(f"KSD1 {len(events)}\n")
+    for e in events:
+        if e[0] == "node+":
+            w.write("NODE+ ")
+            _ksp_node(e[1], w)
+        elif e[0] == "node-":
+            w.write(f"NODE- {_tok(e[1])}")
+        elif e[0] == "bind":
+            w.write(f"BIND {_tok(e[1])} POD ")
+            e[2].ksp(w)
+        elif e[0] == "unbind":
+            w.write(f"UNBIND {_tok(e[1])}")
+        else:
+            raise ValueError(f"unknown snapshot event {e[0]!r}")
+        w.write("\n")
+    w.write("END\n")
+    return w.getvalue()
+
+
 @dataclass
 class ClusterPod:
     """A pod already bound in the cluster, as seen by countDomains (topology.go:231-276) and
@@ -689,24 +735,8 @@ class Problem:
             w.write("\n")
         w.write(f"NODES {len(self.nodes)}\n")
         for n in self.nodes:
-            w.write(f"NODE {_tok(n.name)} {1 if n.in_state else 0} {len(n.labels)}")
-            for k in sorted(n.labels):
-                w.write(f" {_tok(k)} {_tok(n.labels[k])}")
-            w.write(f" {len(n.taints)}")
-            for t in n.taints:
-                w.write(f" {_tok(t.key)} {_tok(t.value)} {_tok(t.effect)}")
-            _ksp_reslist(n.available, w)
-            _ksp_reslist(n.capacity, w)
-            _ksp_reslist(n.daemonset_requests, w)
-            w.write(f" {len(n.host_ports)}")
-            for hp in n.host_ports:
-                w.write(f" {_tok(hp.host_ip)} {int(hp.port)} {_tok(hp.protocol)}")
-            w.write(f" VL {len(n.volume_limits)}")      # (always written: see Pod.ksp)
-            for d in sorted(n.volume_limits):
-                w.write(f" {_tok(d)} {int(n.volume_limits[d])}")
-            w.write(f" VU {len(n.volumes)}")
-            for v in n.volumes:
-                w.write(f" {_tok(v.driver)} {_tok(v.pvc_id)}")
+            w.write("NODE ")
+            _ksp_node(n, w)
             w.write("\n")
         w.write(f"CPODS {len(self.cluster_pods)}\n")
         for cp in self.cluster_pods:

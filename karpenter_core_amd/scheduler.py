@@ -294,6 +294,52 @@ class ParsedProblem:
         self.ingest_ms = float(ms.value)
         return self
 
+    def apply(self, events: Sequence[tuple], pod_node: Optional[Sequence[int]] = None) -> dict:
+        """Keep the snapshot current by events instead of ingesting it again (kshost.h `ksh_env_apply`; state.Cluster's UpdateNode / DeleteNode / UpdatePod /
+        DeletePod, cluster.go): `events` as `model.delta_to_ksd` takes them.  The first call needs the snapshot's bindings (`pod_node`); from then on the library
+        holds them (`bindings()`), and `open_whatifs(..., pod_node=None)` means those.  Returns {"applied", "nodes", "pods", "continued", "ms"}: `continued` says the
+        snapshot's flattening took the short road (same universes), `ms` is the library's time for events + flattening."""
+        import numpy as np, time
+        from .model import delta_to_ksd
+        kh = libs()[1]
+        text = delta_to_ksd(events).encode()
+        pn = None if pod_node is None else np.ascontiguousarray(np.asarray(pod_node, dtype=np.int32))
+        info = (ctypes.c_uint32 * 4)()
+        kh.ksh_env_apply.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32)]
+        t0 = time.perf_counter()
+        rc = kh.ksh_env_apply(self._p, None if pn is None or pn.size == 0 else pn.ctypes.data, text, len(text), info)
+        ms = (time.perf_counter() - t0) * 1e3
+        if rc != KS_OK:
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+        return {"applied": int(info[0]), "nodes": int(info[1]), "pods": int(info[2]), "continued": bool(info[3]), "ms": ms}
+
+    def bindings(self):
+        """(pod -> node index, -1 for a pod that was unbound; number of node slots) as the library holds them after `apply`."""
+        import numpy as np
+        kh = libs()[1]
+        kh.ksh_snapshot_bindings.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+        n_pods, n_nodes = ctypes.c_uint32(), ctypes.c_uint32()
+        if kh.ksh_snapshot_bindings(self._p, None, 0, ctypes.byref(n_pods), ctypes.byref(n_nodes)) != KS_OK:
+            raise KSolveError(KS_ERR_INVALID, kh.ksh_last_error().decode())
+        out = np.full(max(1, n_pods.value), -1, dtype=np.int32)
+        rc = kh.ksh_snapshot_bindings(self._p, out.ctypes.data, n_pods.value, None, None)
+        if rc != KS_OK:
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+        return out[:n_pods.value], int(n_nodes.value)
+
+    def snapshot_fingerprint(self, pod_node: Optional[Sequence[int]] = None, cold: bool = False) -> int:
+        """Hash of the snapshot's flattening (flat problem + the tables the device derivation reads); `cold`: of one made from scratch (tests: a flattening
+        continued after `apply` must equal it)."""
+        import numpy as np
+        kh = libs()[1]
+        kh.ksh_snapshot_fingerprint.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+        pn = None if pod_node is None else np.ascontiguousarray(np.asarray(pod_node, dtype=np.int32))
+        out = ctypes.c_uint64()
+        rc = kh.ksh_snapshot_fingerprint(self._p, None if pn is None or pn.size == 0 else pn.ctypes.data, 0, 1 if cold else 0, ctypes.byref(out))
+        if rc != KS_OK:
+            raise KSolveError(rc, kh.ksh_last_error().decode())
+        return int(out.value)
+
     def close(self):
         if self._p:
             libs()[1].ksh_parsed_free(self._p)
@@ -407,10 +453,11 @@ def open_whatifs(snapshot, pod_node: Sequence[int], candidate_sets: Sequence[Seq
     flat = np.ascontiguousarray(np.concatenate([np.asarray(cs, dtype=np.uint32) for cs in candidate_sets]) if n else np.zeros(1, dtype=np.uint32))
     if flat.size == 0:
         flat = np.zeros(1, dtype=np.uint32)
-    pn = np.ascontiguousarray(np.asarray(pod_node, dtype=np.int32)) if len(pod_node) else np.zeros(1, dtype=np.int32)
+    # pod_node None: the bindings the library holds itself since `ParsedProblem.apply`
+    pn = None if pod_node is None else (np.ascontiguousarray(np.asarray(pod_node, dtype=np.int32)) if len(pod_node) else np.zeros(1, dtype=np.int32))
     c_off = off.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
     c_cand = flat.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
-    c_pn = pn.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    c_pn = None if pn is None else pn.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
     hs = (ctypes.c_void_p * max(1, n))()
     # derive: None = derive the what-ifs on the device when the snapshot allows it (a ParsedProblem without topology terms / volume limits), else flatten
     # them one by one on the host; True = derive or raise; False = always flatten on the host.  Derived what-ifs are resident on `device` at once.
@@ -440,9 +487,9 @@ def check_whatif_derivation(snapshot: "ParsedProblem", pod_node: Sequence[int], 
     import numpy as np
     kh = libs()[1]
     cand = np.ascontiguousarray(np.asarray(list(candidates) or [0], dtype=np.uint32))
-    pn = np.ascontiguousarray(np.asarray(pod_node, dtype=np.int32)) if len(pod_node) else np.zeros(1, dtype=np.int32)
+    pn = None if pod_node is None else (np.ascontiguousarray(np.asarray(pod_node, dtype=np.int32)) if len(pod_node) else np.zeros(1, dtype=np.int32))
     kh.ksh_check_whatif_derivation.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.POINTER(ctypes.c_int32)]
-    rc = kh.ksh_check_whatif_derivation(snapshot._p, 0, cand.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), len(candidates), pn.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    rc = kh.ksh_check_whatif_derivation(snapshot._p, 0, cand.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), len(candidates), None if pn is None else pn.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
     if rc != KS_OK:
         raise KSolveError(rc, kh.ksh_last_error().decode())
 

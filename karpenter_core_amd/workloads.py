@@ -309,3 +309,46 @@ def config4(whatifs: int = 512, existing: int = 2048, sizes: int = 50, seed: int
     """512 what-ifs, one Problem each (the per-what-if construction the oracle and the fingerprint tests use)."""
     its, prov, nodes, bound = cluster_snapshot(existing, sizes, seed)
     return [whatif(its, prov, nodes, bound, cs, with_cluster_pods) for cs in config4_sets(whatifs, existing, seed)]
+
+
+def cluster_after(nodes, bound, events):
+    """What a cluster (`cluster_snapshot`'s nodes / per-node bound pods) looks like after `events` (as `model.delta_to_ksd` takes them), the way state.Cluster
+    keeps it (cluster.go UpdateNode / DeleteNode / UpdatePod / DeletePod; state/node.go:113,161-182: Available() = Allocatable - the requests of the pods bound):
+    returns (nodes, bound, slot) -- fresh lists, removed nodes gone, `slot[i]` = the node's index in the library's snapshot (node slots are never reused: a new
+    node takes the next one).  The model the tests hold ParsedProblem.apply against."""
+    from .model import format_milli, parse_quantity_milli, pod_requests_milli
+    live = [[dataclasses.replace(n, available=dict(n.available)), list(b), i] for i, (n, b) in enumerate(zip(nodes, bound))]
+    next_slot = len(nodes)
+
+    def find(name):
+        for e in live:
+            if e[0].name == name:
+                return e
+        raise KeyError(name)
+
+    def adjust(n, pod, sign):
+        req = pod_requests_milli(pod)
+        for k in list(n.available):
+            if k in req:
+                n.available[k] = format_milli(parse_quantity_milli(n.available[k]) - sign * req[k])
+
+    for ev in events:
+        if ev[0] == "node+":
+            live.append([dataclasses.replace(ev[1], available=dict(ev[1].available)), [], next_slot])
+            next_slot += 1
+        elif ev[0] == "node-":
+            live.remove(find(ev[1]))
+        elif ev[0] == "bind":
+            e = find(ev[1])
+            adjust(e[0], ev[2], +1)
+            e[1].append(ev[2])
+        elif ev[0] == "unbind":
+            for e in live:
+                hit = [p for p in e[1] if p.uid == ev[1]]
+                if hit:
+                    adjust(e[0], hit[0], -1)
+                    e[1].remove(hit[0])
+                    break
+            else:
+                raise KeyError(ev[1])
+    return [e[0] for e in live], [e[1] for e in live], [e[2] for e in live]
