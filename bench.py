@@ -450,6 +450,7 @@ def whatif_snapshot(args, S, W):
     """BASELINE configs[3]'s cluster: 2048 existing nodes with their bound pods, held as objects in host memory (untimed, like the pod list)."""
     c_its, c_prov, c_nodes, c_bound = W.cluster_snapshot(2048, args.sizes, 45)
     c_snap, c_pn = W.snapshot_problem(c_its, c_prov, c_nodes, c_bound, False)
+    whatif_snapshot.its = c_its
     return S.ParsedProblem(c_snap), c_pn, len(c_its), W.config4_sets(args.whatifs or 512, 2048, 45)
 
 
@@ -461,7 +462,7 @@ def whatif_leg(args, rank, world, local_rank, torch, dist, S, W):
 
     rec_e2e = torch.full((len(mine), 3 + words), -1, dtype=torch.int64, device=f"cuda:{local_rank}")
 
-    def end_to_end():
+    def end_to_end(pod_node=pod_node):
         """What a consolidation pass pays per batch of candidate sets over a snapshot it already holds (multinodeconsolidation.go:74-114): open the
         what-ifs (derived on the device from the resident snapshot: candidate masks up, batches built there), one batched launch, the fixed-size
         decision records built on the device and brought to the host."""
@@ -526,6 +527,24 @@ def whatif_leg(args, rank, world, local_rank, torch, dist, S, W):
                         "note": "a batch takes as long as its longest what-if (one wave each); the watermark / run commit skip most of the attempts the reference makes"}}
     for f in flats:
         f.close()
+    # ---- the cluster changed by ONE node (a machine joined, 20 pods were bound to it) -- the events go to the snapshot the library holds
+    # (ksh_env_apply) and the next batch of what-ifs is opened over it, against ingesting + flattening the cluster again (`first_batch_over_the_snapshot`) ----
+    import numpy as np
+    rs = np.random.RandomState(7)
+    incr = []
+    for r in range(3):
+        name = f"joined-{r}"
+        events = [("node+", W.fresh_node(whatif_snapshot.its, name, rs))] + [("bind", name, W.generic_pod(rs, f"joined-{r}-{k}")) for k in range(20)]
+        info = parsed.apply(events, pod_node if r == 0 else None)
+        flats2, rec2, ms2 = end_to_end(None)
+        for f in flats2:
+            f.close()
+        incr.append({"apply_ms": info["ms"], "continued": info["continued"], **ms2, "total_with_apply_ms": info["ms"] + ms2["total_ms"]})
+    out["after_a_one_node_change"] = dict(sorted(incr, key=lambda r: r["total_with_apply_ms"])[1],
+                                          what="SURVEY 8f-1: one node joined and 20 pods were bound to it -- the events patched the resident snapshot (ksh_env_apply: objects in place, the "
+                                               "flattening continued from the one before), then the same 512 candidate sets were opened, solved and their records read; "
+                                               "`first_batch_over_the_snapshot` is what ingesting the changed cluster again would cost on top of the parse",
+                                          events_per_change=21, runs=incr)
     return out
 
 

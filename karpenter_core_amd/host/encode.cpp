@@ -2,6 +2,7 @@
 #include "encode.hpp"
 
 #include <atomic>
+#include <future>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -128,7 +129,7 @@ uint32_t host_threads() {
       if (fscanf(f, "%63s %lld", buf, &period) == 2 && strcmp(buf, "max") != 0) { long long quota = atoll(buf); if (quota > 0 && period > 0) hw = std::min<uint32_t>(hw, (uint32_t)std::max<long long>(1, quota / period)); }
       fclose(f);
     }
-    return std::min(hw, 32u);      // (measured on a 256-thread host: 16 -> 20.6 ms, 32 -> 18.1 ms, 64 -> 17.7 ms for 100k pods)
+    return std::min(hw, 64u);      // (measured on a 256-thread host, round 6: 32 -> 11.9 ms, 64 -> 10.5 ms, 128 -> 12.2 ms for 100k pods; round 3: 16 -> 20.6, 32 -> 18.1, 64 -> 17.7)
   }();
   return n;
 }
@@ -139,7 +140,7 @@ namespace {
 // spawns threads of its own, as does a process that inherited the pool object through fork() without its threads). ----
 class WorkerPool {
  public:
-  static WorkerPool& get() { static WorkerPool p; return p; }
+  static WorkerPool& get(int which) { static WorkerPool p[2]; return p[which & 1]; }      // (a second pool: the queue sort runs beside the classing, encode_pods)
   // body(t) for t in [0, n): t = 0 runs on the caller; returns false (nothing run) when the pool cannot be used right now
   template <class B> bool run(uint32_t n, B&& body) {
     if (n <= 1 || getpid() != pid_ || busy_.exchange(true)) return false;
@@ -181,9 +182,10 @@ class WorkerPool {
   std::function<void(uint32_t)>* job_ = nullptr; uint32_t njobs_ = 0, next_ = 0, pending_ = 0; uint64_t gen_ = 0; bool stop_ = false;
 };
 // body(t) for t in [0, n) on n threads (bodies must not throw)
+thread_local int tl_pool = 0;      // which pool the parallel regions of this thread use
 template <class B> void run_threads(uint32_t n, B&& body) {
   if (n <= 1) { body(0u); return; }
-  if (WorkerPool::get().run(n, body)) return;
+  if (WorkerPool::get(tl_pool).run(n, body)) return;
   std::vector<std::thread> pool; for (uint32_t t = 1; t < n; ++t) pool.emplace_back([&, t] { body(t); });
   body(0u); for (auto& th : pool) th.join();
 }
@@ -315,6 +317,7 @@ struct Builder {
   // universes come out the same (`warm`); every shortcut reproduces what the full run would have written, byte for byte (tests/test_env_apply.py compares fingerprints).
   const Builder* prev = nullptr; bool warm = false, keep_warm_state = false;
   std::vector<Hash128> spec_hs; std::vector<int32_t> spec_tab; std::vector<uint32_t> spec_first;      // kept by dedupe_specs: the hash of every spec's first pod, the table over them, the first pods
+  std::map<std::string, int> pre_it_state_id, pre_it_col_id;      // kept by encode_it_states: the lattice's states / columns before its closure
   std::string act_sig; std::map<std::string, int> act_key_id, act_res_id; size_t n_nodes_built = 0, n_pods_built = 0;      // kept by run(): what collect_active left, how large the problem was
 
   Builder(Encoded& e, uint32_t f) : E(e), pr(*e.src), flags(f), lite(e.batch.get()) {}
@@ -739,6 +742,7 @@ struct Builder {
     const uint32_t NE = (uint32_t)E.existing.size();
     const uint32_t M = (uint32_t)E.templates.size();
     base_existing_of.assign(pr.nodes.size(), -1); for (uint32_t e = 0; e < NE; ++e) base_existing_of[E.existing[e]] = (int)e;
+    std::unordered_map<std::string, int32_t> warm_it_state;
     // remainingResources, scheduler.go:71-75,244-246
     std::vector<ksp::ResList> remaining(M);
     for (uint32_t m = 0; m < M; ++m) if (E.templates[m]->has_limits) remaining[m] = E.templates[m]->limits;
@@ -752,8 +756,15 @@ struct Builder {
         st.present.push_back(B.present[pb]); st.complement.push_back(B.complement[pb]);
         st.mask.insert(st.mask.end(), B.mask.begin() + (size_t)pb * K, B.mask.begin() + (size_t)(pb + 1) * K); st.gt.insert(st.gt.end(), B.gt.begin() + (size_t)pb * K, B.gt.begin() + (size_t)(pb + 1) * K);
         st.lt.insert(st.lt.end(), B.lt.begin() + (size_t)pb * K, B.lt.begin() + (size_t)(pb + 1) * K); st.it_state.push_back(0);
-        { StrMap one; for (auto& kv : n.labels) if (ksp::normalize_key(kv.first) == ksp::kInstanceType) one.emplace(kv.first, kv.second);
-          if (!one.empty()) { const Requirements r1 = Requirements::FromLabels(one); auto f = r1.m.find(ksp::kInstanceType); if (f != r1.m.end()) st.it_state[idx] = it_state_of(f->second); } }
+        { auto il = n.labels.find(ksp::kInstanceType); const bool beta = n.labels.count("beta.kubernetes.io/instance-type") != 0;      // (labels.go:103-109: the one alias of the key)
+          auto seen = (il != n.labels.end() && !beta) ? warm_it_state.find(il->second) : warm_it_state.end();
+          if (seen != warm_it_state.end()) st.it_state[idx] = seen->second;      // (a value met before in this run: the state it was given then -- it_state_of numbers by first use)
+          else if (il != n.labels.end() && !beta) { st.it_state[idx] = it_state_of(Requirement::New(ksp::kInstanceType, Op::In, {il->second})); warm_it_state.emplace(il->second, st.it_state[idx]); }      // (FromLabels of the one label)
+          else if (il != n.labels.end() || beta) {
+            StrMap one; for (auto& kv : n.labels) if (ksp::normalize_key(kv.first) == ksp::kInstanceType) one.emplace(kv.first, kv.second);
+            const Requirements r1 = Requirements::FromLabels(one); auto f = r1.m.find(ksp::kInstanceType);
+            if (f != r1.m.end()) { st.it_state[idx] = it_state_of(f->second); if (!beta) warm_it_state.emplace(il->second, st.it_state[idx]); }
+          } }
         E.en_taints.push_back(taint_mask(n.taints) | (over_volume_limit(n) ? blocked_mask() : 0ull));
         res_vec(n.available, E.en_avail, nullptr);
         ksp::ResList dr; dr["pods"] = 0;
@@ -961,6 +972,15 @@ struct Builder {
 
   void encode_pods() {
     const uint32_t P = (uint32_t)podp.size();
+    // NewQueue's sort starts first and runs beside everything below (queue_sort): it reads the pods' uids / timestamps and, per spec, cpu and memory -- taken here,
+    // before the chains below grow the specs' stage vectors
+    std::future<void> sorter;
+    if (!(base && !env_mode)) {
+      spec_cm.resize(specs.size());
+      parallel_chunks(specs.size(), [&](size_t b, size_t e, uint32_t) { for (size_t s2 = b; s2 < e; ++s2) { const ksp::ResList rq = RequestsForPod(specs[s2].stages[0].spec);
+        auto c = rq.find("cpu"), m = rq.find("memory"); spec_cm[s2] = {c == rq.end() ? 0 : c->second, m == rq.end() ? 0 : m->second}; } }, 256);
+      if (P >= 8192 && host_threads() >= 4 && !getenv("KSH_SYNC_QUEUE_SORT")) { try { sorter = std::async(std::launch::async, [this] { tl_pool = 1; queue_sort(); }); } catch (const std::system_error&) {} }
+    }
     // updateInverseAffinities, topology.go:181-199 (cluster pods with required anti-affinity, not in the batch)
     for (auto& cp : pr.cluster_pods) {
       if (cp.anti_required.empty() || batch_uids.count(cp.uid)) continue;
@@ -1008,14 +1028,24 @@ struct Builder {
       E.queue.resize(P); for (uint32_t i = 0; i < P; ++i) E.queue[i] = k[i].second; sublap("queue from the snapshot's order");
       return;
     }
-    const int rc = res_id.at("cpu"), rm = res_id.at("memory");
+    // NewQueue's sort ran beside the classing (queue_sort, started above): its result, or what it threw
+    sublap("chains");
+    if (sorter.valid()) sorter.get(); else queue_sort();
+    sublap("queue sort (joined)");
+  }
+
+  // NewQueue: byCPUAndMemoryDescending, queue.go:74-110.  cpu and memory of a pod are its spec's RequestsForPods (spec_cm, made before anything else touches the specs);
+  // timestamps and uids are the pods' own: nothing here reads what the classing writes, so it runs on a thread of its own (second worker pool) while the classes are made.
+  std::vector<std::pair<int64_t, int64_t>> spec_cm;
+  void queue_sort() {
+    const uint32_t P = (uint32_t)podp.size();
     // The order is total (UIDs are unique), so any correct sort gives the reference's queue: chunks are sorted on the host threads
     // and merged pairwise.  Keys are gathered first so a comparison touches one 32-byte record per side and the uid only on ties.
-    sublap("chains"); struct QKey { int64_t cpu, mem, ts; uint64_t u0, u1; uint32_t pod, ulen; };     // u0,u1: the uid's first 16 bytes, big-endian (byte-wise string order)
+    struct QKey { int64_t cpu, mem, ts; uint64_t u0, u1; uint32_t pod, ulen; };     // u0,u1: the uid's first 16 bytes, big-endian (byte-wise string order)
     std::vector<QKey> keys(P);
     auto be64 = [](std::string_view s2, size_t off) { uint64_t v = 0; for (size_t j = 0; j < 8; ++j) v = (v << 8) | (off + j < s2.size() ? (unsigned char)s2[off + j] : 0u); return v; };
-    parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t c0 = E.stage_cls[E.pod_stage_off[i]]; const std::string_view u = uidv[i];
-      keys[i] = QKey{E.cls_requests[(size_t)c0 * R + rc], E.cls_requests[(size_t)c0 * R + rm], ts_of(i), be64(u, 0), be64(u, 8), (uint32_t)i, (uint32_t)u.size()}; } });
+    parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const auto& cm0 = spec_cm[pod_spec[i]]; const std::string_view u = uidv[i];
+      keys[i] = QKey{cm0.first, cm0.second, ts_of(i), be64(u, 0), be64(u, 8), (uint32_t)i, (uint32_t)u.size()}; } });
     auto less = [&](const QKey& a, const QKey& b) {
       if (a.cpu != b.cpu) return a.cpu > b.cpu;
       if (a.mem != b.mem) return a.mem > b.mem;
@@ -1030,8 +1060,7 @@ struct Builder {
     // batch that is mostly ONE bucket takes the chunked merge sort below instead.
     bool bucketed = false;
     if (P >= 8192) {
-      std::vector<std::pair<int64_t, int64_t>> cm(specs.size());
-      for (size_t s2 = 0; s2 < specs.size(); ++s2) { const uint32_t c0 = specs[s2].cls[0]; cm[s2] = {E.cls_requests[(size_t)c0 * R + rc], E.cls_requests[(size_t)c0 * R + rm]}; }
+      const std::vector<std::pair<int64_t, int64_t>>& cm = spec_cm;
       std::vector<std::pair<int64_t, int64_t>> dist(cm); std::sort(dist.begin(), dist.end(), [](auto& a, auto& b) { return a.first != b.first ? a.first > b.first : a.second > b.second; });
       dist.erase(std::unique(dist.begin(), dist.end()), dist.end());
       const size_t NB = dist.size();
@@ -1071,8 +1100,8 @@ struct Builder {
       parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = std::max<size_t>(b, 1); i < e; ++i) if (keys[i].u0 == keys[i - 1].u0 && keys[i].u1 == keys[i - 1].u1 && keys[i].ulen == keys[i - 1].ulen && keys[i].ts == keys[i - 1].ts &&
                                                                                                                  keys[i].cpu == keys[i - 1].cpu && keys[i].mem == keys[i - 1].mem && uidv[keys[i].pod] == uidv[keys[i - 1].pod]) dup = true; });
       if (dup) throw ksp::Error("pod UIDs must be unique (queue.go:102-108 needs a total order)"); }
-    E.queue.resize(P); for (uint32_t i = 0; i < P; ++i) E.queue[i] = keys[i].pod; sublap("queue sort");
-    pod_rank.resize(P); for (uint32_t i = 0; i < P; ++i) pod_rank[E.queue[i]] = i;
+    E.queue.resize(P); for (uint32_t i = 0; i < P; ++i) E.queue[i] = keys[i].pod;
+    if (keep_warm_state || !env_mode) { pod_rank.resize(P); for (uint32_t i = 0; i < P; ++i) pod_rank[E.queue[i]] = i; }      // (read by the what-ifs over a snapshot: not by a Solve over a cached environment)
   }
 
   // class_of in two halves: the PURE one -- the signature of everything Node.Add reads of the stage but the ids the serial half hands out (label set, topology groups) --
@@ -1197,6 +1226,14 @@ struct Builder {
     // instance-type requirement by a class's, node.go:79 / existingnode.go:102); it_state_of appends while we iterate.
     if (it_reqs.empty()) it_reqs.push_back(Requirement());   // state 0 placeholder ("absent")
     if (it_cols.empty()) it_cols.push_back(Requirement());
+    if (keep_warm_state) { pre_it_state_id = it_state_id; pre_it_col_id = it_col_id; }
+    if (warm && !prev->pre_it_state_id.empty() && it_state_id == prev->pre_it_state_id && it_col_id == prev->pre_it_col_id && it_reqs.size() == prev->pre_it_state_id.size() + 1) {
+      // the same node-side states and pod-side columns in the same order, over the same catalogue: the closure and its tables are the previous flattening's
+      const Encoded& B = prev->E;
+      it_reqs = prev->it_reqs; it_state_id = prev->it_state_id;
+      E.its_inter = B.its_inter; E.its_fail = B.its_fail; E.its_nidne = B.its_nidne; E.its_types = B.its_types; E.it_states = B.it_states; E.prob.S = B.prob.S; E.prob.SC = B.prob.SC;
+      return;
+    }
     const uint32_t SC = (uint32_t)it_cols.size();
     for (size_t a = 1; a < it_reqs.size(); ++a) for (uint32_t b = 1; b < SC; ++b) it_state_of(it_cols[b].Intersection(it_reqs[a]));
     for (uint32_t b = 1; b < SC; ++b) it_state_of(it_cols[b]);      // absent ∩ b = b

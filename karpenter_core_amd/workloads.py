@@ -311,6 +311,18 @@ def config4(whatifs: int = 512, existing: int = 2048, sizes: int = 50, seed: int
     return [whatif(its, prov, nodes, bound, cs, with_cluster_pods) for cs in config4_sets(whatifs, existing, seed)]
 
 
+def fresh_node(its, name, rs):
+    """An empty owned node of a random instance type / offering of the catalogue, as `cluster_snapshot` makes them (a machine that just joined: cluster.go UpdateNode)."""
+    it = its[int(rs.randint(len(its)))]
+    off = it.offerings[int(rs.randint(len(it.offerings)))]
+    arch = [r for r in it.requirements if r.key == LABEL_ARCH][0].values[0]
+    os_ = [r for r in it.requirements if r.key == LABEL_OS][0].values[0]
+    labels = {LABEL_PROVISIONER: "default", LABEL_INSTANCE_TYPE: it.name, LABEL_ZONE: off.zone, LABEL_CAPACITY_TYPE: off.capacity_type,
+              LABEL_ARCH: arch, LABEL_OS: os_, LABEL_HOSTNAME: name, "karpenter.sh/initialized": "true"}
+    return StateNode(name=name, labels=labels, capacity=dict(it.capacity),
+                     available={"cpu": f"{int(it.capacity['cpu']) * 1000 - 100}m", "memory": f"{int(it.capacity['memory'][:-2]) * 1024 - 10}Mi", "pods": str(int(it.capacity["pods"]))})
+
+
 def cluster_after(nodes, bound, events):
     """What a cluster (`cluster_snapshot`'s nodes / per-node bound pods) looks like after `events` (as `model.delta_to_ksd` takes them), the way state.Cluster
     keeps it (cluster.go UpdateNode / DeleteNode / UpdatePod / DeletePod; state/node.go:113,161-182: Available() = Allocatable - the requests of the pods bound):

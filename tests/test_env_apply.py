@@ -16,15 +16,7 @@ from karpenter_core_amd.model import Pod, Problem, StateNode, TopologySpreadCons
 from karpenter_core_amd import fake
 
 
-def new_node(its, name, rs):
-    it = its[int(rs.randint(len(its)))]
-    off = it.offerings[int(rs.randint(len(it.offerings)))]
-    arch = [r for r in it.requirements if r.key == W.LABEL_ARCH][0].values[0]
-    os_ = [r for r in it.requirements if r.key == W.LABEL_OS][0].values[0]
-    labels = {W.LABEL_PROVISIONER: "default", W.LABEL_INSTANCE_TYPE: it.name, W.LABEL_ZONE: off.zone, W.LABEL_CAPACITY_TYPE: off.capacity_type,
-              W.LABEL_ARCH: arch, W.LABEL_OS: os_, W.LABEL_HOSTNAME: name, "karpenter.sh/initialized": "true"}
-    return StateNode(name=name, labels=labels, capacity=dict(it.capacity),
-                     available={"cpu": f"{int(it.capacity['cpu']) * 1000 - 100}m", "memory": f"{int(it.capacity['memory'][:-2]) * 1024 - 10}Mi", "pods": str(int(it.capacity["pods"]))})
+new_node = W.fresh_node
 
 
 def random_events(rs, its, nodes, bound, n, tag, removes=True, make_pod=W.generic_pod):
@@ -175,3 +167,44 @@ def test_what_the_door_refuses():
     bind, slots = parsed.bindings()
     assert slots == 9 and bind[-1] == 8 and (bind[:len(bound[0])] == -1).all()
     parsed.close()
+
+
+# ---- the GPU half: the what-ifs over the patched snapshot SOLVE like the what-ifs over a snapshot built fresh from the cluster as it is now, and like the oracle ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,topology", [(21, False), (22, False), (23, True), (24, True)])
+def test_whatifs_over_the_patched_snapshot_solve_like_a_fresh_one(seed, topology):
+    from oracle import oracle_py as O
+    its, prov, nodes0, bound0 = W.cluster_snapshot(64, 10, 300 + seed, spare_pod_slots=(6 if seed % 2 else -1))
+    make = (lambda r, u: spread_pod(r, u) if r.randint(3) == 0 else W.generic_pod(r, u)) if topology else W.generic_pod
+    if topology:
+        rs0 = np.random.RandomState(seed)
+        bound0 = [[spread_pod(rs0, p.uid) if rs0.randint(3) == 0 else p for p in b] for b in bound0]
+    snap, pn = W.snapshot_problem(its, prov, nodes0, bound0, topology)
+    parsed = S.ParsedProblem(snap)
+    rs = np.random.RandomState(seed)
+    for f in S.open_whatifs(parsed, pn, [[0], [1, 2], [5]], derive=True):      # (the snapshot is flattened and resident BEFORE the events: they continue that flattening)
+        f.close()
+    all_events, nodes, bound = [], nodes0, bound0
+    for batch in range(3):
+        events, nodes, bound = random_events(rs, its, nodes, bound, 10, f"g{seed}b{batch}", make_pod=make)
+        assert parsed.apply(events, pn if batch == 0 else None)["continued"]
+        all_events += events
+    # the cluster as it is now, the way a caller would list it; its node j sits in the library's slot slot_of[j]
+    nodes, bound, slot_of = W.cluster_after(nodes0, bound0, all_events)
+    fresh_snap, fresh_pn = W.snapshot_problem(its, prov, nodes, bound, topology)
+    fresh = S.ParsedProblem(fresh_snap)
+    sets = [[int(x) for x in rs.choice(len(nodes), size=int(rs.choice([1, 1, 2, 4, 8])), replace=False)] for _ in range(24)]
+    got_f = S.open_whatifs(parsed, None, [[slot_of[j] for j in cs] for cs in sets], derive=True)
+    want_f = S.open_whatifs(fresh, fresh_pn, sets, derive=True)
+    try:
+        got, _, _ = S.solve_batch(got_f)
+        want, _, _ = S.solve_batch(want_f)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g.canonical() == w.canonical() and g.reasons == w.reasons, (seed, i, sets[i])
+        for i in range(0, len(sets), 6):
+            ref = O.solve(W.whatif(its, prov, nodes, bound, sets[i], topology))
+            assert got[i].canonical() == ref.canonical(), (seed, i, sets[i])
+    finally:
+        for f in got_f + want_f:
+            f.close()
+        parsed.close(); fresh.close()
