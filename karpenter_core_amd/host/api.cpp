@@ -367,6 +367,7 @@ int ksh_env_apply(void* parsed, const int32_t* pod_node, const char* ksd_text, s
       std::shared_ptr<const ksh::SnapshotBase> before = P->sb;
       try { P->sb = ksh::make_snapshot_base(P->pr, P->bind.data(), P->sb_flags, before.get()); P->sb_pod_node = P->bind; continued = ksh::snapshot_continued(*P->sb); }
       catch (...) { P->sb.reset(); P->sb_pod_node.clear(); throw; }
+      ksh::dispose_later(std::move(before));      // (the flattening before: torn down off this thread, once the handles that still use it are closed)
     }
     if (info) { info[0] = done; info[1] = (uint32_t)pr.nodes.size(); info[2] = (uint32_t)pr.pods.size(); info[3] = continued ? 1u : 0u; }
     if (done != ev.size()) return set_err(KS_ERR_INVALID, "event " + std::to_string(done) + ": " + why + " (the events before it were applied)");

@@ -183,6 +183,8 @@ class WorkerPool {
 };
 // body(t) for t in [0, n) on n threads (bodies must not throw)
 thread_local int tl_pool = 0;      // which pool the parallel regions of this thread use
+thread_local bool tl_sync_confirm = false;      // this thread's flattening confirms its spec merges in line (the retry after ConfirmFailed)
+struct ConfirmFailed {};
 template <class B> void run_threads(uint32_t n, B&& body) {
   if (n <= 1) { body(0u); return; }
   if (WorkerPool::get(tl_pool).run(n, body)) return;
@@ -955,8 +957,20 @@ struct Builder {
     // needs a 2^-128 event for random inputs, but pod specs are tenant-supplied).  Every merge is therefore confirmed field by field (on the
     // worker pool; KSH_NO_CONFIRM_SPECS=1 skips it for A/B timing only); a pod
     // that merely collided would get a spec of its own.
+    // The Solve of a large batch does not wait for the confirmation: it runs on a thread of its own (second worker pool) beside what follows -- the specs' copies,
+    // the universes, the signature -- and is joined before the classing (encode_pods); should it ever find a merge that does not hold, the flattening starts over
+    // with the confirmation in line (ConfirmFailed, encode()).
+    if (!keep_warm_state && !tl_sync_confirm && P >= 8192 && host_threads() >= 4 && !getenv("KSH_NO_CONFIRM_SPECS") && !getenv("KSH_SYNC_CONFIRM")) {
+      confirm_first = first;
+      try {
+        confirmer = std::async(std::launch::async, [this, P] {
+          tl_pool = 1; std::atomic<bool> any{false};
+          parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t f = confirm_first[pod_spec[i]]; if (f != i && !same_pod(*podp[f], *podp[i])) any = true; } });
+          return any.load() || getenv("KSH_TEST_CONFIRM_FAILS") != nullptr; });
+      } catch (const std::system_error&) {}
+    }
     std::vector<uint8_t> bad(P, 0);
-    if (!getenv("KSH_NO_CONFIRM_SPECS")) parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t f = first[pod_spec[i]]; if (f != i && !same_pod(*podp[f], *podp[i])) bad[i] = 1; } });
+    if (!confirmer.valid() && !getenv("KSH_NO_CONFIRM_SPECS")) parallel_chunks(P, [&](size_t b, size_t e, uint32_t) { for (size_t i = b; i < e; ++i) { const uint32_t f = first[pod_spec[i]]; if (f != i && !same_pod(*podp[f], *podp[i])) bad[i] = 1; } });
     for (uint32_t i = 0; i < P; ++i) if (bad[i]) {
       int found = -1; for (size_t s2 = 0; s2 < first.size() && found < 0; ++s2) if (same_pod(*podp[first[s2]], *podp[i])) found = (int)s2;
       if (found < 0) { found = (int)first.size(); first.push_back(i); }
@@ -974,6 +988,7 @@ struct Builder {
     const uint32_t P = (uint32_t)podp.size();
     // NewQueue's sort starts first and runs beside everything below (queue_sort): it reads the pods' uids / timestamps and, per spec, cpu and memory -- taken here,
     // before the chains below grow the specs' stage vectors
+    if (confirmer.valid() && confirmer.get()) throw ConfirmFailed();      // (the batch's partition into specs, confirmed beside the work since dedupe_specs)
     std::future<void> sorter;
     if (!(base && !env_mode)) {
       spec_cm.resize(specs.size());
@@ -1003,6 +1018,7 @@ struct Builder {
         si.stages.push_back(std::move(st));
         if (si.stages.size() > 64) throw Unsupported("more than 64 relaxation stages");
       } } }, 64);
+    sublap("requirements + chains (pool)");
     // pass A: NewTopology's Update(pod) over the distinct stage-0 specs in order of first occurrence
     for (auto& si : specs) si.stages[0].sg = groups_of(si.stages[0].spec, true);
     sublap("pass A");
@@ -1014,6 +1030,7 @@ struct Builder {
     { std::vector<size_t> soff(specs.size() + 1, 0); for (size_t s2 = 0; s2 < specs.size(); ++s2) soff[s2 + 1] = soff[s2] + specs[s2].stages.size();
       std::vector<ClassPre> pre(soff.back());
       parallel_chunks(specs.size(), [&](size_t b, size_t e, uint32_t) { for (size_t s2 = b; s2 < e; ++s2) for (size_t k = 0; k < specs[s2].stages.size(); ++k) class_pre(specs[s2].stages[k], pre[soff[s2] + k]); }, 64);
+      sublap("class signatures (pool)");
       for (size_t s2 = 0; s2 < specs.size(); ++s2) for (size_t k = 0; k < specs[s2].stages.size(); ++k) specs[s2].cls.push_back(class_of(specs[s2].stages[k], pre[soff[s2] + k])); }
     // pods -> stage chains, queue order
     sublap("classes"); E.pod_stage_off.resize((size_t)P + 1); E.pod_stage_off[0] = 0;
@@ -1036,7 +1053,7 @@ struct Builder {
 
   // NewQueue: byCPUAndMemoryDescending, queue.go:74-110.  cpu and memory of a pod are its spec's RequestsForPods (spec_cm, made before anything else touches the specs);
   // timestamps and uids are the pods' own: nothing here reads what the classing writes, so it runs on a thread of its own (second worker pool) while the classes are made.
-  std::vector<std::pair<int64_t, int64_t>> spec_cm;
+  std::vector<std::pair<int64_t, int64_t>> spec_cm; std::vector<uint32_t> confirm_first; std::future<bool> confirmer;      // (the future last: destroyed -- waited for -- first)
   void queue_sort() {
     const uint32_t P = (uint32_t)podp.size();
     // The order is total (UIDs are unique), so any correct sort gives the reference's queue: chunks are sorted on the host threads
@@ -1357,6 +1374,7 @@ class Reaper {
   }
   std::mutex m_; std::condition_variable cv_; std::vector<std::shared_ptr<void>> q_; bool started_ = false; pid_t pid_ = getpid();
 };
+void dispose_later(std::shared_ptr<const void> p) { Reaper::get().take(std::const_pointer_cast<void>(std::move(p))); }
 struct EnvBase { std::string sig; uint32_t flags = 0; std::shared_ptr<Encoded> enc; std::unique_ptr<Builder> builder; };
 EnvCache::EnvCache() {}
 EnvCache::~EnvCache() {}
@@ -1387,8 +1405,11 @@ static std::unique_ptr<Encoded> encode_cached(std::unique_ptr<Encoded> e, uint32
   return e;
 }
 std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> pr, uint32_t flags, EnvCache* cache) {
-  auto e = std::make_unique<Encoded>(); e->src = std::move(pr);
-  return encode_cached(std::move(e), flags, cache);
+  for (int attempt = 0;; ++attempt) {
+    auto e = std::make_unique<Encoded>(); e->src = pr;
+    struct Flag { bool was = tl_sync_confirm; ~Flag() { tl_sync_confirm = was; } } flag; if (attempt) tl_sync_confirm = true;
+    try { return encode_cached(std::move(e), flags, cache); } catch (const ConfirmFailed&) { if (attempt) throw std::logic_error("spec confirmation failed twice"); }
+  }
 }
 
 std::unique_ptr<Encoded> encode(std::shared_ptr<const ksp::Problem> env, std::shared_ptr<const ksp::PodBatch> batch, uint32_t flags, EnvCache* cache) {

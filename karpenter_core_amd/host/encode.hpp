@@ -103,6 +103,7 @@ struct SnapshotBase;
 // `before`: the flattening of the SAME problem object before ksh_env_apply appended nodes / pods to it (nothing else may have changed but the pods' nodes and the
 // nodes' available resources / in_state): what does not depend on the events is taken from it when the universes come out the same.  pod_node[i] = -1: bound nowhere.
 std::shared_ptr<const SnapshotBase> make_snapshot_base(std::shared_ptr<const ksp::Problem> snapshot, const int32_t* pod_node, uint32_t flags, const SnapshotBase* before = nullptr);
+void dispose_later(std::shared_ptr<const void> p);      // destroyed on the library's teardown thread, not on the caller's (a snapshot's flattening: a millisecond of free())
 bool snapshot_continued(const SnapshotBase& sb);      // did the flattening take the short road
 uint64_t snapshot_fingerprint(const SnapshotBase& sb);      // FNV-1a over the flat problem and the per-node tables behind the device derivation (tests: short road == full run)
 std::unique_ptr<Encoded> encode_whatif(const SnapshotBase& sb, const uint32_t* cand, uint32_t ncand, uint32_t flags);

@@ -63,3 +63,25 @@ def test_concurrent_batches_share_the_cache():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs and got == [want] * 12
+
+
+def test_a_failed_spec_confirmation_starts_the_flattening_over(monkeypatch):
+    """Round 6: a large batch's spec merges are confirmed field by field on a thread of their own, beside the flattening; if that ever finds a merge that does not
+    hold (two specs with one 128-bit hash) the flattening starts over with the confirmation in line.  KSH_TEST_CONFIRM_FAILS makes the first attempt report one."""
+    from karpenter_core_amd import scheduler as S, workloads as W
+    pp = S.ParsedProblem(W.config3(pods=9000, seed=3))
+    kh = S.libs()[1]
+
+    def fingerprint():
+        h = ctypes.c_void_p()
+        assert kh.ksh_open_parsed(pp._p, 0, ctypes.byref(h)) == 0, kh.ksh_last_error()
+        f = int(kh.ksh_fingerprint(h)); kh.ksh_close(h)
+        return f
+    kh.ksh_open_parsed.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+    want = fingerprint()
+    monkeypatch.setenv("KSH_SYNC_CONFIRM", "1"); monkeypatch.setenv("KSH_SYNC_QUEUE_SORT", "1")
+    assert fingerprint() == want          # nothing beside the flattening: the same flat problem
+    monkeypatch.delenv("KSH_SYNC_CONFIRM"); monkeypatch.delenv("KSH_SYNC_QUEUE_SORT")
+    monkeypatch.setenv("KSH_TEST_CONFIRM_FAILS", "1")
+    assert fingerprint() == want          # the first attempt was thrown away
+    pp.close()
