@@ -824,39 +824,19 @@ struct Builder {
     std::string id = key + "|" + std::to_string(type) + "|"; for (auto& n : nss) id += n + ","; id += "|" + selector_identity(sel) + "|" + std::to_string(max_skew) + "|" + filter_identity(f);
     return id;
   }
-  // The PURE half of one get_group call -- the term's node filter, the group's identity, the filter's content --: what a spec's terms cost, made on the worker pool for
-  // every stage at once (terms_pre, in the order groups_of asks); the serial half looks the identity up and, rarely, creates the group.
-  struct TermPre { Filter f; std::string id, fsig; };
-  static TermPre term_pre(int type, const std::string& key, const std::set<std::string>& nss, const ksp::Selector& sel, int32_t max_skew, const Pod& owner) {
-    TermPre t; if (type == 0) t.f = MakeTopologyNodeFilter(owner);
-    t.id = group_id(type, key, nss, sel, max_skew, t.f); t.fsig = filter_content(t.f); return t;
-  }
-  static std::vector<TermPre> terms_pre(const Pod& p) {      // (the order of groups_of's calls)
-    std::vector<TermPre> v;
-    if (!p.anti_required.empty() || !p.anti_preferred.empty()) for (auto& t : p.anti_required) v.push_back(term_pre(2, t.topology_key, ns_list(p.ns, t.namespaces), t.selector, INT32_MAX, p));
-    for (auto& cs : p.spread) v.push_back(term_pre(0, cs.key, {p.ns}, cs.selector, cs.max_skew, p));
-    for (auto& t : p.affinity_required) v.push_back(term_pre(1, t.topology_key, ns_list(p.ns, t.namespaces), t.selector, INT32_MAX, p));
-    for (auto& w : p.affinity_preferred) v.push_back(term_pre(1, w.term.topology_key, ns_list(p.ns, w.term.namespaces), w.term.selector, INT32_MAX, p));
-    for (auto& t : p.anti_required) v.push_back(term_pre(2, t.topology_key, ns_list(p.ns, t.namespaces), t.selector, INT32_MAX, p));
-    for (auto& w : p.anti_preferred) v.push_back(term_pre(2, w.term.topology_key, ns_list(p.ns, w.term.namespaces), w.term.selector, INT32_MAX, p));
-    return v;
-  }
-  const std::vector<TermPre>* cur_terms = nullptr; size_t cur_term = 0;      // groups_of's precomputed terms, consumed in order (null: made on the spot)
   int get_group(bool inverse, int type, const std::string& key, const std::set<std::string>& nss, const ksp::Selector& sel, int32_t max_skew, const Pod& owner, bool active_now) {
-    TermPre local; const TermPre* tp;
-    if (cur_terms) { if (cur_term >= cur_terms->size()) throw std::logic_error("precomputed topology terms out of step"); tp = &(*cur_terms)[cur_term++]; }
-    else { local = term_pre(type, key, nss, sel, max_skew, owner); tp = &local; }
-    const Filter& f = tp->f; const std::string& id = tp->id;
+    Filter f; if (type == 0) f = MakeTopologyNodeFilter(owner);
+    const std::string id = group_id(type, key, nss, sel, max_skew, f);
     auto& index = inverse ? inverse_by_id : topo_by_id;
     auto it = index.find(id);
     if (it != index.end()) {
       Group& g = *groups[it->second];
-      if (!g.active && !active_now && g.filter_sig != tp->fsig) throw Unsupported("late-created topology group whose node filter depends on which pod relaxes first");
-      if (g.filter_sig != tp->fsig) shared_filter_differs = true;      // the group keeps its creator's filter (the identity hashes the filter's KEYS only): which pod came first matters
+      if (!g.active && !active_now && g.filter_sig != filter_content(f)) throw Unsupported("late-created topology group whose node filter depends on which pod relaxes first");
+      if (g.filter_sig != filter_content(f)) shared_filter_differs = true;      // the group keeps its creator's filter (the identity hashes the filter's KEYS only): which pod came first matters
       return it->second;
     }
     auto g = std::make_unique<Group>(); g->type = type; g->key = key; g->namespaces = nss; g->selector = sel; g->max_skew = max_skew; g->filter = f; g->inverse = inverse; g->active = active_now;
-    g->filter_sig = tp->fsig;
+    g->filter_sig = filter_content(f);
     const auto& doms = base ? base->domains : domains;
     auto d = doms.find(key); if (d != doms.end()) for (auto& v : d->second) g->counts[v] = 0;   // NewTopologyGroup, topologygroup.go:64-68
     if (!inverse) count_domains(*g);
@@ -866,8 +846,7 @@ struct Builder {
 
   struct SpecGroups { std::vector<int> own, iown; };
   // Topology.Update for one spec (topology.go:86-117); active_now == called from NewTopology
-  SpecGroups groups_of(const Pod& p, bool active_now, const std::vector<TermPre>* pre = nullptr) {
-    struct Cur { Builder& b; ~Cur() { b.cur_terms = nullptr; } } cur{*this}; cur_terms = pre; cur_term = 0;
+  SpecGroups groups_of(const Pod& p, bool active_now) {
     SpecGroups sg;
     if (!p.anti_required.empty() || !p.anti_preferred.empty())
       for (auto& t : p.anti_required) { int g = get_group(true, 2, t.topology_key, ns_list(p.ns, t.namespaces), t.selector, INT32_MAX, p, true); if (std::find(sg.iown.begin(), sg.iown.end(), g) == sg.iown.end()) sg.iown.push_back(g); }
@@ -881,12 +860,12 @@ struct Builder {
   }
 
   // ---------- pods / classes ----------
-  struct StageInfo { Pod spec; Requirements reqs; SpecGroups sg; std::vector<TermPre> terms; };
+  struct StageInfo { Pod spec; Requirements reqs; SpecGroups sg; };
   struct SpecInfo { std::vector<StageInfo> stages; std::vector<uint32_t> cls; };
   std::vector<SpecInfo> specs; std::unordered_map<std::string, int> spec_by_sig; std::vector<int> pod_spec;
   struct ClassRec { std::string sig; };
   std::unordered_map<std::string, uint32_t> class_by_sig;
-  std::vector<std::pair<std::string, StrMap>> labelsets; std::unordered_map<std::string, int> labelset_id;   // (ns, labels)
+  std::vector<std::pair<std::string, StrMap>> labelsets; std::map<std::string, int> labelset_id;   // (ns, labels)
   std::vector<int> cls_labelset; std::vector<SpecGroups> cls_groups;
 
   // Pods -> distinct specs (everything Solve can read of a pod except uid / creationTimestamp), in order of first occurrence.
@@ -1038,14 +1017,13 @@ struct Builder {
         StageInfo st; st.spec = std::move(next); st.reqs = NewPodRequirements(st.spec);
         si.stages.push_back(std::move(st));
         if (si.stages.size() > 64) throw Unsupported("more than 64 relaxation stages");
-      }
-      for (auto& st : si.stages) st.terms = terms_pre(st.spec); } }, 64);
+      } } }, 64);
     sublap("requirements + chains (pool)");
     // pass A: NewTopology's Update(pod) over the distinct stage-0 specs in order of first occurrence
-    for (auto& si : specs) si.stages[0].sg = groups_of(si.stages[0].spec, true, &si.stages[0].terms);
+    for (auto& si : specs) si.stages[0].sg = groups_of(si.stages[0].spec, true);
     sublap("pass A");
     // pass B: relaxation chains (Topology.Update after each relaxation)
-    for (auto& si : specs) for (size_t k = 1; k < si.stages.size(); ++k) si.stages[k].sg = groups_of(si.stages[k].spec, false, &si.stages[k].terms);
+    for (auto& si : specs) for (size_t k = 1; k < si.stages.size(); ++k) si.stages[k].sg = groups_of(si.stages[k].spec, false);
     sublap("pass B");
     // classes
     E.cls_hn_off.assign(1, 0); E.cls_port_off.assign(1, (uint32_t)E.ports.size()); E.cls_vol_off.assign(1, 0);
@@ -1169,7 +1147,7 @@ struct Builder {
     sig += std::to_string(lsid); sig += '\4';
     for (int g : st.sg.own) { sig += std::to_string(g); sig += ','; } sig += '\4';
     for (int g : st.sg.iown) { sig += std::to_string(g); sig += ','; } sig += '\4';
-    auto ins = class_by_sig.try_emplace(std::move(sig), (uint32_t)E.cls.n); if (!ins.second) return ins.first->second;      // (a new class takes the next row: push_reqs below)
+    auto it = class_by_sig.find(sig); if (it != class_by_sig.end()) return it->second;
     const Requirement* hn = nullptr;
     uint32_t c = push_reqs(E.cls, st.reqs, &hn, true, true);
     uint8_t mode = 0;
@@ -1185,6 +1163,7 @@ struct Builder {
     for (auto e : ve) E.vol_list.push_back(e); E.cls_vol_off.push_back((uint32_t)E.vol_list.size());
     cls_labelset.push_back(lsid); cls_groups.push_back(st.sg);
     if (mode != 0) for (int g : st.sg.own) if (groups[g]->key == ksp::kHostname && groups[g]->type == 1) throw Unsupported("hostname pod-affinity combined with a hostname node selector");
+    class_by_sig.emplace(std::move(sig), c);
     return c;
   }
 
