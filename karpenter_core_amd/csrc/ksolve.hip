@@ -1732,6 +1732,7 @@ __global__ __launch_bounds__(64 * NW) void ks_pack(const DevProb* probs, const D
       const bool relaxed = (u32)stg + 1 < nst;
       u32 tail = q_head + q_len; if (tail >= nP) tail -= nP;
       q_len++; pf_ok = false;
+      LSYNC();      // (every lane has read the pod's stage before lane 0 moves it on: in lockstep that is the order anyway; the lane-fibre emulator runs lane 0 ahead to the next barrier and models readfirstlane as the lane's own read)
       if (lane == 0) {
         G_pod_reason[pod] = why;
         const u32 ncls = relaxed ? G_stage_cls[G_pod_stage_off[gpod] + stg + 1] : cidx;
