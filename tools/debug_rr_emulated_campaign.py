@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""(debug tool: imports the oracle; CPU only) the rr-covered fuzz family through ks_pack_rr's SOURCE on the lane-fibre emulator against the oracle, in worker processes:
+   tools/debug_rr_emulated_campaign.py FIRST_SEED COUNT [PROCS]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def one(seed):
+    import simlib
+    S = simlib.use_sim()
+    from oracle import oracle_py as O
+    import test_fuzz_rr as R
+    p = R.rr_problem(seed); t0 = time.time()
+    want = O.solve(p)
+    f = S.FlatProblem(p)
+    try:
+        got = f.solve(); st = f.rr_status()
+    finally:
+        f.close()
+    ok = got.canonical() == want.canonical() and got.reasons == want.reasons
+    return seed, "ok" if ok else "MISMATCH", len(p.pods), tuple(st), round(time.time() - t0, 1)
+
+
+if __name__ == "__main__":
+    import multiprocessing as mp
+    first, count = int(sys.argv[1]), int(sys.argv[2]); procs = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+    os.environ.setdefault("KS_SIM_ALARM", "900")
+    import simlib; simlib.use_sim()      # (build once, before the workers)
+    with mp.get_context("spawn").Pool(procs) as pool:
+        bad, took = [], 0
+        for seed, verdict, pods, st, secs in pool.imap_unordered(one, range(first, first + count)):
+            took += st == (1, 0)
+            if verdict != "ok": bad.append(seed)
+            print(seed, verdict, pods, st, secs, flush=True)
+    print("emulated rr campaign", first, count, "taken by rr", took, "bad", bad)
