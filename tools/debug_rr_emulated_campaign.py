@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """(debug tool: imports the oracle; CPU only) the rr-covered fuzz family through ks_pack_rr's SOURCE on the lane-fibre emulator against the oracle, in worker processes:
-   tools/debug_rr_emulated_campaign.py FIRST_SEED COUNT [PROCS] [FAMILY]      FAMILY: rr (default) | small | base | wide | general -- the other fuzz families (what ks_pack_rr
+   tools/debug_rr_emulated_campaign.py FIRST_SEED COUNT [PROCS] [FAMILY]      FAMILY: rr (default) | small | base | wide | general | config3 (the benchmark's shape at 500-4 500 pods, 5-24 sizes) | herd (hostname groups crowded: the census of zero counters) -- the other fuzz families (what ks_pack_rr
    declines, and everything small, goes through ks_pack's single-wave variants there: the kernel of every what-if)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,9 @@ def one(job):
     S = simlib.use_sim()
     from oracle import oracle_py as O
     import test_fuzz_rr as R, test_fuzz as F, test_fuzz_mid as M
-    p = {"rr": lambda: R.rr_problem(seed), "small": lambda: F.fuzz_problem(seed), "base": lambda: M.mid_problem(seed, "base"), "wide": lambda: M.mid_problem_wide(seed), "general": lambda: M.mid_problem_general(seed)}[fam](); t0 = time.time()
+    p = {"rr": lambda: R.rr_problem(seed), "small": lambda: F.fuzz_problem(seed), "base": lambda: M.mid_problem(seed, "base"), "wide": lambda: M.mid_problem_wide(seed), "general": lambda: M.mid_problem_general(seed),
+         "config3": lambda: __import__("karpenter_core_amd.workloads", fromlist=["config3"]).config3(pods=500 + (seed * 37) % 4000, sizes=5 + seed % 20, seed=seed),
+         "herd": lambda: __import__("karpenter_core_amd.workloads", fromlist=["hostname_herd"]).hostname_herd(pods=200 + (seed * 53) % 1500, labels=2 + seed % 6, seed=seed)}[fam](); t0 = time.time()
     want = O.solve(p)
     f = S.FlatProblem(p)
     try:
