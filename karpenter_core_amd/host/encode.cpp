@@ -97,25 +97,7 @@ std::string canon_ip(const std::string& s) {
 }
 
 void sig_map(std::string& s, const StrMap& m) { for (auto& kv : m) { s += kv.first; s += '\1'; s += kv.second; s += '\2'; } s += '\3'; }
-void sig_exprs(std::string& s, const std::vector<Expr>& es) { for (auto& e : es) { s += e.key; s += '\1'; s += (char)('0' + (int)e.op); for (auto& v : e.values) { s += v; s += '\1'; } s += '\2'; } s += '\3'; }
 void sig_res(std::string& s, const ksp::ResList& r) { for (auto& kv : r) { s += kv.first; s += '\1'; s += std::to_string(kv.second); s += '\2'; } s += '\3'; }
-void sig_selector(std::string& s, const ksp::Selector& sel) { s += selector_identity(sel); s += '\3'; }
-void sig_term(std::string& s, const ksp::AffinityTerm& t) { s += t.topology_key; s += '\1'; for (auto& n : t.namespaces) { s += n; s += '\1'; } sig_selector(s, t.selector); }
-std::string spec_signature(const Pod& p) {
-  std::string s; s.reserve(256);
-  s += p.ns; s += '\3'; sig_map(s, p.labels); sig_map(s, p.node_selector);
-  for (auto& t : p.required_affinity) sig_exprs(s, t); s += '\4';
-  for (auto& t : p.preferred_affinity) { s += std::to_string(t.weight); sig_exprs(s, t.exprs); } s += '\4';
-  for (auto& t : p.tolerations) { s += t.key; s += '\1'; s += t.op; s += '\1'; s += t.value; s += '\1'; s += t.effect; s += '\2'; } s += '\4';
-  for (auto& c : p.containers) { sig_res(s, c.requests); sig_res(s, c.limits); for (auto& hp : c.ports) { s += hp.ip; s += '\1'; s += std::to_string(hp.port); s += hp.proto; s += '\2'; } s += '\3'; } s += '\4';
-  for (auto& c : p.init_containers) { sig_res(s, c.requests); sig_res(s, c.limits); } s += '\4';
-  for (auto& t : p.spread) { s += std::to_string(t.max_skew); s += t.key; s += t.schedule_anyway ? 'A' : 'D'; sig_selector(s, t.selector); } s += '\4';
-  for (auto& t : p.affinity_required) sig_term(s, t); s += '\4';
-  for (auto& t : p.affinity_preferred) { s += std::to_string(t.weight); sig_term(s, t.term); } s += '\4';
-  for (auto& t : p.anti_required) sig_term(s, t); s += '\4';
-  for (auto& t : p.anti_preferred) { s += std::to_string(t.weight); sig_term(s, t.term); } s += '\4';
-  return s;
-}
 
 // ---- host threads: the cores this process may use (a container usually sees every core of the machine but runs under a cgroup
 // CPU quota, cpu.max = "quota period"; oversubscribing the quota is slower than one thread) ----
