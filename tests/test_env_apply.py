@@ -5,7 +5,7 @@ UpdatePod / DeletePod (reference pkg/controllers/state/cluster.go, state/node.go
 CPU half (no GPU): (1) a flattening CONTINUED after events equals, byte for byte, one made from scratch over the same objects -- flat problem and the per-node tables
 the device derivation reads; (2) with events that only add (no tombstones in the way) the what-ifs over the patched snapshot are, array for array, the what-ifs over a
 snapshot a caller would have built fresh from the cluster as it is now (`workloads.cluster_after`, the model of state.Cluster); (3) the device derivation's CPU
-restatement (`ksh_check_whatif_derivation`) stays green after every batch of events; (4) what the door refuses.  The GPU half (tests/test_env_apply_gpu.py) solves."""
+restatement (`ksh_check_whatif_derivation`) stays green after every batch of events; (4) what the door refuses.  The GPU half (below, `-m gpu`) solves."""
 import dataclasses
 
 import numpy as np
